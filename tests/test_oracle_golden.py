@@ -1,0 +1,155 @@
+"""The oracle against golden vectors produced by the REAL reference code.
+
+tests/golden/*.npz were written by oracle/_ref/ref_driver (reference headers
+SlidingGraphVec.h, cpu/PPRCPURev.h, cpu/PPRCPUPowVec.h compiled from
+/root/reference; generator: tests/golden/make_golden.py). Integer/index work and
+the FIFO schedule are compared BIT-FOR-BIT; the Cilk and synchronous schedules are
+held to the reference's own Validate() criteria (cpu/PPRCPUMTCilkRev.h:291-309)
+against the reference-computed power iteration.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests.util import golden_names, load_golden, oracle_graph_from_golden
+
+NAMES = golden_names()
+
+
+def test_fixtures_present():
+    assert len(NAMES) >= 6
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_workload_config(name):
+    d, m = load_golden(name)
+    flags = str(d["flags"]).split()
+    opt = {flags[i]: flags[i + 1] for i in range(0, len(flags) - 1, 2)}
+    n = len(d["stream.e1"])
+    cfg_type = int(opt["-n"])
+    W, pb, bc, tot = orc.workload_config(n, float(opt.get("-w", 0.1)), cfg_type, float(opt.get("-r", -1.0)),
+                                         int(opt.get("-b", 0)), int(opt.get("-c", 0)), int(opt.get("-l", 0)))
+    assert (W, pb, bc, tot) == (m["W"], m["c"], m["batches"], m["total"])
+    assert m["edge_count"] == (W if m["directed"] else 2 * W)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_window_and_batches_bit_exact(name):
+    """EdgeBatch / new_stream / IncConstruct / ScratchConstruct == reference, element for element."""
+    d, m = load_golden(name)
+    g_inc = oracle_graph_from_golden(d, m)     # mode 0: reference-faithful
+    g_fix = oracle_graph_from_golden(d, m)     # mode 1: stream order
+    for which, key in ((0, "out"), (1, "in")):
+        row, col = g_inc.flatten(which)
+        assert np.array_equal(row, d[f"b0.inc.{key}.row"]) and np.array_equal(col, d[f"b0.inc.{key}.col"])
+    assert np.array_equal(g_inc.deg(), d["b0.deg"])
+    for k in range(1, m["done"] + 1):
+        assert not g_inc.stream_updates() and not g_fix.stream_updates()
+        b1, b2, ins = g_inc.batch()
+        assert np.array_equal(b1, d[f"b{k}.batch.e1"])
+        assert np.array_equal(b2, d[f"b{k}.batch.e2"])
+        assert np.array_equal(ins, d[f"b{k}.batch.ins"])
+        n1, n2 = g_inc.new_stream()
+        assert np.array_equal(n1, d[f"b{k}.new.e1"]) and np.array_equal(n2, d[f"b{k}.new.e2"])
+        g_inc.inc_construct(0)
+        g_fix.inc_construct(1)
+        for which, key in ((0, "out"), (1, "in")):
+            row, col = g_inc.flatten(which)
+            assert np.array_equal(row, d[f"b{k}.inc.{key}.row"]), (k, key)
+            assert np.array_equal(col, d[f"b{k}.inc.{key}.col"]), (k, key)
+            row, col = g_fix.flatten(which)
+            assert np.array_equal(row, d[f"b{k}.scr.{key}.row"]), (k, key)
+            assert np.array_equal(col, d[f"b{k}.scr.{key}.col"]), (k, key)
+        assert np.array_equal(g_inc.deg(), d[f"b{k}.deg"])
+        assert np.array_equal(g_fix.deg(), d[f"b{k}.scr.deg"])
+    # the partial batch after the last one is dropped exactly when the reference drops it
+    assert m["done"] <= m["batches"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_fifo_schedule_bit_exact(name):
+    """cpu/PPRCPURev.h (push rule, update rule, legal-push rule) == reference, bit for bit."""
+    d, m = load_golden(name)
+    g = oracle_graph_from_golden(d, m)
+    s = orc.State(m["V"], m["source"], m["eps"])
+    s.fifo_execute(g)
+    assert np.array_equal(s.p, d["b0.fifo.p"]) and np.array_equal(s.r, d["b0.fifo.r"])
+    for k in range(1, m["done"] + 1):
+        assert not g.stream_updates()
+        g.inc_construct(0)
+        s.fifo_inc_execute(g)
+        assert np.array_equal(s.p, d[f"b{k}.fifo.p"]), k
+        assert np.array_equal(s.r, d[f"b{k}.fifo.r"]), k
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_power_iteration_bit_exact(name):
+    """cpu/PPRCPUPowVec.h:55-83 CalPPRRev == reference, bit for bit."""
+    d, m = load_golden(name)
+    g = oracle_graph_from_golden(d, m)
+    p, _ = orc.pow_rev(g, m["source"])
+    assert np.array_equal(p, d["b0.pow.p"])
+    for k in range(1, m["done"] + 1):
+        assert not g.stream_updates()
+        g.inc_construct(1)
+        p, _ = orc.pow_rev(g, m["source"])
+        assert np.array_equal(p, d[f"b{k}.pow.p"]), k
+
+
+@pytest.mark.parametrize("schedule", ["cilk", "sync"])
+@pytest.mark.parametrize("name", NAMES)
+def test_push_schedules_meet_reference_validate(name, schedule):
+    """Validate() of cpu/PPRCPUMTCilkRev.h:291-309: |r| < eps and |p - p_pow| < 100 eps,
+    with p_pow computed by the reference itself (fixture), plus the loop invariant."""
+    d, m = load_golden(name)
+    eps = m["eps"]
+    g = oracle_graph_from_golden(d, m)
+    s = orc.State(m["V"], m["source"], eps)
+    getattr(s, schedule + "_execute")(g)
+    for k in range(0, m["done"] + 1):
+        if k > 0:
+            assert not g.stream_updates()
+            g.inc_construct(1)
+            getattr(s, schedule + "_inc_execute")(g)
+        assert s.max_abs_residual() < eps
+        assert np.max(np.abs(s.p - d[f"b{k}.pow.p"])) < 100 * eps
+        assert s.invariant_max_err(g) < 1e-13   # rounding only (p <= 1, ulp 1e-16)
+        # the reference's own FIFO answer is a second witness (different schedule, same fixed point)
+        if not (name.startswith("und") and m["W"] % m["c"] != 0):
+            assert np.max(np.abs(s.p - d[f"b{k}.fifo.p"])) < 200 * eps
+
+
+def test_quirk_q1_inc_construct_undirected_misaligned():
+    """Reference quirk Q1: IncConstructWindowGraph appends a batch's direct
+    records before its mirrored ones, but expires by count from the list front; when
+    W % c != 0 on an undirected stream the two orders disagree and the reference's
+    incremental adjacency transiently differs from the true window (as a multiset)."""
+    d, m = load_golden("und_long_misaligned_e9")
+    assert m["W"] % m["c"] != 0 and not m["directed"]
+    differs = False
+    for k in range(1, m["done"] + 1):
+        for key in ("in", "out"):
+            row_i, col_i = d[f"b{k}.inc.{key}.row"], d[f"b{k}.inc.{key}.col"]
+            row_s, col_s = d[f"b{k}.scr.{key}.row"], d[f"b{k}.scr.{key}.col"]
+            assert np.array_equal(row_i, row_s)      # degrees always agree
+            for u in range(m["V"]):
+                a = np.sort(col_i[row_i[u]:row_i[u + 1]])
+                b = np.sort(col_s[row_s[u]:row_s[u + 1]])
+                if not np.array_equal(a, b):
+                    differs = True
+    # aligned case never differs
+    d2, m2 = load_golden("und_aligned_e9")
+    assert m2["W"] % m2["c"] == 0
+    for k in range(1, m2["done"] + 1):
+        row_i, col_i = d2[f"b{k}.inc.in.row"], d2[f"b{k}.inc.in.col"]
+        row_s, col_s = d2[f"b{k}.scr.in.row"], d2[f"b{k}.scr.in.col"]
+        for u in range(m2["V"]):
+            assert np.array_equal(np.sort(col_i[row_i[u]:row_i[u + 1]]), np.sort(col_s[row_s[u]:row_s[u + 1]]))
+    assert differs, "expected the documented reference quirk to show on the misaligned undirected fixture"
+
+
+def test_is_legal_push_strict():
+    eps = 1e-9
+    assert not orc.is_legal_push(eps, 0, eps) and orc.is_legal_push(np.nextafter(eps, 1), 0, eps)
+    assert not orc.is_legal_push(-eps, 1, eps) and orc.is_legal_push(np.nextafter(-eps, -1), 1, eps)
+    assert not orc.is_legal_push(-1.0, 0, eps) and not orc.is_legal_push(1.0, 1, eps)
