@@ -1,0 +1,719 @@
+// dppr_engine.hip -- host side of libdppr_hip.so: the C ABI of include/dppr.h.
+//
+// Owns device memory (replaces gpu/DeviceMemory.cuh, gpu/GPUEdgeBatch.cuh,
+// gpu/SlidingGraphBuilder.cuh), drives the frontier loop (replaces
+// PPRRevPushGPU::ExecuteOptimized, gpu/PPRRevPushGPU.cuh:97-131) and times the
+// region the reference times (gpu/PPRGPU.cuh:138-164).
+//
+// There is NO CPU fallback: without a HIP device dppr_create fails with
+// DPPR_ERR_NO_DEVICE.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp> // device radix sort only (CSR rebuild, batch grouping); no CUB/Thrust in kernels
+
+#include "../../include/dppr.h"
+#include "dppr_kernels.hpp"
+
+using namespace dppr;
+
+namespace {
+
+struct Epoch {
+    int *row_ptr = nullptr; // V+1
+    Adj *adj = nullptr;     // Ed
+    int Ed = 0;
+    // batch that produced this epoch (empty for epoch 0)
+    int *b1 = nullptr, *b2 = nullptr, *deg_after = nullptr; // 4c each
+    uint8_t *ins = nullptr;
+    int L = 0;
+    int id = -1; // global epoch number stored in this ring entry
+};
+
+struct Slot {
+    int source = 0;
+    double *p = nullptr, *r = nullptr, *ft_r = nullptr;
+    int *ft[2] = {nullptr, nullptr};
+    int *neg = nullptr;     // phase-1 candidates
+    int *cnt = nullptr;     // [0..2] rotating frontier counters, [3] neg candidates, [4] scratch
+    IterStats *dstats = nullptr;
+    bool converged = false; // |r| <= eps everywhere (state after a completed solve)
+    double conv_eps = 0.0;
+    bool phase0_done = false; // ExecuteMainLoop(0) completed since the last modification
+    double phase0_eps = 0.0;
+    dppr_stats_t st{};
+    bool trace = false;
+    std::vector<int64_t> trace_off;
+    std::vector<int32_t> trace_ids;
+};
+
+} // namespace
+
+struct dppr_engine {
+    int device = 0;
+    int V = 0, W = 0, c = 0, directed = 1, n_epochs = 1;
+    int Ed = 0;   // directed edges in the window
+    int bits = 1; // bits of a vertex id
+    int schedule = DPPR_SCHEDULE_EAGER;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    bool profiling = false;
+    // window ring, stream order
+    int *w1 = nullptr, *w2 = nullptr;
+    int head = 0;
+    bool loaded = false;
+    int *outdeg = nullptr;
+    // CSR build scratch
+    uint64_t *keys_a = nullptr, *keys_b = nullptr;
+    void *sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    // stream-update scratch
+    uint32_t *su_k[2] = {nullptr, nullptr}, *su_v[2] = {nullptr, nullptr};
+    double *su_term = nullptr;
+    uint8_t *su_ins = nullptr;
+    void *su_tmp = nullptr;
+    size_t su_tmp_bytes = 0;
+    // staged batch (set_batch before slide)
+    std::vector<int32_t> st_b1, st_b2;
+    std::vector<uint8_t> st_ins;
+    bool batch_staged = false;
+    // epochs
+    std::vector<Epoch> epochs;
+    int newest = -1; // global id of newest epoch
+    std::vector<Slot> slots;
+    int *pinned = nullptr; // host-pinned readback words
+    int max_iters = 1 << 20;
+    std::string err;
+};
+
+namespace {
+
+#define HIP_TRY(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (call);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            char _b[512];                                                                               \
+            snprintf(_b, sizeof(_b), "%s in %s at line %d", hipGetErrorString(_e), __FILE__, __LINE__); \
+            e->err = _b;                                                                                \
+            return _e == hipErrorOutOfMemory ? DPPR_ERR_NOMEM : DPPR_ERR_HIP;                           \
+        }                                                                                               \
+    } while (0)
+
+inline int grid_for(int64_t n, int per_block = BLOCK, int cap = 2048) {
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+int fail(dppr_engine *e, int code, const char *msg) {
+    if (e) e->err = msg;
+    return code;
+}
+
+Epoch *find_epoch(dppr_engine *e, int epoch) {
+    if (e->newest < 0) return nullptr;
+    if (epoch < 0) epoch = e->newest;
+    Epoch &ep = e->epochs[epoch % e->n_epochs];
+    return ep.id == epoch ? &ep : nullptr;
+}
+
+// Build row_ptr/adj of `ep` from the current window ring + outdeg.
+int build_csr(dppr_engine *e, Epoch &ep) {
+    const int W = e->W, Ed = e->Ed;
+    if (W > 0) {
+        hipLaunchKernelGGL(k_make_keys, dim3(grid_for(W)), dim3(BLOCK), 0, e->stream, e->w1, e->w2, W, e->directed,
+                           e->bits, e->keys_a);
+        HIP_TRY(hipGetLastError());
+        size_t tmp = e->sort_tmp_bytes;
+        HIP_TRY(rocprim::radix_sort_keys(e->sort_tmp, tmp, e->keys_a, e->keys_b, (size_t)Ed, 0u,
+                                         (unsigned)(2 * e->bits), e->stream));
+    }
+    hipLaunchKernelGGL(k_build_csr, dim3(grid_for(std::max(Ed, e->V + 1))), dim3(BLOCK), 0, e->stream, e->keys_b, Ed,
+                       e->V, e->bits, e->outdeg, ep.row_ptr, ep.adj);
+    HIP_TRY(hipGetLastError());
+    ep.Ed = Ed;
+    return DPPR_OK;
+}
+
+int read_count(dppr_engine *e, const int *dptr, int *out) {
+    HIP_TRY(hipMemcpyAsync(e->pinned, dptr, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    *out = e->pinned[0];
+    return DPPR_OK;
+}
+
+// Frontier loop: PPRRevPushGPU::ExecuteOptimized's while(1) (gpu/PPRRevPushGPU.cuh:106-130).
+// On entry s.ft[buf] holds the frontier and s.cnt[cur] its size; cnt[(cur+1)%3] is zero.
+int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, double eps, int buf, int cur) {
+    bool pending = false; // a profiled push launch awaits its event read-out
+    for (int it = 0;; ++it) {
+        int F = 0;
+        int rc = read_count(e, s.cnt + cur, &F);
+        if (rc) return rc;
+        if (pending) { // the stream is idle after read_count's synchronize
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, e->ev2, e->ev3));
+            s.st.push_ms += ms;
+            s.st.push_launches++;
+            pending = false;
+        }
+        if (F == 0) break;
+        if (it >= e->max_iters) return fail(e, DPPR_ERR_NOT_CONVERGED, "iteration cap hit");
+        if (s.trace) {
+            size_t old = s.trace_ids.size();
+            s.trace_ids.resize(old + (size_t)F);
+            HIP_TRY(hipMemcpyAsync(s.trace_ids.data() + old, s.ft[buf], sizeof(int) * (size_t)F,
+                                   hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            s.trace_off.push_back((int64_t)s.trace_ids.size());
+        }
+        s.st.iterations++;
+        s.st.sum_F += F;
+        const int nxt = (cur + 1) % 3, zer = (cur + 2) % 3;
+        const int tiles = (F + WAVE - 1) / WAVE;
+        const int grid = std::min(std::max((tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 1), 2048);
+        if (e->schedule == DPPR_SCHEDULE_SYNC) {
+            hipLaunchKernelGGL(k_snapshot, dim3(grid_for(F)), dim3(BLOCK), 0, e->stream, s.ft[buf], s.cnt + cur, s.r,
+                               s.p, s.ft_r);
+            if (e->profiling) HIP_TRY(hipEventRecord(e->ev2, e->stream));
+            hipLaunchKernelGGL(k_push_iter<true>, dim3(grid), dim3(BLOCK), 0, e->stream, s.ft[buf], s.cnt + cur,
+                               s.ft[buf ^ 1], s.cnt + nxt, s.cnt + zer, s.ft_r, ep.row_ptr, ep.adj, s.r, s.p, phase,
+                               eps, s.dstats);
+        } else {
+            if (e->profiling) HIP_TRY(hipEventRecord(e->ev2, e->stream));
+            hipLaunchKernelGGL(k_push_iter<false>, dim3(grid), dim3(BLOCK), 0, e->stream, s.ft[buf], s.cnt + cur,
+                               s.ft[buf ^ 1], s.cnt + nxt, s.cnt + zer, (const double *)nullptr, ep.row_ptr, ep.adj,
+                               s.r, s.p, phase, eps, s.dstats);
+        }
+        HIP_TRY(hipGetLastError());
+        if (e->profiling) {
+            HIP_TRY(hipEventRecord(e->ev3, e->stream));
+            pending = true;
+        }
+        buf ^= 1;
+        cur = nxt;
+    }
+    return DPPR_OK;
+}
+
+// full Inspect seeding + loop = ExecuteMainLoop(phase)
+int main_loop_inspect(dppr_engine *e, Slot &s, const Epoch &ep, int phase, double eps) {
+    HIP_TRY(hipMemsetAsync(s.cnt, 0, sizeof(int) * 3, e->stream));
+    hipLaunchKernelGGL(k_inspect, dim3(grid_for(e->V, BLOCK * INSPECT_ITEMS)), dim3(BLOCK), 0, e->stream, s.r, e->V,
+                       phase, eps, s.ft[0], s.cnt + 0);
+    HIP_TRY(hipGetLastError());
+    s.st.inspected += e->V;
+    return run_frontier_loop(e, s, ep, phase, eps, 0, 0);
+}
+
+// IncrementalBatchUpdate; when seed != 0 also seeds ft[0]/cnt[0] (phase 0) and neg/cnt[3].
+int stream_update(dppr_engine *e, Slot &s, const Epoch &ep, double eps, bool seed) {
+    const int L = ep.L;
+    HIP_TRY(hipMemsetAsync(s.cnt, 0, sizeof(int) * 5, e->stream));
+    if (L == 0) return DPPR_OK;
+    hipLaunchKernelGGL(k_su_keys, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->su_k[0], e->su_v[0]);
+    size_t tmp = e->su_tmp_bytes;
+    HIP_TRY(rocprim::radix_sort_pairs(e->su_tmp, tmp, e->su_k[0], e->su_k[1], e->su_v[0], e->su_v[1], (size_t)L, 0u,
+                                      (unsigned)e->bits, e->stream));
+    hipLaunchKernelGGL(k_su_terms, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, e->su_k[1], e->su_v[1], ep.b2, ep.ins,
+                       L, s.p, e->su_term, e->su_ins);
+    // without seeding the lists go to scratch space (cnt[4] / neg) and are ignored
+    hipLaunchKernelGGL(k_su_apply, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, e->su_k[1], e->su_v[1], e->su_term,
+                       e->su_ins, ep.deg_after, L, s.r, s.source, seed ? eps : 1e300, s.ft[0], s.cnt + 0, s.neg,
+                       s.cnt + 3);
+    HIP_TRY(hipGetLastError());
+    s.st.records += L;
+    return DPPR_OK;
+}
+
+int pull_device_stats(dppr_engine *e, Slot &s) {
+    IterStats h;
+    HIP_TRY(hipMemcpyAsync(&h, s.dstats, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    s.st.sum_E = (int64_t)h.sum_E;
+    return DPPR_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int dppr_abi_version(void) { return DPPR_ABI_VERSION; }
+
+const char *dppr_strerror(int status) {
+    switch (status) {
+    case DPPR_OK: return "ok";
+    case DPPR_ERR_INVALID: return "invalid argument or call order";
+    case DPPR_ERR_HIP: return "HIP runtime error";
+    case DPPR_ERR_NOMEM: return "out of device memory";
+    case DPPR_ERR_NO_DEVICE: return "no usable HIP device (the HIP path is mandatory; there is no CPU fallback)";
+    case DPPR_ERR_NOT_CONVERGED: return "iteration cap hit before the frontier emptied";
+    default: return "unknown status";
+    }
+}
+
+const char *dppr_last_error(const dppr_engine *e) { return e ? e->err.c_str() : ""; }
+
+int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directed, int32_t c, int32_t n_epochs) {
+    if (!out || V <= 0 || W < 0 || c < 0 || n_epochs < 1) return DPPR_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return DPPR_ERR_NO_DEVICE;
+    dppr_engine *e = new dppr_engine();
+    auto bail = [&](int code) {
+        dppr_destroy(e);
+        return code;
+    };
+#define HIP_TRY_C(call)                                                                 \
+    do {                                                                                \
+        hipError_t _e = (call);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            fprintf(stderr, "dppr_create: %s at line %d\n", hipGetErrorString(_e), __LINE__); \
+            return bail(_e == hipErrorOutOfMemory ? DPPR_ERR_NOMEM : DPPR_ERR_HIP);     \
+        }                                                                               \
+    } while (0)
+    e->device = device;
+    e->V = V;
+    e->W = W;
+    e->c = c;
+    e->directed = directed ? 1 : 0;
+    e->n_epochs = n_epochs;
+    e->Ed = directed ? W : 2 * W;
+    e->bits = 1;
+    while ((1ll << e->bits) < (long long)V) e->bits++;
+    HIP_TRY_C(hipSetDevice(device));
+    HIP_TRY_C(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIP_TRY_C(hipEventCreate(&e->ev0));
+    HIP_TRY_C(hipEventCreate(&e->ev1));
+    HIP_TRY_C(hipEventCreate(&e->ev2));
+    HIP_TRY_C(hipEventCreate(&e->ev3));
+    HIP_TRY_C(hipHostMalloc((void **)&e->pinned, 64, hipHostMallocDefault));
+    const size_t Wn = (size_t)std::max(W, 1), Edn = (size_t)std::max(e->Ed, 1), Ln = (size_t)std::max(4 * c, 1);
+    HIP_TRY_C(hipMalloc((void **)&e->w1, sizeof(int) * Wn));
+    HIP_TRY_C(hipMalloc((void **)&e->w2, sizeof(int) * Wn));
+    HIP_TRY_C(hipMalloc((void **)&e->outdeg, sizeof(int) * (size_t)V));
+    HIP_TRY_C(hipMemset(e->outdeg, 0, sizeof(int) * (size_t)V));
+    HIP_TRY_C(hipMalloc((void **)&e->keys_a, sizeof(uint64_t) * Edn));
+    HIP_TRY_C(hipMalloc((void **)&e->keys_b, sizeof(uint64_t) * Edn));
+    HIP_TRY_C(rocprim::radix_sort_keys(nullptr, e->sort_tmp_bytes, e->keys_a, e->keys_b, Edn, 0u,
+                                       (unsigned)(2 * e->bits), e->stream));
+    HIP_TRY_C(hipMalloc(&e->sort_tmp, std::max<size_t>(e->sort_tmp_bytes, 16)));
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY_C(hipMalloc((void **)&e->su_k[k], sizeof(uint32_t) * Ln));
+        HIP_TRY_C(hipMalloc((void **)&e->su_v[k], sizeof(uint32_t) * Ln));
+    }
+    HIP_TRY_C(hipMalloc((void **)&e->su_term, sizeof(double) * Ln));
+    HIP_TRY_C(hipMalloc((void **)&e->su_ins, Ln));
+    HIP_TRY_C(rocprim::radix_sort_pairs(nullptr, e->su_tmp_bytes, e->su_k[0], e->su_k[1], e->su_v[0], e->su_v[1], Ln,
+                                        0u, (unsigned)e->bits, e->stream));
+    HIP_TRY_C(hipMalloc(&e->su_tmp, std::max<size_t>(e->su_tmp_bytes, 16)));
+    e->epochs.resize((size_t)n_epochs);
+    for (auto &ep : e->epochs) {
+        HIP_TRY_C(hipMalloc((void **)&ep.row_ptr, sizeof(int) * ((size_t)V + 1)));
+        HIP_TRY_C(hipMalloc((void **)&ep.adj, sizeof(Adj) * Edn));
+        HIP_TRY_C(hipMalloc((void **)&ep.b1, sizeof(int) * Ln));
+        HIP_TRY_C(hipMalloc((void **)&ep.b2, sizeof(int) * Ln));
+        HIP_TRY_C(hipMalloc((void **)&ep.deg_after, sizeof(int) * Ln));
+        HIP_TRY_C(hipMalloc((void **)&ep.ins, Ln));
+    }
+#undef HIP_TRY_C
+    *out = e;
+    return DPPR_OK;
+}
+
+void dppr_destroy(dppr_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto &s : e->slots) {
+        (void)hipFree(s.p); (void)hipFree(s.r); (void)hipFree(s.ft_r);
+        (void)hipFree(s.ft[0]); (void)hipFree(s.ft[1]); (void)hipFree(s.neg);
+        (void)hipFree(s.cnt); (void)hipFree(s.dstats);
+    }
+    for (auto &ep : e->epochs) {
+        (void)hipFree(ep.row_ptr); (void)hipFree(ep.adj); (void)hipFree(ep.b1); (void)hipFree(ep.b2);
+        (void)hipFree(ep.deg_after); (void)hipFree(ep.ins);
+    }
+    (void)hipFree(e->w1); (void)hipFree(e->w2); (void)hipFree(e->outdeg);
+    (void)hipFree(e->keys_a); (void)hipFree(e->keys_b); (void)hipFree(e->sort_tmp);
+    for (int k = 0; k < 2; ++k) { (void)hipFree(e->su_k[k]); (void)hipFree(e->su_v[k]); }
+    (void)hipFree(e->su_term); (void)hipFree(e->su_ins); (void)hipFree(e->su_tmp);
+    if (e->pinned) (void)hipHostFree(e->pinned);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->ev2) (void)hipEventDestroy(e->ev2);
+    if (e->ev3) (void)hipEventDestroy(e->ev3);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int dppr_set_schedule(dppr_engine *e, int schedule) {
+    if (!e || (schedule != DPPR_SCHEDULE_EAGER && schedule != DPPR_SCHEDULE_SYNC)) return DPPR_ERR_INVALID;
+    e->schedule = schedule;
+    return DPPR_OK;
+}
+
+int dppr_set_profiling(dppr_engine *e, int on) {
+    if (!e) return DPPR_ERR_INVALID;
+    e->profiling = on != 0;
+    return DPPR_OK;
+}
+
+int dppr_synchronize(dppr_engine *e) {
+    if (!e) return DPPR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return DPPR_OK;
+}
+
+int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32_t n) {
+    if (!e || n != e->W || (n > 0 && (!e1 || !e2))) return fail(e, DPPR_ERR_INVALID, "load_window: n must equal W");
+    HIP_TRY(hipSetDevice(e->device));
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(e->w1, e1, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->w2, e2, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+    }
+    e->head = 0;
+    HIP_TRY(hipMemsetAsync(e->outdeg, 0, sizeof(int) * (size_t)e->V, e->stream));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_deg_update, dim3(grid_for(n)), dim3(BLOCK), 0, e->stream, e->w1, e->w2, n, e->directed, 1,
+                           e->outdeg);
+        HIP_TRY(hipGetLastError());
+    }
+    for (auto &ep : e->epochs) ep.id = -1;
+    Epoch &ep = e->epochs[0];
+    ep.L = 0;
+    int rc = build_csr(e, ep);
+    if (rc) return rc;
+    ep.id = 0;
+    e->newest = 0;
+    e->loaded = true;
+    e->batch_staged = false;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return DPPR_OK;
+}
+
+int dppr_set_batch(dppr_engine *e, const int32_t *b1, const int32_t *b2, const uint8_t *ins, int32_t L) {
+    if (!e || L < 0 || L > 4 * e->c || (L > 0 && (!b1 || !b2 || !ins)))
+        return fail(e, DPPR_ERR_INVALID, "set_batch: length exceeds 4*max_batch");
+    e->st_b1.assign(b1, b1 + L);
+    e->st_b2.assign(b2, b2 + L);
+    e->st_ins.assign(ins, ins + L);
+    e->batch_staged = true;
+    return DPPR_OK;
+}
+
+int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, int32_t *out_epoch) {
+    if (!e || !e->loaded || c < 0 || c > e->W || (c > 0 && (!n1 || !n2)))
+        return fail(e, DPPR_ERR_INVALID, "slide: window not loaded or bad c");
+    HIP_TRY(hipSetDevice(e->device));
+    const int W = e->W;
+    // the c oldest edges sit at ring positions head .. head+c (mod W): retire their degrees,
+    // overwrite them with the new edges, add the new degrees
+    int done = 0;
+    while (done < c) {
+        const int pos = (e->head + done) % W;
+        const int len = std::min(c - done, W - pos);
+        hipLaunchKernelGGL(k_deg_update, dim3(grid_for(len)), dim3(BLOCK), 0, e->stream, e->w1 + pos, e->w2 + pos, len,
+                           e->directed, -1, e->outdeg);
+        HIP_TRY(hipMemcpyAsync(e->w1 + pos, n1 + done, sizeof(int) * (size_t)len, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->w2 + pos, n2 + done, sizeof(int) * (size_t)len, hipMemcpyHostToDevice, e->stream));
+        hipLaunchKernelGGL(k_deg_update, dim3(grid_for(len)), dim3(BLOCK), 0, e->stream, e->w1 + pos, e->w2 + pos, len,
+                           e->directed, 1, e->outdeg);
+        HIP_TRY(hipGetLastError());
+        done += len;
+    }
+    if (W > 0) e->head = (e->head + c) % W;
+    const int id = e->newest + 1;
+    Epoch &ep = e->epochs[id % e->n_epochs];
+    ep.id = -1;
+    int rc = build_csr(e, ep);
+    if (rc) return rc;
+    ep.L = 0;
+    if (e->batch_staged) {
+        const int L = (int)e->st_b1.size();
+        ep.L = L;
+        if (L > 0) {
+            HIP_TRY(hipMemcpyAsync(ep.b1, e->st_b1.data(), sizeof(int) * (size_t)L, hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(hipMemcpyAsync(ep.b2, e->st_b2.data(), sizeof(int) * (size_t)L, hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(hipMemcpyAsync(ep.ins, e->st_ins.data(), (size_t)L, hipMemcpyHostToDevice, e->stream));
+            // CopyOutDegree (gpu/StreamUpdate.cuh:7-17): post-batch out-degree of every tail
+            hipLaunchKernelGGL(k_gather_deg, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->outdeg,
+                               ep.deg_after);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream)); // staged host vectors may be reused now
+    e->batch_staged = false;
+    ep.id = id;
+    e->newest = id;
+    if (out_epoch) *out_epoch = id;
+    return DPPR_OK;
+}
+
+int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
+    if (!e || source < 0 || source >= e->V) return fail(e, DPPR_ERR_INVALID, "add_source: vertex out of range");
+    HIP_TRY(hipSetDevice(e->device));
+    Slot s;
+    s.source = source;
+    const size_t V = (size_t)e->V;
+    HIP_TRY(hipMalloc((void **)&s.p, sizeof(double) * V));
+    HIP_TRY(hipMalloc((void **)&s.r, sizeof(double) * V));
+    HIP_TRY(hipMalloc((void **)&s.ft_r, sizeof(double) * V));
+    HIP_TRY(hipMalloc((void **)&s.ft[0], sizeof(int) * V));
+    HIP_TRY(hipMalloc((void **)&s.ft[1], sizeof(int) * V));
+    HIP_TRY(hipMalloc((void **)&s.neg, sizeof(int) * (size_t)std::max(4 * e->c, 1)));
+    HIP_TRY(hipMalloc((void **)&s.cnt, sizeof(int) * 8));
+    HIP_TRY(hipMalloc((void **)&s.dstats, sizeof(IterStats)));
+    HIP_TRY(hipMemset(s.cnt, 0, sizeof(int) * 8));
+    HIP_TRY(hipMemset(s.dstats, 0, sizeof(IterStats)));
+    hipLaunchKernelGGL(k_init, dim3(grid_for(e->V)), dim3(BLOCK), 0, e->stream, s.p, s.r, e->V, source);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->slots.push_back(std::move(s));
+    if (out_slot) *out_slot = (int)e->slots.size() - 1;
+    return DPPR_OK;
+}
+
+#define GET_SLOT(e, slot)                                                                       \
+    if (!(e) || (slot) < 0 || (slot) >= (int)(e)->slots.size()) return fail((e), DPPR_ERR_INVALID, "bad slot"); \
+    Slot &s = (e)->slots[(size_t)(slot)]
+#define GET_EPOCH(e, epoch)                                                       \
+    Epoch *epp = find_epoch((e), (epoch));                                        \
+    if (!epp) return fail((e), DPPR_ERR_INVALID, "epoch not resident (evicted or never built)"); \
+    Epoch &ep = *epp
+
+int dppr_init_solve(dppr_engine *e, int32_t slot, double eps, float *out_ms) {
+    GET_SLOT(e, slot);
+    GET_EPOCH(e, -1);
+    if (!(eps > 0)) return fail(e, DPPR_ERR_INVALID, "eps must be positive");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    hipLaunchKernelGGL(k_init, dim3(grid_for(e->V)), dim3(BLOCK), 0, e->stream, s.p, s.r, e->V, s.source);
+    HIP_TRY(hipGetLastError());
+    s.converged = false;
+    int rc = main_loop_inspect(e, s, ep, 0, eps);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(hipEventSynchronize(e->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    if (out_ms) *out_ms = ms;
+    s.converged = true;
+    s.conv_eps = eps;
+    return pull_device_stats(e, s);
+}
+
+int dppr_incremental_batch_update(dppr_engine *e, int32_t slot, int32_t epoch) {
+    GET_SLOT(e, slot);
+    GET_EPOCH(e, epoch);
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = stream_update(e, s, ep, 0.0, false);
+    if (rc) return rc;
+    s.converged = false;
+    s.phase0_done = false;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return DPPR_OK;
+}
+
+int dppr_execute_main_loop(dppr_engine *e, int32_t slot, int32_t epoch, int phase, double eps) {
+    GET_SLOT(e, slot);
+    GET_EPOCH(e, epoch);
+    if ((phase != 0 && phase != 1) || !(eps > 0)) return fail(e, DPPR_ERR_INVALID, "phase must be 0/1, eps > 0");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = main_loop_inspect(e, s, ep, phase, eps);
+    if (rc) return rc;
+    if (phase == 0) {
+        s.phase0_done = true;
+        s.phase0_eps = eps;
+    } else if (s.phase0_done && s.phase0_eps == eps) { // both phases done: |r| <= eps everywhere
+        s.converged = true;
+        s.conv_eps = eps;
+    }
+    return pull_device_stats(e, s);
+}
+
+int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *out_ms) {
+    GET_SLOT(e, slot);
+    GET_EPOCH(e, epoch);
+    if (!(eps > 0)) return fail(e, DPPR_ERR_INVALID, "eps must be positive");
+    HIP_TRY(hipSetDevice(e->device));
+    // Seeding from the batch tails is exact only if every |r| <= eps beforehand
+    // (the state a completed solve leaves). Otherwise fall back to full Inspect passes.
+    const bool seeded = s.converged && s.conv_eps <= eps;
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    int rc = stream_update(e, s, ep, eps, seeded);
+    if (rc) return rc;
+    s.converged = false;
+    if (seeded) {
+        rc = run_frontier_loop(e, s, ep, 0, eps, 0, 0);
+        if (rc) return rc;
+        // phase 1: candidates recorded by the update, re-checked now
+        HIP_TRY(hipMemsetAsync(s.cnt, 0, sizeof(int) * 3, e->stream));
+        hipLaunchKernelGGL(k_filter, dim3(grid_for(std::max(ep.L, 1))), dim3(BLOCK), 0, e->stream, s.neg, s.cnt + 3,
+                           s.r, 1, eps, s.ft[0], s.cnt + 0);
+        HIP_TRY(hipGetLastError());
+        rc = run_frontier_loop(e, s, ep, 1, eps, 0, 0);
+        if (rc) return rc;
+    } else {
+        rc = main_loop_inspect(e, s, ep, 0, eps);
+        if (rc) return rc;
+        rc = main_loop_inspect(e, s, ep, 1, eps);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(hipEventSynchronize(e->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    if (out_ms) *out_ms = ms;
+    s.st.gpu_ms += ms;
+    s.st.batches++;
+    s.converged = true;
+    s.conv_eps = eps;
+    return pull_device_stats(e, s);
+}
+
+int dppr_read(dppr_engine *e, int32_t slot, double *p, double *r) {
+    GET_SLOT(e, slot);
+    HIP_TRY(hipSetDevice(e->device));
+    if (p) HIP_TRY(hipMemcpyAsync(p, s.p, sizeof(double) * (size_t)e->V, hipMemcpyDeviceToHost, e->stream));
+    if (r) HIP_TRY(hipMemcpyAsync(r, s.r, sizeof(double) * (size_t)e->V, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return DPPR_OK;
+}
+
+int dppr_write(dppr_engine *e, int32_t slot, const double *p, const double *r) {
+    GET_SLOT(e, slot);
+    HIP_TRY(hipSetDevice(e->device));
+    if (p) HIP_TRY(hipMemcpyAsync(s.p, p, sizeof(double) * (size_t)e->V, hipMemcpyHostToDevice, e->stream));
+    if (r) HIP_TRY(hipMemcpyAsync(s.r, r, sizeof(double) * (size_t)e->V, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    s.converged = false;
+    s.phase0_done = false;
+    return DPPR_OK;
+}
+
+int dppr_stats(dppr_engine *e, int32_t slot, dppr_stats_t *out) {
+    GET_SLOT(e, slot);
+    if (!out) return DPPR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = pull_device_stats(e, s);
+    if (rc) return rc;
+    // every enqueued vertex is a frontier member of a later iteration, except the seeds
+    s.st.sum_N = s.st.sum_F;
+    s.st.algorithmic_bytes = 16ll * e->V * s.st.batches + 45ll * s.st.records + 72ll * s.st.sum_F +
+                             24ll * s.st.sum_E + 4ll * s.st.sum_N;
+    *out = s.st;
+    return DPPR_OK;
+}
+
+int dppr_reset_stats(dppr_engine *e, int32_t slot) {
+    GET_SLOT(e, slot);
+    HIP_TRY(hipSetDevice(e->device));
+    s.st = dppr_stats_t{};
+    HIP_TRY(hipMemsetAsync(s.dstats, 0, sizeof(IterStats), e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return DPPR_OK;
+}
+
+int dppr_inspect(dppr_engine *e, int32_t slot, int phase, double eps, int32_t *out_ids, int32_t *out_count) {
+    GET_SLOT(e, slot);
+    if (!out_ids || !out_count || (phase != 0 && phase != 1)) return DPPR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemsetAsync(s.cnt + 4, 0, sizeof(int), e->stream));
+    hipLaunchKernelGGL(k_inspect, dim3(grid_for(e->V, BLOCK * INSPECT_ITEMS)), dim3(BLOCK), 0, e->stream, s.r, e->V,
+                       phase, eps, s.ft[1], s.cnt + 4);
+    HIP_TRY(hipGetLastError());
+    int n = 0;
+    int rc = read_count(e, s.cnt + 4, &n);
+    if (rc) return rc;
+    if (n > 0) HIP_TRY(hipMemcpy(out_ids, s.ft[1], sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    *out_count = n;
+    return DPPR_OK;
+}
+
+int dppr_graph_edges(dppr_engine *e, int32_t epoch, int32_t *out) {
+    if (!e || !out) return DPPR_ERR_INVALID;
+    GET_EPOCH(e, epoch);
+    *out = ep.Ed;
+    return DPPR_OK;
+}
+
+int dppr_read_graph(dppr_engine *e, int32_t epoch, int32_t *row_ptr, int32_t *col, int32_t *out_degree) {
+    if (!e) return DPPR_ERR_INVALID;
+    GET_EPOCH(e, epoch);
+    HIP_TRY(hipSetDevice(e->device));
+    if (row_ptr)
+        HIP_TRY(hipMemcpyAsync(row_ptr, ep.row_ptr, sizeof(int) * ((size_t)e->V + 1), hipMemcpyDeviceToHost, e->stream));
+    if (col && ep.Ed > 0) {
+        int *tmp = reinterpret_cast<int *>(e->keys_a); // scratch
+        hipLaunchKernelGGL(k_split_adj, dim3(grid_for(ep.Ed)), dim3(BLOCK), 0, e->stream, ep.adj, ep.Ed, tmp);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(col, tmp, sizeof(int) * (size_t)ep.Ed, hipMemcpyDeviceToHost, e->stream));
+    }
+    if (out_degree)
+        HIP_TRY(hipMemcpyAsync(out_degree, e->outdeg, sizeof(int) * (size_t)e->V, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return DPPR_OK;
+}
+
+int dppr_trace_enable(dppr_engine *e, int32_t slot, int on) {
+    GET_SLOT(e, slot);
+    s.trace = on != 0;
+    s.trace_ids.clear();
+    s.trace_off.assign(1, 0);
+    return DPPR_OK;
+}
+
+int dppr_trace_get(dppr_engine *e, int32_t slot, int64_t *n_iters, int64_t *n_ids, int64_t *offsets, int32_t *ids) {
+    GET_SLOT(e, slot);
+    const int64_t ni = s.trace_off.empty() ? 0 : (int64_t)s.trace_off.size() - 1;
+    if (n_iters) *n_iters = ni;
+    if (n_ids) *n_ids = (int64_t)s.trace_ids.size();
+    if (offsets && !s.trace_off.empty()) memcpy(offsets, s.trace_off.data(), sizeof(int64_t) * s.trace_off.size());
+    if (ids && !s.trace_ids.empty()) memcpy(ids, s.trace_ids.data(), sizeof(int32_t) * s.trace_ids.size());
+    return DPPR_OK;
+}
+
+int dppr_bench_atomics(int device, int64_t table_elems, int64_t n, int scope, int reps, float *out_ms) {
+    if (table_elems <= 0 || (table_elems & (table_elems - 1)) || n <= 0 || reps <= 0 || !out_ms) return DPPR_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return DPPR_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return DPPR_ERR_HIP;
+    double *table = nullptr, *sink = nullptr;
+    hipEvent_t a, b;
+    if (hipMalloc((void **)&table, sizeof(double) * (size_t)table_elems) != hipSuccess) return DPPR_ERR_NOMEM;
+    (void)hipMalloc((void **)&sink, sizeof(double));
+    (void)hipMemset(table, 0, sizeof(double) * (size_t)table_elems);
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    const int grid = 2048;
+    auto launch = [&]() {
+        if (scope == 0)
+            hipLaunchKernelGGL(k_bench_atomics<__HIP_MEMORY_SCOPE_AGENT>, dim3(grid), dim3(BLOCK), 0, 0, table,
+                               (uint64_t)table_elems - 1, n, sink);
+        else
+            hipLaunchKernelGGL(k_bench_atomics<__HIP_MEMORY_SCOPE_WORKGROUP>, dim3(grid), dim3(BLOCK), 0, 0, table,
+                               (uint64_t)table_elems - 1, n, sink);
+    };
+    launch(); // warm-up
+    (void)hipEventRecord(a, 0);
+    for (int i = 0; i < reps; ++i) launch();
+    (void)hipEventRecord(b, 0);
+    hipError_t err = hipEventSynchronize(b);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    *out_ms = ms / reps;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    (void)hipFree(table);
+    (void)hipFree(sink);
+    return err == hipSuccess ? DPPR_OK : DPPR_ERR_HIP;
+}
+
+} // extern "C"

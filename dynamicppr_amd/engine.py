@@ -1,0 +1,250 @@
+"""ctypes binding of libdppr_hip.so (the C ABI of include/dppr.h).
+
+This is plumbing for tests and bench.py; the product's host side is the C++
+program under dynamicppr_amd/host/ (``./pagerank``), which calls the same C ABI.
+There is no CPU fallback: if the HIP library is missing or no device is present
+every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdppr_hip.so")
+
+SCHEDULE_EAGER = 0
+SCHEDULE_SYNC = 1
+
+
+class DpprError(RuntimeError):
+    pass
+
+
+class Stats(C.Structure):
+    _fields_ = [("iterations", C.c_int64), ("sum_F", C.c_int64), ("sum_E", C.c_int64), ("sum_N", C.c_int64),
+                ("records", C.c_int64), ("inspected", C.c_int64), ("batches", C.c_int64),
+                ("algorithmic_bytes", C.c_int64), ("gpu_ms", C.c_double), ("push_ms", C.c_double),
+                ("push_launches", C.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(csrc, f) for f in ("dppr_engine.hip", "dppr_kernels.hpp")]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "dppr.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", csrc, "-s", "all"])
+    return LIB_PATH
+
+
+_lib = None
+EXPORTS = [
+    "dppr_abi_version", "dppr_strerror", "dppr_last_error", "dppr_create", "dppr_destroy", "dppr_set_schedule", "dppr_set_profiling",
+    "dppr_load_window", "dppr_set_batch", "dppr_slide", "dppr_add_source", "dppr_init_solve", "dppr_update",
+    "dppr_incremental_batch_update", "dppr_execute_main_loop", "dppr_read", "dppr_write", "dppr_stats",
+    "dppr_reset_stats", "dppr_inspect", "dppr_read_graph", "dppr_graph_edges", "dppr_trace_enable",
+    "dppr_trace_get", "dppr_synchronize", "dppr_bench_atomics",
+]
+
+
+def lib():
+    """Load the HIP library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DpprError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(the HIP extension is mandatory, there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, ip, dp, u8p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_uint8)
+    i64p, fp = C.POINTER(C.c_int64), C.POINTER(C.c_float)
+    L.dppr_abi_version.restype = C.c_int
+    L.dppr_strerror.argtypes = [C.c_int]
+    L.dppr_strerror.restype = C.c_char_p
+    L.dppr_last_error.argtypes = [vp]
+    L.dppr_last_error.restype = C.c_char_p
+    L.dppr_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int32, C.c_int32, C.c_int, C.c_int32, C.c_int32]
+    L.dppr_destroy.argtypes = [vp]
+    L.dppr_destroy.restype = None
+    L.dppr_set_schedule.argtypes = [vp, C.c_int]
+    L.dppr_set_profiling.argtypes = [vp, C.c_int]
+    L.dppr_load_window.argtypes = [vp, ip, ip, C.c_int32]
+    L.dppr_set_batch.argtypes = [vp, ip, ip, u8p, C.c_int32]
+    L.dppr_slide.argtypes = [vp, ip, ip, C.c_int32, ip]
+    L.dppr_add_source.argtypes = [vp, C.c_int32, ip]
+    L.dppr_init_solve.argtypes = [vp, C.c_int32, C.c_double, fp]
+    L.dppr_update.argtypes = [vp, C.c_int32, C.c_int32, C.c_double, fp]
+    L.dppr_incremental_batch_update.argtypes = [vp, C.c_int32, C.c_int32]
+    L.dppr_execute_main_loop.argtypes = [vp, C.c_int32, C.c_int32, C.c_int, C.c_double]
+    L.dppr_read.argtypes = [vp, C.c_int32, dp, dp]
+    L.dppr_write.argtypes = [vp, C.c_int32, dp, dp]
+    L.dppr_stats.argtypes = [vp, C.c_int32, C.POINTER(Stats)]
+    L.dppr_reset_stats.argtypes = [vp, C.c_int32]
+    L.dppr_inspect.argtypes = [vp, C.c_int32, C.c_int, C.c_double, ip, ip]
+    L.dppr_read_graph.argtypes = [vp, C.c_int32, ip, ip, ip]
+    L.dppr_graph_edges.argtypes = [vp, C.c_int32, ip]
+    L.dppr_trace_enable.argtypes = [vp, C.c_int32, C.c_int]
+    L.dppr_trace_get.argtypes = [vp, C.c_int32, i64p, i64p, i64p, ip]
+    L.dppr_synchronize.argtypes = [vp]
+    L.dppr_bench_atomics.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, fp]
+    for name in EXPORTS:
+        if name not in ("dppr_strerror", "dppr_last_error", "dppr_destroy"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def _i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class Engine:
+    """One device-resident window graph plus any number of source slots.
+
+    Method names follow the reference's driver interface (gpu/PPRGPU.cuh:179-182,
+    gpu/PPRRevPushGPU.cuh): ``GPUBuildSlidingGraph`` -> :meth:`slide`,
+    ``IncrementalBatchUpdate`` -> :meth:`incremental_batch_update`,
+    ``ExecuteMainLoop(phase)`` -> :meth:`execute_main_loop`; :meth:`update` is the
+    whole timed region of ``SlidingWindowExecuteMainLoop``.
+    """
+
+    def __init__(self, V, W, directed, max_batch, n_epochs=1, device=0, schedule=SCHEDULE_EAGER):
+        self._L = lib()
+        self._h = C.c_void_p()
+        self.V, self.W, self.directed, self.c = int(V), int(W), int(directed), int(max_batch)
+        rc = self._L.dppr_create(C.byref(self._h), int(device), self.V, self.W, self.directed, self.c, int(n_epochs))
+        if rc:
+            self._h = C.c_void_p()
+            raise DpprError(f"dppr_create: {self._L.dppr_strerror(rc).decode()}")
+        self.set_schedule(schedule)
+
+    def _ck(self, rc, what):
+        if rc:
+            raise DpprError(f"{what}: {self._L.dppr_strerror(rc).decode()} ({self._L.dppr_last_error(self._h).decode()})")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.dppr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_schedule(self, schedule):
+        self._ck(self._L.dppr_set_schedule(self._h, int(schedule)), "set_schedule")
+
+    def set_profiling(self, on):
+        self._ck(self._L.dppr_set_profiling(self._h, int(on)), "set_profiling")
+
+    def load_window(self, e1, e2):
+        a, pa = _i32(e1)
+        b, pb = _i32(e2)
+        self._ck(self._L.dppr_load_window(self._h, pa, pb, len(a)), "load_window")
+
+    def set_batch(self, b1, b2, ins):
+        a, pa = _i32(b1)
+        b, pb = _i32(b2)
+        i = np.ascontiguousarray(ins, dtype=np.uint8)
+        self._ck(self._L.dppr_set_batch(self._h, pa, pb, i.ctypes.data_as(C.POINTER(C.c_uint8)), len(a)), "set_batch")
+
+    def slide(self, n1, n2):
+        a, pa = _i32(n1)
+        b, pb = _i32(n2)
+        ep = C.c_int32(-1)
+        self._ck(self._L.dppr_slide(self._h, pa, pb, len(a), C.byref(ep)), "slide")
+        return ep.value
+
+    def add_source(self, s):
+        slot = C.c_int32(-1)
+        self._ck(self._L.dppr_add_source(self._h, int(s), C.byref(slot)), "add_source")
+        return slot.value
+
+    def init_solve(self, slot, eps):
+        ms = C.c_float(0)
+        self._ck(self._L.dppr_init_solve(self._h, slot, float(eps), C.byref(ms)), "init_solve")
+        return ms.value
+
+    def update(self, slot, eps, epoch=-1):
+        ms = C.c_float(0)
+        self._ck(self._L.dppr_update(self._h, slot, int(epoch), float(eps), C.byref(ms)), "update")
+        return ms.value
+
+    def incremental_batch_update(self, slot, epoch=-1):
+        self._ck(self._L.dppr_incremental_batch_update(self._h, slot, int(epoch)), "incremental_batch_update")
+
+    def execute_main_loop(self, slot, phase, eps, epoch=-1):
+        self._ck(self._L.dppr_execute_main_loop(self._h, slot, int(epoch), int(phase), float(eps)), "execute_main_loop")
+
+    def read(self, slot):
+        p = np.empty(self.V, dtype=np.float64)
+        r = np.empty(self.V, dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        self._ck(self._L.dppr_read(self._h, slot, p.ctypes.data_as(dp), r.ctypes.data_as(dp)), "read")
+        return p, r
+
+    def write(self, slot, p, r):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        self._ck(self._L.dppr_write(self._h, slot, p.ctypes.data_as(dp), r.ctypes.data_as(dp)), "write")
+
+    def stats(self, slot):
+        st = Stats()
+        self._ck(self._L.dppr_stats(self._h, slot, C.byref(st)), "stats")
+        return st.as_dict()
+
+    def reset_stats(self, slot):
+        self._ck(self._L.dppr_reset_stats(self._h, slot), "reset_stats")
+
+    def inspect(self, slot, phase, eps):
+        out = np.empty(self.V, dtype=np.int32)
+        n = C.c_int32(0)
+        self._ck(self._L.dppr_inspect(self._h, slot, int(phase), float(eps),
+                                      out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n)), "inspect")
+        return out[:n.value].copy()
+
+    def read_graph(self, epoch=-1):
+        ne = C.c_int32(0)
+        self._ck(self._L.dppr_graph_edges(self._h, int(epoch), C.byref(ne)), "graph_edges")
+        row = np.empty(self.V + 1, dtype=np.int32)
+        col = np.empty(max(ne.value, 1), dtype=np.int32)
+        deg = np.empty(self.V, dtype=np.int32)
+        ip = C.POINTER(C.c_int32)
+        self._ck(self._L.dppr_read_graph(self._h, int(epoch), row.ctypes.data_as(ip), col.ctypes.data_as(ip),
+                                         deg.ctypes.data_as(ip)), "read_graph")
+        return row, col[:ne.value], deg
+
+    def trace_enable(self, slot, on=True):
+        self._ck(self._L.dppr_trace_enable(self._h, slot, int(on)), "trace_enable")
+
+    def trace_get(self, slot):
+        ni, nd = C.c_int64(0), C.c_int64(0)
+        self._ck(self._L.dppr_trace_get(self._h, slot, C.byref(ni), C.byref(nd), None, None), "trace_get")
+        off = np.zeros(ni.value + 1, dtype=np.int64)
+        ids = np.zeros(max(nd.value, 1), dtype=np.int32)
+        self._ck(self._L.dppr_trace_get(self._h, slot, None, None, off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                        ids.ctypes.data_as(C.POINTER(C.c_int32))), "trace_get")
+        return [ids[off[i]:off[i + 1]].copy() for i in range(ni.value)]
+
+    def synchronize(self):
+        self._ck(self._L.dppr_synchronize(self._h), "synchronize")
+
+
+def bench_atomics(table_elems, n, scope=0, reps=5, device=0):
+    ms = C.c_float(0)
+    rc = lib().dppr_bench_atomics(int(device), int(table_elems), int(n), int(scope), int(reps), C.byref(ms))
+    if rc:
+        raise DpprError(f"bench_atomics: {lib().dppr_strerror(rc).decode()}")
+    return ms.value

@@ -1,0 +1,182 @@
+/*
+ * dppr.h -- C ABI of libdppr_hip.so: the MI355X-native dynamic reverse-push PPR
+ * engine (hot path of guowentian/dynamicppr, gpu/ tree).
+ *
+ * Drop-in boundary. The reference has no FFI layer; its seam is the C++ virtual
+ * interface PPRGPU::{GPUBuildSlidingGraph, IncrementalBatchUpdate,
+ * ExecuteMainLoop(phase), ValidateResult} (gpu/PPRGPU.cuh:179-182) plus the data
+ * handed across it (DeviceMemory, GPUEdgeBatch, SlidingGraphBuilder). Each entry
+ * point below names the reference interface it replaces. The host program
+ * (./pagerank, dynamicppr_amd/host/) and any other binding call only this.
+ *
+ * Conventions: plain pointers and sizes, no C++ or torch types. Every function
+ * returns 0 (DPPR_OK) or a negative dppr_status; nothing exits the process (the
+ * reference prints and exit(-1)s, gpu/GPUUtil.cuh:7-19). An engine is confined to
+ * one host thread; engines on different devices are independent. Host buffers are
+ * borrowed for the duration of the call only (as EdgeBatch arrays are,
+ * SlidingGraphVec.h:17-26). All device memory is owned by the engine
+ * (DeviceMemory / SlidingGraphBuilder ownership, gpu/DeviceMemory.cuh:31-50).
+ *
+ * Index type int32, value type double, ALPHA = 0.15 (Meta.h:25-31).
+ */
+#ifndef DPPR_H
+#define DPPR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPPR_ABI_VERSION 1
+
+typedef struct dppr_engine dppr_engine; /* opaque */
+
+typedef enum dppr_status {
+    DPPR_OK = 0,
+    DPPR_ERR_INVALID = -1,   /* bad argument / call order */
+    DPPR_ERR_HIP = -2,       /* a HIP runtime call failed (see dppr_last_error) */
+    DPPR_ERR_NOMEM = -3,
+    DPPR_ERR_NO_DEVICE = -4, /* no usable gfx950 device: the HIP path is mandatory, no CPU fallback */
+    DPPR_ERR_NOT_CONVERGED = -5 /* iteration cap hit */
+} dppr_status;
+
+/* Push schedule. Both are legal interleavings of the reference kernels
+ * (gpu/ExpandRev.cuh:8-183 + :708-743); see DESIGN.md "Schedules".
+ *   EAGER : one kernel per iteration; a frontier vertex's residual is taken with an
+ *           atomic exchange at the moment it is pushed (reads whatever has arrived,
+ *           like the racy `ru = residual[u]` of ExpandUnifiedRev). Production mode.
+ *   SYNC  : every frontier residual is snapshotted before any push of the iteration
+ *           lands; results are independent of thread scheduling up to the rounding
+ *           of the atomic sums, and the per-iteration frontier SETS equal the
+ *           oracle's synchronous schedule exactly. Validation mode. */
+#define DPPR_SCHEDULE_EAGER 0
+#define DPPR_SCHEDULE_SYNC 1
+
+typedef struct dppr_stats_t {
+    int64_t iterations;   /* frontier-loop iterations (both phases) since last reset */
+    int64_t sum_F;        /* sum of frontier sizes */
+    int64_t sum_E;        /* traversed in-edges */
+    int64_t sum_N;        /* vertices enqueued into next frontiers */
+    int64_t records;      /* batch records applied by IncrementalBatchUpdate */
+    int64_t inspected;    /* vertices scanned by full Inspect passes */
+    int64_t batches;      /* dppr_update calls */
+    int64_t algorithmic_bytes; /* 16V + 45L + sum(72F + 24E + 4N) per batch */
+    double gpu_ms;        /* sum of event-timed regions */
+    double push_ms;       /* sum of per-launch event times of the push kernel (profiling on only) */
+    int64_t push_launches; /* push-kernel launches timed into push_ms */
+} dppr_stats_t;
+
+/* ---- lifetime ----------------------------------------------------------- */
+
+/* Replaces: DeviceMemory ctor + CudaAllocAppData + InitForDynamicGraph
+ * (gpu/DeviceMemory.cuh:9-74) and SlidingGraphBuilder ctor
+ * (gpu/SlidingGraphBuilder.cuh:64-76), as called from PPRGPU ctor
+ * (gpu/PPRGPU.cuh:23-34).
+ *   window_edges : W, the sliding window size in STREAM edges (undirected streams
+ *                  are mirrored inside, as InitWindowStream does)
+ *   max_batch    : c, stream edges per batch (edge batches hold up to 4c records)
+ *   n_epochs     : how many graph epochs (CSR + batch records) stay resident in
+ *                  HBM; 1 = rebuild in place like the reference, K+1 lets a caller
+ *                  pre-stage K batches and then run the timed path back to back. */
+int dppr_create(dppr_engine **out, int device, int32_t vertex_count, int32_t window_edges,
+                int directed, int32_t max_batch, int32_t n_epochs);
+void dppr_destroy(dppr_engine *e);
+const char *dppr_strerror(int status);
+const char *dppr_last_error(const dppr_engine *e); /* detail of the last failure */
+int dppr_abi_version(void);
+int dppr_set_schedule(dppr_engine *e, int schedule);
+/* When on, every launch of the push kernel (the dominant kernel) is bracketed by its own
+ * hipEvent pair on the engine's stream and summed into dppr_stats_t.push_ms. Off by default
+ * (the extra events perturb the whole-batch time slightly). */
+int dppr_set_profiling(dppr_engine *e, int on);
+
+/* ---- graph side (UNTIMED in the reference's metric) --------------------- */
+
+/* Replaces: SlidingGraphBuilder::InitWindowStream (gpu/SlidingGraphBuilder.cuh:182-192)
+ * + BuildInGraph (:137-153) / DeviceMemory::CudaMemcpyGraph (gpu/DeviceMemory.cuh:76-112).
+ * e1/e2: the n == W window edges in stream order, NOT mirrored. Builds epoch 0. */
+int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32_t n);
+
+/* Replaces: GPUEdgeBatch::CudaMemcpy(EdgeBatch*, HostToDevice) (gpu/GPUEdgeBatch.cuh:20-26).
+ * The L = 2c (directed) or 4c (undirected) records exactly as
+ * SlidingGraphVec::StreamUpdates lays them out (SlidingGraphVec.h:241-272):
+ * [c deletes][c inserts] then the mirrored copy. Stages them for the NEXT epoch. */
+int dppr_set_batch(dppr_engine *e, const int32_t *edge1, const int32_t *edge2,
+                   const uint8_t *is_insert, int32_t length);
+
+/* Replaces: SlidingGraphBuilder::IncBuildInGraph(new_stream, ...)
+ * (gpu/SlidingGraphBuilder.cuh:117-133, :163-181, :193-221) = PPRGPU::GPUBuildSlidingGraph.
+ * Drops the c oldest window edges, appends the c new ones, rebuilds the in-CSR
+ * (rows sorted ascending like the reference's pair sort) and the out-degrees, and
+ * makes the result the newest epoch. Call after dppr_set_batch. *out_epoch (may be
+ * NULL) receives the new epoch id. */
+int dppr_slide(dppr_engine *e, const int32_t *new_e1, const int32_t *new_e2, int32_t c,
+               int32_t *out_epoch);
+
+/* ---- per-source state ---------------------------------------------------- */
+
+/* Allocates pagerank/residual/frontier state for one source vertex
+ * (DeviceMemory::CudaAllocAppData, gpu/DeviceMemory.cuh:51-63). */
+int dppr_add_source(dppr_engine *e, int32_t source_vertex, int32_t *out_slot);
+
+/* Replaces: Init<<<>>> + ExecuteMainLoop(0) of PPRGPU::DynamicExecute
+ * (gpu/PPRGPU.cuh:85-89, gpu/PPRCommon.cuh:12-22). Runs on the newest epoch. */
+int dppr_init_solve(dppr_engine *e, int32_t slot, double eps, float *out_ms);
+
+/* THE TIMED REGION of the reference (gpu/PPRGPU.cuh:138-164):
+ * IncrementalBatchUpdate + ExecuteMainLoop(0) + ExecuteMainLoop(1) for one batch.
+ * epoch < 0 means the newest epoch. *out_ms = hipEvent time of exactly that region
+ * (batch upload and CSR rebuild excluded, as in the reference). */
+int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *out_ms);
+
+/* The same region split along the reference's virtual interface, for callers that
+ * keep the reference's driver loop and for kernel-level parity tests:
+ *   PPRRevPushGPU::IncrementalBatchUpdate (gpu/PPRRevPushGPU.cuh:21-28,
+ *     gpu/StreamUpdate.cuh:7-76)
+ *   PPRRevPushGPU::ExecuteMainLoop(phase) (gpu/PPRRevPushGPU.cuh:97-131): full
+ *     Inspect over V, then the Expand/Repair frontier loop. */
+int dppr_incremental_batch_update(dppr_engine *e, int32_t slot, int32_t epoch);
+int dppr_execute_main_loop(dppr_engine *e, int32_t slot, int32_t epoch, int phase, double eps);
+
+/* Replaces: the cudaMemcpy D2H of pagerank/residual in ValidateResult
+ * (gpu/PPRRevPushGPU.cuh:136-139). p and r each hold vertex_count doubles. */
+int dppr_read(dppr_engine *e, int32_t slot, double *p, double *r);
+/* Overwrite p/r (test hook: lets a kernel be checked from an arbitrary state). */
+int dppr_write(dppr_engine *e, int32_t slot, const double *p, const double *r);
+
+int dppr_stats(dppr_engine *e, int32_t slot, dppr_stats_t *out);
+int dppr_reset_stats(dppr_engine *e, int32_t slot);
+
+/* ---- validation / test hooks -------------------------------------------- */
+
+/* Replaces: InspectPureRev alone (gpu/Inspect.cuh:8-48). Writes the legal vertices
+ * (unordered) to out_ids (capacity vertex_count) and their count to *out_count. */
+int dppr_inspect(dppr_engine *e, int32_t slot, int phase, double eps, int32_t *out_ids, int32_t *out_count);
+
+/* Replaces: the D2H copies of in_row_ptr/in_col_ind in the -DVALIDATE CSR check
+ * (gpu/PPRRevPushGPU.cuh:69-72). row_ptr: V+1, col: directed-edge count, out_degree: V
+ * (any may be NULL). */
+int dppr_read_graph(dppr_engine *e, int32_t epoch, int32_t *row_ptr, int32_t *col, int32_t *out_degree);
+int dppr_graph_edges(dppr_engine *e, int32_t epoch, int32_t *out_directed_edges);
+
+/* Frontier trace (test hook): when enabled the host loop copies every iteration's
+ * frontier back. dppr_trace_get returns them concatenated: offsets has n_iters+1
+ * entries. Pass NULL buffers to query sizes. */
+int dppr_trace_enable(dppr_engine *e, int32_t slot, int on);
+int dppr_trace_get(dppr_engine *e, int32_t slot, int64_t *n_iters, int64_t *n_ids,
+                   int64_t *offsets, int32_t *ids);
+
+/* Stream-wide sync (hipStreamSynchronize on the engine's stream). */
+int dppr_synchronize(dppr_engine *e);
+
+/* Microbenchmark used to calibrate the roofline ceiling of the push kernel
+ * (SURVEY.md 8d): n returning f64 atomic adds per launch at pseudo-random
+ * addresses of a table of table_elems doubles; scope 0 = agent, 1 = workgroup.
+ * Returns the average kernel time in ms over reps launches. */
+int dppr_bench_atomics(int device, int64_t table_elems, int64_t n, int scope, int reps, float *out_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPPR_H */

@@ -37,3 +37,46 @@ def sorted_csr(row, col):
 def small_stream(scale=9, edges=6000, seed=11):
     from dynamicppr_amd import datagen
     return datagen.rmat_stream(scale, edges, seed)
+
+
+def window_directed_edges(g):
+    """Directed (src, dst) arrays of the oracle graph's current window."""
+    s1, s2 = g.window_edges()
+    if g.directed:
+        return s1, s2
+    return np.concatenate([s1, s2]), np.concatenate([s2, s1])
+
+
+def invariant_max_err_np(p, r, src, dst, V, source, alpha=0.15):
+    """SURVEY.md section 0 invariant, evaluated with numpy from the raw window edges:
+    p[u] + a r[u] == a [u==s] + (1-a)/(outdeg(u)+1) * sum_{v in out(u)} p[v]."""
+    outdeg = np.bincount(src, minlength=V)
+    acc = np.bincount(src, weights=p[dst], minlength=V)
+    rhs = (1.0 - alpha) / (outdeg + 1.0) * acc
+    rhs[source] += alpha
+    return float(np.max(np.abs(p + alpha * r - rhs)))
+
+
+class Scenario:
+    """An oracle graph + state and a HIP engine fed with the same stream."""
+
+    def __init__(self, V, e1, e2, directed, W, c, source, eps, schedule=0, n_epochs=1):
+        from dynamicppr_amd import engine as eng
+        self.V, self.W, self.c, self.directed, self.source, self.eps = V, W, c, directed, source, eps
+        self.g = orc.Graph(V, e1, e2, directed, W, c)
+        self.s = orc.State(V, source, eps)
+        self.e = eng.Engine(V, W, directed, c, n_epochs=n_epochs, schedule=schedule)
+        w1, w2 = self.g.window_edges()
+        self.e.load_window(w1, w2)
+        self.slot = self.e.add_source(source)
+
+    def advance_graphs(self):
+        """One StreamUpdates + graph rebuild on both sides. False when the stream is over."""
+        if self.g.stream_updates():
+            return False
+        self.g.inc_construct(1)
+        b1, b2, ins = self.g.batch()
+        n1, n2 = self.g.new_stream()
+        self.e.set_batch(b1, b2, ins)
+        self.e.slide(n1, n2)
+        return True
