@@ -32,6 +32,9 @@ struct Epoch {
     uint8_t *ins = nullptr;
     int L = 0;
     int id = -1; // global epoch number stored in this ring entry
+    // hub directory of this epoch (vertices whose pushes are aggregated in LDS)
+    int *hub_v = nullptr, *hub_degp1 = nullptr;
+    int n_hubs = 0;
 };
 
 struct Slot {
@@ -39,7 +42,9 @@ struct Slot {
     double *p = nullptr, *r = nullptr, *ft_r = nullptr;
     int *ft[2] = {nullptr, nullptr};
     int *neg = nullptr;     // phase-1 candidates
-    int *cnt = nullptr;     // [0..2] rotating frontier counters, [3] neg candidates, [4] scratch
+    int *cnt = nullptr;     // [0..2] rotating frontier counters, [3] neg candidates, [4] scratch, [5..6] big-row counters
+    BigItem *big = nullptr; // deferred big rows of the current iteration
+    long long iter_seq = 0; // running iteration number (selects the big-row counter)
     IterStats *dstats = nullptr;
     bool converged = false; // |r| <= eps everywhere (state after a completed solve)
     double conv_eps = 0.0;
@@ -67,6 +72,10 @@ struct dppr_engine {
     int head = 0;
     bool loaded = false;
     int *outdeg = nullptr;
+    int *hub_slot_of = nullptr; // V, scratch of the CSR build
+    int *hub_hist = nullptr;    // 32 + 1 ints (histogram, hub counter)
+    int hub_min_degree = HUB_MIN_DEGREE_DEFAULT;
+    int big_row = BIG_ROW_DEFAULT;
     // CSR build scratch
     uint64_t *keys_a = nullptr, *keys_b = nullptr;
     void *sort_tmp = nullptr;
@@ -125,6 +134,28 @@ Epoch *find_epoch(dppr_engine *e, int epoch) {
 // Build row_ptr/adj of `ep` from the current window ring + outdeg.
 int build_csr(dppr_engine *e, Epoch &ep) {
     const int W = e->W, Ed = e->Ed;
+    // hub directory: the (at most HUB_CAP) vertices of largest out-degree, at least hub_min_degree
+    {
+        HIP_TRY(hipMemsetAsync(e->hub_hist, 0, sizeof(int) * 33, e->stream));
+        hipLaunchKernelGGL(k_deg_hist, dim3(grid_for(e->V)), dim3(BLOCK), 0, e->stream, e->outdeg, e->V,
+                           e->hub_min_degree, e->hub_hist);
+        int hist[32];
+        HIP_TRY(hipMemcpyAsync(hist, e->hub_hist, sizeof(hist), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        long long above = 0;
+        int k = 31;
+        for (; k >= 0; --k) {
+            if (above + hist[k] > HUB_CAP) break;
+            above += hist[k];
+        }
+        // every bucket > k fits; threshold = lower edge of bucket k+1
+        const long long thresh = (long long)e->hub_min_degree << (k + 1);
+        const int th = (int)std::min<long long>(thresh, 0x7fffffff);
+        hipLaunchKernelGGL(k_assign_hubs, dim3(grid_for(e->V)), dim3(BLOCK), 0, e->stream, e->outdeg, e->V, th,
+                           e->hub_slot_of, ep.hub_v, ep.hub_degp1, e->hub_hist + 32);
+        HIP_TRY(hipGetLastError());
+        ep.n_hubs = (int)above;
+    }
     if (W > 0) {
         hipLaunchKernelGGL(k_make_keys, dim3(grid_for(W)), dim3(BLOCK), 0, e->stream, e->w1, e->w2, W, e->directed,
                            e->bits, e->keys_a);
@@ -134,7 +165,7 @@ int build_csr(dppr_engine *e, Epoch &ep) {
                                          (unsigned)(2 * e->bits), e->stream));
     }
     hipLaunchKernelGGL(k_build_csr, dim3(grid_for(std::max(Ed, e->V + 1))), dim3(BLOCK), 0, e->stream, e->keys_b, Ed,
-                       e->V, e->bits, e->outdeg, ep.row_ptr, ep.adj);
+                       e->V, e->bits, e->outdeg, e->hub_slot_of, ep.row_ptr, ep.adj);
     HIP_TRY(hipGetLastError());
     ep.Ed = Ed;
     return DPPR_OK;
@@ -175,6 +206,9 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
         s.st.iterations++;
         s.st.sum_F += F;
         const int nxt = (cur + 1) % 3, zer = (cur + 2) % 3;
+        int *big_cnt = s.cnt + 5 + (int)(s.iter_seq & 1), *big_zero = s.cnt + 5 + (int)((s.iter_seq + 1) & 1);
+        s.iter_seq++;
+        const HubTable hubs{ep.hub_v, ep.hub_degp1, ep.n_hubs};
         const int tiles = (F + WAVE - 1) / WAVE;
         const int grid = std::min(std::max((tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 1), 2048);
         if (e->schedule == DPPR_SCHEDULE_SYNC) {
@@ -182,14 +216,16 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                                s.p, s.ft_r);
             if (e->profiling) HIP_TRY(hipEventRecord(e->ev2, e->stream));
             hipLaunchKernelGGL(k_push_iter<true>, dim3(grid), dim3(BLOCK), 0, e->stream, s.ft[buf], s.cnt + cur,
-                               s.ft[buf ^ 1], s.cnt + nxt, s.cnt + zer, s.ft_r, ep.row_ptr, ep.adj, s.r, s.p, phase,
-                               eps, s.dstats);
+                               s.ft[buf ^ 1], s.cnt + nxt, s.cnt + zer, s.ft_r, ep.row_ptr, ep.adj, hubs, s.big, big_cnt,
+                               big_zero, e->big_row, s.r, s.p, phase, eps, s.dstats);
         } else {
             if (e->profiling) HIP_TRY(hipEventRecord(e->ev2, e->stream));
             hipLaunchKernelGGL(k_push_iter<false>, dim3(grid), dim3(BLOCK), 0, e->stream, s.ft[buf], s.cnt + cur,
                                s.ft[buf ^ 1], s.cnt + nxt, s.cnt + zer, (const double *)nullptr, ep.row_ptr, ep.adj,
-                               s.r, s.p, phase, eps, s.dstats);
+                               hubs, s.big, big_cnt, big_zero, e->big_row, s.r, s.p, phase, eps, s.dstats);
         }
+        hipLaunchKernelGGL(k_push_big, dim3(512), dim3(BLOCK), 0, e->stream, s.big, big_cnt, s.ft[buf ^ 1], s.cnt + nxt,
+                           ep.adj, hubs, s.r, phase, eps, s.dstats);
         HIP_TRY(hipGetLastError());
         if (e->profiling) {
             HIP_TRY(hipEventRecord(e->ev3, e->stream));
@@ -298,6 +334,8 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     HIP_TRY_C(hipMalloc((void **)&e->w2, sizeof(int) * Wn));
     HIP_TRY_C(hipMalloc((void **)&e->outdeg, sizeof(int) * (size_t)V));
     HIP_TRY_C(hipMemset(e->outdeg, 0, sizeof(int) * (size_t)V));
+    HIP_TRY_C(hipMalloc((void **)&e->hub_slot_of, sizeof(int) * (size_t)V));
+    HIP_TRY_C(hipMalloc((void **)&e->hub_hist, sizeof(int) * 64));
     HIP_TRY_C(hipMalloc((void **)&e->keys_a, sizeof(uint64_t) * Edn));
     HIP_TRY_C(hipMalloc((void **)&e->keys_b, sizeof(uint64_t) * Edn));
     HIP_TRY_C(rocprim::radix_sort_keys(nullptr, e->sort_tmp_bytes, e->keys_a, e->keys_b, Edn, 0u,
@@ -320,6 +358,8 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
         HIP_TRY_C(hipMalloc((void **)&ep.b2, sizeof(int) * Ln));
         HIP_TRY_C(hipMalloc((void **)&ep.deg_after, sizeof(int) * Ln));
         HIP_TRY_C(hipMalloc((void **)&ep.ins, Ln));
+        HIP_TRY_C(hipMalloc((void **)&ep.hub_v, sizeof(int) * HUB_CAP));
+        HIP_TRY_C(hipMalloc((void **)&ep.hub_degp1, sizeof(int) * HUB_CAP));
     }
 #undef HIP_TRY_C
     *out = e;
@@ -333,13 +373,14 @@ void dppr_destroy(dppr_engine *e) {
     for (auto &s : e->slots) {
         (void)hipFree(s.p); (void)hipFree(s.r); (void)hipFree(s.ft_r);
         (void)hipFree(s.ft[0]); (void)hipFree(s.ft[1]); (void)hipFree(s.neg);
-        (void)hipFree(s.cnt); (void)hipFree(s.dstats);
+        (void)hipFree(s.cnt); (void)hipFree(s.dstats); (void)hipFree(s.big);
     }
     for (auto &ep : e->epochs) {
         (void)hipFree(ep.row_ptr); (void)hipFree(ep.adj); (void)hipFree(ep.b1); (void)hipFree(ep.b2);
-        (void)hipFree(ep.deg_after); (void)hipFree(ep.ins);
+        (void)hipFree(ep.deg_after); (void)hipFree(ep.ins); (void)hipFree(ep.hub_v); (void)hipFree(ep.hub_degp1);
     }
     (void)hipFree(e->w1); (void)hipFree(e->w2); (void)hipFree(e->outdeg);
+    (void)hipFree(e->hub_slot_of); (void)hipFree(e->hub_hist);
     (void)hipFree(e->keys_a); (void)hipFree(e->keys_b); (void)hipFree(e->sort_tmp);
     for (int k = 0; k < 2; ++k) { (void)hipFree(e->su_k[k]); (void)hipFree(e->su_v[k]); }
     (void)hipFree(e->su_term); (void)hipFree(e->su_ins); (void)hipFree(e->su_tmp);
@@ -361,6 +402,14 @@ int dppr_set_schedule(dppr_engine *e, int schedule) {
 int dppr_set_profiling(dppr_engine *e, int on) {
     if (!e) return DPPR_ERR_INVALID;
     e->profiling = on != 0;
+    return DPPR_OK;
+}
+
+int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges) {
+    if (!e || hub_min_degree < 1 || big_row_edges < 1 || e->loaded || !e->slots.empty())
+        return fail(e, DPPR_ERR_INVALID, "set_tuning: call right after dppr_create, values >= 1");
+    e->hub_min_degree = hub_min_degree;
+    e->big_row = big_row_edges;
     return DPPR_OK;
 }
 
@@ -469,6 +518,8 @@ int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
     HIP_TRY(hipMalloc((void **)&s.ft[1], sizeof(int) * V));
     HIP_TRY(hipMalloc((void **)&s.neg, sizeof(int) * (size_t)std::max(4 * e->c, 1)));
     HIP_TRY(hipMalloc((void **)&s.cnt, sizeof(int) * 8));
+    // a row is deferred only if it has >= big_row edges, so at most Ed / big_row of them exist
+    HIP_TRY(hipMalloc((void **)&s.big, sizeof(BigItem) * ((size_t)e->Ed / (size_t)std::max(e->big_row, 1) + 64)));
     HIP_TRY(hipMalloc((void **)&s.dstats, sizeof(IterStats)));
     HIP_TRY(hipMemset(s.cnt, 0, sizeof(int) * 8));
     HIP_TRY(hipMemset(s.dstats, 0, sizeof(IterStats)));

@@ -141,67 +141,176 @@ __global__ __launch_bounds__(BLOCK) void k_snapshot(const int *__restrict__ ft, 
 // a4+a5  one frontier iteration: ExpandUnifiedRev (gpu/ExpandRev.cuh:8-183) with
 // RepairFrontierRev (:708-743) fused in.
 //
-// Per wave: a tile of 64 frontier vertices. Lane i owns vertex i of the tile:
+// k_push_iter -- per wave: a tile of 64 frontier vertices. Lane i owns vertex i:
 //   EAGER: ru = atomic_exchange(r[u], 0)  (= "ru = residual[u]" ... "residual[u] -= ru"
 //          collapsed to one instant; everything that arrives later stays and may
 //          cross the threshold again), p[u] += ALPHA*ru.
 //   SYNC : ru = ft_r[i] (snapshot kernel), repair = returning atomic add of -ru;
 //          if the result is still legal the vertex re-enters the next frontier.
-// The tile's row extents are scanned across the wave, staged in LDS, and the wave
-// then walks the concatenated edge list 64 edges at a time: edge e belongs to the
-// vertex found by a binary search of the scan, so consecutive lanes read
-// consecutive Adj entries. Per edge (gpu/ExpandRev.cuh:70-77):
+// Row extents are scanned across the wave and staged in LDS; the wave then walks
+// the concatenated edge list 4 x 64 edges per round (four independent returning
+// atomics in flight per lane): edge e belongs to the vertex found by a binary
+// search of the scan, so consecutive lanes read consecutive Adj entries. Per edge
+// (gpu/ExpandRev.cuh:70-77):
 //   add  = (1.0-ALPHA) * ru / (degv + 1)
 //   prer = atomicAdd(&residual[v], add); curr = prer + add
 //   enqueue v iff !legal(prer) && legal(curr)
+//
+// Load balance (replaces the CTA / warp / scan tiers of gpu/ExpandRev.cuh:44-176):
+//   * rows with >= BIG_ROW edges are not expanded by their wave; (row, ru) goes to a
+//     small device list and k_push_big spreads 1024-edge chunks of those rows over
+//     the whole grid;
+//   * HUB TARGETS: a vertex with a very large out-degree receives one add per
+//     frontier neighbour; thousands of returning atomics on ONE address serialise
+//     at the memory-side atomic unit (~88 per us). The CSR builder tags the top
+//     out-degree vertices (Adj.degp1 < 0 -> hub slot), pushes to them accumulate in a
+//     per-workgroup LDS table (ds_add_f64) and each workgroup issues ONE global atomic
+//     per touched hub. Residual adds within a phase all have the same sign, so the
+//     crossing test on the aggregated add still fires exactly once.
 // Crossing vertices are ranked with ballot+mbcnt into a per-wave LDS tile and
 // flushed with one global counter atomic per workgroup (per wave on overflow).
 //
 // Counter rotation: the kernel reads cnt_in, appends to cnt_out and zeroes cnt_zero
-// (the counter the NEXT kernel appends to), so iteration kernels can be chained
-// without host round trips or memsets.
+// (the counter the NEXT iteration appends to); likewise big_cnt / big_zero. Iteration
+// kernels can therefore be chained without host round trips or memsets.
 // ---------------------------------------------------------------------------
 struct IterStats { // device-side accumulators (per slot)
     unsigned long long sum_E;
 };
+
+struct BigItem { // a deferred big row
+    int row_start;
+    int len;
+    double ru;
+};
+
+constexpr int BIG_ROW_DEFAULT = 512; // rows at least this long go to k_push_big (runtime tunable)
+constexpr int BIG_CHUNK = 1024; // edges per workgroup chunk there
+constexpr int HUB_CAP = 2048;   // hub slots (16 KiB of LDS accumulators)
+constexpr int UNROLL = 4;
+
+struct HubTable { // per-epoch hub directory (device pointers)
+    const int *v;      // hub slot -> vertex
+    const int *degp1;  // hub slot -> outdeg + 1
+    int n;
+};
+
+// per-wave staging of next-frontier entries
+struct OutStage {
+    int *s_out;   // this wave's LDS tile (OUT_CAP ints)
+    int n;        // wave-uniform fill
+    int *ft_out;
+    int *cnt_out;
+    __device__ __forceinline__ void flush_wave() {
+        int gb = 0;
+        if (lane_id() == 0) gb = atomicAdd(cnt_out, n);
+        gb = __shfl(gb, 0, WAVE);
+        for (int i = lane_id(); i < n; i += WAVE) ft_out[gb + i] = s_out[i];
+        n = 0;
+    }
+    __device__ __forceinline__ void stage(bool hit, int v) {
+        const uint64_t m = __ballot(hit);
+        if (m) {
+            if (hit) s_out[n + mbcnt(m)] = v;
+            n += __popcll(m);
+            if (n > OUT_CAP - WAVE) flush_wave();
+        }
+    }
+};
+
+__device__ __forceinline__ void lds_add(double *p, double v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// issue the push of one edge; returns the pre-add residual (or NaN-free dummy for hubs)
+struct EdgePush {
+    int v;
+    double add;
+    double prer;
+    bool direct; // a global atomic was issued and prer is meaningful
+};
+__device__ __forceinline__ EdgePush push_edge(bool valid, Adj a, double ru, double *__restrict__ r,
+                                              double *s_hub, const HubTable &hubs) {
+    EdgePush o;
+    o.v = a.v;
+    o.add = 0.0;
+    o.prer = 0.0;
+    o.direct = false;
+    if (valid) {
+        if (a.degp1 < 0) {
+            const int slot = ~a.degp1;
+            lds_add(&s_hub[slot], ONE_MINUS_ALPHA * ru / (double)hubs.degp1[slot]);
+        } else {
+            o.add = ONE_MINUS_ALPHA * ru / (double)a.degp1;
+            o.prer = atomic_add_ret(&r[a.v], o.add);
+            o.direct = true;
+        }
+    }
+    return o;
+}
+
+// workgroup epilogue shared by both push kernels: flush hub accumulators, then the staged frontier
+__device__ __forceinline__ void push_epilogue(OutStage &out, double *s_hub, const HubTable &hubs,
+                                              double *__restrict__ r, int phase, double eps, int *s_cnt, int *s_base,
+                                              unsigned long long edges, IterStats *stats) {
+    __syncthreads(); // all LDS hub adds of the workgroup done
+    for (int s0 = 0; s0 < hubs.n; s0 += BLOCK) {
+        const int slot = s0 + threadIdx.x;
+        bool hit = false;
+        int v = 0;
+        if (slot < hubs.n) {
+            const double acc = s_hub[slot];
+            if (acc != 0.0) {
+                v = hubs.v[slot];
+                const double prer = atomic_add_ret(&r[v], acc);
+                hit = !legal(prer, phase, eps) && legal(prer + acc, phase, eps);
+            }
+        }
+        out.stage(hit, v);
+    }
+    const int lane = lane_id(), w = wave_id();
+    if (lane == 0) s_cnt[w] = out.n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        *s_base = tot ? atomicAdd(out.cnt_out, tot) : 0;
+    }
+    __syncthreads();
+    int gb = *s_base;
+    for (int k = 0; k < w; ++k) gb += s_cnt[k];
+    for (int i = lane; i < out.n; i += WAVE) out.ft_out[gb + i] = out.s_out[i];
+    if (lane == 0 && edges) atomicAdd(&stats->sum_E, edges);
+}
 
 template <bool SYNC>
 __global__ __launch_bounds__(BLOCK) void k_push_iter(const int *__restrict__ ft, const int *__restrict__ cnt_in,
                                                      int *__restrict__ ft_out, int *__restrict__ cnt_out,
                                                      int *__restrict__ cnt_zero, const double *__restrict__ ft_r,
                                                      const int *__restrict__ row_ptr, const Adj *__restrict__ adj,
-                                                     double *__restrict__ r, double *__restrict__ p, int phase,
-                                                     double eps, IterStats *__restrict__ stats) {
+                                                     HubTable hubs, BigItem *__restrict__ big, int *__restrict__ big_cnt,
+                                                     int *__restrict__ big_zero, int big_row, double *__restrict__ r,
+                                                     double *__restrict__ p, int phase, double eps,
+                                                     IterStats *__restrict__ stats) {
     __shared__ int s_scan[WAVES_PER_BLOCK][WAVE + 1];
     __shared__ int s_start[WAVES_PER_BLOCK][WAVE];
     __shared__ double s_ru[WAVES_PER_BLOCK][WAVE];
     __shared__ int s_out[WAVES_PER_BLOCK][OUT_CAP];
+    __shared__ double s_hub[HUB_CAP];
     __shared__ int s_cnt[WAVES_PER_BLOCK];
     __shared__ int s_base;
 
     const int lane = lane_id();
     const int w = wave_id();
     const int F = *cnt_in;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_zero = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *cnt_zero = 0;
+        *big_zero = 0;
+    }
+    for (int i = threadIdx.x; i < hubs.n; i += BLOCK) s_hub[i] = 0.0;
+    __syncthreads();
 
-    int n_out = 0;              // wave-uniform: staged entries of this wave
+    OutStage out{s_out[w], 0, ft_out, cnt_out};
     unsigned long long edges = 0; // wave-uniform
-
-    auto flush_wave = [&]() { // per-wave overflow flush: one counter atomic for the wave
-        int gb = 0;
-        if (lane == 0) gb = atomicAdd(cnt_out, n_out);
-        gb = __shfl(gb, 0, WAVE);
-        for (int i = lane; i < n_out; i += WAVE) ft_out[gb + i] = s_out[w][i];
-        n_out = 0;
-    };
-    auto stage = [&](bool hit, int v) {
-        const uint64_t m = __ballot(hit);
-        if (m) {
-            if (hit) s_out[w][n_out + mbcnt(m)] = v;
-            n_out += __popcll(m);
-            if (n_out > OUT_CAP - WAVE) flush_wave();
-        }
-    };
 
     const int n_tiles = (F + WAVE - 1) / WAVE;
     // tile t -> (block t % gridDim, wave (t / gridDim) % 4): small frontiers spread over CUs
@@ -225,7 +334,24 @@ __global__ __launch_bounds__(BLOCK) void k_push_iter(const int *__restrict__ ft,
                 p[u] += ALPHA * ru;
             }
         }
-        if (SYNC) stage(requeue, u);
+        if (SYNC) out.stage(requeue, u);
+
+        // big rows: hand (row, ru) to k_push_big
+        const bool is_big = d >= big_row;
+        const uint64_t mb = __ballot(is_big);
+        if (mb) {
+            int gb = 0;
+            if (lane == 0) gb = atomicAdd(big_cnt, __popcll(mb));
+            gb = __shfl(gb, 0, WAVE);
+            if (is_big) {
+                BigItem it;
+                it.row_start = rs;
+                it.len = d;
+                it.ru = ru;
+                big[gb + mbcnt(mb)] = it;
+                d = 0;
+            }
+        }
 
         const int incl = wave_inclusive_scan(d);
         const int total = __shfl(incl, WAVE - 1, WAVE);
@@ -236,42 +362,84 @@ __global__ __launch_bounds__(BLOCK) void k_push_iter(const int *__restrict__ ft,
         __builtin_amdgcn_wave_barrier(); // LDS ops of one wave execute in order
         edges += (unsigned long long)total;
 
-        for (int e0 = 0; e0 < total; e0 += WAVE) {
-            const int e = e0 + lane;
-            bool hit = false;
-            int v = 0;
-            if (e < total) {
-                // owner k: last index with scan[k] <= e
-                int lo = 0, hi = WAVE;
+        for (int e0 = 0; e0 < total; e0 += WAVE * UNROLL) {
+            EdgePush q[UNROLL];
 #pragma unroll
-                for (int s = 0; s < 6; ++s) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_scan[w][mid] <= e) lo = mid; else hi = mid;
+            for (int k = 0; k < UNROLL; ++k) {
+                const int e = e0 + k * WAVE + lane;
+                const bool ok = e < total;
+                Adj a{0, 1};
+                double ruk = 0.0;
+                if (ok) {
+                    int lo = 0, hi = WAVE; // owner: last index with scan[idx] <= e
+#pragma unroll
+                    for (int s = 0; s < 6; ++s) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_scan[w][mid] <= e) lo = mid; else hi = mid;
+                    }
+                    a = adj[s_start[w][lo] + (e - s_scan[w][lo])];
+                    ruk = s_ru[w][lo];
                 }
-                const Adj a = adj[s_start[w][lo] + (e - s_scan[w][lo])];
-                v = a.v;
-                const double add = ONE_MINUS_ALPHA * s_ru[w][lo] / (double)a.degp1;
-                const double prer = atomic_add_ret(&r[v], add);
-                const double curr = prer + add;
-                hit = !legal(prer, phase, eps) && legal(curr, phase, eps);
+                q[k] = push_edge(ok, a, ruk, r, s_hub, hubs);
             }
-            stage(hit, v);
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {
+                const bool hit = q[k].direct && !legal(q[k].prer, phase, eps) && legal(q[k].prer + q[k].add, phase, eps);
+                out.stage(hit, q[k].v);
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
+    push_epilogue(out, s_hub, hubs, r, phase, eps, s_cnt, &s_base, edges, stats);
+}
 
-    // workgroup flush: one global atomic for the four waves
-    if (lane == 0) s_cnt[w] = n_out;
+// Deferred big rows: chunk c of the list goes to workgroup c % gridDim; 256 lanes x 4 edges.
+__global__ __launch_bounds__(BLOCK) void k_push_big(const BigItem *__restrict__ big, const int *__restrict__ big_cnt,
+                                                    int *__restrict__ ft_out, int *__restrict__ cnt_out,
+                                                    const Adj *__restrict__ adj, HubTable hubs, double *__restrict__ r,
+                                                    int phase, double eps, IterStats *__restrict__ stats) {
+    __shared__ int s_out[WAVES_PER_BLOCK][OUT_CAP];
+    __shared__ double s_hub[HUB_CAP];
+    __shared__ int s_cnt[WAVES_PER_BLOCK];
+    __shared__ int s_base;
+    const int nbig = *big_cnt;
+    if (nbig == 0) return; // uniform for the whole grid
+    for (int i = threadIdx.x; i < hubs.n; i += BLOCK) s_hub[i] = 0.0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        s_base = tot ? atomicAdd(cnt_out, tot) : 0;
+    OutStage out{s_out[wave_id()], 0, ft_out, cnt_out};
+    unsigned long long edges = 0;
+
+    int chunk0 = 0; // global index of the first chunk of item `it`
+    for (int it = 0; it < nbig; ++it) {
+        const BigItem item = big[it];
+        const int nch = (item.len + BIG_CHUNK - 1) / BIG_CHUNK;
+        // chunks of this item owned by this workgroup: global chunk id == blockIdx (mod gridDim)
+        int first = (int)blockIdx.x - chunk0 % (int)gridDim.x;
+        if (first < 0) first += gridDim.x;
+        for (int ch = first; ch < nch; ch += gridDim.x) {
+            const int base = ch * BIG_CHUNK;
+            EdgePush q[UNROLL];
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {
+                const int e = base + k * BLOCK + threadIdx.x;
+                const bool ok = e < item.len;
+                Adj a{0, 1};
+                if (ok) a = adj[item.row_start + e];
+                q[k] = push_edge(ok, a, item.ru, r, s_hub, hubs);
+            }
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {
+                const bool hit = q[k].direct && !legal(q[k].prer, phase, eps) && legal(q[k].prer + q[k].add, phase, eps);
+                out.stage(hit, q[k].v);
+            }
+            if (wave_id() == 0) {
+                const int left = item.len - base;
+                edges += (unsigned long long)(left < BIG_CHUNK ? left : BIG_CHUNK);
+            }
+        }
+        chunk0 += nch;
     }
-    __syncthreads();
-    int gb = s_base;
-    for (int k = 0; k < w; ++k) gb += s_cnt[k];
-    for (int i = lane; i < n_out; i += WAVE) ft_out[gb + i] = s_out[w][i];
-    if (lane == 0 && edges) atomicAdd(&stats->sum_E, edges);
+    push_epilogue(out, s_hub, hubs, r, phase, eps, s_cnt, &s_base, edges, stats);
 }
 
 // ---------------------------------------------------------------------------
@@ -425,9 +593,39 @@ __global__ __launch_bounds__(BLOCK) void k_make_keys(const int *__restrict__ w1,
     }
 }
 
+// hub selection: hist[b] = #vertices with min_deg * 2^b <= outdeg < min_deg * 2^(b+1)
+constexpr int HUB_MIN_DEGREE_DEFAULT = 256;
+__global__ __launch_bounds__(BLOCK) void k_deg_hist(const int *__restrict__ outdeg, int V, int min_deg,
+                                                    int *__restrict__ hist) {
+    for (int v = blockIdx.x * BLOCK + threadIdx.x; v < V; v += gridDim.x * BLOCK) {
+        const int d = outdeg[v];
+        if (d >= min_deg) atomicAdd(&hist[31 - __clz(d / min_deg)], 1);
+    }
+}
+// hub_slot_of[v] = slot for vertices with outdeg >= thresh (first HUB_CAP takers), else -1
+__global__ __launch_bounds__(BLOCK) void k_assign_hubs(const int *__restrict__ outdeg, int V, int thresh,
+                                                       int *__restrict__ hub_slot_of, int *__restrict__ hub_v,
+                                                       int *__restrict__ hub_degp1, int *__restrict__ n_hubs) {
+    for (int v = blockIdx.x * BLOCK + threadIdx.x; v < V; v += gridDim.x * BLOCK) {
+        int slot = -1;
+        const int d = outdeg[v];
+        if (d >= thresh) {
+            slot = atomicAdd(n_hubs, 1);
+            if (slot < HUB_CAP) {
+                hub_v[slot] = v;
+                hub_degp1[slot] = d + 1;
+            } else {
+                slot = -1;
+            }
+        }
+        hub_slot_of[v] = slot;
+    }
+}
+
 // sorted keys -> row_ptr + Adj entries (cusparseXcoo2csr + EdgePairGather, :214-220)
 __global__ __launch_bounds__(BLOCK) void k_build_csr(const uint64_t *__restrict__ skeys, int Ed, int V, int bits,
-                                                     const int *__restrict__ outdeg, int *__restrict__ row_ptr,
+                                                     const int *__restrict__ outdeg,
+                                                     const int *__restrict__ hub_slot_of, int *__restrict__ row_ptr,
                                                      Adj *__restrict__ adj) {
     const uint64_t mask = (1ull << bits) - 1;
     for (int j = blockIdx.x * BLOCK + threadIdx.x; j < Ed; j += gridDim.x * BLOCK) {
@@ -435,7 +633,8 @@ __global__ __launch_bounds__(BLOCK) void k_build_csr(const uint64_t *__restrict_
         const int dst = (int)(k >> bits), src = (int)(k & mask);
         Adj a;
         a.v = src;
-        a.degp1 = outdeg[src] + 1;
+        const int slot = hub_slot_of[src];
+        a.degp1 = slot >= 0 ? ~slot : outdeg[src] + 1; // negative: hub slot (see k_push_iter)
         adj[j] = a;
         const int prev = (j == 0) ? -1 : (int)(skeys[j - 1] >> bits);
         for (int x = prev + 1; x <= dst; ++x) row_ptr[x] = j;

@@ -47,7 +47,7 @@ def build(force: bool = False) -> str:
 
 _lib = None
 EXPORTS = [
-    "dppr_abi_version", "dppr_strerror", "dppr_last_error", "dppr_create", "dppr_destroy", "dppr_set_schedule", "dppr_set_profiling",
+    "dppr_abi_version", "dppr_strerror", "dppr_last_error", "dppr_create", "dppr_destroy", "dppr_set_schedule", "dppr_set_profiling", "dppr_set_tuning",
     "dppr_load_window", "dppr_set_batch", "dppr_slide", "dppr_add_source", "dppr_init_solve", "dppr_update",
     "dppr_incremental_batch_update", "dppr_execute_main_loop", "dppr_read", "dppr_write", "dppr_stats",
     "dppr_reset_stats", "dppr_inspect", "dppr_read_graph", "dppr_graph_edges", "dppr_trace_enable",
@@ -76,6 +76,7 @@ def lib():
     L.dppr_destroy.restype = None
     L.dppr_set_schedule.argtypes = [vp, C.c_int]
     L.dppr_set_profiling.argtypes = [vp, C.c_int]
+    L.dppr_set_tuning.argtypes = [vp, C.c_int, C.c_int]
     L.dppr_load_window.argtypes = [vp, ip, ip, C.c_int32]
     L.dppr_set_batch.argtypes = [vp, ip, ip, u8p, C.c_int32]
     L.dppr_slide.argtypes = [vp, ip, ip, C.c_int32, ip]
@@ -117,7 +118,8 @@ class Engine:
     whole timed region of ``SlidingWindowExecuteMainLoop``.
     """
 
-    def __init__(self, V, W, directed, max_batch, n_epochs=1, device=0, schedule=SCHEDULE_EAGER):
+    def __init__(self, V, W, directed, max_batch, n_epochs=1, device=0, schedule=SCHEDULE_EAGER,
+                 hub_min_degree=None, big_row_edges=None):
         self._L = lib()
         self._h = C.c_void_p()
         self.V, self.W, self.directed, self.c = int(V), int(W), int(directed), int(max_batch)
@@ -126,6 +128,9 @@ class Engine:
             self._h = C.c_void_p()
             raise DpprError(f"dppr_create: {self._L.dppr_strerror(rc).decode()}")
         self.set_schedule(schedule)
+        if hub_min_degree is not None or big_row_edges is not None:
+            self._ck(self._L.dppr_set_tuning(self._h, int(hub_min_degree or 256), int(big_row_edges or 512)),
+                     "set_tuning")
 
     def _ck(self, rc, what):
         if rc:

@@ -1,0 +1,210 @@
+// ppr_gpu.hpp -- driver classes of ./pagerank over the C ABI (include/dppr.h).
+//
+// PPRGPU keeps the reference's driver shape (gpu/PPRGPU.cuh:21-198): DynamicExecute(),
+// SlidingWindowExecuteMainLoop() and the four virtuals GPUBuildSlidingGraph /
+// IncrementalBatchUpdate / ExecuteMainLoop(phase) / ValidateResult, the same timed scope
+// (gpu/PPRGPU.cuh:138-164) and the same stdout contract (:116-124, :170-176). What differs:
+//   * one engine (= one device, one window-graph replica) serves SEVERAL source vertices;
+//   * no CUDA types here -- everything device-side sits behind libdppr_hip.so;
+//   * validation is a run-time flag (--validate) instead of -DVALIDATE;
+//   * errors come back as status codes; this layer prints and exits like CUDA_ERROR did
+//     (gpu/GPUUtil.cuh:7-19).
+#pragma once
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../include/dppr.h"
+#include "graph_vec.hpp"
+#include "meta.hpp"
+
+#define DPPR_CHECK(eng, call)                                                                       \
+    do {                                                                                            \
+        int _rc = (call);                                                                           \
+        if (_rc != DPPR_OK) {                                                                       \
+            std::cout << dppr_strerror(_rc) << " (" << dppr_last_error(eng) << ") in " << __FILE__  \
+                      << " at line " << __LINE__ << std::endl;                                      \
+            std::exit(-1);                                                                          \
+        }                                                                                           \
+    } while (0)
+
+class PPRGPU {
+public:
+    PPRGPU(SlidingGraphVec *g, int device, const std::vector<IndexType> &sources, bool quiet)
+        : graph(g), device_id(device), source_vertex_ids(sources), quiet_(quiet) {
+        if (!quiet_)
+            for (IndexType s : sources) std::cout << "choose " << s << " as source vertex id" << std::endl;
+        int rc = dppr_create(&engine, device, g->vertex_count, g->sliding_window_size, g->directed ? 1 : 0,
+                             (int32_t)gStreamUpdateCountPerBatch, 1);
+        if (rc != DPPR_OK) {
+            std::cout << "dppr_create: " << dppr_strerror(rc) << std::endl;
+            std::exit(-1);
+        }
+        DPPR_CHECK(engine, dppr_set_schedule(engine, gSchedule));
+        ppr_time.assign(sources.size(), 0.0f);
+    }
+    virtual ~PPRGPU() { dppr_destroy(engine); }
+
+    // gpu/PPRGPU.cuh:64-108
+    virtual void DynamicExecute() {
+        {
+            EdgeBatch init_stream(graph->sliding_window_size);
+            graph->SerializeEdgeStream(&init_stream);
+            DPPR_CHECK(engine, dppr_load_window(engine, init_stream.edge1, init_stream.edge2, init_stream.length));
+        }
+        slots.resize(source_vertex_ids.size());
+        for (size_t i = 0; i < slots.size(); ++i)
+            DPPR_CHECK(engine, dppr_add_source(engine, source_vertex_ids[i], &slots[i]));
+        if (!quiet_) std::cout << "start..." << std::endl;
+        for (size_t i = 0; i < slots.size(); ++i) { // Init + ExecuteMainLoop(0)
+            float ms = 0;
+            DPPR_CHECK(engine, dppr_init_solve(engine, slots[i], gTolerance, &ms));
+            if (!quiet_) std::cout << "elapsed time=" << ms << "ms" << std::endl;
+            if (gValidate) ValidateResult(i);
+        }
+        SlidingWindowExecuteMainLoop();
+        if (!quiet_) std::cout << "finish!" << std::endl;
+    }
+
+    // gpu/PPRGPU.cuh:109-177
+    virtual void SlidingWindowExecuteMainLoop() {
+        size_t stream_batch_count = 0;
+        while (stream_batch_count++ < gStreamBatchCount) {
+            if (!quiet_ && (gStreamUpdateCountPerBatch > 100 || stream_batch_count % 100 == 0))
+                Report(stream_batch_count);
+            if (graph->StreamUpdates(gStreamUpdateCountPerBatch)) break; // partial batch: dropped
+            // ---- untimed: batch upload + device graph rebuild ----
+            DPPR_CHECK(engine, dppr_set_batch(engine, graph->edge_batch->edge1, graph->edge_batch->edge2,
+                                              graph->edge_batch->is_insert, graph->edge_batch->length));
+            GPUBuildSlidingGraph();
+            // ---- timed: per source, IncrementalBatchUpdate + ExecuteMainLoop(0) + (1) ----
+            for (size_t i = 0; i < slots.size(); ++i) {
+                float ms = 0;
+                if (gSplitInterface) {
+                    // timed on the host: the three calls each synchronise the stream
+                    struct timespec a, b;
+                    clock_gettime(CLOCK_MONOTONIC, &a);
+                    IncrementalBatchUpdate(i);
+                    ExecuteMainLoop(i, 0);
+                    ExecuteMainLoop(i, 1);
+                    clock_gettime(CLOCK_MONOTONIC, &b);
+                    ms = (float)((b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6);
+                } else {
+                    DPPR_CHECK(engine, dppr_update(engine, slots[i], -1, gTolerance, &ms));
+                }
+                ppr_time[i] += ms;
+                if (gValidate) ValidateResult(i);
+            }
+        }
+        batches_done = stream_batch_count - 1;
+        if (!quiet_) Report(stream_batch_count);
+    }
+
+    // the reference's four virtuals (gpu/PPRGPU.cuh:179-182), per source slot
+    virtual void GPUBuildSlidingGraph() {
+        DPPR_CHECK(engine, dppr_slide(engine, graph->new_stream->edge1, graph->new_stream->edge2,
+                                      graph->new_stream->length, nullptr));
+    }
+    virtual void IncrementalBatchUpdate(size_t i) { DPPR_CHECK(engine, dppr_incremental_batch_update(engine, slots[i], -1)); }
+    virtual void ExecuteMainLoop(size_t i, size_t phase_id) {
+        DPPR_CHECK(engine, dppr_execute_main_loop(engine, slots[i], -1, (int)phase_id, gTolerance));
+    }
+
+    // gpu/PPRRevPushGPU.cuh:134-164: residual bound, then |p - p_pow| < 100 eps with the
+    // power iteration of cpu/PPRCPUPowVec.h:55-83 on the current window graph.
+    virtual void ValidateResult(size_t i) {
+        const IndexType V = graph->vertex_count, s = source_vertex_ids[i];
+        std::vector<double> p((size_t)V), r((size_t)V);
+        DPPR_CHECK(engine, dppr_read(engine, slots[i], p.data(), r.data()));
+        for (IndexType u = 0; u < V; ++u) {
+            if (!(r[u] < gTolerance && r[u] > -gTolerance)) {
+                std::cout << "VALIDATE FAILED: residual[" << u << "]=" << r[u] << std::endl;
+                std::exit(-1);
+            }
+        }
+        std::vector<IndexType> row, col;
+        graph->ConstructGraph(row, col);
+        std::vector<double> a((size_t)V), b((size_t)V);
+        for (IndexType u = 0; u < V; ++u) a[u] = (u == s) ? 1 : 0;
+        size_t iters = 0;
+        for (;;) { // Jacobi sweep until no component moves by more than 1e-14
+            bool stop = true;
+            for (IndexType u = 0; u < V; ++u) {
+                double acc = 0.0;
+                const size_t d = (size_t)(row[u + 1] - row[u]);
+                for (IndexType j = row[u]; j < row[u + 1]; ++j) acc += a[col[j]] / (d + 1);
+                acc = (1.0 - ALPHA) * acc;
+                if (u == s) acc += ALPHA * 1.0;
+                b[u] = acc;
+                if (std::fabs(acc - a[u]) > 1e-14) stop = false;
+            }
+            if (stop) break;
+            a.swap(b);
+            ++iters;
+        }
+        const double bound = gTolerance * 100;
+        for (IndexType u = 0; u < V; ++u) {
+            const double err = std::fabs(a[u] - p[u]);
+            if (!(err < bound)) {
+                std::cout << "VALIDATE FAILED: " << err << "," << bound << " at vertex " << u << std::endl;
+                std::exit(-1);
+            }
+        }
+        if (!quiet_) std::cout << "validate ok (power iterations=" << iters << ")" << std::endl;
+    }
+
+    void Dump(const std::string &path) {
+        FILE *f = std::fopen(path.c_str(), "wb");
+        if (!f) return;
+        const IndexType V = graph->vertex_count;
+        std::vector<double> p((size_t)V), r((size_t)V);
+        for (size_t i = 0; i < slots.size(); ++i) {
+            DPPR_CHECK(engine, dppr_read(engine, slots[i], p.data(), r.data()));
+            std::fwrite(&source_vertex_ids[i], sizeof(IndexType), 1, f);
+            std::fwrite(&V, sizeof(IndexType), 1, f);
+            std::fwrite(p.data(), sizeof(double), (size_t)V, f);
+            std::fwrite(r.data(), sizeof(double), (size_t)V, f);
+        }
+        std::fclose(f);
+    }
+
+    double TotalPprTime() const {
+        double t = 0;
+        for (float x : ppr_time) t += x;
+        return t;
+    }
+
+    SlidingGraphVec *graph;
+    dppr_engine *engine = nullptr;
+    int device_id;
+    std::vector<IndexType> source_vertex_ids;
+    std::vector<int32_t> slots;
+    std::vector<float> ppr_time; // ms per source, timed region only
+    size_t batches_done = 0;
+
+protected:
+    // the progress / summary lines scripts/extract_gpu.py scrapes (gpu/PPRGPU.cuh:116-124,170-176);
+    // with several sources, time is summed over sources and edges counted once per source
+    void Report(size_t stream_batch_count) const {
+        const double t = TotalPprTime();
+        long long cur_edge_num = (long long)gStreamUpdateCountPerBatch * (long long)(stream_batch_count - 1) *
+                                 (long long)slots.size();
+        const size_t solves = (stream_batch_count - 1) * slots.size();
+        std::cout << "coming stream_batch_count=" << stream_batch_count << std::endl;
+        std::cout << "ppr_time " << t << std::endl;
+        std::cout << "edge_num " << cur_edge_num << std::endl;
+        std::cout << "ppr_latency " << (solves > 0 ? t / solves : 0) << std::endl;
+        std::cout << "ppr_throughput " << cur_edge_num / t * 1000.0 << std::endl;
+    }
+    bool quiet_;
+};
+
+// The one variant built: OPTIMIZED (-o 0), the reference's PPRRevPushGPU (gpu/PPRRevPushGPU.cuh).
+class PPRRevPushGPU : public PPRGPU {
+public:
+    using PPRGPU::PPRGPU;
+};

@@ -90,6 +90,12 @@ int dppr_set_schedule(dppr_engine *e, int schedule);
  * hipEvent pair on the engine's stream and summed into dppr_stats_t.push_ms. Off by default
  * (the extra events perturb the whole-batch time slightly). */
 int dppr_set_profiling(dppr_engine *e, int on);
+/* Load-balance knobs of the push kernels (defaults 256 / 512); only valid right after
+ * dppr_create. hub_min_degree: out-degree from which a vertex's incoming pushes are
+ * aggregated in LDS (at most 2048 hubs per epoch); big_row_edges: in-degree from which a
+ * frontier vertex's row is expanded by the whole grid. Results never depend on them beyond
+ * floating-point summation order; tests lower them so small graphs exercise both paths. */
+int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges);
 
 /* ---- graph side (UNTIMED in the reference's metric) --------------------- */
 

@@ -1,0 +1,120 @@
+"""./pagerank (C++ host over the C ABI): flag contract on CPU, end-to-end on the GPU."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from dynamicppr_amd import datagen
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "dynamicppr_amd", "host", "pagerank")
+
+
+@pytest.fixture(scope="module")
+def pagerank():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "dynamicppr_amd", "host"), "-s", "all"])
+    return BIN
+
+
+@pytest.fixture(scope="module")
+def small_bin(tmp_path_factory):
+    V, e1, e2 = datagen.rmat_stream(9, 6000, 11)
+    path = str(tmp_path_factory.mktemp("data") / "syn.bin")
+    datagen.write_bin(path, V, e1, e2)
+    return path, V, e1, e2
+
+
+def run(args, **kw):
+    return subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, **kw)
+
+
+def test_invalid_arguments_print_usage_and_exit(pagerank, small_bin):
+    path = small_bin[0]
+    for bad in ([], ["-d", path, "-a", "0", "-i", "1", "-y", "1"],            # no workload flags
+                ["-d", path, "-a", "1", "-i", "1", "-y", "1", "-r", "0.01", "-b", "5"],  # gAppType out of range
+                ["-d", path, "-a", "0", "-i", "1", "-y", "1", "-n", "1", "-c", "0", "-l", "10"],
+                ["-d", path, "-a", "0", "-i", "1", "-y", "0", "-r", "0.01", "-b", "5"],   # static mode
+                ["-d", path, "-a", "0", "-i", "1", "-y", "1", "-r", "0.01", "-b", "5", "-o", "2"]):
+        r = run([pagerank] + bad)
+        assert r.returncode != 0
+        assert "invalid arguments" in r.stdout and "[USAGE]" in r.stdout
+    r = run([pagerank, "-d", path, "-a", "0", "-i", "1", "-y", "1", "-r", "0.01", "-b"])  # dangling flag
+    assert r.returncode != 0 and "missing value" in r.stdout
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="only meaningful without a GPU")
+def test_no_device_is_a_loud_failure(pagerank, small_bin):
+    r = run([pagerank, "-d", small_bin[0], "-a", "0", "-i", "1", "-y", "1", "-n", "0", "-r", "0.01", "-b", "3", "-s", "1"])
+    assert r.returncode != 0
+    assert "no CPU fallback" in r.stdout
+    # the workload derivation is printed before the device is touched (SlidingGraphVec.h:67-71)
+    assert "sliding window size=600,gStreamUpdateCountPerBatch=6" in r.stdout
+
+
+def read_dump(path):
+    out = {}
+    raw = open(path, "rb").read()
+    off = 0
+    while off < len(raw):
+        s, V = np.frombuffer(raw, dtype="<i4", count=2, offset=off)
+        off += 8
+        p = np.frombuffer(raw, dtype="<f8", count=V, offset=off); off += 8 * V
+        r = np.frombuffer(raw, dtype="<f8", count=V, offset=off); off += 8 * V
+        out[int(s)] = (p, r)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("directed", [1, 0])
+@pytest.mark.parametrize("extra", [[], ["--split"], ["--sync"]])
+def test_cli_end_to_end_matches_oracle(pagerank, small_bin, tmp_path, directed, extra):
+    path, V, e1, e2 = small_bin
+    W, c = 600, 6
+    src = int(datagen.top_sources(V, e1, e2, W, directed, 1)[0])
+    dump = str(tmp_path / "out.dump")
+    r = run([pagerank, "-d", path, "-a", "0", "-i", str(directed), "-y", "1", "-w", "0.1", "-n", "0", "-r", "0.01",
+             "-b", "5", "-s", str(src), "--validate", "--dump", dump] + extra)
+    assert r.returncode == 0, r.stdout
+    assert r.stdout.count("validate ok") == 6          # after init and after each of 5 batches
+    # stdout contract scraped by scripts/extract_gpu.py (last occurrence wins)
+    last = {k: float(v) for k, v in re.findall(r"^(ppr_time|edge_num|ppr_latency|ppr_throughput) ([-+.e\d]+)$",
+                                               r.stdout, flags=re.M)}
+    assert last["edge_num"] == c * 5
+    assert abs(last["ppr_latency"] - last["ppr_time"] / 5) < 1e-3
+    assert "coming stream_batch_count=6" in r.stdout    # batches_done + 1, gpu/PPRGPU.cuh:112,170
+    g = orc.Graph(V, e1, e2, directed, W, c)
+    s = orc.State(V, src, 1e-9)
+    s.cilk_execute(g)
+    for _ in range(5):
+        assert not g.stream_updates()
+        g.inc_construct(1)
+        s.cilk_inc_execute(g)
+    p, rr = read_dump(dump)[src]
+    assert np.max(np.abs(p - s.p)) < 1e-9 and np.max(np.abs(rr)) < 1e-9
+
+
+@pytest.mark.gpu
+def test_cli_multiple_sources_one_gpu(pagerank, small_bin, tmp_path):
+    path, V, e1, e2 = small_bin
+    srcs = [int(x) for x in datagen.top_sources(V, e1, e2, 600, 1, 3)]
+    sf = tmp_path / "sources.txt"
+    sf.write_text("\n".join(map(str, srcs)) + "\n")
+    dump = str(tmp_path / "out.dump")
+    r = run([pagerank, "-d", path, "-a", "0", "-i", "1", "-y", "1", "-n", "1", "-c", "7", "-l", "21",
+             "--sources", str(sf), "--dump", dump, "-g", "1"])
+    assert r.returncode == 0, r.stdout
+    assert "aggregate_edge_num %d" % (7 * 3 * 3) in r.stdout
+    got = read_dump(dump)
+    assert sorted(got) == sorted(srcs)
+    for sv in srcs:
+        g = orc.Graph(V, e1, e2, 1, 600, 7)
+        s = orc.State(V, sv, 1e-9)
+        s.cilk_execute(g)
+        for _ in range(3):
+            assert not g.stream_updates()
+            g.inc_construct(1)
+            s.cilk_inc_execute(g)
+        assert np.max(np.abs(got[sv][0] - s.p)) < 1e-9

@@ -60,12 +60,12 @@ def invariant_max_err_np(p, r, src, dst, V, source, alpha=0.15):
 class Scenario:
     """An oracle graph + state and a HIP engine fed with the same stream."""
 
-    def __init__(self, V, e1, e2, directed, W, c, source, eps, schedule=0, n_epochs=1):
+    def __init__(self, V, e1, e2, directed, W, c, source, eps, schedule=0, n_epochs=1, **tuning):
         from dynamicppr_amd import engine as eng
         self.V, self.W, self.c, self.directed, self.source, self.eps = V, W, c, directed, source, eps
         self.g = orc.Graph(V, e1, e2, directed, W, c)
         self.s = orc.State(V, source, eps)
-        self.e = eng.Engine(V, W, directed, c, n_epochs=n_epochs, schedule=schedule)
+        self.e = eng.Engine(V, W, directed, c, n_epochs=n_epochs, schedule=schedule, **tuning)
         w1, w2 = self.g.window_edges()
         self.e.load_window(w1, w2)
         self.slot = self.e.add_source(source)
