@@ -149,7 +149,7 @@ def main():
         push_bytes = 72 * ps["sum_F"] + 24 * ps["sum_E"] + 4 * ps["sum_N"]
         achieved = push_bytes / (ps["push_ms"] * 1e-3) / 1e9 if ps["push_ms"] > 0 else 0.0
         roof = {
-            "bound": "hbm", "kernel": "k_push_iter", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+            "bound": "hbm", "kernel": "k_pull_iter / k_push_iter (one frontier iteration)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
             "launches": ps["push_launches"], "avg_launch_us": round(1e3 * ps["push_ms"] / max(ps["push_launches"], 1), 3),
             "algorithmic_bytes_per_launch": round(push_bytes / max(ps["push_launches"], 1), 1),
@@ -171,6 +171,7 @@ def main():
                        "source": source, "schedule": a.schedule, "parallelism": f"sources x{world} (replicated graph)"},
             "event_ms_per_step": round(ev_ms / a.steps, 4), "init_solve_ms": round(init_ms, 3),
             "iterations_per_step": round(stats["iterations"] / a.steps, 2),
+            "pull_iterations_per_step": round(stats["pull_iterations"] / a.steps, 2),
             "edges_pushed_per_step": round(stats["sum_E"] / a.steps, 1),
             "roofline": roof, "cpu_baseline": cpu,
         }

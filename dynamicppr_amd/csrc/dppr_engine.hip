@@ -24,8 +24,10 @@ using namespace dppr;
 namespace {
 
 struct Epoch {
-    int *row_ptr = nullptr; // V+1
+    int *row_ptr = nullptr; // V+1   in-CSR (push)
     Adj *adj = nullptr;     // Ed
+    int *out_row_ptr = nullptr; // V+1  out-CSR (pull)
+    int *out_col = nullptr;     // Ed
     int Ed = 0;
     // batch that produced this epoch (empty for epoch 0)
     int *b1 = nullptr, *b2 = nullptr, *deg_after = nullptr; // 4c each
@@ -39,7 +41,8 @@ struct Epoch {
 
 struct Slot {
     int source = 0;
-    double *p = nullptr, *r = nullptr, *ft_r = nullptr;
+    double *p = nullptr, *r = nullptr;
+    double *x = nullptr, *x2 = nullptr; // dense per-iteration push amounts (x) and pull output (x2)
     int *ft[2] = {nullptr, nullptr};
     int *neg = nullptr;     // phase-1 candidates
     int *cnt = nullptr;     // [0..2] rotating frontier counters, [3] neg candidates, [4] scratch, [5..6] big-row counters
@@ -76,6 +79,7 @@ struct dppr_engine {
     int *hub_hist = nullptr;    // 32 + 1 ints (histogram, hub counter)
     int hub_min_degree = HUB_MIN_DEGREE_DEFAULT;
     int big_row = BIG_ROW_DEFAULT;
+    int pull_min_frontier = 0; // 0: auto (max(4096, Ed/16)); < 0: never pull; > 0: pull when F >= value
     // CSR build scratch
     uint64_t *keys_a = nullptr, *keys_b = nullptr;
     void *sort_tmp = nullptr;
@@ -167,6 +171,17 @@ int build_csr(dppr_engine *e, Epoch &ep) {
     hipLaunchKernelGGL(k_build_csr, dim3(grid_for(std::max(Ed, e->V + 1))), dim3(BLOCK), 0, e->stream, e->keys_b, Ed,
                        e->V, e->bits, e->outdeg, e->hub_slot_of, ep.row_ptr, ep.adj);
     HIP_TRY(hipGetLastError());
+    // out-CSR for the pull sweep (same scratch, second sort)
+    if (W > 0) {
+        hipLaunchKernelGGL(k_make_out_keys, dim3(grid_for(W)), dim3(BLOCK), 0, e->stream, e->w1, e->w2, W, e->directed,
+                           e->bits, e->keys_a);
+        size_t tmp = e->sort_tmp_bytes;
+        HIP_TRY(rocprim::radix_sort_keys(e->sort_tmp, tmp, e->keys_a, e->keys_b, (size_t)Ed, 0u,
+                                         (unsigned)(2 * e->bits), e->stream));
+    }
+    hipLaunchKernelGGL(k_build_out_csr, dim3(grid_for(std::max(Ed, e->V + 1))), dim3(BLOCK), 0, e->stream, e->keys_b,
+                       Ed, e->V, e->bits, ep.out_row_ptr, ep.out_col);
+    HIP_TRY(hipGetLastError());
     ep.Ed = Ed;
     return DPPR_OK;
 }
@@ -179,9 +194,16 @@ int read_count(dppr_engine *e, const int *dptr, int *out) {
 }
 
 // Frontier loop: PPRRevPushGPU::ExecuteOptimized's while(1) (gpu/PPRRevPushGPU.cuh:106-130).
-// On entry s.ft[buf] holds the frontier and s.cnt[cur] its size; cnt[(cur+1)%3] is zero.
+// On entry s.ft[buf] holds the frontier and s.cnt[cur] its size; cnt[(cur+1)%3] is zero and
+// the dense vector s.x is all zero (no snapshot taken yet).
+// Every iteration is either SPARSE (push kernels, atomics) or DENSE (pull sweep, no atomics);
+// the choice only changes which hardware path evaluates the same sums.
 int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, double eps, int buf, int cur) {
-    bool pending = false; // a profiled push launch awaits its event read-out
+    bool pending = false;     // a profiled launch awaits its event read-out
+    bool dense_valid = false; // s.x holds the snapshot of the current frontier (p already updated)
+    const int pull_min = e->pull_min_frontier > 0   ? e->pull_min_frontier
+                         : e->pull_min_frontier < 0 ? 0x7fffffff
+                                                    : std::max(4096, e->Ed / 16);
     for (int it = 0;; ++it) {
         int F = 0;
         int rc = read_count(e, s.cnt + cur, &F);
@@ -206,26 +228,39 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
         s.st.iterations++;
         s.st.sum_F += F;
         const int nxt = (cur + 1) % 3, zer = (cur + 2) % 3;
-        int *big_cnt = s.cnt + 5 + (int)(s.iter_seq & 1), *big_zero = s.cnt + 5 + (int)((s.iter_seq + 1) & 1);
-        s.iter_seq++;
-        const HubTable hubs{ep.hub_v, ep.hub_degp1, ep.n_hubs};
-        const int tiles = (F + WAVE - 1) / WAVE;
-        const int grid = std::min(std::max((tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 1), 2048);
-        if (e->schedule == DPPR_SCHEDULE_SYNC) {
-            hipLaunchKernelGGL(k_snapshot, dim3(grid_for(F)), dim3(BLOCK), 0, e->stream, s.ft[buf], s.cnt + cur, s.r,
-                               s.p, s.ft_r);
-            if (e->profiling) HIP_TRY(hipEventRecord(e->ev2, e->stream));
-            hipLaunchKernelGGL(k_push_iter<true>, dim3(grid), dim3(BLOCK), 0, e->stream, s.ft[buf], s.cnt + cur,
-                               s.ft[buf ^ 1], s.cnt + nxt, s.cnt + zer, s.ft_r, ep.row_ptr, ep.adj, hubs, s.big, big_cnt,
-                               big_zero, e->big_row, s.r, s.p, phase, eps, s.dstats);
-        } else {
-            if (e->profiling) HIP_TRY(hipEventRecord(e->ev2, e->stream));
-            hipLaunchKernelGGL(k_push_iter<false>, dim3(grid), dim3(BLOCK), 0, e->stream, s.ft[buf], s.cnt + cur,
-                               s.ft[buf ^ 1], s.cnt + nxt, s.cnt + zer, (const double *)nullptr, ep.row_ptr, ep.adj,
-                               hubs, s.big, big_cnt, big_zero, e->big_row, s.r, s.p, phase, eps, s.dstats);
+        const bool pull = F >= pull_min;
+        const bool need_snapshot = !dense_valid && (pull || e->schedule == DPPR_SCHEDULE_SYNC);
+        if (need_snapshot) {
+            hipLaunchKernelGGL(k_snapshot_dense, dim3(grid_for(F)), dim3(BLOCK), 0, e->stream, s.ft[buf], s.cnt + cur,
+                               s.r, s.p, s.x);
+            dense_valid = true;
         }
-        hipLaunchKernelGGL(k_push_big, dim3(512), dim3(BLOCK), 0, e->stream, s.big, big_cnt, s.ft[buf ^ 1], s.cnt + nxt,
-                           ep.adj, hubs, s.r, phase, eps, s.dstats);
+        if (e->profiling) HIP_TRY(hipEventRecord(e->ev2, e->stream));
+        if (pull) {
+            s.st.pull_iterations++;
+            hipLaunchKernelGGL(k_pull_iter, dim3(grid_for(e->V, PULL_BLOCK, 512)), dim3(PULL_BLOCK), 0, e->stream, e->V,
+                               ep.out_row_ptr, ep.out_col, s.x, s.x2, s.r, s.p, s.ft[buf ^ 1], s.cnt + nxt, s.cnt + zer,
+                               phase, eps, s.dstats);
+            std::swap(s.x, s.x2); // the sweep wrote every entry of x2: it is the next snapshot
+            dense_valid = true;
+        } else {
+            int *big_cnt = s.cnt + 5 + (int)(s.iter_seq & 1), *big_zero = s.cnt + 5 + (int)((s.iter_seq + 1) & 1);
+            s.iter_seq++;
+            const HubTable hubs{ep.hub_v, ep.hub_degp1, ep.n_hubs};
+            const int tiles = (F + WAVE - 1) / WAVE;
+            const int grid = std::min(std::max((tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 1), 2048);
+            if (dense_valid)
+                hipLaunchKernelGGL(k_push_iter<true>, dim3(grid), dim3(BLOCK), 0, e->stream, s.ft[buf], s.cnt + cur,
+                                   s.ft[buf ^ 1], s.cnt + nxt, s.cnt + zer, s.x, ep.row_ptr, ep.adj, hubs, s.big,
+                                   big_cnt, big_zero, e->big_row, s.r, s.p, phase, eps, s.dstats);
+            else
+                hipLaunchKernelGGL(k_push_iter<false>, dim3(grid), dim3(BLOCK), 0, e->stream, s.ft[buf], s.cnt + cur,
+                                   s.ft[buf ^ 1], s.cnt + nxt, s.cnt + zer, s.x, ep.row_ptr, ep.adj, hubs, s.big,
+                                   big_cnt, big_zero, e->big_row, s.r, s.p, phase, eps, s.dstats);
+            hipLaunchKernelGGL(k_push_big, dim3(512), dim3(BLOCK), 0, e->stream, s.big, big_cnt, s.ft[buf ^ 1],
+                               s.cnt + nxt, ep.adj, hubs, s.r, phase, eps, s.dstats);
+            dense_valid = false; // the push consumed (and zeroed) the snapshot
+        }
         HIP_TRY(hipGetLastError());
         if (e->profiling) {
             HIP_TRY(hipEventRecord(e->ev3, e->stream));
@@ -268,10 +303,12 @@ int stream_update(dppr_engine *e, Slot &s, const Epoch &ep, double eps, bool see
 }
 
 int pull_device_stats(dppr_engine *e, Slot &s) {
-    IterStats h;
+    static thread_local IterStats h;
     HIP_TRY(hipMemcpyAsync(&h, s.dstats, sizeof(h), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    s.st.sum_E = (int64_t)h.sum_E;
+    unsigned long long t = 0;
+    for (int i = 0; i < STAT_SLOTS; ++i) t += h.blk_E[i];
+    s.st.sum_E = (int64_t)t;
     return DPPR_OK;
 }
 
@@ -354,6 +391,8 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     for (auto &ep : e->epochs) {
         HIP_TRY_C(hipMalloc((void **)&ep.row_ptr, sizeof(int) * ((size_t)V + 1)));
         HIP_TRY_C(hipMalloc((void **)&ep.adj, sizeof(Adj) * Edn));
+        HIP_TRY_C(hipMalloc((void **)&ep.out_row_ptr, sizeof(int) * ((size_t)V + 1)));
+        HIP_TRY_C(hipMalloc((void **)&ep.out_col, sizeof(int) * Edn));
         HIP_TRY_C(hipMalloc((void **)&ep.b1, sizeof(int) * Ln));
         HIP_TRY_C(hipMalloc((void **)&ep.b2, sizeof(int) * Ln));
         HIP_TRY_C(hipMalloc((void **)&ep.deg_after, sizeof(int) * Ln));
@@ -371,12 +410,12 @@ void dppr_destroy(dppr_engine *e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto &s : e->slots) {
-        (void)hipFree(s.p); (void)hipFree(s.r); (void)hipFree(s.ft_r);
+        (void)hipFree(s.p); (void)hipFree(s.r); (void)hipFree(s.x); (void)hipFree(s.x2);
         (void)hipFree(s.ft[0]); (void)hipFree(s.ft[1]); (void)hipFree(s.neg);
         (void)hipFree(s.cnt); (void)hipFree(s.dstats); (void)hipFree(s.big);
     }
     for (auto &ep : e->epochs) {
-        (void)hipFree(ep.row_ptr); (void)hipFree(ep.adj); (void)hipFree(ep.b1); (void)hipFree(ep.b2);
+        (void)hipFree(ep.row_ptr); (void)hipFree(ep.adj); (void)hipFree(ep.out_row_ptr); (void)hipFree(ep.out_col); (void)hipFree(ep.b1); (void)hipFree(ep.b2);
         (void)hipFree(ep.deg_after); (void)hipFree(ep.ins); (void)hipFree(ep.hub_v); (void)hipFree(ep.hub_degp1);
     }
     (void)hipFree(e->w1); (void)hipFree(e->w2); (void)hipFree(e->outdeg);
@@ -405,11 +444,12 @@ int dppr_set_profiling(dppr_engine *e, int on) {
     return DPPR_OK;
 }
 
-int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges) {
+int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges, int pull_min_frontier) {
     if (!e || hub_min_degree < 1 || big_row_edges < 1 || e->loaded || !e->slots.empty())
         return fail(e, DPPR_ERR_INVALID, "set_tuning: call right after dppr_create, values >= 1");
     e->hub_min_degree = hub_min_degree;
     e->big_row = big_row_edges;
+    e->pull_min_frontier = pull_min_frontier;
     return DPPR_OK;
 }
 
@@ -513,7 +553,10 @@ int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
     const size_t V = (size_t)e->V;
     HIP_TRY(hipMalloc((void **)&s.p, sizeof(double) * V));
     HIP_TRY(hipMalloc((void **)&s.r, sizeof(double) * V));
-    HIP_TRY(hipMalloc((void **)&s.ft_r, sizeof(double) * V));
+    HIP_TRY(hipMalloc((void **)&s.x, sizeof(double) * V));
+    HIP_TRY(hipMalloc((void **)&s.x2, sizeof(double) * V));
+    HIP_TRY(hipMemset(s.x, 0, sizeof(double) * V));
+    HIP_TRY(hipMemset(s.x2, 0, sizeof(double) * V));
     HIP_TRY(hipMalloc((void **)&s.ft[0], sizeof(int) * V));
     HIP_TRY(hipMalloc((void **)&s.ft[1], sizeof(int) * V));
     HIP_TRY(hipMalloc((void **)&s.neg, sizeof(int) * (size_t)std::max(4 * e->c, 1)));
@@ -557,7 +600,7 @@ int dppr_init_solve(dppr_engine *e, int32_t slot, double eps, float *out_ms) {
     if (out_ms) *out_ms = ms;
     s.converged = true;
     s.conv_eps = eps;
-    return pull_device_stats(e, s);
+    return DPPR_OK;
 }
 
 int dppr_incremental_batch_update(dppr_engine *e, int32_t slot, int32_t epoch) {
@@ -586,7 +629,7 @@ int dppr_execute_main_loop(dppr_engine *e, int32_t slot, int32_t epoch, int phas
         s.converged = true;
         s.conv_eps = eps;
     }
-    return pull_device_stats(e, s);
+    return DPPR_OK;
 }
 
 int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *out_ms) {
@@ -626,7 +669,7 @@ int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *
     s.st.batches++;
     s.converged = true;
     s.conv_eps = eps;
-    return pull_device_stats(e, s);
+    return DPPR_OK;
 }
 
 int dppr_read(dppr_engine *e, int32_t slot, double *p, double *r) {
@@ -709,6 +752,19 @@ int dppr_read_graph(dppr_engine *e, int32_t epoch, int32_t *row_ptr, int32_t *co
     }
     if (out_degree)
         HIP_TRY(hipMemcpyAsync(out_degree, e->outdeg, sizeof(int) * (size_t)e->V, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return DPPR_OK;
+}
+
+int dppr_read_out_graph(dppr_engine *e, int32_t epoch, int32_t *row_ptr, int32_t *col) {
+    if (!e) return DPPR_ERR_INVALID;
+    GET_EPOCH(e, epoch);
+    HIP_TRY(hipSetDevice(e->device));
+    if (row_ptr)
+        HIP_TRY(hipMemcpyAsync(row_ptr, ep.out_row_ptr, sizeof(int) * ((size_t)e->V + 1), hipMemcpyDeviceToHost,
+                               e->stream));
+    if (col && ep.Ed > 0)
+        HIP_TRY(hipMemcpyAsync(col, ep.out_col, sizeof(int) * (size_t)ep.Ed, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return DPPR_OK;
 }

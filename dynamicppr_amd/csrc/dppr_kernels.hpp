@@ -121,18 +121,21 @@ __global__ __launch_bounds__(BLOCK) void k_inspect(const double *__restrict__ r,
 }
 
 // ---------------------------------------------------------------------------
-// SYNC schedule only: snapshot the frontier residuals before any push lands.
-// The head of ExpandUnifiedRev (gpu/ExpandRev.cuh:34-42) for ALL frontier
-// vertices: ru = residual[u]; vertex_ft_r[i] = ru; pagerank[u] += ALPHA * ru.
+// Snapshot of the frontier residuals into the DENSE vector x (x[u] = amount u pushes
+// this iteration, 0 for every vertex outside the frontier). The head of
+// ExpandUnifiedRev (gpu/ExpandRev.cuh:34-42) for ALL frontier vertices before any push
+// lands: ru = residual[u]; (vertex_ft_r =) x[u] = ru; pagerank[u] += ALPHA * ru.
+// Used by the synchronous schedule and when a sparse (push) iteration is followed by a
+// dense (pull) one.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_snapshot(const int *__restrict__ ft, const int *__restrict__ cnt_in,
-                                                    const double *__restrict__ r, double *__restrict__ p,
-                                                    double *__restrict__ ft_r) {
+__global__ __launch_bounds__(BLOCK) void k_snapshot_dense(const int *__restrict__ ft, const int *__restrict__ cnt_in,
+                                                          const double *__restrict__ r, double *__restrict__ p,
+                                                          double *__restrict__ x) {
     const int F = *cnt_in;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < F; i += gridDim.x * BLOCK) {
         const int u = ft[i];
         const double ru = r[u];
-        ft_r[i] = ru;
+        x[u] = ru;
         p[u] += ALPHA * ru;
     }
 }
@@ -145,8 +148,9 @@ __global__ __launch_bounds__(BLOCK) void k_snapshot(const int *__restrict__ ft, 
 //   EAGER: ru = atomic_exchange(r[u], 0)  (= "ru = residual[u]" ... "residual[u] -= ru"
 //          collapsed to one instant; everything that arrives later stays and may
 //          cross the threshold again), p[u] += ALPHA*ru.
-//   SYNC : ru = ft_r[i] (snapshot kernel), repair = returning atomic add of -ru;
-//          if the result is still legal the vertex re-enters the next frontier.
+//   DENSE: ru = x[u] (snapshot taken by k_snapshot_dense or by the preceding pull sweep;
+//          p already updated), x[u] = 0, repair = returning atomic add of -ru; if the
+//          result is still legal the vertex re-enters the next frontier.
 // Row extents are scanned across the wave and staged in LDS; the wave then walks
 // the concatenated edge list 4 x 64 edges per round (four independent returning
 // atomics in flight per lane): edge e belongs to the vertex found by a binary
@@ -174,9 +178,27 @@ __global__ __launch_bounds__(BLOCK) void k_snapshot(const int *__restrict__ ft, 
 // (the counter the NEXT iteration appends to); likewise big_cnt / big_zero. Iteration
 // kernels can therefore be chained without host round trips or memsets.
 // ---------------------------------------------------------------------------
-struct IterStats { // device-side accumulators (per slot)
-    unsigned long long sum_E;
+// Device-side statistics. Same-address global atomics serialise at ~11 ns each, so one
+// atomic per wave (or per workgroup) on a shared counter would cost more than the kernels'
+// real work; every workgroup owns one slot instead (a slot stream runs one kernel at a
+// time) and the host sums the slots when statistics are read.
+constexpr int STAT_SLOTS = 4096; // >= the largest grid of the iteration kernels
+struct IterStats {
+    unsigned long long blk_E[STAT_SLOTS]; // traversed edges, per workgroup slot
 };
+// workgroup total of a wave-uniform per-wave value -> this workgroup's slot (call from all threads)
+template <int NWAVES>
+__device__ __forceinline__ void stat_add_edges(IterStats *stats, unsigned long long wave_edges,
+                                               unsigned long long *s_edges) {
+    if (lane_id() == 0) s_edges[wave_id()] = wave_edges;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+#pragma unroll
+        for (int k = 0; k < NWAVES; ++k) t += s_edges[k];
+        if (t) stats->blk_E[blockIdx.x] += t;
+    }
+}
 
 struct BigItem { // a deferred big row
     int row_start;
@@ -252,7 +274,8 @@ __device__ __forceinline__ EdgePush push_edge(bool valid, Adj a, double ru, doub
 // workgroup epilogue shared by both push kernels: flush hub accumulators, then the staged frontier
 __device__ __forceinline__ void push_epilogue(OutStage &out, double *s_hub, const HubTable &hubs,
                                               double *__restrict__ r, int phase, double eps, int *s_cnt, int *s_base,
-                                              unsigned long long edges, IterStats *stats) {
+                                              unsigned long long edges, IterStats *stats,
+                                              unsigned long long *s_edges) {
     __syncthreads(); // all LDS hub adds of the workgroup done
     for (int s0 = 0; s0 < hubs.n; s0 += BLOCK) {
         const int slot = s0 + threadIdx.x;
@@ -279,13 +302,13 @@ __device__ __forceinline__ void push_epilogue(OutStage &out, double *s_hub, cons
     int gb = *s_base;
     for (int k = 0; k < w; ++k) gb += s_cnt[k];
     for (int i = lane; i < out.n; i += WAVE) out.ft_out[gb + i] = out.s_out[i];
-    if (lane == 0 && edges) atomicAdd(&stats->sum_E, edges);
+    stat_add_edges<WAVES_PER_BLOCK>(stats, edges, s_edges);
 }
 
-template <bool SYNC>
+template <bool DENSE>
 __global__ __launch_bounds__(BLOCK) void k_push_iter(const int *__restrict__ ft, const int *__restrict__ cnt_in,
                                                      int *__restrict__ ft_out, int *__restrict__ cnt_out,
-                                                     int *__restrict__ cnt_zero, const double *__restrict__ ft_r,
+                                                     int *__restrict__ cnt_zero, double *__restrict__ x,
                                                      const int *__restrict__ row_ptr, const Adj *__restrict__ adj,
                                                      HubTable hubs, BigItem *__restrict__ big, int *__restrict__ big_cnt,
                                                      int *__restrict__ big_zero, int big_row, double *__restrict__ r,
@@ -297,6 +320,7 @@ __global__ __launch_bounds__(BLOCK) void k_push_iter(const int *__restrict__ ft,
     __shared__ int s_out[WAVES_PER_BLOCK][OUT_CAP];
     __shared__ double s_hub[HUB_CAP];
     __shared__ int s_cnt[WAVES_PER_BLOCK];
+    __shared__ unsigned long long s_edges[WAVES_PER_BLOCK];
     __shared__ int s_base;
 
     const int lane = lane_id();
@@ -324,8 +348,9 @@ __global__ __launch_bounds__(BLOCK) void k_push_iter(const int *__restrict__ ft,
             u = ft[i];
             rs = row_ptr[u];
             d = row_ptr[u + 1] - rs;
-            if (SYNC) {
-                ru = ft_r[i];
+            if (DENSE) {
+                ru = x[u];
+                x[u] = 0.0; // x is all-zero again once the sparse iteration is over
                 // RepairFrontierRev: residual[u] -= vertex_ft_r[i]; still legal -> next frontier
                 const double prer = atomic_add_ret(&r[u], -ru);
                 requeue = legal(prer - ru, phase, eps);
@@ -334,7 +359,7 @@ __global__ __launch_bounds__(BLOCK) void k_push_iter(const int *__restrict__ ft,
                 p[u] += ALPHA * ru;
             }
         }
-        if (SYNC) out.stage(requeue, u);
+        if (DENSE) out.stage(requeue, u);
 
         // big rows: hand (row, ru) to k_push_big
         const bool is_big = d >= big_row;
@@ -390,7 +415,7 @@ __global__ __launch_bounds__(BLOCK) void k_push_iter(const int *__restrict__ ft,
         }
         __builtin_amdgcn_wave_barrier();
     }
-    push_epilogue(out, s_hub, hubs, r, phase, eps, s_cnt, &s_base, edges, stats);
+    push_epilogue(out, s_hub, hubs, r, phase, eps, s_cnt, &s_base, edges, stats, s_edges);
 }
 
 // Deferred big rows: chunk c of the list goes to workgroup c % gridDim; 256 lanes x 4 edges.
@@ -401,6 +426,7 @@ __global__ __launch_bounds__(BLOCK) void k_push_big(const BigItem *__restrict__ 
     __shared__ int s_out[WAVES_PER_BLOCK][OUT_CAP];
     __shared__ double s_hub[HUB_CAP];
     __shared__ int s_cnt[WAVES_PER_BLOCK];
+    __shared__ unsigned long long s_edges[WAVES_PER_BLOCK];
     __shared__ int s_base;
     const int nbig = *big_cnt;
     if (nbig == 0) return; // uniform for the whole grid
@@ -439,7 +465,138 @@ __global__ __launch_bounds__(BLOCK) void k_push_big(const BigItem *__restrict__ 
         }
         chunk0 += nch;
     }
-    push_epilogue(out, s_hub, hubs, r, phase, eps, s_cnt, &s_base, edges, stats);
+    push_epilogue(out, s_hub, hubs, r, phase, eps, s_cnt, &s_base, edges, stats, s_edges);
+}
+
+// ---------------------------------------------------------------------------
+// a4+a5, DENSE iterations: the same frontier iteration evaluated as a PULL sweep.
+//
+// When the frontier covers a large part of the graph (on the benchmark streams it is
+// the whole active component for most iterations) one random returning atomic per
+// traversed edge is bounded by the memory-side atomic units (~23 G/s).
+// The identical arithmetic can be gathered instead: for every vertex v
+//     rv = residual[v]
+//     for u in out(v), ascending:  if x[u] != 0:  rv += (1.0-ALPHA) * x[u] / (outdeg(v)+1)
+//     rv -= x[v]                                   (RepairFrontierRev for frontier members)
+// which is exactly what the pushes u -> v of gpu/ExpandRev.cuh:70-73 followed by the
+// repair of :708-743 leave in residual[v] when the atomics happen to arrive in CSR
+// order. No atomics on global memory: out_col is streamed (the rows of 64 consecutive
+// vertices are one contiguous range), x[u] is an 8-byte gather, the per-vertex sums are
+// LDS atomics inside the owning wave. The next frontier is {v : legal(rv)} (residual
+// adds of a phase all have one sign, so this equals the reference's crossing test plus
+// repaired members); for those the kernel immediately takes the next snapshot
+// (x_new[v] = rv, pagerank[v] += ALPHA*rv), so consecutive dense iterations are ONE
+// kernel each. The sparse list / counter are produced as well, so a push iteration
+// can follow.
+// ---------------------------------------------------------------------------
+constexpr int PULL_BLOCK = 1024; // 16 waves: few workgroups -> few counter atomics per sweep
+constexpr int PULL_WAVES = PULL_BLOCK / WAVE;
+constexpr int PULL_OUT_CAP = 512; // per-wave staged list entries
+__global__ __launch_bounds__(PULL_BLOCK) void k_pull_iter(int V, const int *__restrict__ out_row_ptr,
+                                                          const int *__restrict__ out_col,
+                                                          const double *__restrict__ x, double *__restrict__ x_new,
+                                                          double *__restrict__ r, double *__restrict__ p,
+                                                          int *__restrict__ ft_out, int *__restrict__ cnt_out,
+                                                          int *__restrict__ cnt_zero, int phase, double eps,
+                                                          IterStats *__restrict__ stats) {
+    __shared__ int s_scan[PULL_WAVES][WAVE + 1];
+    __shared__ double s_acc[PULL_WAVES][WAVE];
+    __shared__ int s_out[PULL_WAVES][PULL_OUT_CAP];
+    __shared__ int s_cnt[PULL_WAVES];
+    __shared__ unsigned long long s_edges[PULL_WAVES];
+    __shared__ int s_base;
+    const int lane = lane_id(), w = wave_id();
+    if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_zero = 0;
+    int n_out = 0; // wave-uniform
+    unsigned long long edges = 0;
+
+    const int n_tiles = (V + WAVE - 1) / WAVE;
+    for (int t = blockIdx.x * PULL_WAVES + w; t < n_tiles; t += gridDim.x * PULL_WAVES) {
+        const int v = t * WAVE + lane;
+        const bool valid = v < V;
+        int rs = 0, d = 0;
+        double rv = 0.0, xv = 0.0;
+        if (valid) {
+            rs = out_row_ptr[v];
+            d = out_row_ptr[v + 1] - rs;
+            rv = r[v];
+            xv = x[v];
+        }
+        const int incl = wave_inclusive_scan(d);
+        const int total = __shfl(incl, WAVE - 1, WAVE);
+        double rn = rv;
+        if (total) { // wave-uniform: tiles of isolated vertices skip the gather machinery
+            const int base = __shfl(rs, 0, WAVE); // rows of the tile are contiguous from here
+            s_scan[w][lane] = incl - d;
+            if (lane == 0) s_scan[w][WAVE] = total;
+            s_acc[w][lane] = rv;
+            __builtin_amdgcn_wave_barrier();
+            for (int e0 = 0; e0 < total; e0 += WAVE * UNROLL) {
+                int owner[UNROLL];
+                double xu[UNROLL];
+#pragma unroll
+                for (int k = 0; k < UNROLL; ++k) {
+                    const int e = e0 + k * WAVE + lane;
+                    owner[k] = -1;
+                    xu[k] = 0.0;
+                    if (e < total) {
+                        int lo = 0, hi = WAVE;
+#pragma unroll
+                        for (int s = 0; s < 6; ++s) {
+                            const int mid = (lo + hi) >> 1;
+                            if (s_scan[w][mid] <= e) lo = mid; else hi = mid;
+                        }
+                        owner[k] = lo;
+                        xu[k] = x[out_col[base + e]];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < UNROLL; ++k) {
+                    const bool nz = xu[k] != 0.0;
+                    if (nz) {
+                        const int dk = s_scan[w][owner[k] + 1] - s_scan[w][owner[k]];
+                        lds_add(&s_acc[w][owner[k]], ONE_MINUS_ALPHA * xu[k] / (double)(dk + 1));
+                    }
+                    edges += (unsigned long long)__popcll(__ballot(nz));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            rn = s_acc[w][lane];
+        }
+        if (xv != 0.0) rn -= xv;
+        const bool lg = valid && legal(rn, phase, eps);
+        if (valid) {
+            if (rn != rv) r[v] = rn;
+            x_new[v] = lg ? rn : 0.0; // every entry is rewritten: x_new is a complete snapshot
+            if (lg) p[v] += ALPHA * rn;
+        }
+        const uint64_t m = __ballot(lg);
+        if (m) {
+            if (n_out + WAVE > PULL_OUT_CAP) { // overflow: flush this wave's tile (rare)
+                int gb = 0;
+                if (lane == 0) gb = atomicAdd(cnt_out, n_out);
+                gb = __shfl(gb, 0, WAVE);
+                for (int i = lane; i < n_out; i += WAVE) ft_out[gb + i] = s_out[w][i];
+                n_out = 0;
+            }
+            if (lg) s_out[w][n_out + mbcnt(m)] = v;
+            n_out += __popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // workgroup flush of the sparse list: ONE counter atomic per 1024-thread workgroup
+    if (lane == 0) s_cnt[w] = n_out;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int k = 0; k < PULL_WAVES; ++k) tot += s_cnt[k];
+        s_base = tot ? atomicAdd(cnt_out, tot) : 0;
+    }
+    __syncthreads();
+    int gb = s_base;
+    for (int k = 0; k < w; ++k) gb += s_cnt[k];
+    for (int i = lane; i < n_out; i += WAVE) ft_out[gb + i] = s_out[w][i];
+    stat_add_edges<PULL_WAVES>(stats, edges, s_edges);
 }
 
 // ---------------------------------------------------------------------------
@@ -643,6 +800,31 @@ __global__ __launch_bounds__(BLOCK) void k_build_csr(const uint64_t *__restrict_
     }
     if (Ed == 0)
         for (int x = blockIdx.x * BLOCK + threadIdx.x; x <= V; x += gridDim.x * BLOCK) row_ptr[x] = 0;
+}
+
+// out-CSR for the pull sweep: key = src << bits | dst, sorted -> out_row_ptr + out_col
+__global__ __launch_bounds__(BLOCK) void k_make_out_keys(const int *__restrict__ w1, const int *__restrict__ w2, int W,
+                                                         int directed, int bits, uint64_t *__restrict__ keys) {
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < W; i += gridDim.x * BLOCK) {
+        const uint64_t a = (uint32_t)w1[i], b = (uint32_t)w2[i];
+        keys[i] = (a << bits) | b;
+        if (!directed) keys[(int64_t)W + i] = (b << bits) | a;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_build_out_csr(const uint64_t *__restrict__ skeys, int Ed, int V, int bits,
+                                                         int *__restrict__ row_ptr, int *__restrict__ col) {
+    const uint64_t mask = (1ull << bits) - 1;
+    for (int j = blockIdx.x * BLOCK + threadIdx.x; j < Ed; j += gridDim.x * BLOCK) {
+        const uint64_t k = skeys[j];
+        const int src = (int)(k >> bits);
+        col[j] = (int)(k & mask);
+        const int prev = (j == 0) ? -1 : (int)(skeys[j - 1] >> bits);
+        for (int xx = prev + 1; xx <= src; ++xx) row_ptr[xx] = j;
+        if (j == Ed - 1)
+            for (int xx = src + 1; xx <= V; ++xx) row_ptr[xx] = Ed;
+    }
+    if (Ed == 0)
+        for (int xx = blockIdx.x * BLOCK + threadIdx.x; xx <= V; xx += gridDim.x * BLOCK) row_ptr[xx] = 0;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_gather_deg(const int *__restrict__ e1, int L, const int *__restrict__ outdeg,

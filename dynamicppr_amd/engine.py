@@ -27,6 +27,7 @@ class DpprError(RuntimeError):
 class Stats(C.Structure):
     _fields_ = [("iterations", C.c_int64), ("sum_F", C.c_int64), ("sum_E", C.c_int64), ("sum_N", C.c_int64),
                 ("records", C.c_int64), ("inspected", C.c_int64), ("batches", C.c_int64),
+                ("pull_iterations", C.c_int64),
                 ("algorithmic_bytes", C.c_int64), ("gpu_ms", C.c_double), ("push_ms", C.c_double),
                 ("push_launches", C.c_int64)]
 
@@ -50,7 +51,7 @@ EXPORTS = [
     "dppr_abi_version", "dppr_strerror", "dppr_last_error", "dppr_create", "dppr_destroy", "dppr_set_schedule", "dppr_set_profiling", "dppr_set_tuning",
     "dppr_load_window", "dppr_set_batch", "dppr_slide", "dppr_add_source", "dppr_init_solve", "dppr_update",
     "dppr_incremental_batch_update", "dppr_execute_main_loop", "dppr_read", "dppr_write", "dppr_stats",
-    "dppr_reset_stats", "dppr_inspect", "dppr_read_graph", "dppr_graph_edges", "dppr_trace_enable",
+    "dppr_reset_stats", "dppr_inspect", "dppr_read_graph", "dppr_graph_edges", "dppr_read_out_graph", "dppr_trace_enable",
     "dppr_trace_get", "dppr_synchronize", "dppr_bench_atomics",
 ]
 
@@ -76,7 +77,7 @@ def lib():
     L.dppr_destroy.restype = None
     L.dppr_set_schedule.argtypes = [vp, C.c_int]
     L.dppr_set_profiling.argtypes = [vp, C.c_int]
-    L.dppr_set_tuning.argtypes = [vp, C.c_int, C.c_int]
+    L.dppr_set_tuning.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.dppr_load_window.argtypes = [vp, ip, ip, C.c_int32]
     L.dppr_set_batch.argtypes = [vp, ip, ip, u8p, C.c_int32]
     L.dppr_slide.argtypes = [vp, ip, ip, C.c_int32, ip]
@@ -92,6 +93,7 @@ def lib():
     L.dppr_inspect.argtypes = [vp, C.c_int32, C.c_int, C.c_double, ip, ip]
     L.dppr_read_graph.argtypes = [vp, C.c_int32, ip, ip, ip]
     L.dppr_graph_edges.argtypes = [vp, C.c_int32, ip]
+    L.dppr_read_out_graph.argtypes = [vp, C.c_int32, ip, ip]
     L.dppr_trace_enable.argtypes = [vp, C.c_int32, C.c_int]
     L.dppr_trace_get.argtypes = [vp, C.c_int32, i64p, i64p, i64p, ip]
     L.dppr_synchronize.argtypes = [vp]
@@ -119,7 +121,7 @@ class Engine:
     """
 
     def __init__(self, V, W, directed, max_batch, n_epochs=1, device=0, schedule=SCHEDULE_EAGER,
-                 hub_min_degree=None, big_row_edges=None):
+                 hub_min_degree=None, big_row_edges=None, pull_min_frontier=None):
         self._L = lib()
         self._h = C.c_void_p()
         self.V, self.W, self.directed, self.c = int(V), int(W), int(directed), int(max_batch)
@@ -128,9 +130,9 @@ class Engine:
             self._h = C.c_void_p()
             raise DpprError(f"dppr_create: {self._L.dppr_strerror(rc).decode()}")
         self.set_schedule(schedule)
-        if hub_min_degree is not None or big_row_edges is not None:
-            self._ck(self._L.dppr_set_tuning(self._h, int(hub_min_degree or 256), int(big_row_edges or 512)),
-                     "set_tuning")
+        if hub_min_degree is not None or big_row_edges is not None or pull_min_frontier is not None:
+            self._ck(self._L.dppr_set_tuning(self._h, int(hub_min_degree or 256), int(big_row_edges or 512),
+                                             int(pull_min_frontier or 0)), "set_tuning")
 
     def _ck(self, rc, what):
         if rc:
@@ -230,6 +232,16 @@ class Engine:
         self._ck(self._L.dppr_read_graph(self._h, int(epoch), row.ctypes.data_as(ip), col.ctypes.data_as(ip),
                                          deg.ctypes.data_as(ip)), "read_graph")
         return row, col[:ne.value], deg
+
+    def read_out_graph(self, epoch=-1):
+        ne = C.c_int32(0)
+        self._ck(self._L.dppr_graph_edges(self._h, int(epoch), C.byref(ne)), "graph_edges")
+        row = np.empty(self.V + 1, dtype=np.int32)
+        col = np.empty(max(ne.value, 1), dtype=np.int32)
+        ip = C.POINTER(C.c_int32)
+        self._ck(self._L.dppr_read_out_graph(self._h, int(epoch), row.ctypes.data_as(ip), col.ctypes.data_as(ip)),
+                 "read_out_graph")
+        return row, col[:ne.value]
 
     def trace_enable(self, slot, on=True):
         self._ck(self._L.dppr_trace_enable(self._h, slot, int(on)), "trace_enable")

@@ -43,13 +43,14 @@ typedef enum dppr_status {
 
 /* Push schedule. Both are legal interleavings of the reference kernels
  * (gpu/ExpandRev.cuh:8-183 + :708-743); see DESIGN.md "Schedules".
- *   EAGER : one kernel per iteration; a frontier vertex's residual is taken with an
- *           atomic exchange at the moment it is pushed (reads whatever has arrived,
- *           like the racy `ru = residual[u]` of ExpandUnifiedRev). Production mode.
+ *   EAGER : sparse (push) iterations take a frontier vertex's residual with an atomic
+ *           exchange at the moment it is pushed (reads whatever has arrived, like the
+ *           racy `ru = residual[u]` of ExpandUnifiedRev); dense iterations run as pull
+ *           sweeps, which are synchronous by construction. Production mode.
  *   SYNC  : every frontier residual is snapshotted before any push of the iteration
- *           lands; results are independent of thread scheduling up to the rounding
- *           of the atomic sums, and the per-iteration frontier SETS equal the
- *           oracle's synchronous schedule exactly. Validation mode. */
+ *           lands, in sparse iterations too; results are independent of thread
+ *           scheduling up to the rounding of the sums, and the per-iteration frontier
+ *           SETS equal the oracle's synchronous schedule exactly. Validation mode. */
 #define DPPR_SCHEDULE_EAGER 0
 #define DPPR_SCHEDULE_SYNC 1
 
@@ -61,6 +62,7 @@ typedef struct dppr_stats_t {
     int64_t records;      /* batch records applied by IncrementalBatchUpdate */
     int64_t inspected;    /* vertices scanned by full Inspect passes */
     int64_t batches;      /* dppr_update calls */
+    int64_t pull_iterations; /* iterations evaluated as a dense pull sweep (subset of iterations) */
     int64_t algorithmic_bytes; /* 16V + 45L + sum(72F + 24E + 4N) per batch */
     double gpu_ms;        /* sum of event-timed regions */
     double push_ms;       /* sum of per-launch event times of the push kernel (profiling on only) */
@@ -90,12 +92,14 @@ int dppr_set_schedule(dppr_engine *e, int schedule);
  * hipEvent pair on the engine's stream and summed into dppr_stats_t.push_ms. Off by default
  * (the extra events perturb the whole-batch time slightly). */
 int dppr_set_profiling(dppr_engine *e, int on);
-/* Load-balance knobs of the push kernels (defaults 256 / 512); only valid right after
- * dppr_create. hub_min_degree: out-degree from which a vertex's incoming pushes are
- * aggregated in LDS (at most 2048 hubs per epoch); big_row_edges: in-degree from which a
- * frontier vertex's row is expanded by the whole grid. Results never depend on them beyond
- * floating-point summation order; tests lower them so small graphs exercise both paths. */
-int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges);
+/* Execution-path knobs (defaults 256 / 512 / 0); only valid right after dppr_create.
+ * hub_min_degree: out-degree from which a vertex's incoming pushes are aggregated in LDS (at
+ * most 2048 hubs per epoch); big_row_edges: in-degree from which a frontier vertex's row is
+ * expanded by the whole grid; pull_min_frontier: frontier size from which an iteration is
+ * evaluated as a dense pull sweep instead of push atomics (0 = auto: max(4096, edges/16),
+ * negative = never). Results never depend on them beyond floating-point summation order;
+ * tests set them so small graphs exercise every path. */
+int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges, int pull_min_frontier);
 
 /* ---- graph side (UNTIMED in the reference's metric) --------------------- */
 
@@ -165,6 +169,8 @@ int dppr_inspect(dppr_engine *e, int32_t slot, int phase, double eps, int32_t *o
  * (any may be NULL). */
 int dppr_read_graph(dppr_engine *e, int32_t epoch, int32_t *row_ptr, int32_t *col, int32_t *out_degree);
 int dppr_graph_edges(dppr_engine *e, int32_t epoch, int32_t *out_directed_edges);
+/* The out-CSR the pull sweep reads (rows sorted ascending). row_ptr: V+1, col: directed edges. */
+int dppr_read_out_graph(dppr_engine *e, int32_t epoch, int32_t *row_ptr, int32_t *col);
 
 /* Frontier trace (test hook): when enabled the host loop copies every iteration's
  * frontier back. dppr_trace_get returns them concatenated: offsets has n_iters+1

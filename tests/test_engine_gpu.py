@@ -26,8 +26,11 @@ INVARIANT_TOL = 1e-13   # rounding only
 
 # load-balance paths: default thresholds (no hubs / big rows on these small graphs) and
 # lowered ones that send most pushes through the LDS hub table and the big-row kernel
-TUNINGS = [dict(), dict(hub_min_degree=3, big_row_edges=8), dict(hub_min_degree=1, big_row_edges=1)]
-TUNING_IDS = ["default", "hubs+bigrows", "all-hub-all-big"]
+# and the three iteration policies: never pull, always pull, pull only for large frontiers
+TUNINGS = [dict(pull_min_frontier=-1), dict(hub_min_degree=3, big_row_edges=8, pull_min_frontier=-1),
+           dict(hub_min_degree=1, big_row_edges=1, pull_min_frontier=-1), dict(pull_min_frontier=1),
+           dict(hub_min_degree=3, big_row_edges=8, pull_min_frontier=40), dict()]
+TUNING_IDS = ["push-only", "push-hubs+bigrows", "push-all-hub-all-big", "pull-only", "mixed-pull>=40", "default"]
 
 
 def make(directed, schedule=eng.SCHEDULE_EAGER, scale=9, edges=6000, seed=11, W=600, c=6, eps=1e-9, n_epochs=1,
@@ -44,6 +47,10 @@ def check_csr(sc):
     assert np.array_equal(row, orow)
     assert np.array_equal(col, sorted_csr(orow, ocol))
     assert np.array_equal(deg, sc.g.deg())
+    row, col = sc.e.read_out_graph()          # the out-CSR of the pull sweep
+    orow, ocol = sc.g.flatten(0)
+    assert np.array_equal(row, orow)
+    assert np.array_equal(col, sorted_csr(orow, ocol))
 
 
 @pytest.mark.parametrize("directed", [1, 0])
