@@ -21,6 +21,8 @@
 
 using namespace dppr;
 
+static constexpr int MAX_CHUNK = 64;
+
 namespace {
 
 struct Epoch {
@@ -47,6 +49,7 @@ struct Slot {
     int *neg = nullptr;     // phase-1 candidates
     int *cnt = nullptr;     // [0..2] rotating frontier counters, [3] neg candidates, [4] scratch, [5..6] big-row counters
     BigItem *big = nullptr; // deferred big rows of the current iteration
+    int *log = nullptr;     // per-chunk log: frontier size seen by each enqueued iteration
     long long iter_seq = 0; // running iteration number (selects the big-row counter)
     IterStats *dstats = nullptr;
     bool converged = false; // |r| <= eps everywhere (state after a completed solve)
@@ -68,8 +71,10 @@ struct dppr_engine {
     int bits = 1; // bits of a vertex id
     int schedule = DPPR_SCHEDULE_EAGER;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t evpool[2 * 64] = {};
     bool profiling = false;
+    int chunk_iters = 8; // iterations enqueued between two host read-backs of the frontier size
     // window ring, stream order
     int *w1 = nullptr, *w2 = nullptr;
     int head = 0;
@@ -195,27 +200,28 @@ int read_count(dppr_engine *e, const int *dptr, int *out) {
 
 // Frontier loop: PPRRevPushGPU::ExecuteOptimized's while(1) (gpu/PPRRevPushGPU.cuh:106-130).
 // On entry s.ft[buf] holds the frontier and s.cnt[cur] its size; cnt[(cur+1)%3] is zero and
-// the dense vector s.x is all zero (no snapshot taken yet).
-// Every iteration is either SPARSE (push kernels, atomics) or DENSE (pull sweep, no atomics);
-// the choice only changes which hardware path evaluates the same sums.
+// both dense vectors s.x / s.x2 are all zero (no snapshot taken yet).
+//
+// The reference reads the frontier count back after EVERY iteration (blocking 4-byte D2H,
+// :107). Here iterations are enqueued in CHUNKS: every kernel takes F from device memory,
+// rotates the three counters itself and exits at once when F == 0, so the host only reads
+// the count (and the per-iteration log of F) once per chunk. The host also picks, per chunk,
+// how the iterations are evaluated: SPARSE (push kernels, atomics) or DENSE (pull sweep, no
+// atomics) -- the same sums either way.
 int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, double eps, int buf, int cur) {
-    bool pending = false;     // a profiled launch awaits its event read-out
-    bool dense_valid = false; // s.x holds the snapshot of the current frontier (p already updated)
     const int pull_min = e->pull_min_frontier > 0   ? e->pull_min_frontier
                          : e->pull_min_frontier < 0 ? 0x7fffffff
                                                     : std::max(4096, e->Ed / 16);
-    for (int it = 0;; ++it) {
-        int F = 0;
-        int rc = read_count(e, s.cnt + cur, &F);
-        if (rc) return rc;
-        if (pending) { // the stream is idle after read_count's synchronize
-            float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, e->ev2, e->ev3));
-            s.st.push_ms += ms;
-            s.st.push_launches++;
-            pending = false;
-        }
-        if (F == 0) break;
+    const bool sync_sched = e->schedule == DPPR_SCHEDULE_SYNC;
+    const HubTable hubs{ep.hub_v, ep.hub_degp1, ep.n_hubs};
+    // the sparse grid must cover the largest frontier a push chunk can meet
+    const int push_grid = pull_min == 0x7fffffff ? 2048 : std::min(2048, std::max(64, (pull_min * 4 / WAVE + 3) / 4));
+    bool dense_valid = false; // s.x holds the snapshot of the current frontier (p already updated)
+    bool any_pull = false;
+    int F = 0, prevF = 0;
+    int rc = read_count(e, s.cnt + cur, &F);
+    if (rc) return rc;
+    for (int it = 0; F > 0;) {
         if (it >= e->max_iters) return fail(e, DPPR_ERR_NOT_CONVERGED, "iteration cap hit");
         if (s.trace) {
             size_t old = s.trace_ids.size();
@@ -225,49 +231,74 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             HIP_TRY(hipStreamSynchronize(e->stream));
             s.trace_off.push_back((int64_t)s.trace_ids.size());
         }
-        s.st.iterations++;
-        s.st.sum_F += F;
-        const int nxt = (cur + 1) % 3, zer = (cur + 2) % 3;
         const bool pull = F >= pull_min;
-        const bool need_snapshot = !dense_valid && (pull || e->schedule == DPPR_SCHEDULE_SYNC);
-        if (need_snapshot) {
-            hipLaunchKernelGGL(k_snapshot_dense, dim3(grid_for(F)), dim3(BLOCK), 0, e->stream, s.ft[buf], s.cnt + cur,
-                               s.r, s.p, s.x);
-            dense_valid = true;
-        }
-        if (e->profiling) HIP_TRY(hipEventRecord(e->ev2, e->stream));
-        if (pull) {
-            s.st.pull_iterations++;
-            hipLaunchKernelGGL(k_pull_iter, dim3(grid_for(e->V, PULL_BLOCK, 512)), dim3(PULL_BLOCK), 0, e->stream, e->V,
-                               ep.out_row_ptr, ep.out_col, s.x, s.x2, s.r, s.p, s.ft[buf ^ 1], s.cnt + nxt, s.cnt + zer,
-                               phase, eps, s.dstats);
-            std::swap(s.x, s.x2); // the sweep wrote every entry of x2: it is the next snapshot
-            dense_valid = true;
-        } else {
-            int *big_cnt = s.cnt + 5 + (int)(s.iter_seq & 1), *big_zero = s.cnt + 5 + (int)((s.iter_seq + 1) & 1);
-            s.iter_seq++;
-            const HubTable hubs{ep.hub_v, ep.hub_degp1, ep.n_hubs};
-            const int tiles = (F + WAVE - 1) / WAVE;
-            const int grid = std::min(std::max((tiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 1), 2048);
-            if (dense_valid)
-                hipLaunchKernelGGL(k_push_iter<true>, dim3(grid), dim3(BLOCK), 0, e->stream, s.ft[buf], s.cnt + cur,
-                                   s.ft[buf ^ 1], s.cnt + nxt, s.cnt + zer, s.x, ep.row_ptr, ep.adj, hubs, s.big,
-                                   big_cnt, big_zero, e->big_row, s.r, s.p, phase, eps, s.dstats);
-            else
-                hipLaunchKernelGGL(k_push_iter<false>, dim3(grid), dim3(BLOCK), 0, e->stream, s.ft[buf], s.cnt + cur,
-                                   s.ft[buf ^ 1], s.cnt + nxt, s.cnt + zer, s.x, ep.row_ptr, ep.adj, hubs, s.big,
-                                   big_cnt, big_zero, e->big_row, s.r, s.p, phase, eps, s.dstats);
-            hipLaunchKernelGGL(k_push_big, dim3(512), dim3(BLOCK), 0, e->stream, s.big, big_cnt, s.ft[buf ^ 1],
-                               s.cnt + nxt, ep.adj, hubs, s.r, phase, eps, s.dstats);
-            dense_valid = false; // the push consumed (and zeroed) the snapshot
+        int n;
+        if (s.trace || e->chunk_iters <= 1) n = 1;
+        else if (pull) n = e->chunk_iters;
+        else if ((long long)F * 4 >= pull_min) n = 1;          // about to turn dense: re-decide next iteration
+        else n = F > prevF ? 2 : e->chunk_iters;                // growing: short chunks; decaying tail: long
+        n = std::min(n, MAX_CHUNK);
+        for (int k = 0; k < n; ++k) {
+            const int nxt = (cur + 1) % 3, zer = (cur + 2) % 3;
+            int *log_slot = s.log + k;
+            if ((pull || sync_sched) && !dense_valid) {
+                hipLaunchKernelGGL(k_snapshot_dense, dim3(std::min(grid_for(std::max(F, pull_min == 0x7fffffff ? F : pull_min)), 1024)),
+                                   dim3(BLOCK), 0, e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x);
+                dense_valid = true;
+            }
+            if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k], e->stream));
+            if (pull) {
+                hipLaunchKernelGGL(k_pull_iter, dim3(grid_for(e->V, PULL_BLOCK, 512)), dim3(PULL_BLOCK), 0, e->stream, e->V,
+                                   s.cnt + cur, ep.out_row_ptr, ep.out_col, s.x, s.x2, s.r, s.p, s.ft[buf ^ 1],
+                                   s.cnt + nxt, s.cnt + zer, phase, eps, s.dstats, log_slot,
+                                   std::min(e->big_row, PULL_BIG_ROW_DEFAULT));
+                std::swap(s.x, s.x2); // the sweep wrote every entry of x2: it is the next snapshot
+                dense_valid = true;
+                any_pull = true;
+            } else {
+                int *big_cnt = s.cnt + 5 + (int)(s.iter_seq & 1), *big_zero = s.cnt + 5 + (int)((s.iter_seq + 1) & 1);
+                s.iter_seq++;
+                if (dense_valid)
+                    hipLaunchKernelGGL(k_push_iter<true>, dim3(push_grid), dim3(BLOCK), 0, e->stream, s.ft[buf],
+                                       s.cnt + cur, s.ft[buf ^ 1], s.cnt + nxt, s.cnt + zer, s.x, ep.row_ptr, ep.adj, hubs,
+                                       s.big, big_cnt, big_zero, e->big_row, s.r, s.p, phase, eps, s.dstats, log_slot);
+                else
+                    hipLaunchKernelGGL(k_push_iter<false>, dim3(push_grid), dim3(BLOCK), 0, e->stream, s.ft[buf],
+                                       s.cnt + cur, s.ft[buf ^ 1], s.cnt + nxt, s.cnt + zer, s.x, ep.row_ptr, ep.adj, hubs,
+                                       s.big, big_cnt, big_zero, e->big_row, s.r, s.p, phase, eps, s.dstats, log_slot);
+                hipLaunchKernelGGL(k_push_big, dim3(512), dim3(BLOCK), 0, e->stream, s.big, big_cnt, s.ft[buf ^ 1],
+                                   s.cnt + nxt, ep.adj, hubs, s.r, phase, eps, s.dstats);
+                dense_valid = false; // the push consumed (and zeroed) the snapshot
+            }
+            if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k + 1], e->stream));
+            buf ^= 1;
+            cur = nxt;
         }
         HIP_TRY(hipGetLastError());
-        if (e->profiling) {
-            HIP_TRY(hipEventRecord(e->ev3, e->stream));
-            pending = true;
+        // one read-back per chunk: the new frontier size and the F of each iteration just run
+        HIP_TRY(hipMemcpyAsync(e->pinned, s.cnt + cur, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->pinned + 1, s.log, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (int k = 0; k < n; ++k) {
+            const int f = e->pinned[1 + k];
+            if (f <= 0) continue; // the frontier emptied inside the chunk: the rest were no-ops
+            s.st.iterations++;
+            s.st.sum_F += f;
+            if (pull) s.st.pull_iterations++;
+            if (e->profiling) {
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, e->evpool[2 * k], e->evpool[2 * k + 1]));
+                s.st.push_ms += ms;
+                s.st.push_launches++;
+            }
         }
-        buf ^= 1;
-        cur = nxt;
+        prevF = F;
+        F = e->pinned[0];
+        it += n;
+    }
+    if (any_pull) { // leave both dense vectors all-zero for the next loop
+        HIP_TRY(hipMemsetAsync(s.x, 0, sizeof(double) * (size_t)e->V, e->stream));
+        HIP_TRY(hipMemsetAsync(s.x2, 0, sizeof(double) * (size_t)e->V, e->stream));
     }
     return DPPR_OK;
 }
@@ -363,9 +394,8 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     HIP_TRY_C(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIP_TRY_C(hipEventCreate(&e->ev0));
     HIP_TRY_C(hipEventCreate(&e->ev1));
-    HIP_TRY_C(hipEventCreate(&e->ev2));
-    HIP_TRY_C(hipEventCreate(&e->ev3));
-    HIP_TRY_C(hipHostMalloc((void **)&e->pinned, 64, hipHostMallocDefault));
+    for (auto &ev : e->evpool) HIP_TRY_C(hipEventCreate(&ev));
+    HIP_TRY_C(hipHostMalloc((void **)&e->pinned, sizeof(int) * (MAX_CHUNK + 16), hipHostMallocDefault));
     const size_t Wn = (size_t)std::max(W, 1), Edn = (size_t)std::max(e->Ed, 1), Ln = (size_t)std::max(4 * c, 1);
     HIP_TRY_C(hipMalloc((void **)&e->w1, sizeof(int) * Wn));
     HIP_TRY_C(hipMalloc((void **)&e->w2, sizeof(int) * Wn));
@@ -412,7 +442,7 @@ void dppr_destroy(dppr_engine *e) {
     for (auto &s : e->slots) {
         (void)hipFree(s.p); (void)hipFree(s.r); (void)hipFree(s.x); (void)hipFree(s.x2);
         (void)hipFree(s.ft[0]); (void)hipFree(s.ft[1]); (void)hipFree(s.neg);
-        (void)hipFree(s.cnt); (void)hipFree(s.dstats); (void)hipFree(s.big);
+        (void)hipFree(s.cnt); (void)hipFree(s.dstats); (void)hipFree(s.big); (void)hipFree(s.log);
     }
     for (auto &ep : e->epochs) {
         (void)hipFree(ep.row_ptr); (void)hipFree(ep.adj); (void)hipFree(ep.out_row_ptr); (void)hipFree(ep.out_col); (void)hipFree(ep.b1); (void)hipFree(ep.b2);
@@ -426,8 +456,8 @@ void dppr_destroy(dppr_engine *e) {
     if (e->pinned) (void)hipHostFree(e->pinned);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
-    if (e->ev2) (void)hipEventDestroy(e->ev2);
-    if (e->ev3) (void)hipEventDestroy(e->ev3);
+    for (auto &ev : e->evpool)
+        if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -444,12 +474,13 @@ int dppr_set_profiling(dppr_engine *e, int on) {
     return DPPR_OK;
 }
 
-int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges, int pull_min_frontier) {
+int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges, int pull_min_frontier, int chunk_iters) {
     if (!e || hub_min_degree < 1 || big_row_edges < 1 || e->loaded || !e->slots.empty())
         return fail(e, DPPR_ERR_INVALID, "set_tuning: call right after dppr_create, values >= 1");
     e->hub_min_degree = hub_min_degree;
     e->big_row = big_row_edges;
     e->pull_min_frontier = pull_min_frontier;
+    if (chunk_iters > 0) e->chunk_iters = std::min(chunk_iters, MAX_CHUNK);
     return DPPR_OK;
 }
 
@@ -561,6 +592,7 @@ int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
     HIP_TRY(hipMalloc((void **)&s.ft[1], sizeof(int) * V));
     HIP_TRY(hipMalloc((void **)&s.neg, sizeof(int) * (size_t)std::max(4 * e->c, 1)));
     HIP_TRY(hipMalloc((void **)&s.cnt, sizeof(int) * 8));
+    HIP_TRY(hipMalloc((void **)&s.log, sizeof(int) * MAX_CHUNK));
     // a row is deferred only if it has >= big_row edges, so at most Ed / big_row of them exist
     HIP_TRY(hipMalloc((void **)&s.big, sizeof(BigItem) * ((size_t)e->Ed / (size_t)std::max(e->big_row, 1) + 64)));
     HIP_TRY(hipMalloc((void **)&s.dstats, sizeof(IterStats)));

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(BLOCK) void k_push_iter(const int *__restrict__ ft,
                                                      HubTable hubs, BigItem *__restrict__ big, int *__restrict__ big_cnt,
                                                      int *__restrict__ big_zero, int big_row, double *__restrict__ r,
                                                      double *__restrict__ p, int phase, double eps,
-                                                     IterStats *__restrict__ stats) {
+                                                     IterStats *__restrict__ stats, int *__restrict__ log_slot) {
     __shared__ int s_scan[WAVES_PER_BLOCK][WAVE + 1];
     __shared__ int s_start[WAVES_PER_BLOCK][WAVE];
     __shared__ double s_ru[WAVES_PER_BLOCK][WAVE];
@@ -329,14 +329,16 @@ __global__ __launch_bounds__(BLOCK) void k_push_iter(const int *__restrict__ ft,
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *cnt_zero = 0;
         *big_zero = 0;
+        *log_slot = F; // frontier size of this iteration (0: the loop is over), read by the host per chunk
     }
+    const int n_tiles = (F + WAVE - 1) / WAVE;
+    if ((int)blockIdx.x >= n_tiles) return; // the grid is sized for the largest sparse frontier
     for (int i = threadIdx.x; i < hubs.n; i += BLOCK) s_hub[i] = 0.0;
     __syncthreads();
 
     OutStage out{s_out[w], 0, ft_out, cnt_out};
     unsigned long long edges = 0; // wave-uniform
 
-    const int n_tiles = (F + WAVE - 1) / WAVE;
     // tile t -> (block t % gridDim, wave (t / gridDim) % 4): small frontiers spread over CUs
     for (int t = blockIdx.x + gridDim.x * w; t < n_tiles; t += gridDim.x * WAVES_PER_BLOCK) {
         const int i = t * WAVE + lane;
@@ -492,84 +494,52 @@ __global__ __launch_bounds__(BLOCK) void k_push_big(const BigItem *__restrict__ 
 constexpr int PULL_BLOCK = 1024; // 16 waves: few workgroups -> few counter atomics per sweep
 constexpr int PULL_WAVES = PULL_BLOCK / WAVE;
 constexpr int PULL_OUT_CAP = 512; // per-wave staged list entries
-__global__ __launch_bounds__(PULL_BLOCK) void k_pull_iter(int V, const int *__restrict__ out_row_ptr,
-                                                          const int *__restrict__ out_col,
-                                                          const double *__restrict__ x, double *__restrict__ x_new,
-                                                          double *__restrict__ r, double *__restrict__ p,
-                                                          int *__restrict__ ft_out, int *__restrict__ cnt_out,
-                                                          int *__restrict__ cnt_zero, int phase, double eps,
-                                                          IterStats *__restrict__ stats) {
+constexpr int PULL_BIG_ROW_DEFAULT = 128; // rows at least this long are gathered by the whole workgroup
+constexpr int PULL_BIG_CAP = 64;  // such rows per workgroup pass (more: the owning wave does them itself)
+constexpr int PU = 2;             // gathers in flight per lane (register budget: 8 waves/SIMD)
+
+struct PullBig {
+    int v, rs, d;
+    double rv, xv;
+};
+
+// wave-wide sum (butterfly; every lane gets the total, fixed order -> deterministic)
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int d = WAVE / 2; d >= 1; d >>= 1) x += __shfl_xor(x, d, WAVE);
+    return x;
+}
+
+__global__ __launch_bounds__(PULL_BLOCK, 8) void k_pull_iter(int V, const int *__restrict__ cnt_in,
+                                                             const int *__restrict__ out_row_ptr,
+                                                             const int *__restrict__ out_col,
+                                                             const double *__restrict__ x, double *__restrict__ x_new,
+                                                             double *__restrict__ r, double *__restrict__ p,
+                                                             int *__restrict__ ft_out, int *__restrict__ cnt_out,
+                                                             int *__restrict__ cnt_zero, int phase, double eps,
+                                                             IterStats *__restrict__ stats,
+                                                             int *__restrict__ log_slot, int pull_big_row) {
     __shared__ int s_scan[PULL_WAVES][WAVE + 1];
+    __shared__ int s_start[PULL_WAVES][WAVE];
     __shared__ double s_acc[PULL_WAVES][WAVE];
     __shared__ int s_out[PULL_WAVES][PULL_OUT_CAP];
     __shared__ int s_cnt[PULL_WAVES];
     __shared__ unsigned long long s_edges[PULL_WAVES];
+    __shared__ PullBig s_big[PULL_BIG_CAP];
+    __shared__ double s_bigacc[PULL_BIG_CAP];
+    __shared__ int s_nbig;
     __shared__ int s_base;
     const int lane = lane_id(), w = wave_id();
-    if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_zero = 0;
-    int n_out = 0; // wave-uniform
+    const int F = *cnt_in;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *cnt_zero = 0;
+        *log_slot = F;
+    }
+    if (F == 0) return; // empty frontier: x / x_new are not touched
+    int n_out = 0;      // wave-uniform
     unsigned long long edges = 0;
 
-    const int n_tiles = (V + WAVE - 1) / WAVE;
-    for (int t = blockIdx.x * PULL_WAVES + w; t < n_tiles; t += gridDim.x * PULL_WAVES) {
-        const int v = t * WAVE + lane;
-        const bool valid = v < V;
-        int rs = 0, d = 0;
-        double rv = 0.0, xv = 0.0;
-        if (valid) {
-            rs = out_row_ptr[v];
-            d = out_row_ptr[v + 1] - rs;
-            rv = r[v];
-            xv = x[v];
-        }
-        const int incl = wave_inclusive_scan(d);
-        const int total = __shfl(incl, WAVE - 1, WAVE);
-        double rn = rv;
-        if (total) { // wave-uniform: tiles of isolated vertices skip the gather machinery
-            const int base = __shfl(rs, 0, WAVE); // rows of the tile are contiguous from here
-            s_scan[w][lane] = incl - d;
-            if (lane == 0) s_scan[w][WAVE] = total;
-            s_acc[w][lane] = rv;
-            __builtin_amdgcn_wave_barrier();
-            for (int e0 = 0; e0 < total; e0 += WAVE * UNROLL) {
-                int owner[UNROLL];
-                double xu[UNROLL];
-#pragma unroll
-                for (int k = 0; k < UNROLL; ++k) {
-                    const int e = e0 + k * WAVE + lane;
-                    owner[k] = -1;
-                    xu[k] = 0.0;
-                    if (e < total) {
-                        int lo = 0, hi = WAVE;
-#pragma unroll
-                        for (int s = 0; s < 6; ++s) {
-                            const int mid = (lo + hi) >> 1;
-                            if (s_scan[w][mid] <= e) lo = mid; else hi = mid;
-                        }
-                        owner[k] = lo;
-                        xu[k] = x[out_col[base + e]];
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < UNROLL; ++k) {
-                    const bool nz = xu[k] != 0.0;
-                    if (nz) {
-                        const int dk = s_scan[w][owner[k] + 1] - s_scan[w][owner[k]];
-                        lds_add(&s_acc[w][owner[k]], ONE_MINUS_ALPHA * xu[k] / (double)(dk + 1));
-                    }
-                    edges += (unsigned long long)__popcll(__ballot(nz));
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            rn = s_acc[w][lane];
-        }
-        if (xv != 0.0) rn -= xv;
-        const bool lg = valid && legal(rn, phase, eps);
-        if (valid) {
-            if (rn != rv) r[v] = rn;
-            x_new[v] = lg ? rn : 0.0; // every entry is rewritten: x_new is a complete snapshot
-            if (lg) p[v] += ALPHA * rn;
-        }
+    auto emit = [&](bool lg, int v) { // stage a next-frontier vertex (all lanes of the wave call this)
         const uint64_t m = __ballot(lg);
         if (m) {
             if (n_out + WAVE > PULL_OUT_CAP) { // overflow: flush this wave's tile (rare)
@@ -582,7 +552,124 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_pull_iter(int V, const int *__re
             if (lg) s_out[w][n_out + mbcnt(m)] = v;
             n_out += __popcll(m);
         }
-        __builtin_amdgcn_wave_barrier();
+    };
+    auto finish = [&](bool valid, int v, double rv, double xv, double rn) { // repair, threshold, next snapshot
+        if (xv != 0.0) rn -= xv;
+        const bool lg = valid && legal(rn, phase, eps);
+        if (valid) {
+            if (rn != rv) r[v] = rn;
+            x_new[v] = lg ? rn : 0.0; // every entry is rewritten: x_new is a complete snapshot
+            if (lg) p[v] += ALPHA * rn;
+        }
+        emit(lg, v);
+    };
+
+    const int n_tiles = (V + WAVE - 1) / WAVE;
+    const int n_groups = (n_tiles + PULL_WAVES - 1) / PULL_WAVES; // one tile per wave per pass
+    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {      // workgroup-uniform loop
+        if (threadIdx.x == 0) s_nbig = 0;
+        __syncthreads();
+        const int t = g * PULL_WAVES + w;
+        const int v = t * WAVE + lane;
+        const bool valid = v < V;
+        int rs = 0, d = 0;
+        double rv = 0.0, xv = 0.0;
+        if (valid) {
+            rs = out_row_ptr[v];
+            d = out_row_ptr[v + 1] - rs;
+            rv = r[v];
+            xv = x[v];
+        }
+        // long rows go to the workgroup list (phase B); the owning lane keeps them only if the list is full
+        bool deferred = false;
+        if (d >= pull_big_row) {
+            const int slot = atomicAdd(&s_nbig, 1);
+            if (slot < PULL_BIG_CAP) {
+                s_big[slot] = PullBig{v, rs, d, rv, xv};
+                s_bigacc[slot] = 0.0;
+                deferred = true;
+            }
+        }
+        const int dd = deferred ? 0 : d;
+        const int incl = wave_inclusive_scan(dd);
+        const int total = __shfl(incl, WAVE - 1, WAVE);
+        double rn = rv;
+        if (total) { // wave-uniform: tiles without (short) rows skip the gather machinery
+            s_scan[w][lane] = incl - dd; // deferred rows have length 0 here and are never visited
+            s_start[w][lane] = rs;
+            if (lane == 0) s_scan[w][WAVE] = total;
+            s_acc[w][lane] = rv;
+            __builtin_amdgcn_wave_barrier();
+            for (int e0 = 0; e0 < total; e0 += WAVE * PU) {
+                int owner[PU];
+                double xu[PU];
+#pragma unroll
+                for (int k = 0; k < PU; ++k) {
+                    const int e = e0 + k * WAVE + lane;
+                    owner[k] = -1;
+                    xu[k] = 0.0;
+                    if (e < total) {
+                        int lo = 0, hi = WAVE;
+#pragma unroll
+                        for (int s = 0; s < 6; ++s) {
+                            const int mid = (lo + hi) >> 1;
+                            if (s_scan[w][mid] <= e) lo = mid; else hi = mid;
+                        }
+                        owner[k] = lo;
+                        xu[k] = x[out_col[s_start[w][lo] + (e - s_scan[w][lo])]];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < PU; ++k) {
+                    const bool nz = xu[k] != 0.0;
+                    if (nz) {
+                        const int dk = s_scan[w][owner[k] + 1] - s_scan[w][owner[k]];
+                        lds_add(&s_acc[w][owner[k]], ONE_MINUS_ALPHA * xu[k] / (double)(dk + 1));
+                    }
+                    edges += (unsigned long long)__popcll(__ballot(nz));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            rn = s_acc[w][lane];
+        }
+        finish(valid && !deferred, v, rv, xv, rn); // deferred vertices are finished in phase C
+
+        // ---- phase B: the workgroup's long rows, 16 waves x 64 lanes x PU gathers per pass ----
+        __syncthreads();
+        const int nbig = min(s_nbig, PULL_BIG_CAP);
+        for (int b = 0; b < nbig; ++b) {
+            const PullBig big = s_big[b];
+            double part = 0.0;
+            for (int e0 = w * WAVE * PU; e0 < big.d; e0 += PULL_WAVES * WAVE * PU) {
+                double xu[PU];
+#pragma unroll
+                for (int k = 0; k < PU; ++k) {
+                    const int e = e0 + k * WAVE + lane;
+                    xu[k] = e < big.d ? x[out_col[big.rs + e]] : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < PU; ++k) {
+                    const bool nz = xu[k] != 0.0;
+                    if (nz) part += ONE_MINUS_ALPHA * xu[k] / (double)(big.d + 1);
+                    edges += (unsigned long long)__popcll(__ballot(nz));
+                }
+            }
+            part = wave_sum(part);
+            if (lane == 0 && part != 0.0) lds_add(&s_bigacc[b], part);
+        }
+        __syncthreads();
+        // ---- phase C: finish the long-row vertices (wave 0, one lane each) ----
+        if (w == 0) {
+            const bool has = lane < nbig;
+            PullBig big{0, 0, 0, 0.0, 0.0};
+            double acc = 0.0;
+            if (has) {
+                big = s_big[lane];
+                acc = s_bigacc[lane];
+            }
+            finish(has, big.v, big.rv, big.xv, big.rv + acc);
+        }
+        __syncthreads();
     }
     // workgroup flush of the sparse list: ONE counter atomic per 1024-thread workgroup
     if (lane == 0) s_cnt[w] = n_out;

@@ -29,8 +29,10 @@ INVARIANT_TOL = 1e-13   # rounding only
 # and the three iteration policies: never pull, always pull, pull only for large frontiers
 TUNINGS = [dict(pull_min_frontier=-1), dict(hub_min_degree=3, big_row_edges=8, pull_min_frontier=-1),
            dict(hub_min_degree=1, big_row_edges=1, pull_min_frontier=-1), dict(pull_min_frontier=1),
-           dict(hub_min_degree=3, big_row_edges=8, pull_min_frontier=40), dict()]
-TUNING_IDS = ["push-only", "push-hubs+bigrows", "push-all-hub-all-big", "pull-only", "mixed-pull>=40", "default"]
+           dict(hub_min_degree=3, big_row_edges=8, pull_min_frontier=40), dict(),
+           dict(pull_min_frontier=40, chunk_iters=1), dict(hub_min_degree=3, pull_min_frontier=60, chunk_iters=3)]
+TUNING_IDS = ["push-only", "push-hubs+bigrows", "push-all-hub-all-big", "pull-only", "mixed-pull>=40", "default",
+              "mixed-chunk1", "mixed-chunk3"]
 
 
 def make(directed, schedule=eng.SCHEDULE_EAGER, scale=9, edges=6000, seed=11, W=600, c=6, eps=1e-9, n_epochs=1,
@@ -157,6 +159,26 @@ def test_sync_schedule_frontier_sets_bit_exact(directed, tuning):
         compare()
     st = sc.e.stats(sc.slot)
     assert st["sum_E"] == sc.s.stats()["E"] and st["sum_F"] == sc.s.stats()["F"]
+
+
+@pytest.mark.parametrize("tuning", TUNINGS, ids=TUNING_IDS)
+@pytest.mark.parametrize("directed", [1, 0])
+def test_sync_schedule_chunked_launches_same_work(directed, tuning):
+    """Without the frontier trace the loop enqueues iterations in chunks (one host read-back per
+    chunk). The synchronous schedule must still do exactly the oracle's work: same number of
+    iterations, same sum of frontier sizes, same traversed edges, p/r to rounding."""
+    sc = make(directed, schedule=eng.SCHEDULE_SYNC, c=20, tuning=tuning)
+    sc.s.sync_execute(sc.g)
+    sc.e.init_solve(sc.slot, sc.eps)
+    for k in range(5):
+        if k:
+            assert sc.advance_graphs()
+            sc.s.sync_inc_execute(sc.g)
+            sc.e.update(sc.slot, sc.eps)
+        p, r = sc.e.read(sc.slot)
+        assert np.max(np.abs(p - sc.s.p)) < SYNC_TOL and np.max(np.abs(r - sc.s.r)) < SYNC_TOL
+        st, want = sc.e.stats(sc.slot), sc.s.stats()
+        assert (st["iterations"], st["sum_F"], st["sum_E"]) == (want["iters"], want["F"], want["E"])
 
 
 @pytest.mark.parametrize("tuning", TUNINGS, ids=TUNING_IDS)
