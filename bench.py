@@ -61,7 +61,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from dynamicppr_amd import datagen, engine as eng, stream as st
+    from dynamicppr_amd import datagen, engine as eng, shard, stream as st
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback)")
@@ -88,8 +88,8 @@ def main():
     max_batches = (len(e1) - W) // max(c, 1)
     if n_steps > max_batches:
         sys.exit(f"stream too short for {n_steps} batches (max {max_batches})")
-    sources = datagen.top_sources(V, e1, e2, W, directed, max(10, world))
-    source = int(sources[rank % len(sources)])
+    sources = datagen.top_sources(V, e1, e2, W, directed, 10)
+    source = shard.assign_sources(sources, rank, world, per_rank=1)[0]   # one top-10 source per GPU
 
     schedule = eng.SCHEDULE_EAGER if a.schedule == "eager" else eng.SCHEDULE_SYNC
     e = eng.Engine(V, W, directed, c, n_epochs=n_steps + 1, device=local_rank, schedule=schedule)
@@ -107,11 +107,9 @@ def main():
         n1, n2 = ss.new_arrays()
         e.slide(n1, n2)
 
-    def barrier():
+    def device_sync():
         torch.cuda.synchronize()
         e.synchronize()
-        if world > 1:
-            dist.barrier()
 
     # ---------------- warmup ----------------
     for k in range(1, a.warmup + 1):
@@ -119,19 +117,17 @@ def main():
     p0, r0 = e.read(slot)                         # state at the start of the timed region
     e.reset_stats(slot)
 
-    # ---------------- timed region: exactly K steps ----------------
-    barrier()
-    t0 = time.perf_counter()
-    ev_ms = 0.0
-    for k in range(a.warmup + 1, n_steps + 1):
-        ev_ms += e.update(slot, a.eps, epoch=k)
-    barrier()
-    dt = time.perf_counter() - t0
+    # ---------------- timed region: exactly K steps, barrier + synchronize on both sides ----------------
+    ev = [0.0]
+
+    def run_steps():
+        for k in range(a.warmup + 1, n_steps + 1):
+            ev[0] += e.update(slot, a.eps, epoch=k)
+
+    dt, _ = shard.timed_region(run_steps, device_sync, dist if world > 1 else None)
+    ev_ms = ev[0]
     stats = e.stats(slot)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    units = shard.aggregate_units(c * a.steps, dist if world > 1 else None)
 
     # ---------------- roofline of the dominant kernel (profiled replay of the same K steps) ----------------
     roof = None
@@ -159,7 +155,7 @@ def main():
             cpu = cpu_baseline(V, e1, e2, directed, W, c, source, a.eps, a.cpu_batches)
 
     if rank == 0:
-        value = world * c * a.steps / dt
+        value = units / dt
         line = {
             "metric": "edge-updates/sec (ppr_throughput); ms_per_step = mean per-batch PPR update time",
             "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -42,7 +42,8 @@ struct Epoch {
 };
 
 struct Slot {
-    int source = 0;
+    int source = 0;     // internal id
+    int source_ext = 0; // id the caller gave
     double *p = nullptr, *r = nullptr;
     double *x = nullptr, *x2 = nullptr; // dense per-iteration push amounts (x) and pull output (x2)
     int *ft[2] = {nullptr, nullptr};
@@ -104,6 +105,13 @@ struct dppr_engine {
     int newest = -1; // global id of newest epoch
     std::vector<Slot> slots;
     int *pinned = nullptr; // host-pinned readback words
+    // vertex compaction: external id <-> internal id (assigned on first appearance)
+    std::vector<int32_t> ext2int, int2ext;
+    int n_int = 0;
+    int *d_ext2int = nullptr;  // device copy of ext2int, refreshed on demand
+    bool map_dirty = true;
+    double *d_xfer = nullptr;  // V doubles: staging of p / r in external order
+    std::vector<int32_t> h_tmp1, h_tmp2;
     int max_iters = 1 << 20;
     std::string err;
 };
@@ -133,6 +141,35 @@ int fail(dppr_engine *e, int code, const char *msg) {
     return code;
 }
 
+inline int to_int(dppr_engine *e, int ext) { // external -> internal id, assigning a new one on first sight
+    int32_t &m = e->ext2int[(size_t)ext];
+    if (m < 0) {
+        m = e->n_int++;
+        e->int2ext.push_back(ext);
+        e->map_dirty = true;
+    }
+    return m;
+}
+
+// translate an id array; returns false if any id is outside [0, V)
+bool translate(dppr_engine *e, const int32_t *src, int n, std::vector<int32_t> &dst) {
+    dst.resize((size_t)std::max(n, 1));
+    for (int i = 0; i < n; ++i) {
+        const int v = src[i];
+        if (v < 0 || v >= e->V) return false;
+        dst[(size_t)i] = to_int(e, v);
+    }
+    return true;
+}
+
+int sync_map(dppr_engine *e) {
+    if (!e->map_dirty) return DPPR_OK;
+    HIP_TRY(hipMemcpyAsync(e->d_ext2int, e->ext2int.data(), sizeof(int) * (size_t)e->V, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->map_dirty = false;
+    return DPPR_OK;
+}
+
 Epoch *find_epoch(dppr_engine *e, int epoch) {
     if (e->newest < 0) return nullptr;
     if (epoch < 0) epoch = e->newest;
@@ -143,10 +180,11 @@ Epoch *find_epoch(dppr_engine *e, int epoch) {
 // Build row_ptr/adj of `ep` from the current window ring + outdeg.
 int build_csr(dppr_engine *e, Epoch &ep) {
     const int W = e->W, Ed = e->Ed;
+    const int NV = e->n_int; // only vertices that ever had an edge (or are a source) exist internally
     // hub directory: the (at most HUB_CAP) vertices of largest out-degree, at least hub_min_degree
     {
         HIP_TRY(hipMemsetAsync(e->hub_hist, 0, sizeof(int) * 33, e->stream));
-        hipLaunchKernelGGL(k_deg_hist, dim3(grid_for(e->V)), dim3(BLOCK), 0, e->stream, e->outdeg, e->V,
+        hipLaunchKernelGGL(k_deg_hist, dim3(grid_for(NV)), dim3(BLOCK), 0, e->stream, e->outdeg, NV,
                            e->hub_min_degree, e->hub_hist);
         int hist[32];
         HIP_TRY(hipMemcpyAsync(hist, e->hub_hist, sizeof(hist), hipMemcpyDeviceToHost, e->stream));
@@ -160,7 +198,7 @@ int build_csr(dppr_engine *e, Epoch &ep) {
         // every bucket > k fits; threshold = lower edge of bucket k+1
         const long long thresh = (long long)e->hub_min_degree << (k + 1);
         const int th = (int)std::min<long long>(thresh, 0x7fffffff);
-        hipLaunchKernelGGL(k_assign_hubs, dim3(grid_for(e->V)), dim3(BLOCK), 0, e->stream, e->outdeg, e->V, th,
+        hipLaunchKernelGGL(k_assign_hubs, dim3(grid_for(NV)), dim3(BLOCK), 0, e->stream, e->outdeg, NV, th,
                            e->hub_slot_of, ep.hub_v, ep.hub_degp1, e->hub_hist + 32);
         HIP_TRY(hipGetLastError());
         ep.n_hubs = (int)above;
@@ -173,6 +211,7 @@ int build_csr(dppr_engine *e, Epoch &ep) {
         HIP_TRY(rocprim::radix_sort_keys(e->sort_tmp, tmp, e->keys_a, e->keys_b, (size_t)Ed, 0u,
                                          (unsigned)(2 * e->bits), e->stream));
     }
+    // row pointers are filled for the whole id capacity: ids assigned later read as empty rows
     hipLaunchKernelGGL(k_build_csr, dim3(grid_for(std::max(Ed, e->V + 1))), dim3(BLOCK), 0, e->stream, e->keys_b, Ed,
                        e->V, e->bits, e->outdeg, e->hub_slot_of, ep.row_ptr, ep.adj);
     HIP_TRY(hipGetLastError());
@@ -229,6 +268,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             HIP_TRY(hipMemcpyAsync(s.trace_ids.data() + old, s.ft[buf], sizeof(int) * (size_t)F,
                                    hipMemcpyDeviceToHost, e->stream));
             HIP_TRY(hipStreamSynchronize(e->stream));
+            for (size_t i = old; i < s.trace_ids.size(); ++i) s.trace_ids[i] = e->int2ext[(size_t)s.trace_ids[i]];
             s.trace_off.push_back((int64_t)s.trace_ids.size());
         }
         const bool pull = F >= pull_min;
@@ -248,7 +288,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             }
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k], e->stream));
             if (pull) {
-                hipLaunchKernelGGL(k_pull_iter, dim3(grid_for(e->V, PULL_BLOCK, 512)), dim3(PULL_BLOCK), 0, e->stream, e->V,
+                hipLaunchKernelGGL(k_pull_iter, dim3(grid_for(e->n_int, PULL_BLOCK, 512)), dim3(PULL_BLOCK), 0, e->stream, e->n_int,
                                    s.cnt + cur, ep.out_row_ptr, ep.out_col, s.x, s.x2, s.r, s.p, s.ft[buf ^ 1],
                                    s.cnt + nxt, s.cnt + zer, phase, eps, s.dstats, log_slot,
                                    std::min(e->big_row, PULL_BIG_ROW_DEFAULT));
@@ -306,10 +346,10 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
 // full Inspect seeding + loop = ExecuteMainLoop(phase)
 int main_loop_inspect(dppr_engine *e, Slot &s, const Epoch &ep, int phase, double eps) {
     HIP_TRY(hipMemsetAsync(s.cnt, 0, sizeof(int) * 3, e->stream));
-    hipLaunchKernelGGL(k_inspect, dim3(grid_for(e->V, BLOCK * INSPECT_ITEMS)), dim3(BLOCK), 0, e->stream, s.r, e->V,
-                       phase, eps, s.ft[0], s.cnt + 0);
+    hipLaunchKernelGGL(k_inspect, dim3(grid_for(e->n_int, BLOCK * INSPECT_ITEMS)), dim3(BLOCK), 0, e->stream, s.r,
+                       e->n_int, phase, eps, s.ft[0], s.cnt + 0);
     HIP_TRY(hipGetLastError());
-    s.st.inspected += e->V;
+    s.st.inspected += e->n_int;
     return run_frontier_loop(e, s, ep, phase, eps, 0, 0);
 }
 
@@ -402,6 +442,10 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     HIP_TRY_C(hipMalloc((void **)&e->outdeg, sizeof(int) * (size_t)V));
     HIP_TRY_C(hipMemset(e->outdeg, 0, sizeof(int) * (size_t)V));
     HIP_TRY_C(hipMalloc((void **)&e->hub_slot_of, sizeof(int) * (size_t)V));
+    HIP_TRY_C(hipMalloc((void **)&e->d_ext2int, sizeof(int) * (size_t)V));
+    HIP_TRY_C(hipMalloc((void **)&e->d_xfer, sizeof(double) * (size_t)V));
+    e->ext2int.assign((size_t)V, -1);
+    e->int2ext.reserve(1024);
     HIP_TRY_C(hipMalloc((void **)&e->hub_hist, sizeof(int) * 64));
     HIP_TRY_C(hipMalloc((void **)&e->keys_a, sizeof(uint64_t) * Edn));
     HIP_TRY_C(hipMalloc((void **)&e->keys_b, sizeof(uint64_t) * Edn));
@@ -449,7 +493,7 @@ void dppr_destroy(dppr_engine *e) {
         (void)hipFree(ep.deg_after); (void)hipFree(ep.ins); (void)hipFree(ep.hub_v); (void)hipFree(ep.hub_degp1);
     }
     (void)hipFree(e->w1); (void)hipFree(e->w2); (void)hipFree(e->outdeg);
-    (void)hipFree(e->hub_slot_of); (void)hipFree(e->hub_hist);
+    (void)hipFree(e->hub_slot_of); (void)hipFree(e->hub_hist); (void)hipFree(e->d_ext2int); (void)hipFree(e->d_xfer);
     (void)hipFree(e->keys_a); (void)hipFree(e->keys_b); (void)hipFree(e->sort_tmp);
     for (int k = 0; k < 2; ++k) { (void)hipFree(e->su_k[k]); (void)hipFree(e->su_v[k]); }
     (void)hipFree(e->su_term); (void)hipFree(e->su_ins); (void)hipFree(e->su_tmp);
@@ -494,9 +538,36 @@ int dppr_synchronize(dppr_engine *e) {
 int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32_t n) {
     if (!e || n != e->W || (n > 0 && (!e1 || !e2))) return fail(e, DPPR_ERR_INVALID, "load_window: n must equal W");
     HIP_TRY(hipSetDevice(e->device));
+    {
+        // Number the window's vertices in a pseudo-random order (hash of the external id), not by
+        // first appearance: high-degree vertices show up early in a stream, and packing them into
+        // the first tiles would serialise the sweeps on a few workgroups.
+        std::vector<std::pair<uint64_t, int32_t>> fresh;
+        for (int k = 0; k < 2; ++k) {
+            const int32_t *a = k ? e2 : e1;
+            for (int i = 0; i < n; ++i) {
+                const int v = a[i];
+                if (v < 0 || v >= e->V) return fail(e, DPPR_ERR_INVALID, "load_window: vertex id out of range");
+                if (e->ext2int[(size_t)v] == -1) {
+                    e->ext2int[(size_t)v] = -2; // seen, not numbered yet
+                    uint64_t z = (uint64_t)v + 0x9E3779B97F4A7C15ull;
+                    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                    fresh.emplace_back(z ^ (z >> 31), v);
+                }
+            }
+        }
+        std::sort(fresh.begin(), fresh.end());
+        for (auto &kv : fresh) {
+            e->ext2int[(size_t)kv.second] = -1;
+            (void)to_int(e, kv.second);
+        }
+    }
+    if (!translate(e, e1, n, e->h_tmp1) || !translate(e, e2, n, e->h_tmp2))
+        return fail(e, DPPR_ERR_INVALID, "load_window: vertex id out of range");
     if (n > 0) {
-        HIP_TRY(hipMemcpyAsync(e->w1, e1, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(hipMemcpyAsync(e->w2, e2, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->w1, e->h_tmp1.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->w2, e->h_tmp2.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, e->stream));
     }
     e->head = 0;
     HIP_TRY(hipMemsetAsync(e->outdeg, 0, sizeof(int) * (size_t)e->V, e->stream));
@@ -521,8 +592,10 @@ int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32
 int dppr_set_batch(dppr_engine *e, const int32_t *b1, const int32_t *b2, const uint8_t *ins, int32_t L) {
     if (!e || L < 0 || L > 4 * e->c || (L > 0 && (!b1 || !b2 || !ins)))
         return fail(e, DPPR_ERR_INVALID, "set_batch: length exceeds 4*max_batch");
-    e->st_b1.assign(b1, b1 + L);
-    e->st_b2.assign(b2, b2 + L);
+    if (!translate(e, b1, L, e->st_b1) || !translate(e, b2, L, e->st_b2))
+        return fail(e, DPPR_ERR_INVALID, "set_batch: vertex id out of range");
+    e->st_b1.resize((size_t)L);
+    e->st_b2.resize((size_t)L);
     e->st_ins.assign(ins, ins + L);
     e->batch_staged = true;
     return DPPR_OK;
@@ -533,6 +606,10 @@ int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, 
         return fail(e, DPPR_ERR_INVALID, "slide: window not loaded or bad c");
     HIP_TRY(hipSetDevice(e->device));
     const int W = e->W;
+    if (!translate(e, n1, c, e->h_tmp1) || !translate(e, n2, c, e->h_tmp2))
+        return fail(e, DPPR_ERR_INVALID, "slide: vertex id out of range");
+    n1 = e->h_tmp1.data();
+    n2 = e->h_tmp2.data();
     // the c oldest edges sit at ring positions head .. head+c (mod W): retire their degrees,
     // overwrite them with the new edges, add the new degrees
     int done = 0;
@@ -580,7 +657,9 @@ int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
     if (!e || source < 0 || source >= e->V) return fail(e, DPPR_ERR_INVALID, "add_source: vertex out of range");
     HIP_TRY(hipSetDevice(e->device));
     Slot s;
-    s.source = source;
+    s.source_ext = source;
+    s.source = to_int(e, source);
+    source = s.source;
     const size_t V = (size_t)e->V;
     HIP_TRY(hipMalloc((void **)&s.p, sizeof(double) * V));
     HIP_TRY(hipMalloc((void **)&s.r, sizeof(double) * V));
@@ -707,18 +786,38 @@ int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *
 int dppr_read(dppr_engine *e, int32_t slot, double *p, double *r) {
     GET_SLOT(e, slot);
     HIP_TRY(hipSetDevice(e->device));
-    if (p) HIP_TRY(hipMemcpyAsync(p, s.p, sizeof(double) * (size_t)e->V, hipMemcpyDeviceToHost, e->stream));
-    if (r) HIP_TRY(hipMemcpyAsync(r, s.r, sizeof(double) * (size_t)e->V, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    int rc = sync_map(e);
+    if (rc) return rc;
+    const double *src[2] = {s.p, s.r};
+    double *dst[2] = {p, r};
+    for (int k = 0; k < 2; ++k) {
+        if (!dst[k]) continue;
+        hipLaunchKernelGGL(k_int_to_ext, dim3(grid_for(e->V)), dim3(BLOCK), 0, e->stream, src[k], e->d_ext2int, e->V,
+                           e->d_xfer);
+        HIP_TRY(hipMemcpyAsync(dst[k], e->d_xfer, sizeof(double) * (size_t)e->V, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
     return DPPR_OK;
 }
 
 int dppr_write(dppr_engine *e, int32_t slot, const double *p, const double *r) {
     GET_SLOT(e, slot);
     HIP_TRY(hipSetDevice(e->device));
-    if (p) HIP_TRY(hipMemcpyAsync(s.p, p, sizeof(double) * (size_t)e->V, hipMemcpyHostToDevice, e->stream));
-    if (r) HIP_TRY(hipMemcpyAsync(s.r, r, sizeof(double) * (size_t)e->V, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    // vertices that carry a value get an internal id first
+    for (int v = 0; v < e->V; ++v)
+        if ((p && p[v] != 0.0) || (r && r[v] != 0.0)) (void)to_int(e, v);
+    int rc = sync_map(e);
+    if (rc) return rc;
+    const double *src[2] = {p, r};
+    double *dst[2] = {s.p, s.r};
+    for (int k = 0; k < 2; ++k) {
+        if (!src[k]) continue;
+        HIP_TRY(hipMemcpyAsync(e->d_xfer, src[k], sizeof(double) * (size_t)e->V, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemsetAsync(dst[k], 0, sizeof(double) * (size_t)e->V, e->stream));
+        hipLaunchKernelGGL(k_ext_to_int, dim3(grid_for(e->V)), dim3(BLOCK), 0, e->stream, e->d_xfer, e->d_ext2int, e->V,
+                           dst[k]);
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
     s.converged = false;
     s.phase0_done = false;
     return DPPR_OK;
@@ -752,13 +851,14 @@ int dppr_inspect(dppr_engine *e, int32_t slot, int phase, double eps, int32_t *o
     if (!out_ids || !out_count || (phase != 0 && phase != 1)) return DPPR_ERR_INVALID;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemsetAsync(s.cnt + 4, 0, sizeof(int), e->stream));
-    hipLaunchKernelGGL(k_inspect, dim3(grid_for(e->V, BLOCK * INSPECT_ITEMS)), dim3(BLOCK), 0, e->stream, s.r, e->V,
-                       phase, eps, s.ft[1], s.cnt + 4);
+    hipLaunchKernelGGL(k_inspect, dim3(grid_for(e->n_int, BLOCK * INSPECT_ITEMS)), dim3(BLOCK), 0, e->stream, s.r,
+                       e->n_int, phase, eps, s.ft[1], s.cnt + 4);
     HIP_TRY(hipGetLastError());
     int n = 0;
     int rc = read_count(e, s.cnt + 4, &n);
     if (rc) return rc;
     if (n > 0) HIP_TRY(hipMemcpy(out_ids, s.ft[1], sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) out_ids[i] = e->int2ext[(size_t)out_ids[i]];
     *out_count = n;
     return DPPR_OK;
 }
@@ -770,21 +870,45 @@ int dppr_graph_edges(dppr_engine *e, int32_t epoch, int32_t *out) {
     return DPPR_OK;
 }
 
+// internal CSR (rows by internal id, columns internal) -> external CSR with ascending rows
+static void csr_to_external(const dppr_engine *e, const std::vector<int> &irow, const std::vector<int> &icol,
+                            int32_t *row_ptr, int32_t *col) {
+    int off = 0;
+    std::vector<int> tmp;
+    for (int v = 0; v < e->V; ++v) {
+        if (row_ptr) row_ptr[v] = off;
+        const int m = e->ext2int[(size_t)v];
+        if (m >= 0) {
+            tmp.clear();
+            for (int j = irow[(size_t)m]; j < irow[(size_t)m + 1]; ++j) tmp.push_back(e->int2ext[(size_t)icol[(size_t)j]]);
+            std::sort(tmp.begin(), tmp.end());
+            if (col) std::copy(tmp.begin(), tmp.end(), col + off);
+            off += (int)tmp.size();
+        }
+    }
+    if (row_ptr) row_ptr[e->V] = off;
+}
+
 int dppr_read_graph(dppr_engine *e, int32_t epoch, int32_t *row_ptr, int32_t *col, int32_t *out_degree) {
     if (!e) return DPPR_ERR_INVALID;
     GET_EPOCH(e, epoch);
     HIP_TRY(hipSetDevice(e->device));
-    if (row_ptr)
-        HIP_TRY(hipMemcpyAsync(row_ptr, ep.row_ptr, sizeof(int) * ((size_t)e->V + 1), hipMemcpyDeviceToHost, e->stream));
-    if (col && ep.Ed > 0) {
+    std::vector<int> irow((size_t)e->V + 1), icol((size_t)std::max(ep.Ed, 1)), ideg((size_t)e->V);
+    HIP_TRY(hipMemcpyAsync(irow.data(), ep.row_ptr, sizeof(int) * ((size_t)e->V + 1), hipMemcpyDeviceToHost, e->stream));
+    if (ep.Ed > 0) {
         int *tmp = reinterpret_cast<int *>(e->keys_a); // scratch
         hipLaunchKernelGGL(k_split_adj, dim3(grid_for(ep.Ed)), dim3(BLOCK), 0, e->stream, ep.adj, ep.Ed, tmp);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(col, tmp, sizeof(int) * (size_t)ep.Ed, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(icol.data(), tmp, sizeof(int) * (size_t)ep.Ed, hipMemcpyDeviceToHost, e->stream));
     }
-    if (out_degree)
-        HIP_TRY(hipMemcpyAsync(out_degree, e->outdeg, sizeof(int) * (size_t)e->V, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(ideg.data(), e->outdeg, sizeof(int) * (size_t)e->V, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    csr_to_external(e, irow, icol, row_ptr, col);
+    if (out_degree)
+        for (int v = 0; v < e->V; ++v) {
+            const int m = e->ext2int[(size_t)v];
+            out_degree[v] = m >= 0 ? ideg[(size_t)m] : 0;
+        }
     return DPPR_OK;
 }
 
@@ -792,12 +916,12 @@ int dppr_read_out_graph(dppr_engine *e, int32_t epoch, int32_t *row_ptr, int32_t
     if (!e) return DPPR_ERR_INVALID;
     GET_EPOCH(e, epoch);
     HIP_TRY(hipSetDevice(e->device));
-    if (row_ptr)
-        HIP_TRY(hipMemcpyAsync(row_ptr, ep.out_row_ptr, sizeof(int) * ((size_t)e->V + 1), hipMemcpyDeviceToHost,
-                               e->stream));
-    if (col && ep.Ed > 0)
-        HIP_TRY(hipMemcpyAsync(col, ep.out_col, sizeof(int) * (size_t)ep.Ed, hipMemcpyDeviceToHost, e->stream));
+    std::vector<int> irow((size_t)e->V + 1), icol((size_t)std::max(ep.Ed, 1));
+    HIP_TRY(hipMemcpyAsync(irow.data(), ep.out_row_ptr, sizeof(int) * ((size_t)e->V + 1), hipMemcpyDeviceToHost, e->stream));
+    if (ep.Ed > 0)
+        HIP_TRY(hipMemcpyAsync(icol.data(), ep.out_col, sizeof(int) * (size_t)ep.Ed, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    csr_to_external(e, irow, icol, row_ptr, col);
     return DPPR_OK;
 }
 

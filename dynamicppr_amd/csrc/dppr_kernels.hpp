@@ -527,6 +527,7 @@ __global__ __launch_bounds__(PULL_BLOCK, 8) void k_pull_iter(int V, const int *_
     __shared__ unsigned long long s_edges[PULL_WAVES];
     __shared__ PullBig s_big[PULL_BIG_CAP];
     __shared__ double s_bigacc[PULL_BIG_CAP];
+    __shared__ int s_bigscan[WAVE + 1];
     __shared__ int s_nbig;
     __shared__ int s_base;
     const int lane = lane_id(), w = wave_id();
@@ -634,28 +635,46 @@ __global__ __launch_bounds__(PULL_BLOCK, 8) void k_pull_iter(int V, const int *_
         }
         finish(valid && !deferred, v, rv, xv, rn); // deferred vertices are finished in phase C
 
-        // ---- phase B: the workgroup's long rows, 16 waves x 64 lanes x PU gathers per pass ----
+        // ---- phase B: the workgroup's long rows, concatenated, 1024 lanes x PU gathers per pass ----
         __syncthreads();
         const int nbig = min(s_nbig, PULL_BIG_CAP);
-        for (int b = 0; b < nbig; ++b) {
-            const PullBig big = s_big[b];
-            double part = 0.0;
-            for (int e0 = w * WAVE * PU; e0 < big.d; e0 += PULL_WAVES * WAVE * PU) {
-                double xu[PU];
+        if (nbig) { // workgroup-uniform
+            if (w == 0) { // exclusive scan of the long-row lengths (nbig <= 64: one wave)
+                const int len = lane < nbig ? s_big[lane].d : 0;
+                const int inc = wave_inclusive_scan(len);
+                s_bigscan[lane] = inc - len;
+                if (lane == WAVE - 1) s_bigscan[WAVE] = inc;
+            }
+            __syncthreads();
+            const int big_total = s_bigscan[WAVE];
+            for (int e0 = 0; e0 < big_total; e0 += PULL_BLOCK * PU) {
 #pragma unroll
                 for (int k = 0; k < PU; ++k) {
-                    const int e = e0 + k * WAVE + lane;
-                    xu[k] = e < big.d ? x[out_col[big.rs + e]] : 0.0;
-                }
+                    const int e = e0 + k * PULL_BLOCK + (int)threadIdx.x;
+                    int own = -1;
+                    double c = 0.0;
+                    if (e < big_total) {
+                        int lo = 0, hi = WAVE;
 #pragma unroll
-                for (int k = 0; k < PU; ++k) {
-                    const bool nz = xu[k] != 0.0;
-                    if (nz) part += ONE_MINUS_ALPHA * xu[k] / (double)(big.d + 1);
-                    edges += (unsigned long long)__popcll(__ballot(nz));
+                        for (int s = 0; s < 6; ++s) {
+                            const int mid = (lo + hi) >> 1;
+                            if (s_bigscan[mid] <= e) lo = mid; else hi = mid;
+                        }
+                        own = lo;
+                        const double xu = x[out_col[s_big[lo].rs + (e - s_bigscan[lo])]];
+                        if (xu != 0.0) c = ONE_MINUS_ALPHA * xu / (double)(s_big[lo].d + 1);
+                    }
+                    edges += (unsigned long long)__popcll(__ballot(c != 0.0));
+                    // 64 consecutive edges mostly belong to ONE long row: reduce in the wave first
+                    const int own0 = __shfl(own, 0, WAVE);
+                    if (__all(own == own0)) {
+                        const double t = wave_sum(c);
+                        if (lane == 0 && own0 >= 0 && t != 0.0) lds_add(&s_bigacc[own0], t);
+                    } else if (c != 0.0) {
+                        lds_add(&s_bigacc[own], c);
+                    }
                 }
             }
-            part = wave_sum(part);
-            if (lane == 0 && part != 0.0) lds_add(&s_bigacc[b], part);
         }
         __syncthreads();
         // ---- phase C: finish the long-row vertices (wave 0, one lane each) ----
@@ -882,11 +901,10 @@ __global__ __launch_bounds__(BLOCK) void k_build_csr(const uint64_t *__restrict_
         adj[j] = a;
         const int prev = (j == 0) ? -1 : (int)(skeys[j - 1] >> bits);
         for (int x = prev + 1; x <= dst; ++x) row_ptr[x] = j;
-        if (j == Ed - 1)
-            for (int x = dst + 1; x <= V; ++x) row_ptr[x] = Ed;
     }
-    if (Ed == 0)
-        for (int x = blockIdx.x * BLOCK + threadIdx.x; x <= V; x += gridDim.x * BLOCK) row_ptr[x] = 0;
+    // rows after the last non-empty one (with compacted ids: most of the id capacity), in parallel
+    const int last = Ed ? (int)(skeys[Ed - 1] >> bits) : -1;
+    for (int x = last + 1 + blockIdx.x * BLOCK + threadIdx.x; x <= V; x += gridDim.x * BLOCK) row_ptr[x] = Ed;
 }
 
 // out-CSR for the pull sweep: key = src << bits | dst, sorted -> out_row_ptr + out_col
@@ -907,11 +925,9 @@ __global__ __launch_bounds__(BLOCK) void k_build_out_csr(const uint64_t *__restr
         col[j] = (int)(k & mask);
         const int prev = (j == 0) ? -1 : (int)(skeys[j - 1] >> bits);
         for (int xx = prev + 1; xx <= src; ++xx) row_ptr[xx] = j;
-        if (j == Ed - 1)
-            for (int xx = src + 1; xx <= V; ++xx) row_ptr[xx] = Ed;
     }
-    if (Ed == 0)
-        for (int xx = blockIdx.x * BLOCK + threadIdx.x; xx <= V; xx += gridDim.x * BLOCK) row_ptr[xx] = 0;
+    const int last = Ed ? (int)(skeys[Ed - 1] >> bits) : -1;
+    for (int xx = last + 1 + blockIdx.x * BLOCK + threadIdx.x; xx <= V; xx += gridDim.x * BLOCK) row_ptr[xx] = Ed;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_gather_deg(const int *__restrict__ e1, int L, const int *__restrict__ outdeg,
@@ -921,6 +937,29 @@ __global__ __launch_bounds__(BLOCK) void k_gather_deg(const int *__restrict__ e1
 
 __global__ __launch_bounds__(BLOCK) void k_split_adj(const Adj *__restrict__ adj, int Ed, int *__restrict__ col) {
     for (int j = blockIdx.x * BLOCK + threadIdx.x; j < Ed; j += gridDim.x * BLOCK) col[j] = adj[j].v;
+}
+
+// ---------------------------------------------------------------------------
+// Vertex compaction. The .bin header's V is an id RANGE (encoder/GraphEncoder.h:27-44) and a
+// 10 % window touches only a fraction of it (14 % on the configs[1] stand-in). The engine
+// numbers vertices by first appearance (internal ids 0..n_int) so every Theta(V) pass --
+// Inspect, the pull sweep, hub selection, the CSR row fill -- covers only vertices that
+// ever had an edge, and the hot state is contiguous. The C ABI speaks external ids; these
+// two kernels translate p / r at the boundary.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_int_to_ext(const double *__restrict__ a_int, const int *__restrict__ ext2int,
+                                                      int V, double *__restrict__ a_ext) {
+    for (int v = blockIdx.x * BLOCK + threadIdx.x; v < V; v += gridDim.x * BLOCK) {
+        const int m = ext2int[v];
+        a_ext[v] = m >= 0 ? a_int[m] : 0.0;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_ext_to_int(const double *__restrict__ a_ext, const int *__restrict__ ext2int,
+                                                      int V, double *__restrict__ a_int) {
+    for (int v = blockIdx.x * BLOCK + threadIdx.x; v < V; v += gridDim.x * BLOCK) {
+        const int m = ext2int[v];
+        if (m >= 0) a_int[m] = a_ext[v];
+    }
 }
 
 // ---------------------------------------------------------------------------

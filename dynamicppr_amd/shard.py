@@ -1,0 +1,51 @@
+"""Source sharding across GPUs: independent source vertices are dealt
+round-robin over ranks, every rank holds a full replica of the window graph, and there is
+no data-path collective. torch.distributed is used only for the barrier around the timed
+region and for reducing the bracket time (MAX) and the processed units (SUM)."""
+from __future__ import annotations
+
+import time
+from typing import Callable, Sequence
+
+
+def assign_sources(sources: Sequence[int], rank: int, world: int, per_rank: int | None = None) -> list[int]:
+    """Round-robin deal (./pagerank -g N does the same). With ``per_rank`` every rank gets
+    exactly that many (weak scaling: config 4 of BASELINE.json = one top-10 source per GPU),
+    wrapping around the list if there are fewer sources than slots."""
+    if per_rank is None:
+        return [int(s) for i, s in enumerate(sources) if i % world == rank]
+    return [int(sources[(rank + k * world) % len(sources)]) for k in range(per_rank)]
+
+
+def timed_region(run_steps: Callable[[], None], device_sync: Callable[[], None], dist=None):
+    """Barrier + device sync on both sides of ``run_steps``; returns (max-over-ranks seconds, world)."""
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+
+    def fence():
+        device_sync()
+        if world > 1:
+            dist.barrier()
+
+    fence()
+    t0 = time.perf_counter()
+    run_steps()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, world
+
+
+def aggregate_units(units_local: int, dist=None) -> int:
+    """Whole-job units (edge updates) = SUM over ranks."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return int(units_local)
+    import torch
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([units_local], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
