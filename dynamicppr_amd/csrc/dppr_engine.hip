@@ -75,7 +75,7 @@ struct dppr_engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t evpool[2 * 64] = {};
     bool profiling = false;
-    int chunk_iters = 8; // iterations enqueued between two host read-backs of the frontier size
+    int chunk_iters = 12; // iterations enqueued between two host read-backs of the frontier size
     // window ring, stream order
     int *w1 = nullptr, *w2 = nullptr;
     int head = 0;
@@ -85,7 +85,7 @@ struct dppr_engine {
     int *hub_hist = nullptr;    // 32 + 1 ints (histogram, hub counter)
     int hub_min_degree = HUB_MIN_DEGREE_DEFAULT;
     int big_row = BIG_ROW_DEFAULT;
-    int pull_min_frontier = 0; // 0: auto (max(4096, Ed/16)); < 0: never pull; > 0: pull when F >= value
+    int pull_min_frontier = 0; // 0: auto (max(2048, Ed/48)); < 0: never pull; > 0: pull when F >= value
     // CSR build scratch
     uint64_t *keys_a = nullptr, *keys_b = nullptr;
     void *sort_tmp = nullptr;
@@ -250,7 +250,7 @@ int read_count(dppr_engine *e, const int *dptr, int *out) {
 int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, double eps, int buf, int cur) {
     const int pull_min = e->pull_min_frontier > 0   ? e->pull_min_frontier
                          : e->pull_min_frontier < 0 ? 0x7fffffff
-                                                    : std::max(4096, e->Ed / 16);
+                                                    : std::max(2048, e->Ed / 48);
     const bool sync_sched = e->schedule == DPPR_SCHEDULE_SYNC;
     const HubTable hubs{ep.hub_v, ep.hub_degp1, ep.n_hubs};
     // the sparse grid must cover the largest frontier a push chunk can meet
@@ -316,11 +316,10 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
         }
         HIP_TRY(hipGetLastError());
         // one read-back per chunk: the new frontier size and the F of each iteration just run
-        HIP_TRY(hipMemcpyAsync(e->pinned, s.cnt + cur, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipMemcpyAsync(e->pinned + 1, s.log, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->pinned, s.cnt, sizeof(int) * (size_t)(8 + n), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
         for (int k = 0; k < n; ++k) {
-            const int f = e->pinned[1 + k];
+            const int f = e->pinned[8 + k];
             if (f <= 0) continue; // the frontier emptied inside the chunk: the rest were no-ops
             s.st.iterations++;
             s.st.sum_F += f;
@@ -333,7 +332,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             }
         }
         prevF = F;
-        F = e->pinned[0];
+        F = e->pinned[cur];
         it += n;
     }
     if (any_pull) { // leave both dense vectors all-zero for the next loop
@@ -486,7 +485,7 @@ void dppr_destroy(dppr_engine *e) {
     for (auto &s : e->slots) {
         (void)hipFree(s.p); (void)hipFree(s.r); (void)hipFree(s.x); (void)hipFree(s.x2);
         (void)hipFree(s.ft[0]); (void)hipFree(s.ft[1]); (void)hipFree(s.neg);
-        (void)hipFree(s.cnt); (void)hipFree(s.dstats); (void)hipFree(s.big); (void)hipFree(s.log);
+        (void)hipFree(s.cnt); (void)hipFree(s.dstats); (void)hipFree(s.big);
     }
     for (auto &ep : e->epochs) {
         (void)hipFree(ep.row_ptr); (void)hipFree(ep.adj); (void)hipFree(ep.out_row_ptr); (void)hipFree(ep.out_col); (void)hipFree(ep.b1); (void)hipFree(ep.b2);
@@ -670,8 +669,8 @@ int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
     HIP_TRY(hipMalloc((void **)&s.ft[0], sizeof(int) * V));
     HIP_TRY(hipMalloc((void **)&s.ft[1], sizeof(int) * V));
     HIP_TRY(hipMalloc((void **)&s.neg, sizeof(int) * (size_t)std::max(4 * e->c, 1)));
-    HIP_TRY(hipMalloc((void **)&s.cnt, sizeof(int) * 8));
-    HIP_TRY(hipMalloc((void **)&s.log, sizeof(int) * MAX_CHUNK));
+    HIP_TRY(hipMalloc((void **)&s.cnt, sizeof(int) * (8 + MAX_CHUNK)));
+    s.log = s.cnt + 8; // the per-chunk log sits right behind the counters: one read-back fetches both
     // a row is deferred only if it has >= big_row edges, so at most Ed / big_row of them exist
     HIP_TRY(hipMalloc((void **)&s.big, sizeof(BigItem) * ((size_t)e->Ed / (size_t)std::max(e->big_row, 1) + 64)));
     HIP_TRY(hipMalloc((void **)&s.dstats, sizeof(IterStats)));

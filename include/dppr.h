@@ -96,9 +96,9 @@ int dppr_set_profiling(dppr_engine *e, int on);
  * hub_min_degree: out-degree from which a vertex's incoming pushes are aggregated in LDS (at
  * most 2048 hubs per epoch); big_row_edges: in-degree from which a frontier vertex's row is
  * expanded by the whole grid; pull_min_frontier: frontier size from which an iteration is
- * evaluated as a dense pull sweep instead of push atomics (0 = auto: max(4096, edges/16),
+ * evaluated as a dense pull sweep instead of push atomics (0 = auto: max(2048, edges/48),
  * negative = never); chunk_iters: iterations enqueued per host read-back of the frontier size
- * (default 8, 1 = read back every iteration like the reference, <= 0 keeps the default).
+ * (default 12, 1 = read back every iteration like the reference, <= 0 keeps the default).
  * Results never depend on them beyond floating-point summation order; tests set them so
  * small graphs exercise every path. */
 int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges, int pull_min_frontier,
