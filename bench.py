@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--directed", type=int, default=None)
     ap.add_argument("--cpu-batches", type=int, default=8, help="batches timed on the CPU oracle (bounded sample)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
+                    help="engine tuning knob (hub_min_degree, big_row_edges, pull_min_frontier, chunk_iters, pull_block)")
     return ap.parse_args()
 
 
@@ -92,7 +94,8 @@ def main():
     source = shard.assign_sources(sources, rank, world, per_rank=1)[0]   # one top-10 source per GPU
 
     schedule = eng.SCHEDULE_EAGER if a.schedule == "eager" else eng.SCHEDULE_SYNC
-    e = eng.Engine(V, W, directed, c, n_epochs=n_steps + 1, device=local_rank, schedule=schedule)
+    tune = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.tune}
+    e = eng.Engine(V, W, directed, c, n_epochs=n_steps + 1, device=local_rank, schedule=schedule, **tune)
     ss = st.SlidingStream(V, e1, e2, directed, wl)
     w1, w2 = ss.serialize_edge_stream()
     e.load_window(w1, w2)

@@ -52,6 +52,7 @@ struct Slot {
     BigItem *big = nullptr; // deferred big rows of the current iteration
     int *log = nullptr;     // per-chunk log: frontier size seen by each enqueued iteration
     long long iter_seq = 0; // running iteration number (selects the big-row counter)
+    int iter_hint[2] = {0, 0}; // iterations the last loop of each phase took (sizes the next chunks)
     IterStats *dstats = nullptr;
     bool converged = false; // |r| <= eps everywhere (state after a completed solve)
     double conv_eps = 0.0;
@@ -75,7 +76,8 @@ struct dppr_engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t evpool[2 * 64] = {};
     bool profiling = false;
-    int chunk_iters = 12; // iterations enqueued between two host read-backs of the frontier size
+    int pull_block = 0;   // sweep workgroup size (0: by graph size; 256 / 512 / 1024)
+    int chunk_iters = 24; // iterations enqueued between two host read-backs of the frontier size
     // window ring, stream order
     int *w1 = nullptr, *w2 = nullptr;
     int head = 0;
@@ -256,13 +258,23 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
     // the sparse grid must cover the largest frontier a push chunk can meet
     const int push_grid = pull_min == 0x7fffffff ? 2048 : std::min(2048, std::max(64, (pull_min * 4 / WAVE + 3) / 4));
     bool dense_valid = false; // s.x holds the snapshot of the current frontier (p already updated)
+    bool list_valid = true;   // s.ft[buf] holds the frontier as a list (sweeps only count it)
     bool any_pull = false;
-    int F = 0, prevF = 0;
+    auto make_list = [&]() -> int { // dense snapshot -> sparse list (after a sweep)
+        HIP_TRY(hipMemsetAsync(s.cnt + 7, 0, sizeof(int), e->stream));
+        hipLaunchKernelGGL(k_list_from_dense, dim3(grid_for(e->n_int, BLOCK * INSPECT_ITEMS)), dim3(BLOCK), 0, e->stream,
+                           s.x, e->n_int, s.cnt + cur, s.ft[buf], s.cnt + 7);
+        HIP_TRY(hipGetLastError());
+        list_valid = true;
+        return DPPR_OK;
+    };
+    int F = 0, prevF = 0, active_iters = 0;
     int rc = read_count(e, s.cnt + cur, &F);
     if (rc) return rc;
     for (int it = 0; F > 0;) {
         if (it >= e->max_iters) return fail(e, DPPR_ERR_NOT_CONVERGED, "iteration cap hit");
         if (s.trace) {
+            if (!list_valid && (rc = make_list())) return rc;
             size_t old = s.trace_ids.size();
             s.trace_ids.resize(old + (size_t)F);
             HIP_TRY(hipMemcpyAsync(s.trace_ids.data() + old, s.ft[buf], sizeof(int) * (size_t)F,
@@ -274,10 +286,12 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
         const bool pull = F >= pull_min;
         int n;
         if (s.trace || e->chunk_iters <= 1) n = 1;
-        else if (pull) n = e->chunk_iters;
+        else if (pull) // consecutive batches take almost the same number of iterations: aim just past the end
+            n = s.iter_hint[phase] > it ? s.iter_hint[phase] - it + 1 : e->chunk_iters;
         else if ((long long)F * 4 >= pull_min) n = 1;          // about to turn dense: re-decide next iteration
         else n = F > prevF ? 2 : e->chunk_iters;                // growing: short chunks; decaying tail: long
         n = std::min(n, MAX_CHUNK);
+        if (!pull && !list_valid && (rc = make_list())) return rc;
         for (int k = 0; k < n; ++k) {
             const int nxt = (cur + 1) % 3, zer = (cur + 2) % 3;
             int *log_slot = s.log + k;
@@ -288,12 +302,20 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             }
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k], e->stream));
             if (pull) {
-                hipLaunchKernelGGL(k_pull_iter, dim3(grid_for(e->n_int, PULL_BLOCK, 512)), dim3(PULL_BLOCK), 0, e->stream, e->n_int,
-                                   s.cnt + cur, ep.out_row_ptr, ep.out_col, s.x, s.x2, s.r, s.p, s.ft[buf ^ 1],
-                                   s.cnt + nxt, s.cnt + zer, phase, eps, s.dstats, log_slot,
-                                   std::min(e->big_row, PULL_BIG_ROW_DEFAULT));
+                // workgroup size: 1024 vertices per pass unless that leaves CUs idle
+                const int pb = e->pull_block ? e->pull_block
+                                             : (e->n_int >= 1024 * 512 ? 1024 : (e->n_int >= 512 * 128 ? 512 : 256));
+#define DPPR_LAUNCH_PULL(PB)                                                                                        \
+    hipLaunchKernelGGL(k_pull_iter<PB>, dim3(grid_for(e->n_int, PB, 1024)), dim3(PB), 0, e->stream, e->n_int,       \
+                       s.cnt + cur, ep.out_row_ptr, ep.out_col, s.x, s.x2, s.r, s.p, s.cnt + nxt, s.cnt + zer, phase, \
+                       eps, s.dstats, log_slot, std::min(e->big_row, PULL_BIG_ROW_DEFAULT))
+                if (pb == 1024) DPPR_LAUNCH_PULL(1024);
+                else if (pb == 512) DPPR_LAUNCH_PULL(512);
+                else DPPR_LAUNCH_PULL(256);
+#undef DPPR_LAUNCH_PULL
                 std::swap(s.x, s.x2); // the sweep wrote every entry of x2: it is the next snapshot
                 dense_valid = true;
+                list_valid = false;
                 any_pull = true;
             } else {
                 int *big_cnt = s.cnt + 5 + (int)(s.iter_seq & 1), *big_zero = s.cnt + 5 + (int)((s.iter_seq + 1) & 1);
@@ -309,6 +331,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 hipLaunchKernelGGL(k_push_big, dim3(512), dim3(BLOCK), 0, e->stream, s.big, big_cnt, s.ft[buf ^ 1],
                                    s.cnt + nxt, ep.adj, hubs, s.r, phase, eps, s.dstats);
                 dense_valid = false; // the push consumed (and zeroed) the snapshot
+                list_valid = true;
             }
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k + 1], e->stream));
             buf ^= 1;
@@ -324,6 +347,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             s.st.iterations++;
             s.st.sum_F += f;
             if (pull) s.st.pull_iterations++;
+            active_iters = it + k + 1;
             if (e->profiling) {
                 float ms = 0;
                 HIP_TRY(hipEventElapsedTime(&ms, e->evpool[2 * k], e->evpool[2 * k + 1]));
@@ -335,6 +359,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
         F = e->pinned[cur];
         it += n;
     }
+    s.iter_hint[phase] = active_iters;
     if (any_pull) { // leave both dense vectors all-zero for the next loop
         HIP_TRY(hipMemsetAsync(s.x, 0, sizeof(double) * (size_t)e->V, e->stream));
         HIP_TRY(hipMemsetAsync(s.x2, 0, sizeof(double) * (size_t)e->V, e->stream));
@@ -517,13 +542,15 @@ int dppr_set_profiling(dppr_engine *e, int on) {
     return DPPR_OK;
 }
 
-int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges, int pull_min_frontier, int chunk_iters) {
+int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges, int pull_min_frontier, int chunk_iters,
+                    int pull_block) {
     if (!e || hub_min_degree < 1 || big_row_edges < 1 || e->loaded || !e->slots.empty())
         return fail(e, DPPR_ERR_INVALID, "set_tuning: call right after dppr_create, values >= 1");
     e->hub_min_degree = hub_min_degree;
     e->big_row = big_row_edges;
     e->pull_min_frontier = pull_min_frontier;
     if (chunk_iters > 0) e->chunk_iters = std::min(chunk_iters, MAX_CHUNK);
+    if (pull_block == 256 || pull_block == 512 || pull_block == 1024) e->pull_block = pull_block;
     return DPPR_OK;
 }
 

@@ -491,12 +491,11 @@ __global__ __launch_bounds__(BLOCK) void k_push_big(const BigItem *__restrict__ 
 // kernel each. The sparse list / counter are produced as well, so a push iteration
 // can follow.
 // ---------------------------------------------------------------------------
-constexpr int PULL_BLOCK = 1024; // 16 waves: few workgroups -> few counter atomics per sweep
-constexpr int PULL_WAVES = PULL_BLOCK / WAVE;
-constexpr int PULL_OUT_CAP = 512; // per-wave staged list entries
+// workgroup size of the sweep = consecutive vertices per pass: 1024 for large graphs (few
+// workgroups -> few counter atomics), 512 / 256 when that would leave CUs idle
 constexpr int PULL_BIG_ROW_DEFAULT = 128; // rows at least this long are gathered by the whole workgroup
 constexpr int PULL_BIG_CAP = 64;  // such rows per workgroup pass (more: the owning wave does them itself)
-constexpr int PU = 2;             // gathers in flight per lane (register budget: 8 waves/SIMD)
+constexpr int PU = 2;             // gathers in flight per lane and list (register budget: 8 waves/SIMD)
 
 struct PullBig {
     int v, rs, d;
@@ -510,26 +509,28 @@ __device__ __forceinline__ double wave_sum(double x) {
     return x;
 }
 
-__global__ __launch_bounds__(PULL_BLOCK, 8) void k_pull_iter(int V, const int *__restrict__ cnt_in,
+// The sweep does not build the sparse frontier list (a following dense iteration does not
+// need it): it only COUNTS the next frontier, with one fire-and-forget atomic per workgroup.
+// k_list_from_dense materialises the list when a sparse iteration follows (or for tracing).
+template <int PULL_BLOCK>
+__global__ __launch_bounds__(PULL_BLOCK) void k_pull_iter(int V, const int *__restrict__ cnt_in,
                                                              const int *__restrict__ out_row_ptr,
                                                              const int *__restrict__ out_col,
                                                              const double *__restrict__ x, double *__restrict__ x_new,
                                                              double *__restrict__ r, double *__restrict__ p,
-                                                             int *__restrict__ ft_out, int *__restrict__ cnt_out,
-                                                             int *__restrict__ cnt_zero, int phase, double eps,
-                                                             IterStats *__restrict__ stats,
+                                                             int *__restrict__ cnt_out, int *__restrict__ cnt_zero,
+                                                             int phase, double eps, IterStats *__restrict__ stats,
                                                              int *__restrict__ log_slot, int pull_big_row) {
+    constexpr int PULL_WAVES = PULL_BLOCK / WAVE;
     __shared__ int s_scan[PULL_WAVES][WAVE + 1];
     __shared__ int s_start[PULL_WAVES][WAVE];
     __shared__ double s_acc[PULL_WAVES][WAVE];
-    __shared__ int s_out[PULL_WAVES][PULL_OUT_CAP];
     __shared__ int s_cnt[PULL_WAVES];
     __shared__ unsigned long long s_edges[PULL_WAVES];
     __shared__ PullBig s_big[PULL_BIG_CAP];
     __shared__ double s_bigacc[PULL_BIG_CAP];
-    __shared__ int s_bigscan[WAVE + 1];
+    __shared__ int s_bigscan[PULL_WAVES][WAVE + 1];
     __shared__ int s_nbig;
-    __shared__ int s_base;
     const int lane = lane_id(), w = wave_id();
     const int F = *cnt_in;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -537,23 +538,9 @@ __global__ __launch_bounds__(PULL_BLOCK, 8) void k_pull_iter(int V, const int *_
         *log_slot = F;
     }
     if (F == 0) return; // empty frontier: x / x_new are not touched
-    int n_out = 0;      // wave-uniform
+    int n_legal = 0;    // per-lane count of next-frontier vertices
     unsigned long long edges = 0;
 
-    auto emit = [&](bool lg, int v) { // stage a next-frontier vertex (all lanes of the wave call this)
-        const uint64_t m = __ballot(lg);
-        if (m) {
-            if (n_out + WAVE > PULL_OUT_CAP) { // overflow: flush this wave's tile (rare)
-                int gb = 0;
-                if (lane == 0) gb = atomicAdd(cnt_out, n_out);
-                gb = __shfl(gb, 0, WAVE);
-                for (int i = lane; i < n_out; i += WAVE) ft_out[gb + i] = s_out[w][i];
-                n_out = 0;
-            }
-            if (lg) s_out[w][n_out + mbcnt(m)] = v;
-            n_out += __popcll(m);
-        }
-    };
     auto finish = [&](bool valid, int v, double rv, double xv, double rn) { // repair, threshold, next snapshot
         if (xv != 0.0) rn -= xv;
         const bool lg = valid && legal(rn, phase, eps);
@@ -562,16 +549,14 @@ __global__ __launch_bounds__(PULL_BLOCK, 8) void k_pull_iter(int V, const int *_
             x_new[v] = lg ? rn : 0.0; // every entry is rewritten: x_new is a complete snapshot
             if (lg) p[v] += ALPHA * rn;
         }
-        emit(lg, v);
+        n_legal += lg ? 1 : 0;
     };
 
-    const int n_tiles = (V + WAVE - 1) / WAVE;
-    const int n_groups = (n_tiles + PULL_WAVES - 1) / PULL_WAVES; // one tile per wave per pass
-    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {      // workgroup-uniform loop
+    const int n_groups = (V + PULL_BLOCK - 1) / PULL_BLOCK; // 1024 consecutive vertices per pass
+    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) { // workgroup-uniform loop
         if (threadIdx.x == 0) s_nbig = 0;
         __syncthreads();
-        const int t = g * PULL_WAVES + w;
-        const int v = t * WAVE + lane;
+        const int v = (g * PULL_WAVES + w) * WAVE + lane;
         const bool valid = v < V;
         int rs = 0, d = 0;
         double rv = 0.0, xv = 0.0;
@@ -581,7 +566,7 @@ __global__ __launch_bounds__(PULL_BLOCK, 8) void k_pull_iter(int V, const int *_
             rv = r[v];
             xv = x[v];
         }
-        // long rows go to the workgroup list (phase B); the owning lane keeps them only if the list is full
+        // long rows go to the workgroup list; the owning lane keeps them only if the list is full
         bool deferred = false;
         if (d >= pull_big_row) {
             const int slot = atomicAdd(&s_nbig, 1);
@@ -594,115 +579,157 @@ __global__ __launch_bounds__(PULL_BLOCK, 8) void k_pull_iter(int V, const int *_
         const int dd = deferred ? 0 : d;
         const int incl = wave_inclusive_scan(dd);
         const int total = __shfl(incl, WAVE - 1, WAVE);
-        double rn = rv;
-        if (total) { // wave-uniform: tiles without (short) rows skip the gather machinery
-            s_scan[w][lane] = incl - dd; // deferred rows have length 0 here and are never visited
-            s_start[w][lane] = rs;
-            if (lane == 0) s_scan[w][WAVE] = total;
-            s_acc[w][lane] = rv;
-            __builtin_amdgcn_wave_barrier();
-            for (int e0 = 0; e0 < total; e0 += WAVE * PU) {
-                int owner[PU];
-                double xu[PU];
-#pragma unroll
-                for (int k = 0; k < PU; ++k) {
-                    const int e = e0 + k * WAVE + lane;
-                    owner[k] = -1;
-                    xu[k] = 0.0;
-                    if (e < total) {
-                        int lo = 0, hi = WAVE;
-#pragma unroll
-                        for (int s = 0; s < 6; ++s) {
-                            const int mid = (lo + hi) >> 1;
-                            if (s_scan[w][mid] <= e) lo = mid; else hi = mid;
-                        }
-                        owner[k] = lo;
-                        xu[k] = x[out_col[s_start[w][lo] + (e - s_scan[w][lo])]];
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < PU; ++k) {
-                    const bool nz = xu[k] != 0.0;
-                    if (nz) {
-                        const int dk = s_scan[w][owner[k] + 1] - s_scan[w][owner[k]];
-                        lds_add(&s_acc[w][owner[k]], ONE_MINUS_ALPHA * xu[k] / (double)(dk + 1));
-                    }
-                    edges += (unsigned long long)__popcll(__ballot(nz));
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            rn = s_acc[w][lane];
-        }
-        finish(valid && !deferred, v, rv, xv, rn); // deferred vertices are finished in phase C
-
-        // ---- phase B: the workgroup's long rows, concatenated, 1024 lanes x PU gathers per pass ----
-        __syncthreads();
+        s_scan[w][lane] = incl - dd; // deferred rows have length 0 here and are never visited
+        s_start[w][lane] = rs;
+        if (lane == 0) s_scan[w][WAVE] = total;
+        s_acc[w][lane] = rv;
+        __syncthreads(); // long-row list complete (also orders this wave's LDS tile)
         const int nbig = min(s_nbig, PULL_BIG_CAP);
-        if (nbig) { // workgroup-uniform
-            if (w == 0) { // exclusive scan of the long-row lengths (nbig <= 64: one wave)
-                const int len = lane < nbig ? s_big[lane].d : 0;
-                const int inc = wave_inclusive_scan(len);
-                s_bigscan[lane] = inc - len;
-                if (lane == WAVE - 1) s_bigscan[WAVE] = inc;
+        int big_total = 0;
+        if (nbig) { // every wave scans the <= 64 long-row lengths into its own copy (no second barrier)
+            const int len = lane < nbig ? s_big[lane].d : 0;
+            const int inc = wave_inclusive_scan(len);
+            s_bigscan[w][lane] = inc - len;
+            big_total = __shfl(inc, WAVE - 1, WAVE);
+            if (lane == 0) s_bigscan[w][WAVE] = big_total;
+            __builtin_amdgcn_wave_barrier();
+        }
+        // One merged loop: each round issues the column loads of the wave's own (short-row) edges
+        // AND of its share of the concatenated long rows, then both sets of x gathers, so the two
+        // dependent chains overlap instead of running back to back.
+        const int rounds_a = (total + WAVE * PU - 1) / (WAVE * PU);
+        const int rounds_b = (big_total + PULL_BLOCK * PU - 1) / (PULL_BLOCK * PU);
+        const int rounds = max(rounds_a, rounds_b);
+        for (int rd = 0; rd < rounds; ++rd) {
+            int own_a[PU], own_b[PU], col_a[PU], col_b[PU];
+#pragma unroll
+            for (int k = 0; k < PU; ++k) {
+                const int e = (rd * PU + k) * WAVE + lane;
+                own_a[k] = -1;
+                col_a[k] = 0;
+                if (e < total) {
+                    int lo = 0, hi = WAVE;
+#pragma unroll
+                    for (int s2 = 0; s2 < 6; ++s2) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_scan[w][mid] <= e) lo = mid; else hi = mid;
+                    }
+                    own_a[k] = lo;
+                    col_a[k] = out_col[s_start[w][lo] + (e - s_scan[w][lo])];
+                }
             }
-            __syncthreads();
-            const int big_total = s_bigscan[WAVE];
-            for (int e0 = 0; e0 < big_total; e0 += PULL_BLOCK * PU) {
+#pragma unroll
+            for (int k = 0; k < PU; ++k) {
+                const int e = (rd * PU + k) * PULL_BLOCK + (int)threadIdx.x;
+                own_b[k] = -1;
+                col_b[k] = 0;
+                if (e < big_total) {
+                    int lo = 0, hi = WAVE;
+#pragma unroll
+                    for (int s2 = 0; s2 < 6; ++s2) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_bigscan[w][mid] <= e) lo = mid; else hi = mid;
+                    }
+                    own_b[k] = lo;
+                    col_b[k] = out_col[s_big[lo].rs + (e - s_bigscan[w][lo])];
+                }
+            }
+            double xa[PU], xb[PU];
+#pragma unroll
+            for (int k = 0; k < PU; ++k) xa[k] = own_a[k] >= 0 ? x[col_a[k]] : 0.0;
+#pragma unroll
+            for (int k = 0; k < PU; ++k) xb[k] = own_b[k] >= 0 ? x[col_b[k]] : 0.0;
+#pragma unroll
+            for (int k = 0; k < PU; ++k) {
+                const bool nz = xa[k] != 0.0;
+                if (nz) {
+                    const int dk = s_scan[w][own_a[k] + 1] - s_scan[w][own_a[k]];
+                    lds_add(&s_acc[w][own_a[k]], ONE_MINUS_ALPHA * xa[k] / (double)(dk + 1));
+                }
+                edges += (unsigned long long)__popcll(__ballot(nz));
+            }
+            if (rd < rounds_b) { // wave-uniform
 #pragma unroll
                 for (int k = 0; k < PU; ++k) {
-                    const int e = e0 + k * PULL_BLOCK + (int)threadIdx.x;
-                    int own = -1;
                     double c = 0.0;
-                    if (e < big_total) {
-                        int lo = 0, hi = WAVE;
-#pragma unroll
-                        for (int s = 0; s < 6; ++s) {
-                            const int mid = (lo + hi) >> 1;
-                            if (s_bigscan[mid] <= e) lo = mid; else hi = mid;
-                        }
-                        own = lo;
-                        const double xu = x[out_col[s_big[lo].rs + (e - s_bigscan[lo])]];
-                        if (xu != 0.0) c = ONE_MINUS_ALPHA * xu / (double)(s_big[lo].d + 1);
-                    }
+                    if (xb[k] != 0.0) c = ONE_MINUS_ALPHA * xb[k] / (double)(s_big[own_b[k]].d + 1);
                     edges += (unsigned long long)__popcll(__ballot(c != 0.0));
                     // 64 consecutive edges mostly belong to ONE long row: reduce in the wave first
-                    const int own0 = __shfl(own, 0, WAVE);
-                    if (__all(own == own0)) {
+                    const int own0 = __shfl(own_b[k], 0, WAVE);
+                    if (__all(own_b[k] == own0)) {
                         const double t = wave_sum(c);
                         if (lane == 0 && own0 >= 0 && t != 0.0) lds_add(&s_bigacc[own0], t);
                     } else if (c != 0.0) {
-                        lds_add(&s_bigacc[own], c);
+                        lds_add(&s_bigacc[own_b[k]], c);
                     }
                 }
             }
         }
-        __syncthreads();
-        // ---- phase C: finish the long-row vertices (wave 0, one lane each) ----
-        if (w == 0) {
-            const bool has = lane < nbig;
-            PullBig big{0, 0, 0, 0.0, 0.0};
-            double acc = 0.0;
-            if (has) {
-                big = s_big[lane];
-                acc = s_bigacc[lane];
+        __builtin_amdgcn_wave_barrier();
+        finish(valid && !deferred, v, rv, xv, s_acc[w][lane]); // deferred vertices are finished below
+        if (nbig) {                                            // workgroup-uniform
+            __syncthreads();                                   // all long-row partial sums are in
+            if (w == 0) {
+                const bool has = lane < nbig;
+                PullBig big{0, 0, 0, 0.0, 0.0};
+                double acc = 0.0;
+                if (has) {
+                    big = s_big[lane];
+                    acc = s_bigacc[lane];
+                }
+                finish(has, big.v, big.rv, big.xv, big.rv + acc);
             }
-            finish(has, big.v, big.rv, big.xv, big.rv + acc);
         }
         __syncthreads();
     }
-    // workgroup flush of the sparse list: ONE counter atomic per 1024-thread workgroup
-    if (lane == 0) s_cnt[w] = n_out;
+    // count of the next frontier: wave reduce, then ONE fire-and-forget atomic per workgroup
+    int cw = n_legal;
+#pragma unroll
+    for (int dlt = WAVE / 2; dlt >= 1; dlt >>= 1) cw += __shfl_xor(cw, dlt, WAVE);
+    if (lane == 0) s_cnt[w] = cw;
     __syncthreads();
     if (threadIdx.x == 0) {
         int tot = 0;
         for (int k = 0; k < PULL_WAVES; ++k) tot += s_cnt[k];
-        s_base = tot ? atomicAdd(cnt_out, tot) : 0;
+        if (tot) atomicAdd(cnt_out, tot);
     }
-    __syncthreads();
-    int gb = s_base;
-    for (int k = 0; k < w; ++k) gb += s_cnt[k];
-    for (int i = lane; i < n_out; i += WAVE) ft_out[gb + i] = s_out[w][i];
     stat_add_edges<PULL_WAVES>(stats, edges, s_edges);
+}
+
+// dense -> sparse: the frontier list {v : x[v] != 0} (k_inspect's compaction on the snapshot).
+// Used when a sparse iteration follows a sweep, and by the frontier trace.
+__global__ __launch_bounds__(BLOCK) void k_list_from_dense(const double *__restrict__ x, int V, const int *__restrict__ cnt_f,
+                                                           int *__restrict__ ft, int *__restrict__ cnt) {
+    __shared__ int s_buf[BLOCK * INSPECT_ITEMS];
+    __shared__ int s_n;
+    __shared__ int s_base;
+    if (*cnt_f == 0) return;
+    const int64_t chunk = (int64_t)BLOCK * INSPECT_ITEMS;
+    for (int64_t base = (int64_t)blockIdx.x * chunk; base < V; base += (int64_t)gridDim.x * chunk) {
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < INSPECT_ITEMS; ++k) {
+            const int64_t u = base + (int64_t)k * BLOCK + threadIdx.x;
+            const bool hit = (u < V) && x[u] != 0.0;
+            const uint64_t m = __ballot(hit);
+            if (m) {
+                int wbase = 0;
+                if (lane_id() == 0) wbase = atomicAdd(&s_n, __popcll(m));
+                wbase = __shfl(wbase, 0, WAVE);
+                if (hit) s_buf[wbase + mbcnt(m)] = (int)u;
+            }
+        }
+        __syncthreads();
+        const int n = s_n;
+        if (n) {
+            if (threadIdx.x == 0) s_base = atomicAdd(cnt, n);
+            __syncthreads();
+            const int gb = s_base;
+            for (int i = threadIdx.x; i < n; i += BLOCK) ft[gb + i] = s_buf[i];
+        }
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -77,7 +77,7 @@ def lib():
     L.dppr_destroy.restype = None
     L.dppr_set_schedule.argtypes = [vp, C.c_int]
     L.dppr_set_profiling.argtypes = [vp, C.c_int]
-    L.dppr_set_tuning.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.dppr_set_tuning.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.dppr_load_window.argtypes = [vp, ip, ip, C.c_int32]
     L.dppr_set_batch.argtypes = [vp, ip, ip, u8p, C.c_int32]
     L.dppr_slide.argtypes = [vp, ip, ip, C.c_int32, ip]
@@ -121,7 +121,7 @@ class Engine:
     """
 
     def __init__(self, V, W, directed, max_batch, n_epochs=1, device=0, schedule=SCHEDULE_EAGER,
-                 hub_min_degree=None, big_row_edges=None, pull_min_frontier=None, chunk_iters=None):
+                 hub_min_degree=None, big_row_edges=None, pull_min_frontier=None, chunk_iters=None, pull_block=None):
         self._L = lib()
         self._h = C.c_void_p()
         self.V, self.W, self.directed, self.c = int(V), int(W), int(directed), int(max_batch)
@@ -130,9 +130,10 @@ class Engine:
             self._h = C.c_void_p()
             raise DpprError(f"dppr_create: {self._L.dppr_strerror(rc).decode()}")
         self.set_schedule(schedule)
-        if any(v is not None for v in (hub_min_degree, big_row_edges, pull_min_frontier, chunk_iters)):
+        if any(v is not None for v in (hub_min_degree, big_row_edges, pull_min_frontier, chunk_iters, pull_block)):
             self._ck(self._L.dppr_set_tuning(self._h, int(hub_min_degree or 256), int(big_row_edges or 512),
-                                             int(pull_min_frontier or 0), int(chunk_iters or 0)), "set_tuning")
+                                             int(pull_min_frontier or 0), int(chunk_iters or 0),
+                                             int(pull_block or 0)), "set_tuning")
 
     def _ck(self, rc, what):
         if rc:

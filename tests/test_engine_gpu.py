@@ -30,9 +30,10 @@ INVARIANT_TOL = 1e-13   # rounding only
 TUNINGS = [dict(pull_min_frontier=-1), dict(hub_min_degree=3, big_row_edges=8, pull_min_frontier=-1),
            dict(hub_min_degree=1, big_row_edges=1, pull_min_frontier=-1), dict(pull_min_frontier=1),
            dict(hub_min_degree=3, big_row_edges=8, pull_min_frontier=40), dict(),
-           dict(pull_min_frontier=40, chunk_iters=1), dict(hub_min_degree=3, pull_min_frontier=60, chunk_iters=3)]
+           dict(pull_min_frontier=40, chunk_iters=1), dict(hub_min_degree=3, pull_min_frontier=60, chunk_iters=3),
+           dict(pull_min_frontier=1, pull_block=512, big_row_edges=8), dict(pull_min_frontier=30, pull_block=1024, big_row_edges=4)]
 TUNING_IDS = ["push-only", "push-hubs+bigrows", "push-all-hub-all-big", "pull-only", "mixed-pull>=40", "default",
-              "mixed-chunk1", "mixed-chunk3"]
+              "mixed-chunk1", "mixed-chunk3", "pull-wg512", "mixed-wg1024"]
 
 
 def make(directed, schedule=eng.SCHEDULE_EAGER, scale=9, edges=6000, seed=11, W=600, c=6, eps=1e-9, n_epochs=1,
