@@ -131,7 +131,10 @@ def stand_in_stream(key: str, cache_dir: str | None = None):
             return V, e1, e2, cfg
     V, e1, e2 = rmat_stream(cfg.scale, cfg.edges, cfg.seed)
     if cache_dir:
-        write_bin(path, V, e1, e2)
+        # several ranks may generate the same file at once: write privately, publish atomically
+        tmp = f"{path}.{os.getpid()}.tmp"
+        write_bin(tmp, V, e1, e2)
+        os.replace(tmp, path)
     return V, e1, e2, cfg
 
 
