@@ -9,6 +9,7 @@
 
 #include <assert.h>
 #include <math.h>
+#include <omp.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -240,6 +241,7 @@ void orc_state_destroy(orc_state *s) {
     if (!s) return;
     free(s->p); free(s->r); free(s->predeg); free(s->ft); free(s->ft2); free(s->ft_r);
     free(s->status); free(s->q); free(s->trace_v); free(s->trace_off);
+    free(s->edge_ind); free(s->edge_flag); free(s->vertex_offset);
     free(s);
 }
 void orc_state_trace(orc_state *s, int on) {
@@ -407,6 +409,104 @@ void orc_cilk_inc_execute(orc_state *s, const orc_graph *g) { /* :43-73 */
     ++s->iteration_id;
     orc_dyn_push_init(s, g, 1);
     orc_cilk_main_loop(s, g, 1);
+}
+
+/* ------------------------------------------------------------------ schedule A with T workers */
+int orc_max_threads(void) { return omp_get_max_threads(); }
+
+/* cpu/PPRCPUMTCilkRev.h:82-96 AtomicAddResidual: CAS loop, returns the old value */
+static inline double atomic_add_residual(double *addr, double add) {
+    union { double d; long long i; } old_v, new_v;
+    do {
+        old_v.d = *(volatile double *)addr;
+        new_v.d = old_v.d + add;
+    } while (!__sync_bool_compare_and_swap((long long *)addr, old_v.i, new_v.i));
+    return old_v.d;
+}
+
+/* stable parallel pack (sequence::pack, cpu/CilkUtil.h:246-262): out gets In[i] where Fl[i] */
+static int64_t pack_mt(const int *in, const unsigned char *fl, int64_t n, int *out, int threads) {
+    if (n <= 0) return 0;
+    int nb = threads * 4;
+    if (nb > n) nb = (int)n;
+    int64_t *sums = (int64_t *)malloc(sizeof(int64_t) * ((size_t)nb + 1));
+    const int64_t bs = (n + nb - 1) / nb;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int b = 0; b < nb; ++b) {
+        int64_t lo = b * bs, hi = lo + bs < n ? lo + bs : n, c = 0;
+        for (int64_t i = lo; i < hi; ++i) c += fl[i];
+        sums[b] = c;
+    }
+    int64_t tot = 0;
+    for (int b = 0; b < nb; ++b) { int64_t c = sums[b]; sums[b] = tot; tot += c; }
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int b = 0; b < nb; ++b) {
+        int64_t lo = b * bs, hi = lo + bs < n ? lo + bs : n, k = sums[b];
+        for (int64_t i = lo; i < hi; ++i) if (fl[i]) out[k++] = in[i];
+    }
+    free(sums);
+    return tot;
+}
+
+/* cpu/PPRCPUMTCilkRev.h:184-289 with parallel_for == omp parallel for */
+void orc_cilk_main_loop_mt(orc_state *s, const orc_graph *g, int phase, int threads) {
+    double *residual = s->r, *pagerank = s->p;
+    const int *deg = g->deg;
+    const int64_t need = (int64_t)g->edge_count + s->V + 16;
+    if (s->edge_cap < need) {
+        free(s->edge_ind); free(s->edge_flag); free(s->vertex_offset);
+        s->edge_ind = (int *)malloc(sizeof(int) * (size_t)need);
+        s->edge_flag = (unsigned char *)malloc((size_t)need);
+        s->vertex_offset = (int64_t *)malloc(sizeof(int64_t) * ((size_t)s->V + 2));
+        s->edge_cap = need;
+    }
+    for (;;) {
+        const int F = s->ft_count;
+        if (F == 0) break;
+        int64_t total = 0; /* vertex_offset = plusScan(indeg), :200-205 */
+        for (int i = 0; i < F; ++i) { s->vertex_offset[i] = total; total += g->in[s->ft[i]].n; }
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 64)
+        for (int i = 0; i < F; ++i) { /* :208-257 */
+            const int u = s->ft[i];
+            const double ru = residual[u];
+            s->ft_r[i] = ru;
+            pagerank[u] += ORC_ALPHA * ru;
+            const orc_vec *nb = &g->in[u];
+            for (int j = 0; j < nb->n; ++j) {
+                const int64_t off = s->vertex_offset[i] + j;
+                const int v = vec_at(nb, j);
+                const double add = (1.0 - ORC_ALPHA) * ru / (deg[v] + 1);
+                const double prer = atomic_add_residual(&residual[v], add);
+                const double curr = prer + add;
+                if (LEGAL(prer) == 0 && LEGAL(curr) == 1) { s->edge_ind[off] = v; s->edge_flag[off] = 1; }
+                else s->edge_flag[off] = 0;
+            }
+        }
+        const int64_t n1 = pack_mt(s->edge_ind, s->edge_flag, total, s->ft2, threads); /* :265 */
+#pragma omp parallel for num_threads(threads) schedule(static)
+        for (int i = 0; i < F; ++i) { /* :267-277 */
+            const int u = s->ft[i];
+            residual[u] -= s->ft_r[i];
+            if (LEGAL(residual[u])) { s->edge_flag[i] = 1; s->edge_ind[i] = u; }
+            else s->edge_flag[i] = 0;
+        }
+        const int64_t n2 = pack_mt(s->edge_ind, s->edge_flag, F, s->ft2 + n1, threads); /* :279 */
+        s->stat_iters++; s->stat_F += F; s->stat_E += total; s->stat_N += n1 + n2;
+        int *t = s->ft; s->ft = s->ft2; s->ft2 = t;
+        s->ft_count = (int)(n1 + n2);
+        ++s->iteration_id;
+    }
+}
+
+void orc_cilk_inc_execute_mt(orc_state *s, const orc_graph *g, int threads) { /* :43-73 */
+    orc_copy_revert_out_degree(s, g);
+    orc_stream_update(s, g); /* 0.3 % of the region; per-u locks of :108-124 serialise same-tail records anyway */
+    ++s->iteration_id;
+    orc_dyn_push_init(s, g, 0);
+    orc_cilk_main_loop_mt(s, g, 0, threads);
+    ++s->iteration_id;
+    orc_dyn_push_init(s, g, 1);
+    orc_cilk_main_loop_mt(s, g, 1, threads);
 }
 
 /* ------------------------------------------------------------------ schedule B (FIFO, cpu/PPRCPURev.h) */

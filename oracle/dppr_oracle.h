@@ -90,6 +90,11 @@ typedef struct orc_state {
     int *ft, *ft2;
     double *ft_r;
     int ft_count;
+    /* -t > 1 schedule scratch (edge_ind / edge_flag / vertex_offset of cpu/PPRCPUMTCilkRev.h:8-18) */
+    int *edge_ind;
+    unsigned char *edge_flag;
+    int64_t *vertex_offset;
+    int64_t edge_cap;
     int iteration_id;
     /* fifo schedule */
     int *status;
@@ -118,6 +123,14 @@ void orc_cilk_init(orc_state *s);                                   /* :175-182 
 void orc_cilk_main_loop(orc_state *s, const orc_graph *g, int phase); /* :184-289 */
 void orc_cilk_execute(orc_state *s, const orc_graph *g);            /* :38-41 ExecuteImpl */
 void orc_cilk_inc_execute(orc_state *s, const orc_graph *g);        /* :43-73 IncExecuteImpl */
+
+/* The same schedule with T > 1 workers (OpenMP in place of Cilk Plus): parallel_for over the
+ * frontier, CAS-loop atomic adds (cpu/PPRCPUMTCilkRev.h:82-96), per-edge flag array + pack
+ * (cpu/CilkUtil.h:246-262). Like the reference at -t > 1 the result depends on thread timing
+ * (racy `ru = residual[u]`); it is held to Validate() only. This is the timed CPU baseline. */
+void orc_cilk_main_loop_mt(orc_state *s, const orc_graph *g, int phase, int threads);
+void orc_cilk_inc_execute_mt(orc_state *s, const orc_graph *g, int threads);
+int orc_max_threads(void);
 
 /* pieces, exposed for kernel-level parity tests */
 void orc_copy_revert_out_degree(orc_state *s, const orc_graph *g);  /* cpu/PPRCPUMTCilk.h:157-174 */

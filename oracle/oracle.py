@@ -47,7 +47,10 @@ class _State(C.Structure):
         ("V", C.c_int), ("source", C.c_int), ("eps", C.c_double),
         ("p", C.POINTER(C.c_double)), ("r", C.POINTER(C.c_double)), ("predeg", C.POINTER(C.c_int)),
         ("ft", C.POINTER(C.c_int)), ("ft2", C.POINTER(C.c_int)), ("ft_r", C.POINTER(C.c_double)),
-        ("ft_count", C.c_int), ("iteration_id", C.c_int),
+        ("ft_count", C.c_int),
+        ("edge_ind", C.POINTER(C.c_int)), ("edge_flag", C.POINTER(C.c_uint8)),
+        ("vertex_offset", C.POINTER(C.c_int64)), ("edge_cap", C.c_int64),
+        ("iteration_id", C.c_int),
         ("status", C.POINTER(C.c_int)), ("q", C.POINTER(C.c_int)),
         ("qhead", C.c_int64), ("qtail", C.c_int64), ("qcap", C.c_int64),
         ("stat_iters", C.c_int64), ("stat_F", C.c_int64), ("stat_E", C.c_int64), ("stat_N", C.c_int64),
@@ -92,6 +95,11 @@ def lib():
         getattr(L, name).argtypes = [SP, GP]
         getattr(L, name).restype = None
     L.orc_cilk_init.argtypes = [SP]
+    L.orc_cilk_inc_execute_mt.argtypes = [SP, GP, C.c_int]
+    L.orc_cilk_inc_execute_mt.restype = None
+    L.orc_cilk_main_loop_mt.argtypes = [SP, GP, C.c_int, C.c_int]
+    L.orc_cilk_main_loop_mt.restype = None
+    L.orc_max_threads.restype = C.c_int
     for name in ("orc_cilk_main_loop", "orc_sync_main_loop", "orc_dyn_push_init"):
         getattr(L, name).argtypes = [SP, GP, C.c_int]
         getattr(L, name).restype = None
@@ -231,6 +239,8 @@ class State:
     # schedules
     def cilk_execute(self, g): lib().orc_cilk_execute(self._s, g._g)
     def cilk_inc_execute(self, g): lib().orc_cilk_inc_execute(self._s, g._g)
+    def cilk_inc_execute_mt(self, g, threads): lib().orc_cilk_inc_execute_mt(self._s, g._g, int(threads))
+    def cilk_main_loop_mt(self, g, phase, threads): lib().orc_cilk_main_loop_mt(self._s, g._g, phase, int(threads))
     def fifo_execute(self, g): lib().orc_fifo_execute(self._s, g._g)
     def fifo_inc_execute(self, g): lib().orc_fifo_inc_execute(self._s, g._g)
     def sync_execute(self, g): lib().orc_sync_execute(self._s, g._g)
@@ -257,6 +267,10 @@ def pow_rev(g: Graph, source, alpha=0.15):
     out = np.empty(g.V, dtype=np.float64)
     iters = lib().orc_pow_rev(g._g, int(source), float(alpha), out.ctypes.data_as(C.POINTER(C.c_double)))
     return out, iters
+
+
+def max_threads():
+    return int(lib().orc_max_threads())
 
 
 def is_legal_push(r, phase, eps):

@@ -119,6 +119,24 @@ def test_push_schedules_meet_reference_validate(name, schedule):
             assert np.max(np.abs(s.p - d[f"b{k}.fifo.p"])) < 200 * eps
 
 
+@pytest.mark.parametrize("name", ["dir_ratio_e9", "und_ratio_e9"])
+def test_multithread_schedule_meets_reference_validate(name):
+    """The -t > 1 restatement (OpenMP workers, CAS atomics, flag arrays + pack) is timing dependent
+    like the reference; it must meet Validate() and the invariant at every batch."""
+    d, m = load_golden(name)
+    eps = m["eps"]
+    g = oracle_graph_from_golden(d, m)
+    s = orc.State(m["V"], m["source"], eps)
+    s.cilk_execute(g)
+    for k in range(1, m["done"] + 1):
+        assert not g.stream_updates()
+        g.inc_construct(1)
+        s.cilk_inc_execute_mt(g, 4)
+        assert s.max_abs_residual() < eps
+        assert np.max(np.abs(s.p - d[f"b{k}.pow.p"])) < 100 * eps
+        assert s.invariant_max_err(g) < 1e-13
+
+
 def test_quirk_q1_inc_construct_undirected_misaligned():
     """Reference quirk Q1: IncConstructWindowGraph appends a batch's direct
     records before its mirrored ones, but expires by count from the list front; when
