@@ -349,3 +349,37 @@ def test_full_size_youtube_standin_properties():
         assert p[src] >= 0.15
     st = e.stats(slot)
     assert st["batches"] == 3 and st["sum_E"] > 0 and st["algorithmic_bytes"] > 16 * V * 3
+
+
+def test_full_size_livejournal_standin_two_sources():
+    """BASELINE.json configs[2] size (soc-LiveJournal1 stand-in, directed, 69 M stream edges):
+    two sources drawn from degree ranks [10, 1000) share one device graph; size-independent
+    properties after the from-scratch solve and two batches each."""
+    from dynamicppr_amd import stream as st
+    V, e1, e2, cfg = datagen.stand_in_stream("livejournal", "/tmp/dppr_data")
+    wl = st.workload_config(len(e1), 0.1, 0, 0.01, 100)
+    W, c = wl.window, wl.per_batch
+    ranked = datagen.top_sources(V, e1, e2, W, cfg.directed, 1000)
+    sources = [int(ranked[10]), int(ranked[500])]
+    eps = 1e-9
+    e = eng.Engine(V, W, cfg.directed, c)
+    ss = st.SlidingStream(V, e1, e2, cfg.directed, wl)
+    e.load_window(*ss.serialize_edge_stream())
+    slots = [e.add_source(s) for s in sources]
+    for sl in slots:
+        e.init_solve(sl, eps)
+    for k in range(3):
+        if k:
+            assert not ss.stream_updates()
+            e.set_batch(*ss.batch_arrays())
+            e.slide(*ss.new_arrays())
+            for sl in slots:
+                e.update(sl, eps)
+        w1, w2 = ss.serialize_edge_stream()
+        for sl, src in zip(slots, sources):
+            p, r = e.read(sl)
+            assert np.max(np.abs(r)) < eps
+            assert invariant_max_err_np(p, r, w1, w2, V, src) < INVARIANT_TOL
+            assert p[src] >= 0.15
+    st0 = e.stats(slots[0])
+    assert st0["batches"] == 2 and st0["pull_iterations"] > 0 and st0["sum_E"] > 10 * len(w1)
