@@ -77,7 +77,7 @@ def main():
         directed = 1 if a.directed is None else a.directed
         name, flags = os.path.basename(a.bin), "-n 0 -r 0.01 -b 100"
     else:
-        V, e1, e2, cfg = datagen.stand_in_stream(a.config, a.data_dir)
+        V, e1, e2, cfg = datagen.stand_in_stream(a.config, a.data_dir or None)
         directed = cfg.directed if a.directed is None else a.directed
         name, flags = f"{cfg.name} stand-in (R-MAT scale {cfg.scale}, seed {cfg.seed})", cfg.flags
     f = flags.split()

@@ -87,7 +87,7 @@ struct dppr_engine {
     int *hub_hist = nullptr;    // 32 + 1 ints (histogram, hub counter)
     int hub_min_degree = HUB_MIN_DEGREE_DEFAULT;
     int big_row = BIG_ROW_DEFAULT;
-    int pull_min_frontier = 0; // 0: auto (max(2048, Ed/48)); < 0: never pull; > 0: pull when F >= value
+    int pull_min_frontier = 0; // 0: auto (max(1024, Ed/192)); < 0: never pull; > 0: pull when F >= value
     // CSR build scratch
     uint64_t *keys_a = nullptr, *keys_b = nullptr;
     void *sort_tmp = nullptr;
@@ -252,7 +252,7 @@ int read_count(dppr_engine *e, const int *dptr, int *out) {
 int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, double eps, int buf, int cur) {
     const int pull_min = e->pull_min_frontier > 0   ? e->pull_min_frontier
                          : e->pull_min_frontier < 0 ? 0x7fffffff
-                                                    : std::max(2048, e->Ed / 48);
+                                                    : std::max(1024, e->Ed / 192);
     const bool sync_sched = e->schedule == DPPR_SCHEDULE_SYNC;
     const HubTable hubs{ep.hub_v, ep.hub_degp1, ep.n_hubs};
     // the sparse grid must cover the largest frontier a push chunk can meet
@@ -361,8 +361,9 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
     }
     s.iter_hint[phase] = active_iters;
     if (any_pull) { // leave both dense vectors all-zero for the next loop
-        HIP_TRY(hipMemsetAsync(s.x, 0, sizeof(double) * (size_t)e->V, e->stream));
-        HIP_TRY(hipMemsetAsync(s.x2, 0, sizeof(double) * (size_t)e->V, e->stream));
+        // only internal ids below n_int are ever written
+        HIP_TRY(hipMemsetAsync(s.x, 0, sizeof(double) * (size_t)e->n_int, e->stream));
+        HIP_TRY(hipMemsetAsync(s.x2, 0, sizeof(double) * (size_t)e->n_int, e->stream));
     }
     return DPPR_OK;
 }

@@ -499,7 +499,7 @@ constexpr int PU = 2;             // gathers in flight per lane and list (regist
 
 struct PullBig {
     int v, rs, d;
-    double rv, xv;
+    double rv, xv, pv;
 };
 
 // wave-wide sum (butterfly; every lane gets the total, fixed order -> deterministic)
@@ -541,13 +541,15 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_pull_iter(int V, const int *__re
     int n_legal = 0;    // per-lane count of next-frontier vertices
     unsigned long long edges = 0;
 
-    auto finish = [&](bool valid, int v, double rv, double xv, double rn) { // repair, threshold, next snapshot
+    // repair, threshold, next snapshot. pv = pagerank[v], loaded up front with r and x so the
+    // "pagerank[v] += ALPHA*rn" of the next snapshot costs no extra round trip
+    auto finish = [&](bool valid, int v, double rv, double xv, double pv, double rn) {
         if (xv != 0.0) rn -= xv;
         const bool lg = valid && legal(rn, phase, eps);
         if (valid) {
             if (rn != rv) r[v] = rn;
             x_new[v] = lg ? rn : 0.0; // every entry is rewritten: x_new is a complete snapshot
-            if (lg) p[v] += ALPHA * rn;
+            if (lg) p[v] = pv + ALPHA * rn;
         }
         n_legal += lg ? 1 : 0;
     };
@@ -559,19 +561,20 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_pull_iter(int V, const int *__re
         const int v = (g * PULL_WAVES + w) * WAVE + lane;
         const bool valid = v < V;
         int rs = 0, d = 0;
-        double rv = 0.0, xv = 0.0;
+        double rv = 0.0, xv = 0.0, pv = 0.0;
         if (valid) {
             rs = out_row_ptr[v];
             d = out_row_ptr[v + 1] - rs;
             rv = r[v];
             xv = x[v];
+            pv = p[v];
         }
         // long rows go to the workgroup list; the owning lane keeps them only if the list is full
         bool deferred = false;
         if (d >= pull_big_row) {
             const int slot = atomicAdd(&s_nbig, 1);
             if (slot < PULL_BIG_CAP) {
-                s_big[slot] = PullBig{v, rs, d, rv, xv};
+                s_big[slot] = PullBig{v, rs, d, rv, xv, pv};
                 s_bigacc[slot] = 0.0;
                 deferred = true;
             }
@@ -666,18 +669,18 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_pull_iter(int V, const int *__re
             }
         }
         __builtin_amdgcn_wave_barrier();
-        finish(valid && !deferred, v, rv, xv, s_acc[w][lane]); // deferred vertices are finished below
+        finish(valid && !deferred, v, rv, xv, pv, s_acc[w][lane]); // deferred vertices are finished below
         if (nbig) {                                            // workgroup-uniform
             __syncthreads();                                   // all long-row partial sums are in
             if (w == 0) {
                 const bool has = lane < nbig;
-                PullBig big{0, 0, 0, 0.0, 0.0};
+                PullBig big{0, 0, 0, 0.0, 0.0, 0.0};
                 double acc = 0.0;
                 if (has) {
                     big = s_big[lane];
                     acc = s_bigacc[lane];
                 }
-                finish(has, big.v, big.rv, big.xv, big.rv + acc);
+                finish(has, big.v, big.rv, big.xv, big.pv, big.rv + acc);
             }
         }
         __syncthreads();

@@ -96,7 +96,7 @@ int dppr_set_profiling(dppr_engine *e, int on);
  * hub_min_degree: out-degree from which a vertex's incoming pushes are aggregated in LDS (at
  * most 2048 hubs per epoch); big_row_edges: in-degree from which a frontier vertex's row is
  * expanded by the whole grid; pull_min_frontier: frontier size from which an iteration is
- * evaluated as a dense pull sweep instead of push atomics (0 = auto: max(2048, edges/48),
+ * evaluated as a dense pull sweep instead of push atomics (0 = auto: max(1024, edges/192),
  * negative = never); chunk_iters: iterations enqueued per host read-back of the frontier size
  * (default 24, 1 = read back every iteration like the reference, <= 0 keeps the default);
  * pull_block: workgroup size of the sweep, 256 / 512 / 1024 (0 = chosen from the graph size).
