@@ -970,6 +970,14 @@ int dppr_trace_get(dppr_engine *e, int32_t slot, int64_t *n_iters, int64_t *n_id
     return DPPR_OK;
 }
 
+#ifdef DPPR_STAMPS
+// diagnostic build only: copy the stage stamps of the last sweep (rows x 8 clock values)
+extern "C" int dppr_debug_stamps(unsigned long long *out, int rows) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dppr::g_stamps), sizeof(unsigned long long) * 8 * (size_t)rows) == hipSuccess
+               ? 0 : -2;
+}
+#endif
+
 int dppr_bench_atomics(int device, int64_t table_elems, int64_t n, int scope, int reps, float *out_ms) {
     if (table_elems <= 0 || (table_elems & (table_elems - 1)) || n <= 0 || reps <= 0 || !out_ms) return DPPR_ERR_INVALID;
     int ndev = 0;

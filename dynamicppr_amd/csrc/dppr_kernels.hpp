@@ -47,14 +47,29 @@ __device__ __forceinline__ int mbcnt(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 
-// wave64 inclusive scan (shuffle based; 6 steps)
+// wave64 inclusive scans on the DPP path (ALU latency, no LDS crossbar): Hillis-Steele inside each
+// row of 16 lanes (row_shr 1,2,4,8), then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3.
+// Lanes without a source keep `old` (the operation's identity).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_take(int identity, int x) {
+    return __builtin_amdgcn_update_dpp(identity, x, CTRL, ROW_MASK, 0xf, false);
+}
 __device__ __forceinline__ int wave_inclusive_scan(int x) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        int y = __shfl_up(x, d, WAVE);
-        if (lane >= d) x += y;
-    }
+    x += dpp_take<0x111, 0xf>(0, x);
+    x += dpp_take<0x112, 0xf>(0, x);
+    x += dpp_take<0x114, 0xf>(0, x);
+    x += dpp_take<0x118, 0xf>(0, x);
+    x += dpp_take<0x142, 0xa>(0, x);
+    x += dpp_take<0x143, 0xc>(0, x);
+    return x;
+}
+__device__ __forceinline__ int wave_inclusive_max(int x) { // for values >= -1
+    x = max(x, dpp_take<0x111, 0xf>(-1, x));
+    x = max(x, dpp_take<0x112, 0xf>(-1, x));
+    x = max(x, dpp_take<0x114, 0xf>(-1, x));
+    x = max(x, dpp_take<0x118, 0xf>(-1, x));
+    x = max(x, dpp_take<0x142, 0xa>(-1, x));
+    x = max(x, dpp_take<0x143, 0xc>(-1, x));
     return x;
 }
 
@@ -495,7 +510,7 @@ __global__ __launch_bounds__(BLOCK) void k_push_big(const BigItem *__restrict__ 
 // workgroups -> few counter atomics), 512 / 256 when that would leave CUs idle
 constexpr int PULL_BIG_ROW_DEFAULT = 128; // rows at least this long are gathered by the whole workgroup
 constexpr int PULL_BIG_CAP = 64;  // such rows per workgroup pass (more: the owning wave does them itself)
-constexpr int PU = 2;             // gathers in flight per lane and list (register budget: 8 waves/SIMD)
+constexpr int PU = 4;             // gathers in flight per lane (short rows)
 
 struct PullBig {
     int v, rs, d;
@@ -512,16 +527,29 @@ __device__ __forceinline__ double wave_sum(double x) {
 // The sweep does not build the sparse frontier list (a following dense iteration does not
 // need it): it only COUNTS the next frontier, with one fire-and-forget atomic per workgroup.
 // k_list_from_dense materialises the list when a sparse iteration follows (or for tracing).
+// Diagnostic build only (-DDPPR_STAMPS, tools/stamps.sh): shader-clock stamps of the sweep's
+// stages, one row per workgroup, written to a buffer nothing else reads.
+#ifdef DPPR_STAMPS
+__device__ unsigned long long g_stamps[4096 * 8];
+#define STAMP(i)                                                                         \
+    do {                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (i)] = clock64(); \
+    } while (0)
+#else
+#define STAMP(i) ((void)0)
+#endif
+
 template <int PULL_BLOCK>
 __global__ __launch_bounds__(PULL_BLOCK) void k_pull_iter(int V, const int *__restrict__ cnt_in,
-                                                             const int *__restrict__ out_row_ptr,
-                                                             const int *__restrict__ out_col,
-                                                             const double *__restrict__ x, double *__restrict__ x_new,
-                                                             double *__restrict__ r, double *__restrict__ p,
-                                                             int *__restrict__ cnt_out, int *__restrict__ cnt_zero,
-                                                             int phase, double eps, IterStats *__restrict__ stats,
-                                                             int *__restrict__ log_slot, int pull_big_row) {
+                                                          const int *__restrict__ out_row_ptr,
+                                                          const int *__restrict__ out_col,
+                                                          const double *__restrict__ x, double *__restrict__ x_new,
+                                                          double *__restrict__ r, double *__restrict__ p,
+                                                          int *__restrict__ cnt_out, int *__restrict__ cnt_zero,
+                                                          int phase, double eps, IterStats *__restrict__ stats,
+                                                          int *__restrict__ log_slot, int pull_big_row) {
     constexpr int PULL_WAVES = PULL_BLOCK / WAVE;
+    __shared__ int s_own[PULL_WAVES][WAVE * PU];   // per round: owner marks of the wave's edge window
     __shared__ int s_scan[PULL_WAVES][WAVE + 1];
     __shared__ int s_start[PULL_WAVES][WAVE];
     __shared__ double s_acc[PULL_WAVES][WAVE];
@@ -529,7 +557,7 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_pull_iter(int V, const int *__re
     __shared__ unsigned long long s_edges[PULL_WAVES];
     __shared__ PullBig s_big[PULL_BIG_CAP];
     __shared__ double s_bigacc[PULL_BIG_CAP];
-    __shared__ int s_bigscan[PULL_WAVES][WAVE + 1];
+    __shared__ int s_chunk0[PULL_WAVES][WAVE + 1]; // per wave copy: first chunk id of each long row
     __shared__ int s_nbig;
     const int lane = lane_id(), w = wave_id();
     const int F = *cnt_in;
@@ -538,6 +566,7 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_pull_iter(int V, const int *__re
         *log_slot = F;
     }
     if (F == 0) return; // empty frontier: x / x_new are not touched
+    STAMP(0);
     int n_legal = 0;    // per-lane count of next-frontier vertices
     unsigned long long edges = 0;
 
@@ -554,7 +583,7 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_pull_iter(int V, const int *__re
         n_legal += lg ? 1 : 0;
     };
 
-    const int n_groups = (V + PULL_BLOCK - 1) / PULL_BLOCK; // 1024 consecutive vertices per pass
+    const int n_groups = (V + PULL_BLOCK - 1) / PULL_BLOCK; // PULL_BLOCK consecutive vertices per pass
     for (int g = blockIdx.x; g < n_groups; g += gridDim.x) { // workgroup-uniform loop
         if (threadIdx.x == 0) s_nbig = 0;
         __syncthreads();
@@ -581,97 +610,100 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_pull_iter(int V, const int *__re
         }
         const int dd = deferred ? 0 : d;
         const int incl = wave_inclusive_scan(dd);
-        const int total = __shfl(incl, WAVE - 1, WAVE);
-        s_scan[w][lane] = incl - dd; // deferred rows have length 0 here and are never visited
+        const int scan_ex = incl - dd;
+        const int total = __builtin_amdgcn_readlane(incl, WAVE - 1);
+        s_scan[w][lane] = scan_ex; // deferred rows have length 0 here and are never visited
         s_start[w][lane] = rs;
         if (lane == 0) s_scan[w][WAVE] = total;
         s_acc[w][lane] = rv;
-        __syncthreads(); // long-row list complete (also orders this wave's LDS tile)
-        const int nbig = min(s_nbig, PULL_BIG_CAP);
-        int big_total = 0;
-        if (nbig) { // every wave scans the <= 64 long-row lengths into its own copy (no second barrier)
-            const int len = lane < nbig ? s_big[lane].d : 0;
-            const int inc = wave_inclusive_scan(len);
-            s_bigscan[w][lane] = inc - len;
-            big_total = __shfl(inc, WAVE - 1, WAVE);
-            if (lane == 0) s_bigscan[w][WAVE] = big_total;
+        STAMP(1);
+
+        // ---- the wave's own (short) rows: 64*PU consecutive edges of the concatenated list per
+        // round. Owner of edge e = last non-empty row whose start is <= e: rows starting inside the
+        // round's window mark their lane id at their start position, a max-scan propagates it.
+        for (int e0 = 0; e0 < total; e0 += WAVE * PU) {
+#pragma unroll
+            for (int k = 0; k < PU; ++k) s_own[w][k * WAVE + lane] = -1;
             __builtin_amdgcn_wave_barrier();
-        }
-        // One merged loop: each round issues the column loads of the wave's own (short-row) edges
-        // AND of its share of the concatenated long rows, then both sets of x gathers, so the two
-        // dependent chains overlap instead of running back to back.
-        const int rounds_a = (total + WAVE * PU - 1) / (WAVE * PU);
-        const int rounds_b = (big_total + PULL_BLOCK * PU - 1) / (PULL_BLOCK * PU);
-        const int rounds = max(rounds_a, rounds_b);
-        for (int rd = 0; rd < rounds; ++rd) {
-            int own_a[PU], own_b[PU], col_a[PU], col_b[PU];
+            const int pos = scan_ex - e0;
+            if (dd > 0 && pos >= 0 && pos < WAVE * PU) s_own[w][pos] = lane;
+            __builtin_amdgcn_wave_barrier();
+            const uint64_t before = __ballot(dd > 0 && scan_ex <= e0);
+            int carry = before ? 63 - __clzll(before) : -1; // row that owns edge e0
+            int own[PU], col[PU];
 #pragma unroll
             for (int k = 0; k < PU; ++k) {
-                const int e = (rd * PU + k) * WAVE + lane;
-                own_a[k] = -1;
-                col_a[k] = 0;
-                if (e < total) {
-                    int lo = 0, hi = WAVE;
-#pragma unroll
-                    for (int s2 = 0; s2 < 6; ++s2) {
-                        const int mid = (lo + hi) >> 1;
-                        if (s_scan[w][mid] <= e) lo = mid; else hi = mid;
-                    }
-                    own_a[k] = lo;
-                    col_a[k] = out_col[s_start[w][lo] + (e - s_scan[w][lo])];
-                }
+                const int e = e0 + k * WAVE + lane;
+                int o = wave_inclusive_max(s_own[w][k * WAVE + lane]);
+                o = max(o, carry);
+                carry = __builtin_amdgcn_readlane(o, WAVE - 1);
+                own[k] = e < total ? o : -1;
+                col[k] = 0;
+                if (own[k] >= 0) col[k] = out_col[s_start[w][o] + (e - s_scan[w][o])];
             }
+            double xa[PU];
 #pragma unroll
-            for (int k = 0; k < PU; ++k) {
-                const int e = (rd * PU + k) * PULL_BLOCK + (int)threadIdx.x;
-                own_b[k] = -1;
-                col_b[k] = 0;
-                if (e < big_total) {
-                    int lo = 0, hi = WAVE;
-#pragma unroll
-                    for (int s2 = 0; s2 < 6; ++s2) {
-                        const int mid = (lo + hi) >> 1;
-                        if (s_bigscan[w][mid] <= e) lo = mid; else hi = mid;
-                    }
-                    own_b[k] = lo;
-                    col_b[k] = out_col[s_big[lo].rs + (e - s_bigscan[w][lo])];
-                }
-            }
-            double xa[PU], xb[PU];
-#pragma unroll
-            for (int k = 0; k < PU; ++k) xa[k] = own_a[k] >= 0 ? x[col_a[k]] : 0.0;
-#pragma unroll
-            for (int k = 0; k < PU; ++k) xb[k] = own_b[k] >= 0 ? x[col_b[k]] : 0.0;
+            for (int k = 0; k < PU; ++k) xa[k] = own[k] >= 0 ? x[col[k]] : 0.0;
 #pragma unroll
             for (int k = 0; k < PU; ++k) {
                 const bool nz = xa[k] != 0.0;
                 if (nz) {
-                    const int dk = s_scan[w][own_a[k] + 1] - s_scan[w][own_a[k]];
-                    lds_add(&s_acc[w][own_a[k]], ONE_MINUS_ALPHA * xa[k] / (double)(dk + 1));
+                    const int dk = s_scan[w][own[k] + 1] - s_scan[w][own[k]];
+                    lds_add(&s_acc[w][own[k]], ONE_MINUS_ALPHA * xa[k] / (double)(dk + 1));
                 }
                 edges += (unsigned long long)__popcll(__ballot(nz));
             }
-            if (rd < rounds_b) { // wave-uniform
-#pragma unroll
-                for (int k = 0; k < PU; ++k) {
-                    double c = 0.0;
-                    if (xb[k] != 0.0) c = ONE_MINUS_ALPHA * xb[k] / (double)(s_big[own_b[k]].d + 1);
-                    edges += (unsigned long long)__popcll(__ballot(c != 0.0));
-                    // 64 consecutive edges mostly belong to ONE long row: reduce in the wave first
-                    const int own0 = __shfl(own_b[k], 0, WAVE);
-                    if (__all(own_b[k] == own0)) {
-                        const double t = wave_sum(c);
-                        if (lane == 0 && own0 >= 0 && t != 0.0) lds_add(&s_bigacc[own0], t);
-                    } else if (c != 0.0) {
-                        lds_add(&s_bigacc[own_b[k]], c);
-                    }
-                }
-            }
+            __builtin_amdgcn_wave_barrier();
         }
         __builtin_amdgcn_wave_barrier();
+        STAMP(2);
         finish(valid && !deferred, v, rv, xv, pv, s_acc[w][lane]); // deferred vertices are finished below
-        if (nbig) {                                            // workgroup-uniform
-            __syncthreads();                                   // all long-row partial sums are in
+        STAMP(3);
+
+        // ---- the workgroup's long rows, cut into chunks of PULL_CHUNK edges dealt round-robin to
+        // the waves: no per-edge search, per-lane partial sums, one wave reduction per chunk.
+        __syncthreads(); // long-row list complete
+        const int nbig = min(s_nbig, PULL_BIG_CAP);
+        if (nbig) { // workgroup-uniform
+            constexpr int PULL_CHUNK = WAVE * 8;
+            const int nch = lane < nbig ? (s_big[lane].d + PULL_CHUNK - 1) / PULL_CHUNK : 0;
+            const int inc = wave_inclusive_scan(nch);
+            s_chunk0[w][lane] = inc - nch;
+            const int n_chunks = __builtin_amdgcn_readlane(inc, WAVE - 1);
+            if (lane == 0) s_chunk0[w][WAVE] = n_chunks;
+            __builtin_amdgcn_wave_barrier();
+            for (int ch = w; ch < n_chunks; ch += PULL_WAVES) {
+                int lo = 0, hi = WAVE; // row of this chunk: wave-uniform search, once per 512 edges
+#pragma unroll
+                for (int s2 = 0; s2 < 6; ++s2) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_chunk0[w][mid] <= ch) lo = mid; else hi = mid;
+                }
+                const int row_rs = s_big[lo].rs, row_d = s_big[lo].d;
+                const int c0 = (ch - s_chunk0[w][lo]) * PULL_CHUNK;
+                const int c1 = min(c0 + PULL_CHUNK, row_d);
+                const double denom = (double)(row_d + 1);
+                double part = 0.0;
+                constexpr int CH_SLOTS = PULL_CHUNK / WAVE; // all of a chunk's loads are issued before any use
+                int colb[CH_SLOTS];
+                double xb[CH_SLOTS];
+#pragma unroll
+                for (int k = 0; k < CH_SLOTS; ++k) {
+                    const int e = c0 + k * WAVE + lane;
+                    colb[k] = e < c1 ? out_col[row_rs + e] : -1;
+                }
+#pragma unroll
+                for (int k = 0; k < CH_SLOTS; ++k) xb[k] = colb[k] >= 0 ? x[colb[k]] : 0.0;
+#pragma unroll
+                for (int k = 0; k < CH_SLOTS; ++k) {
+                    const bool nz = xb[k] != 0.0;
+                    if (nz) part += ONE_MINUS_ALPHA * xb[k] / denom;
+                    edges += (unsigned long long)__popcll(__ballot(nz));
+                }
+                part = wave_sum(part);
+                if (lane == 0 && part != 0.0) lds_add(&s_bigacc[lo], part);
+            }
+            __syncthreads(); // all long-row partial sums are in
             if (w == 0) {
                 const bool has = lane < nbig;
                 PullBig big{0, 0, 0, 0.0, 0.0, 0.0};
@@ -683,13 +715,13 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_pull_iter(int V, const int *__re
                 finish(has, big.v, big.rv, big.xv, big.pv, big.rv + acc);
             }
         }
+        STAMP(4);
         __syncthreads();
     }
+    STAMP(5);
     // count of the next frontier: wave reduce, then ONE fire-and-forget atomic per workgroup
-    int cw = n_legal;
-#pragma unroll
-    for (int dlt = WAVE / 2; dlt >= 1; dlt >>= 1) cw += __shfl_xor(cw, dlt, WAVE);
-    if (lane == 0) s_cnt[w] = cw;
+    int cw = wave_inclusive_scan(n_legal);
+    if (lane == WAVE - 1) s_cnt[w] = cw;
     __syncthreads();
     if (threadIdx.x == 0) {
         int tot = 0;
@@ -697,6 +729,7 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_pull_iter(int V, const int *__re
         if (tot) atomicAdd(cnt_out, tot);
     }
     stat_add_edges<PULL_WAVES>(stats, edges, s_edges);
+    STAMP(6);
 }
 
 // dense -> sparse: the frontier list {v : x[v] != 0} (k_inspect's compaction on the snapshot).

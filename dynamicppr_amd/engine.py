@@ -14,7 +14,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdppr_hip.so")
+LIB_PATH = os.environ.get("DPPR_LIB") or os.path.join(_HERE, "libdppr_hip.so")  # DPPR_LIB: diagnostic builds only
 
 SCHEDULE_EAGER = 0
 SCHEDULE_SYNC = 1
