@@ -183,11 +183,11 @@ def main():
 
 def pmc_traffic_per_iteration():
     """HBM bytes per frontier iteration from the committed rocprofv3 --pmc summary of this same
-    workload (tools/prof_pmc.sh -> profiles/r01_f_pmc_traffic_youtube.json; FETCH_SIZE and
+    workload (tools/prof_pmc.sh -> profiles/r01_final_pmc_traffic_youtube.json; FETCH_SIZE and
     WRITE_SIZE in separate passes, 2 x FETCH + WRITE per the gfx950 correction of
     MI355X_MICROARCH.md). bench.py cannot run the profiler on itself, so this is read back;
     None when the file is missing or the workload differs."""
-    path = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic_youtube.json")
+    path = os.path.join(ROOT, "profiles", "r01_final_pmc_traffic_youtube.json")
     if not os.path.exists(path):
         return None
     d = json.load(open(path))
