@@ -383,3 +383,62 @@ def test_full_size_livejournal_standin_two_sources():
             assert p[src] >= 0.15
     st0 = e.stats(slots[0])
     assert st0["batches"] == 2 and st0["pull_iterations"] > 0 and st0["sum_E"] > 10 * len(w1)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_randomised_streams_sync_frontiers(seed):
+    """Different seeded streams / shapes, each with the path thresholds lowered in a different way:
+    per-iteration frontier sets must equal the oracle's synchronous schedule on every one."""
+    rng = np.random.default_rng(seed)
+    scale = int(rng.integers(7, 12))
+    edges = int(rng.integers(2000, 12000))
+    directed = int(seed % 2)
+    W = int(edges * rng.uniform(0.05, 0.3))
+    c = int(max(1, W * rng.uniform(0.005, 0.08)))
+    tuning = dict(hub_min_degree=int(rng.integers(1, 6)), big_row_edges=int(rng.integers(1, 12)),
+                  pull_min_frontier=int(rng.choice([-1, 1, 8, 64])), chunk_iters=int(rng.choice([1, 2, 5, 24])),
+                  pull_block=int(rng.choice([256, 512, 1024])))
+    V, e1, e2 = datagen.rmat_stream(scale, edges, 100 + seed)
+    src = int(datagen.top_sources(V, e1, e2, W, directed, 3)[seed % 3])
+    eps = float(rng.choice([1e-9, 1e-7]))
+    sc = Scenario(V, e1, e2, directed, W, c, src, eps, schedule=eng.SCHEDULE_SYNC, **tuning)
+    sc.s.trace(True)
+    sc.e.trace_enable(sc.slot, True)
+    sc.s.sync_execute(sc.g)
+    sc.e.init_solve(sc.slot, eps)
+    for k in range(4):
+        if k:
+            if not sc.advance_graphs():
+                break
+            sc.s.trace(True)
+            sc.e.trace_enable(sc.slot, True)
+            sc.s.sync_inc_execute(sc.g)
+            sc.e.update(sc.slot, eps)
+        want, got = sc.s.traced_frontiers(), sc.e.trace_get(sc.slot)
+        assert len(want) == len(got), (tuning, k)
+        for a, b in zip(got, want):
+            assert np.array_equal(np.sort(a), np.sort(b)), (tuning, k)
+        p, r = sc.e.read(sc.slot)
+        assert np.max(np.abs(p - sc.s.p)) < SYNC_TOL * max(1.0, eps / 1e-9) and np.max(np.abs(r)) < eps
+
+
+def test_hub_table_overflow_and_long_row_list_overflow():
+    """More candidate hubs than the 2048-slot table (threshold selection kicks in) and more long
+    rows per sweep group than the 64-entry workgroup list (owning wave keeps the rest)."""
+    V, e1, e2 = datagen.rmat_stream(13, 60000, 21)
+    W, c, eps = 30000, 300, 1e-9
+    src = int(datagen.top_sources(V, e1, e2, W, 0, 1)[0])
+    for tuning in (dict(hub_min_degree=1, big_row_edges=1, pull_min_frontier=-1),   # all hubs, all big (push)
+                   dict(hub_min_degree=1, big_row_edges=1, pull_min_frontier=1)):   # every row "long" (pull)
+        sc = Scenario(V, e1, e2, 0, W, c, src, eps, schedule=eng.SCHEDULE_SYNC, **tuning)
+        sc.s.sync_execute(sc.g)
+        sc.e.init_solve(sc.slot, eps)
+        for k in range(3):
+            if k:
+                assert sc.advance_graphs()
+                sc.s.sync_inc_execute(sc.g)
+                sc.e.update(sc.slot, eps)
+            p, r = sc.e.read(sc.slot)
+            assert np.max(np.abs(p - sc.s.p)) < SYNC_TOL and np.max(np.abs(r - sc.s.r)) < SYNC_TOL
+            st, want = sc.e.stats(sc.slot), sc.s.stats()
+            assert (st["iterations"], st["sum_F"], st["sum_E"]) == (want["iters"], want["F"], want["E"])
