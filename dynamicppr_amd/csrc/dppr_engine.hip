@@ -302,16 +302,32 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             }
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k], e->stream));
             if (pull) {
-                // workgroup size: 1024 vertices per pass unless that leaves CUs idle
-                const int pb = e->pull_block ? e->pull_block
-                                             : (e->n_int >= 1024 * 512 ? 1024 : (e->n_int >= 512 * 128 ? 512 : 256));
+                // workgroup size = vertices per group: the smallest size that puts ONE group on each of
+                // (at most) 256 CUs; larger graphs take 1024 and stride
+                int pb = e->pull_block;
+                if (!pb) {
+                    static const int sizes[] = {256, 384, 512, 576, 640, 768, 896, 1024};
+                    pb = 1024;
+                    for (int sz : sizes)
+                        if ((e->n_int + sz - 1) / sz <= 256) {
+                            pb = sz;
+                            break;
+                        }
+                }
 #define DPPR_LAUNCH_PULL(PB)                                                                                        \
     hipLaunchKernelGGL(k_pull_iter<PB>, dim3(grid_for(e->n_int, PB, 1024)), dim3(PB), 0, e->stream, e->n_int,       \
                        s.cnt + cur, ep.out_row_ptr, ep.out_col, s.x, s.x2, s.r, s.p, s.cnt + nxt, s.cnt + zer, phase, \
                        eps, s.dstats, log_slot, std::min(e->big_row, PULL_BIG_ROW_DEFAULT))
-                if (pb == 1024) DPPR_LAUNCH_PULL(1024);
-                else if (pb == 512) DPPR_LAUNCH_PULL(512);
-                else DPPR_LAUNCH_PULL(256);
+                switch (pb) {
+                case 256: DPPR_LAUNCH_PULL(256); break;
+                case 384: DPPR_LAUNCH_PULL(384); break;
+                case 512: DPPR_LAUNCH_PULL(512); break;
+                case 576: DPPR_LAUNCH_PULL(576); break;
+                case 640: DPPR_LAUNCH_PULL(640); break;
+                case 768: DPPR_LAUNCH_PULL(768); break;
+                case 896: DPPR_LAUNCH_PULL(896); break;
+                default: DPPR_LAUNCH_PULL(1024); break;
+                }
 #undef DPPR_LAUNCH_PULL
                 std::swap(s.x, s.x2); // the sweep wrote every entry of x2: it is the next snapshot
                 dense_valid = true;
@@ -465,7 +481,9 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     HIP_TRY_C(hipMalloc((void **)&e->w1, sizeof(int) * Wn));
     HIP_TRY_C(hipMalloc((void **)&e->w2, sizeof(int) * Wn));
     HIP_TRY_C(hipMalloc((void **)&e->outdeg, sizeof(int) * (size_t)V));
-    HIP_TRY_C(hipMemset(e->outdeg, 0, sizeof(int) * (size_t)V));
+    // every memset / copy of the engine goes on ITS stream: the stream is non-blocking, so work on
+    // the null stream (plain hipMemset / hipMemcpy) is not ordered with it
+    HIP_TRY_C(hipMemsetAsync(e->outdeg, 0, sizeof(int) * (size_t)V, e->stream));
     HIP_TRY_C(hipMalloc((void **)&e->hub_slot_of, sizeof(int) * (size_t)V));
     HIP_TRY_C(hipMalloc((void **)&e->d_ext2int, sizeof(int) * (size_t)V));
     HIP_TRY_C(hipMalloc((void **)&e->d_xfer, sizeof(double) * (size_t)V));
@@ -551,7 +569,7 @@ int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges, int p
     e->big_row = big_row_edges;
     e->pull_min_frontier = pull_min_frontier;
     if (chunk_iters > 0) e->chunk_iters = std::min(chunk_iters, MAX_CHUNK);
-    if (pull_block == 256 || pull_block == 512 || pull_block == 1024) e->pull_block = pull_block;
+    if (pull_block >= 256 && pull_block <= 1024 && pull_block % 64 == 0) e->pull_block = pull_block;
     return DPPR_OK;
 }
 
@@ -692,8 +710,8 @@ int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
     HIP_TRY(hipMalloc((void **)&s.r, sizeof(double) * V));
     HIP_TRY(hipMalloc((void **)&s.x, sizeof(double) * V));
     HIP_TRY(hipMalloc((void **)&s.x2, sizeof(double) * V));
-    HIP_TRY(hipMemset(s.x, 0, sizeof(double) * V));
-    HIP_TRY(hipMemset(s.x2, 0, sizeof(double) * V));
+    HIP_TRY(hipMemsetAsync(s.x, 0, sizeof(double) * V, e->stream));
+    HIP_TRY(hipMemsetAsync(s.x2, 0, sizeof(double) * V, e->stream));
     HIP_TRY(hipMalloc((void **)&s.ft[0], sizeof(int) * V));
     HIP_TRY(hipMalloc((void **)&s.ft[1], sizeof(int) * V));
     HIP_TRY(hipMalloc((void **)&s.neg, sizeof(int) * (size_t)std::max(4 * e->c, 1)));
@@ -702,8 +720,8 @@ int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
     // a row is deferred only if it has >= big_row edges, so at most Ed / big_row of them exist
     HIP_TRY(hipMalloc((void **)&s.big, sizeof(BigItem) * ((size_t)e->Ed / (size_t)std::max(e->big_row, 1) + 64)));
     HIP_TRY(hipMalloc((void **)&s.dstats, sizeof(IterStats)));
-    HIP_TRY(hipMemset(s.cnt, 0, sizeof(int) * 8));
-    HIP_TRY(hipMemset(s.dstats, 0, sizeof(IterStats)));
+    HIP_TRY(hipMemsetAsync(s.cnt, 0, sizeof(int) * (8 + MAX_CHUNK), e->stream));
+    HIP_TRY(hipMemsetAsync(s.dstats, 0, sizeof(IterStats), e->stream));
     hipLaunchKernelGGL(k_init, dim3(grid_for(e->V)), dim3(BLOCK), 0, e->stream, s.p, s.r, e->V, source);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -884,7 +902,10 @@ int dppr_inspect(dppr_engine *e, int32_t slot, int phase, double eps, int32_t *o
     int n = 0;
     int rc = read_count(e, s.cnt + 4, &n);
     if (rc) return rc;
-    if (n > 0) HIP_TRY(hipMemcpy(out_ids, s.ft[1], sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(out_ids, s.ft[1], sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
     for (int i = 0; i < n; ++i) out_ids[i] = e->int2ext[(size_t)out_ids[i]];
     *out_count = n;
     return DPPR_OK;

@@ -560,7 +560,22 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_pull_iter(int V, const int *__re
     __shared__ int s_chunk0[PULL_WAVES][WAVE + 1]; // per wave copy: first chunk id of each long row
     __shared__ int s_nbig;
     const int lane = lane_id(), w = wave_id();
+    const int n_groups = (V + PULL_BLOCK - 1) / PULL_BLOCK; // PULL_BLOCK consecutive vertices per pass
     const int F = *cnt_in;
+    // the first group's tile loads are issued BEFORE F is consumed: the (cold) read of the
+    // frontier size overlaps them instead of heading the dependent chain
+    int rs = 0, d = 0;
+    double rv = 0.0, xv = 0.0, pv = 0.0;
+    {
+        const int v0 = ((int)blockIdx.x * PULL_WAVES + w) * WAVE + lane;
+        if ((int)blockIdx.x < n_groups && v0 < V) {
+            rs = out_row_ptr[v0];
+            d = out_row_ptr[v0 + 1] - rs;
+            rv = r[v0];
+            xv = x[v0];
+            pv = p[v0];
+        }
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *cnt_zero = 0;
         *log_slot = F;
@@ -583,20 +598,20 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_pull_iter(int V, const int *__re
         n_legal += lg ? 1 : 0;
     };
 
-    const int n_groups = (V + PULL_BLOCK - 1) / PULL_BLOCK; // PULL_BLOCK consecutive vertices per pass
     for (int g = blockIdx.x; g < n_groups; g += gridDim.x) { // workgroup-uniform loop
         if (threadIdx.x == 0) s_nbig = 0;
         __syncthreads();
         const int v = (g * PULL_WAVES + w) * WAVE + lane;
         const bool valid = v < V;
-        int rs = 0, d = 0;
-        double rv = 0.0, xv = 0.0, pv = 0.0;
-        if (valid) {
-            rs = out_row_ptr[v];
-            d = out_row_ptr[v + 1] - rs;
-            rv = r[v];
-            xv = x[v];
-            pv = p[v];
+        if (g != (int)blockIdx.x) { // later groups (the first one was loaded above)
+            rs = 0; d = 0; rv = 0.0; xv = 0.0; pv = 0.0;
+            if (valid) {
+                rs = out_row_ptr[v];
+                d = out_row_ptr[v + 1] - rs;
+                rv = r[v];
+                xv = x[v];
+                pv = p[v];
+            }
         }
         // long rows go to the workgroup list; the owning lane keeps them only if the list is full
         bool deferred = false;

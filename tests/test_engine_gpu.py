@@ -397,7 +397,7 @@ def test_randomised_streams_sync_frontiers(seed):
     c = int(max(1, W * rng.uniform(0.005, 0.08)))
     tuning = dict(hub_min_degree=int(rng.integers(1, 6)), big_row_edges=int(rng.integers(1, 12)),
                   pull_min_frontier=int(rng.choice([-1, 1, 8, 64])), chunk_iters=int(rng.choice([1, 2, 5, 24])),
-                  pull_block=int(rng.choice([256, 512, 1024])))
+                  pull_block=int(rng.choice([256, 384, 576, 640, 896, 1024])))
     V, e1, e2 = datagen.rmat_stream(scale, edges, 100 + seed)
     src = int(datagen.top_sources(V, e1, e2, W, directed, 3)[seed % 3])
     eps = float(rng.choice([1e-9, 1e-7]))
