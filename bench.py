@@ -157,6 +157,8 @@ def main():
         }
         if not a.no_cpu_baseline:
             cpu = cpu_baseline(V, e1, e2, directed, W, c, source, a.eps, a.cpu_batches)
+            bin_path = a.bin or (datagen.stand_in_path(a.config, a.data_dir) if a.data_dir else None)
+            cpu["reference_fifo"] = reference_fifo_baseline(bin_path, directed, flags, source, a.eps, c)
 
     if rank == 0:
         value = units / dt
@@ -253,6 +255,33 @@ def cpu_baseline(V, e1, e2, directed, W, c, source, eps, batches):
             "t1_value": round(c * n1 / t1, 1) if t1 > 0 else None, "t1_ms_per_step": round(1e3 * t1 / max(n1, 1), 2),
             "sample": f"first {nm} batches of the same stream/source after the from-scratch solve; oracle "
                       f"restatement of cpu/PPRCPUMTCilkRev with OpenMP workers ({threads} threads) and at -t 1, gcc -O2"}
+
+
+def reference_fifo_baseline(bin_path, directed, flags, source, eps, c, batches=4):
+    """The REAL reference code that can be built here: cpu/PPRCPURev.h, the reference's (deprecated)
+    single-thread FIFO reverse push, compiled from /root/reference by oracle/Makefile into
+    oracle/_ref/ref_driver (the binary travels to the GPU box, the sources do not). Timed scope:
+    IncExecuteImpl only. None when the binary or the .bin file is not there."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    if not bin_path or not os.path.exists(exe) or not os.path.exists(bin_path):
+        return None
+    f = flags.split()
+    if "-b" in f:
+        f[f.index("-b") + 1] = str(batches)
+    elif "-l" in f:
+        f[f.index("-l") + 1] = str(batches * c)
+    try:
+        out = subprocess.run([exe, "-d", bin_path, "-a", "0", "-i", str(directed), "-y", "1", "-w", "0.1", *f,
+                              "-s", str(source), "-e", repr(eps), "--dump", "/dev/null"],
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=600).stdout
+        line = [ln for ln in out.splitlines() if ln.startswith("ref_fifo_inc_ms")][-1].split()
+        ms, done = float(line[1]), int(line[3])
+        return {"value": round(c * done / (ms * 1e-3), 1), "unit": "edges/s", "cores": 1, "kind": "reference",
+                "ms_per_step": round(ms / max(done, 1), 2),
+                "sample": f"first {done} batches, cpu/PPRCPURev.h (single-thread FIFO schedule) built from the reference sources"}
+    except Exception as exc:  # noqa: BLE001 - a baseline must never break the benchmark line
+        return {"error": str(exc)[:200]}
 
 
 if __name__ == "__main__":

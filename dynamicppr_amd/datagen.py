@@ -120,12 +120,17 @@ STAND_INS = {
 }
 
 
+def stand_in_path(key: str, cache_dir: str) -> str:
+    cfg = STAND_INS[key]
+    return os.path.join(cache_dir, f"{cfg.name}.rmat{cfg.scale}.s{cfg.seed}.bin")
+
+
 def stand_in_stream(key: str, cache_dir: str | None = None):
     """``(V, e1, e2, StandIn)`` for a named config; cached as ``.bin`` when asked."""
     cfg = STAND_INS[key]
     if cache_dir:
         os.makedirs(cache_dir, exist_ok=True)
-        path = os.path.join(cache_dir, f"{cfg.name}.rmat{cfg.scale}.s{cfg.seed}.bin")
+        path = stand_in_path(key, cache_dir)
         if os.path.exists(path):
             V, e1, e2 = read_bin(path)
             return V, e1, e2, cfg

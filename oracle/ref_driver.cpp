@@ -21,6 +21,7 @@
 #include "PPRCPUPowVec.h"
 #include "Arguments.h"
 
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -82,36 +83,46 @@ int main(int argc, char *argv[]) {
     double tol = gTolerance;
     put("tolerance", 1, &tol, 1);
 
+    // --dump /dev/null = timing only: run the reference's FIFO push code, skip dumps and ground truth
+    const bool timing_only = dump == "/dev/null";
     PPRCPURev *ppr = new PPRCPURev(g);
-    put_adj("b0.inc.out", g->col_ind);
-    put_adj("b0.inc.in", g->in_col_ind);
-    put("b0.deg", 0, g->deg.data(), g->deg.size());
+    if (!timing_only) {
+        put_adj("b0.inc.out", g->col_ind);
+        put_adj("b0.inc.in", g->in_col_ind);
+        put("b0.deg", 0, g->deg.data(), g->deg.size());
+    }
     ppr->ExecuteImpl();
     put("b0.fifo.p", 1, ppr->pagerank, g->vertex_count);
     put("b0.fifo.r", 1, ppr->residual, g->vertex_count);
-    {
+    if (!timing_only) {
         PPRCPUPowVec pow(g2);
         pow.CalPPRRev(gSourceVertexId);
         put("b0.pow.p", 1, pow.pagerank, g->vertex_count);
     }
 
+    double fifo_inc_ms = 0.0; // wall time of IncExecuteImpl only (the scope cpu/PPRCPUMTCilk.h:131-137 times)
     size_t k = 0;
     while (k++ < gStreamBatchCount) {
         bool over = g->StreamUpdates(gStreamUpdateCountPerBatch);
         bool over2 = g2->StreamUpdates(gStreamUpdateCountPerBatch);
         if (over || over2) break;
         std::string b = "b" + std::to_string(k);
-        put_batch(b + ".batch", g->edge_batch);
-        put_batch(b + ".new", g->new_stream);
         g->IncConstructWindowGraph();
-        g2->ScratchConstructWindowGraph();
-        put_adj(b + ".inc.out", g->col_ind);
-        put_adj(b + ".inc.in", g->in_col_ind);
-        put_adj(b + ".scr.out", g2->col_ind);
-        put_adj(b + ".scr.in", g2->in_col_ind);
-        put(b + ".deg", 0, g->deg.data(), g->deg.size());
-        put(b + ".scr.deg", 0, g2->deg.data(), g2->deg.size());
+        if (!timing_only) {
+            put_batch(b + ".batch", g->edge_batch);
+            put_batch(b + ".new", g->new_stream);
+            g2->ScratchConstructWindowGraph();
+            put_adj(b + ".inc.out", g->col_ind);
+            put_adj(b + ".inc.in", g->in_col_ind);
+            put_adj(b + ".scr.out", g2->col_ind);
+            put_adj(b + ".scr.in", g2->in_col_ind);
+            put(b + ".deg", 0, g->deg.data(), g->deg.size());
+            put(b + ".scr.deg", 0, g2->deg.data(), g2->deg.size());
+        }
+        const auto t0 = std::chrono::steady_clock::now();
         ppr->IncExecuteImpl();
+        fifo_inc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (timing_only) continue;
         put(b + ".fifo.p", 1, ppr->pagerank, g->vertex_count);
         put(b + ".fifo.r", 1, ppr->residual, g->vertex_count);
         PPRCPUPowVec pow(g2);
@@ -120,6 +131,8 @@ int main(int argc, char *argv[]) {
     }
     int done = (int)(k - 1);
     put("batches_done", 0, &done, 1);
+    std::cout << "ref_fifo_inc_ms " << fifo_inc_ms << " batches " << done << " per_batch "
+              << gStreamUpdateCountPerBatch << std::endl;
     fclose(g_out);
     return 0;
 }

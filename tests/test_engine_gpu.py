@@ -442,3 +442,37 @@ def test_hub_table_overflow_and_long_row_list_overflow():
             assert np.max(np.abs(p - sc.s.p)) < SYNC_TOL and np.max(np.abs(r - sc.s.r)) < SYNC_TOL
             st, want = sc.e.stats(sc.slot), sc.s.stats()
             assert (st["iterations"], st["sum_F"], st["sum_E"]) == (want["iters"], want["F"], want["E"])
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_randomised_streams_eager_production_mode(seed):
+    """Production (eager) schedule on random shapes / thresholds, chunked launches, no trace:
+    north-star tolerance vs the cpu/PPRCPUMTCilkRev restatement, Validate() criteria, invariant."""
+    rng = np.random.default_rng(seed)
+    scale = int(rng.integers(8, 13))
+    edges = int(rng.integers(3000, 30000))
+    directed = int(seed % 2)
+    W = int(edges * rng.uniform(0.05, 0.3))
+    c = int(max(1, W * rng.uniform(0.005, 0.05)))
+    tuning = dict(hub_min_degree=int(rng.integers(1, 8)), big_row_edges=int(rng.integers(1, 40)),
+                  pull_min_frontier=int(rng.choice([-1, 1, 16, 0])), chunk_iters=int(rng.choice([1, 3, 24])),
+                  pull_block=int(rng.choice([0, 256, 512, 768])))
+    V, e1, e2 = datagen.rmat_stream(scale, edges, 200 + seed)
+    src = int(datagen.top_sources(V, e1, e2, W, directed, 2)[seed % 2])
+    eps = 1e-9
+    sc = Scenario(V, e1, e2, directed, W, c, src, eps, **tuning)
+    sc.s.cilk_execute(sc.g)
+    sc.e.init_solve(sc.slot, eps)
+    for k in range(6):
+        if k:
+            if not sc.advance_graphs():
+                break
+            sc.s.cilk_inc_execute(sc.g)
+            sc.e.update(sc.slot, eps)
+        p, r = sc.e.read(sc.slot)
+        assert np.max(np.abs(r)) < eps, (tuning, k)
+        assert np.max(np.abs(p - sc.s.p)) < NORTH_STAR_TOL, (tuning, k)
+        pw, _ = orc.pow_rev(sc.g, sc.source)
+        assert np.max(np.abs(p - pw)) < 100 * eps
+        s_, d_ = window_directed_edges(sc.g)
+        assert invariant_max_err_np(p, r, s_, d_, sc.V, sc.source) < INVARIANT_TOL
