@@ -88,10 +88,19 @@ struct dppr_engine {
     int hub_min_degree = HUB_MIN_DEGREE_DEFAULT;
     int big_row = BIG_ROW_DEFAULT;
     int pull_min_frontier = 0; // 0: auto (max(1024, Ed/192)); < 0: never pull; > 0: pull when F >= value
-    // CSR build scratch
+    // CSR build: persistent sorted key arrays (in-orientation dst<<bits|src, out-orientation
+    // src<<bits|dst; undirected graphs share one) + scratch of the same size
+    uint64_t *in_sorted = nullptr, *out_sorted = nullptr;
     uint64_t *keys_a = nullptr, *keys_b = nullptr;
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
+    // incremental maintenance (f1): batch keys, keep flags, select/merge scratch
+    uint64_t *bk[4] = {nullptr, nullptr, nullptr, nullptr}; // del-in, ins-in, del-out, ins-out (unsorted)
+    uint64_t *bks[4] = {nullptr, nullptr, nullptr, nullptr}; // the same, sorted
+    uint8_t *keep = nullptr;
+    void *inc_tmp = nullptr;
+    size_t inc_tmp_bytes = 0;
+    bool incremental = true; // dppr_slide merges the batch into the sorted keys (false: full re-sort)
     // stream-update scratch
     uint32_t *su_k[2] = {nullptr, nullptr}, *su_v[2] = {nullptr, nullptr};
     double *su_term = nullptr;
@@ -179,15 +188,59 @@ Epoch *find_epoch(dppr_engine *e, int epoch) {
     return ep.id == epoch ? &ep : nullptr;
 }
 
-// Build row_ptr/adj of `ep` from the current window ring + outdeg.
-int build_csr(dppr_engine *e, Epoch &ep) {
+// Sort the whole window into the persistent key arrays (load_window; also the non-incremental
+// slide = what gpu/SlidingGraphBuilder.cuh:203-221 does every batch).
+int sort_window_full(dppr_engine *e) {
     const int W = e->W, Ed = e->Ed;
+    if (W == 0) return DPPR_OK;
+    hipLaunchKernelGGL(k_make_keys, dim3(grid_for(W)), dim3(BLOCK), 0, e->stream, e->w1, e->w2, W, e->directed, e->bits,
+                       e->keys_a);
+    HIP_TRY(hipGetLastError());
+    size_t tmp = e->sort_tmp_bytes;
+    HIP_TRY(rocprim::radix_sort_keys(e->sort_tmp, tmp, e->keys_a, e->in_sorted, (size_t)Ed, 0u, (unsigned)(2 * e->bits),
+                                     e->stream));
+    if (e->directed) { // undirected: the out-orientation is the same multiset, out_sorted aliases in_sorted
+        hipLaunchKernelGGL(k_make_out_keys, dim3(grid_for(W)), dim3(BLOCK), 0, e->stream, e->w1, e->w2, W, e->directed,
+                           e->bits, e->keys_a);
+        tmp = e->sort_tmp_bytes;
+        HIP_TRY(rocprim::radix_sort_keys(e->sort_tmp, tmp, e->keys_a, e->out_sorted, (size_t)Ed, 0u,
+                                         (unsigned)(2 * e->bits), e->stream));
+    }
+    return DPPR_OK;
+}
+
+// One orientation of the incremental update: sorted' = (sorted minus deleted instances) merged with inserted.
+int merge_batch_keys(dppr_engine *e, uint64_t *&sorted, uint64_t *del_unsorted, uint64_t *del_sorted, int nd,
+                     uint64_t *ins_unsorted, uint64_t *ins_sorted, int ni) {
+    const int Ed = e->Ed;
+    size_t tmp = e->sort_tmp_bytes;
+    HIP_TRY(rocprim::radix_sort_keys(e->sort_tmp, tmp, del_unsorted, del_sorted, (size_t)nd, 0u, (unsigned)(2 * e->bits),
+                                     e->stream));
+    tmp = e->sort_tmp_bytes;
+    HIP_TRY(rocprim::radix_sort_keys(e->sort_tmp, tmp, ins_unsorted, ins_sorted, (size_t)ni, 0u, (unsigned)(2 * e->bits),
+                                     e->stream));
+    HIP_TRY(hipMemsetAsync(e->keep, 1, (size_t)Ed, e->stream));
+    hipLaunchKernelGGL(k_mark_deleted, dim3(grid_for(nd)), dim3(BLOCK), 0, e->stream, sorted, Ed, del_sorted, nd, e->keep);
+    HIP_TRY(hipGetLastError());
+    int *d_count = e->hub_hist + 40; // scratch word
+    tmp = e->inc_tmp_bytes;
+    HIP_TRY(rocprim::select(e->inc_tmp, tmp, sorted, e->keep, e->keys_a, d_count, (size_t)Ed, e->stream));
+    tmp = e->inc_tmp_bytes;
+    HIP_TRY(rocprim::merge(e->inc_tmp, tmp, e->keys_a, ins_sorted, e->keys_b, (size_t)(Ed - nd), (size_t)ni,
+                           rocprim::less<uint64_t>(), e->stream));
+    std::swap(sorted, e->keys_b); // the merged array is the new persistent one; the old becomes scratch
+    return DPPR_OK;
+}
+
+// Hub directory + in-CSR + out-CSR of `ep` from the persistent sorted keys and outdeg.
+int build_epoch(dppr_engine *e, Epoch &ep) {
+    const int Ed = e->Ed;
     const int NV = e->n_int; // only vertices that ever had an edge (or are a source) exist internally
     // hub directory: the (at most HUB_CAP) vertices of largest out-degree, at least hub_min_degree
     {
         HIP_TRY(hipMemsetAsync(e->hub_hist, 0, sizeof(int) * 33, e->stream));
-        hipLaunchKernelGGL(k_deg_hist, dim3(grid_for(NV)), dim3(BLOCK), 0, e->stream, e->outdeg, NV,
-                           e->hub_min_degree, e->hub_hist);
+        hipLaunchKernelGGL(k_deg_hist, dim3(grid_for(NV)), dim3(BLOCK), 0, e->stream, e->outdeg, NV, e->hub_min_degree,
+                           e->hub_hist);
         int hist[32];
         HIP_TRY(hipMemcpyAsync(hist, e->hub_hist, sizeof(hist), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
@@ -205,28 +258,11 @@ int build_csr(dppr_engine *e, Epoch &ep) {
         HIP_TRY(hipGetLastError());
         ep.n_hubs = (int)above;
     }
-    if (W > 0) {
-        hipLaunchKernelGGL(k_make_keys, dim3(grid_for(W)), dim3(BLOCK), 0, e->stream, e->w1, e->w2, W, e->directed,
-                           e->bits, e->keys_a);
-        HIP_TRY(hipGetLastError());
-        size_t tmp = e->sort_tmp_bytes;
-        HIP_TRY(rocprim::radix_sort_keys(e->sort_tmp, tmp, e->keys_a, e->keys_b, (size_t)Ed, 0u,
-                                         (unsigned)(2 * e->bits), e->stream));
-    }
     // row pointers are filled for the whole id capacity: ids assigned later read as empty rows
-    hipLaunchKernelGGL(k_build_csr, dim3(grid_for(std::max(Ed, e->V + 1))), dim3(BLOCK), 0, e->stream, e->keys_b, Ed,
+    hipLaunchKernelGGL(k_build_csr, dim3(grid_for(std::max(Ed, e->V + 1))), dim3(BLOCK), 0, e->stream, e->in_sorted, Ed,
                        e->V, e->bits, e->outdeg, e->hub_slot_of, ep.row_ptr, ep.adj);
-    HIP_TRY(hipGetLastError());
-    // out-CSR for the pull sweep (same scratch, second sort)
-    if (W > 0) {
-        hipLaunchKernelGGL(k_make_out_keys, dim3(grid_for(W)), dim3(BLOCK), 0, e->stream, e->w1, e->w2, W, e->directed,
-                           e->bits, e->keys_a);
-        size_t tmp = e->sort_tmp_bytes;
-        HIP_TRY(rocprim::radix_sort_keys(e->sort_tmp, tmp, e->keys_a, e->keys_b, (size_t)Ed, 0u,
-                                         (unsigned)(2 * e->bits), e->stream));
-    }
-    hipLaunchKernelGGL(k_build_out_csr, dim3(grid_for(std::max(Ed, e->V + 1))), dim3(BLOCK), 0, e->stream, e->keys_b,
-                       Ed, e->V, e->bits, ep.out_row_ptr, ep.out_col);
+    hipLaunchKernelGGL(k_build_out_csr, dim3(grid_for(std::max(Ed, e->V + 1))), dim3(BLOCK), 0, e->stream,
+                       e->directed ? e->out_sorted : e->in_sorted, Ed, e->V, e->bits, ep.out_row_ptr, ep.out_col);
     HIP_TRY(hipGetLastError());
     ep.Ed = Ed;
     return DPPR_OK;
@@ -492,6 +528,22 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     HIP_TRY_C(hipMalloc((void **)&e->hub_hist, sizeof(int) * 64));
     HIP_TRY_C(hipMalloc((void **)&e->keys_a, sizeof(uint64_t) * Edn));
     HIP_TRY_C(hipMalloc((void **)&e->keys_b, sizeof(uint64_t) * Edn));
+    HIP_TRY_C(hipMalloc((void **)&e->in_sorted, sizeof(uint64_t) * Edn));
+    if (e->directed) HIP_TRY_C(hipMalloc((void **)&e->out_sorted, sizeof(uint64_t) * Edn));
+    HIP_TRY_C(hipMalloc((void **)&e->keep, Edn));
+    {
+        const size_t bn = (size_t)std::max(2 * c, 1);
+        for (int k = 0; k < 4; ++k) {
+            HIP_TRY_C(hipMalloc((void **)&e->bk[k], sizeof(uint64_t) * bn));
+            HIP_TRY_C(hipMalloc((void **)&e->bks[k], sizeof(uint64_t) * bn));
+        }
+        size_t a = 0, b = 0;
+        HIP_TRY_C(rocprim::select(nullptr, a, e->in_sorted, e->keep, e->keys_a, e->hub_hist, Edn, e->stream));
+        HIP_TRY_C(rocprim::merge(nullptr, b, e->keys_a, e->bks[1], e->keys_b, Edn, bn, rocprim::less<uint64_t>(),
+                                 e->stream));
+        e->inc_tmp_bytes = std::max(a, b);
+        HIP_TRY_C(hipMalloc(&e->inc_tmp, std::max<size_t>(e->inc_tmp_bytes, 16)));
+    }
     HIP_TRY_C(rocprim::radix_sort_keys(nullptr, e->sort_tmp_bytes, e->keys_a, e->keys_b, Edn, 0u,
                                        (unsigned)(2 * e->bits), e->stream));
     HIP_TRY_C(hipMalloc(&e->sort_tmp, std::max<size_t>(e->sort_tmp_bytes, 16)));
@@ -538,6 +590,8 @@ void dppr_destroy(dppr_engine *e) {
     (void)hipFree(e->w1); (void)hipFree(e->w2); (void)hipFree(e->outdeg);
     (void)hipFree(e->hub_slot_of); (void)hipFree(e->hub_hist); (void)hipFree(e->d_ext2int); (void)hipFree(e->d_xfer);
     (void)hipFree(e->keys_a); (void)hipFree(e->keys_b); (void)hipFree(e->sort_tmp);
+    (void)hipFree(e->in_sorted); (void)hipFree(e->out_sorted); (void)hipFree(e->keep); (void)hipFree(e->inc_tmp);
+    for (int k = 0; k < 4; ++k) { (void)hipFree(e->bk[k]); (void)hipFree(e->bks[k]); }
     for (int k = 0; k < 2; ++k) { (void)hipFree(e->su_k[k]); (void)hipFree(e->su_v[k]); }
     (void)hipFree(e->su_term); (void)hipFree(e->su_ins); (void)hipFree(e->su_tmp);
     if (e->pinned) (void)hipHostFree(e->pinned);
@@ -570,6 +624,12 @@ int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges, int p
     e->pull_min_frontier = pull_min_frontier;
     if (chunk_iters > 0) e->chunk_iters = std::min(chunk_iters, MAX_CHUNK);
     if (pull_block >= 256 && pull_block <= 1024 && pull_block % 64 == 0) e->pull_block = pull_block;
+    return DPPR_OK;
+}
+
+int dppr_set_incremental_graph(dppr_engine *e, int on) {
+    if (!e) return DPPR_ERR_INVALID;
+    e->incremental = on != 0;
     return DPPR_OK;
 }
 
@@ -624,7 +684,9 @@ int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32
     for (auto &ep : e->epochs) ep.id = -1;
     Epoch &ep = e->epochs[0];
     ep.L = 0;
-    int rc = build_csr(e, ep);
+    int rc = sort_window_full(e);
+    if (rc) return rc;
+    rc = build_epoch(e, ep);
     if (rc) return rc;
     ep.id = 0;
     e->newest = 0;
@@ -655,18 +717,26 @@ int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, 
         return fail(e, DPPR_ERR_INVALID, "slide: vertex id out of range");
     n1 = e->h_tmp1.data();
     n2 = e->h_tmp2.data();
-    // the c oldest edges sit at ring positions head .. head+c (mod W): retire their degrees,
-    // overwrite them with the new edges, add the new degrees
+    // the c oldest edges sit at ring positions head .. head+c (mod W): retire their degrees (and
+    // note their keys), overwrite them with the new edges, add the new degrees (and note those keys)
+    const bool inc = e->incremental && c > 0 && 2 * c <= e->Ed;
+    const int per = e->directed ? 1 : 2; // keys per stream edge in the in-orientation array
     int done = 0;
     while (done < c) {
         const int pos = (e->head + done) % W;
         const int len = std::min(c - done, W - pos);
         hipLaunchKernelGGL(k_deg_update, dim3(grid_for(len)), dim3(BLOCK), 0, e->stream, e->w1 + pos, e->w2 + pos, len,
                            e->directed, -1, e->outdeg);
+        if (inc)
+            hipLaunchKernelGGL(k_make_keys_seg, dim3(grid_for(len)), dim3(BLOCK), 0, e->stream, e->w1 + pos, e->w2 + pos,
+                               len, e->directed, e->bits, e->bk[0] + (size_t)done * per, e->bk[2] + done);
         HIP_TRY(hipMemcpyAsync(e->w1 + pos, n1 + done, sizeof(int) * (size_t)len, hipMemcpyHostToDevice, e->stream));
         HIP_TRY(hipMemcpyAsync(e->w2 + pos, n2 + done, sizeof(int) * (size_t)len, hipMemcpyHostToDevice, e->stream));
         hipLaunchKernelGGL(k_deg_update, dim3(grid_for(len)), dim3(BLOCK), 0, e->stream, e->w1 + pos, e->w2 + pos, len,
                            e->directed, 1, e->outdeg);
+        if (inc)
+            hipLaunchKernelGGL(k_make_keys_seg, dim3(grid_for(len)), dim3(BLOCK), 0, e->stream, e->w1 + pos, e->w2 + pos,
+                               len, e->directed, e->bits, e->bk[1] + (size_t)done * per, e->bk[3] + done);
         HIP_TRY(hipGetLastError());
         done += len;
     }
@@ -674,7 +744,15 @@ int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, 
     const int id = e->newest + 1;
     Epoch &ep = e->epochs[id % e->n_epochs];
     ep.id = -1;
-    int rc = build_csr(e, ep);
+    int rc;
+    if (inc) { // f1: merge the batch into the previous sorted keys
+        rc = merge_batch_keys(e, e->in_sorted, e->bk[0], e->bks[0], c * per, e->bk[1], e->bks[1], c * per);
+        if (!rc && e->directed) rc = merge_batch_keys(e, e->out_sorted, e->bk[2], e->bks[2], c, e->bk[3], e->bks[3], c);
+    } else {
+        rc = sort_window_full(e);
+    }
+    if (rc) return rc;
+    rc = build_epoch(e, ep);
     if (rc) return rc;
     ep.L = 0;
     if (e->batch_staged) {

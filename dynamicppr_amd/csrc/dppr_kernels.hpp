@@ -934,6 +934,54 @@ __global__ __launch_bounds__(BLOCK) void k_make_keys(const int *__restrict__ w1,
     }
 }
 
+// ---------------------------------------------------------------------------
+// f1  Incremental CSR maintenance. The reference re-sorts the WHOLE window every batch
+// (thrust::sort in BuildCSRGraph, gpu/SlidingGraphBuilder.cuh:203-221). Here the sorted key
+// array of the previous epoch is kept; a slide sorts only the batch's own keys (c deleted +
+// c inserted edges), marks the deleted instances in the old array by binary search, and
+// produces the new sorted array with one select + one merge pass: O(Ed) streaming instead
+// of O(Ed log Ed). Duplicate edges are handled by rank (the i-th deletion of a key removes
+// its i-th instance).
+// ---------------------------------------------------------------------------
+// keys of a segment of the ring: in-orientation (dst << bits | src) and, for directed graphs,
+// out-orientation (src << bits | dst). Undirected: both directions go to `in` (the two
+// orientations are the same multiset, one array serves both CSRs).
+__global__ __launch_bounds__(BLOCK) void k_make_keys_seg(const int *__restrict__ w1, const int *__restrict__ w2, int n,
+                                                         int directed, int bits, uint64_t *__restrict__ in_keys,
+                                                         uint64_t *__restrict__ out_keys) {
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const uint64_t a = (uint32_t)w1[i], b = (uint32_t)w2[i];
+        if (directed) {
+            in_keys[i] = (b << bits) | a;
+            out_keys[i] = (a << bits) | b;
+        } else {
+            in_keys[2 * i] = (b << bits) | a;
+            in_keys[2 * i + 1] = (a << bits) | b;
+        }
+    }
+}
+
+__device__ __forceinline__ int lower_bound_u64(const uint64_t *__restrict__ a, int n, uint64_t key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// keep[] is all ones on entry; the rank-th deletion of a key clears the rank-th instance
+__global__ __launch_bounds__(BLOCK) void k_mark_deleted(const uint64_t *__restrict__ sorted, int n,
+                                                        const uint64_t *__restrict__ del_sorted, int nd,
+                                                        uint8_t *__restrict__ keep) {
+    for (int j = blockIdx.x * BLOCK + threadIdx.x; j < nd; j += gridDim.x * BLOCK) {
+        const uint64_t key = del_sorted[j];
+        const int rank = j - lower_bound_u64(del_sorted, nd, key);
+        const int pos = lower_bound_u64(sorted, n, key) + rank;
+        if (pos < n && sorted[pos] == key) keep[pos] = 0;
+    }
+}
+
 // hub selection: hist[b] = #vertices with min_deg * 2^b <= outdeg < min_deg * 2^(b+1)
 constexpr int HUB_MIN_DEGREE_DEFAULT = 256;
 __global__ __launch_bounds__(BLOCK) void k_deg_hist(const int *__restrict__ outdeg, int V, int min_deg,

@@ -48,7 +48,7 @@ def build(force: bool = False) -> str:
 
 _lib = None
 EXPORTS = [
-    "dppr_abi_version", "dppr_strerror", "dppr_last_error", "dppr_create", "dppr_destroy", "dppr_set_schedule", "dppr_set_profiling", "dppr_set_tuning",
+    "dppr_abi_version", "dppr_strerror", "dppr_last_error", "dppr_create", "dppr_destroy", "dppr_set_schedule", "dppr_set_profiling", "dppr_set_tuning", "dppr_set_incremental_graph",
     "dppr_load_window", "dppr_set_batch", "dppr_slide", "dppr_add_source", "dppr_init_solve", "dppr_update",
     "dppr_incremental_batch_update", "dppr_execute_main_loop", "dppr_read", "dppr_write", "dppr_stats",
     "dppr_reset_stats", "dppr_inspect", "dppr_read_graph", "dppr_graph_edges", "dppr_read_out_graph", "dppr_trace_enable",
@@ -77,6 +77,7 @@ def lib():
     L.dppr_destroy.restype = None
     L.dppr_set_schedule.argtypes = [vp, C.c_int]
     L.dppr_set_profiling.argtypes = [vp, C.c_int]
+    L.dppr_set_incremental_graph.argtypes = [vp, C.c_int]
     L.dppr_set_tuning.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.dppr_load_window.argtypes = [vp, ip, ip, C.c_int32]
     L.dppr_set_batch.argtypes = [vp, ip, ip, u8p, C.c_int32]
@@ -152,6 +153,9 @@ class Engine:
 
     def set_schedule(self, schedule):
         self._ck(self._L.dppr_set_schedule(self._h, int(schedule)), "set_schedule")
+
+    def set_incremental_graph(self, on):
+        self._ck(self._L.dppr_set_incremental_graph(self._h, int(on)), "set_incremental_graph")
 
     def set_profiling(self, on):
         self._ck(self._L.dppr_set_profiling(self._h, int(on)), "set_profiling")

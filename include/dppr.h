@@ -128,6 +128,12 @@ int dppr_set_batch(dppr_engine *e, const int32_t *edge1, const int32_t *edge2,
 int dppr_slide(dppr_engine *e, const int32_t *new_e1, const int32_t *new_e2, int32_t c,
                int32_t *out_epoch);
 
+/* How dppr_slide maintains the device CSR. on (default): the previous epoch's sorted edge keys
+ * are kept and the batch is merged in (sort of the 2c batch keys + mark + select + merge, O(Ed)
+ * streaming). off: the whole window is re-sorted every batch, which is what the reference does
+ * (thrust::sort in BuildCSRGraph, gpu/SlidingGraphBuilder.cuh:203-221). Same CSR either way. */
+int dppr_set_incremental_graph(dppr_engine *e, int on);
+
 /* ---- per-source state ---------------------------------------------------- */
 
 /* Allocates pagerank/residual/frontier state for one source vertex

@@ -476,3 +476,26 @@ def test_randomised_streams_eager_production_mode(seed):
         assert np.max(np.abs(p - pw)) < 100 * eps
         s_, d_ = window_directed_edges(sc.g)
         assert invariant_max_err_np(p, r, s_, d_, sc.V, sc.source) < INVARIANT_TOL
+
+
+@pytest.mark.parametrize("directed", [1, 0])
+def test_incremental_graph_equals_full_rebuild(directed):
+    """f1: merging each batch into the previous sorted keys gives the same device CSRs (in, out,
+    degrees) as re-sorting the whole window -- duplicate edges, ring wrap-around and a batch larger
+    than half the window (falls back to the full sort) included."""
+    rng = np.random.default_rng(9)
+    V, n = 40, 3000
+    e1 = rng.integers(0, V, n).astype(np.int32)          # tiny id range: many duplicate edges, self loops
+    e2 = rng.integers(0, V, n).astype(np.int32)
+    for W, c in ((300, 7), (300, 100), (64, 40)):
+        a = Scenario(V, e1, e2, directed, W, c, 1, 1e-9)
+        b = Scenario(V, e1, e2, directed, W, c, 1, 1e-9)
+        b.e.set_incremental_graph(False)
+        for _ in range(12):
+            assert a.advance_graphs() and b.advance_graphs()
+            check_csr(a)
+            ra, ca, da = a.e.read_graph()
+            rb, cb, db = b.e.read_graph()
+            assert np.array_equal(ra, rb) and np.array_equal(ca, cb) and np.array_equal(da, db)
+            oa, ob = a.e.read_out_graph(), b.e.read_out_graph()
+            assert np.array_equal(oa[0], ob[0]) and np.array_equal(oa[1], ob[1])
