@@ -18,6 +18,7 @@
 
 #include "../../include/dppr.h"
 #include "dppr_kernels.hpp"
+#include "dppr_multi.hpp"
 
 using namespace dppr;
 
@@ -62,6 +63,18 @@ struct Slot {
     bool trace = false;
     std::vector<int64_t> trace_off;
     std::vector<int32_t> trace_ids;
+};
+
+// f2: up to 8 sources solved together on interleaved state (dppr_multi.hpp)
+struct Group {
+    int n = 0;             // sources in use (1..8)
+    int src_ext[GS] = {0}; // ids the caller gave
+    Src8 src{};            // internal ids, -1 = unused lane
+    D8 *p = nullptr, *r = nullptr, *x = nullptr, *x2 = nullptr;
+    int *cnt = nullptr;    // [3][8] rotating frontier sizes, then the per-chunk log [MAX][8]
+    IterStats *dstats = nullptr;
+    dppr_stats_t st{};
+    int iter_hint[2] = {0, 0};
 };
 
 } // namespace
@@ -115,6 +128,7 @@ struct dppr_engine {
     std::vector<Epoch> epochs;
     int newest = -1; // global id of newest epoch
     std::vector<Slot> slots;
+    std::vector<Group> groups;
     int *pinned = nullptr; // host-pinned readback words
     // vertex compaction: external id <-> internal id (assigned on first appearance)
     std::vector<int32_t> ext2int, int2ext;
@@ -440,10 +454,12 @@ int stream_update(dppr_engine *e, Slot &s, const Epoch &ep, double eps, bool see
     HIP_TRY(rocprim::radix_sort_pairs(e->su_tmp, tmp, e->su_k[0], e->su_k[1], e->su_v[0], e->su_v[1], (size_t)L, 0u,
                                       (unsigned)e->bits, e->stream));
     hipLaunchKernelGGL(k_su_terms, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, e->su_k[1], e->su_v[1], ep.b2, ep.ins,
-                       L, s.p, e->su_term, e->su_ins);
+                       L, s.p, 1, e->su_term, e->su_ins);
     // without seeding the lists go to scratch space (cnt[4] / neg) and are ignored
+    SuSources one{};
+    one.s[0] = s.source;
     hipLaunchKernelGGL(k_su_apply, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, e->su_k[1], e->su_v[1], e->su_term,
-                       e->su_ins, ep.deg_after, L, s.r, s.source, seed ? eps : 1e300, s.ft[0], s.cnt + 0, s.neg,
+                       e->su_ins, ep.deg_after, L, s.r, 1, one, seed ? eps : 1e300, s.ft[0], s.cnt + 0, s.neg,
                        s.cnt + 3);
     HIP_TRY(hipGetLastError());
     s.st.records += L;
@@ -457,6 +473,80 @@ int pull_device_stats(dppr_engine *e, Slot &s) {
     unsigned long long t = 0;
     for (int i = 0; i < STAT_SLOTS; ++i) t += h.blk_E[i];
     s.st.sum_E = (int64_t)t;
+    return DPPR_OK;
+}
+
+// ---------------------------------------------------------------------------- f2: groups
+int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps) {
+    // dense seeding: every legal vertex of every source enters, snapshot taken (k_gseed)
+    int cur = 0;
+    HIP_TRY(hipMemsetAsync(g.cnt, 0, sizeof(int) * 3 * GS, e->stream));
+    hipLaunchKernelGGL(k_gseed, dim3(grid_for(e->n_int)), dim3(BLOCK), 0, e->stream, e->n_int, g.r, g.x, g.p, phase, eps,
+                       g.cnt + cur * GS);
+    HIP_TRY(hipGetLastError());
+    g.st.inspected += (int64_t)e->n_int * g.n;
+    int *log = g.cnt + 3 * GS;
+    auto any_left = [&](const int *c) {
+        for (int s = 0; s < GS; ++s)
+            if (c[s] > 0) return true;
+        return false;
+    };
+    HIP_TRY(hipMemcpyAsync(e->pinned, g.cnt + cur * GS, sizeof(int) * GS, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    bool more = any_left(e->pinned);
+    int active_iters = 0;
+    const int max_chunk = MAX_CHUNK;
+    for (int it = 0; more;) {
+        if (it >= e->max_iters) return fail(e, DPPR_ERR_NOT_CONVERGED, "iteration cap hit");
+        int n = g.iter_hint[phase] > it ? g.iter_hint[phase] - it + 1 : e->chunk_iters;
+        n = std::max(1, std::min(n, max_chunk));
+        for (int k = 0; k < n; ++k) {
+            const int nxt = (cur + 1) % 3, zer = (cur + 2) % 3;
+            hipLaunchKernelGGL(k_pull_multi, dim3(grid_for(e->n_int, GPB, 1024)), dim3(GPB), 0, e->stream, e->n_int,
+                               g.cnt + cur * GS, ep.out_row_ptr, ep.out_col, g.x, g.x2, g.r, g.p, g.cnt + nxt * GS,
+                               g.cnt + zer * GS, phase, eps, g.dstats, log + k * GS,
+                               std::min(e->big_row, PULL_BIG_ROW_DEFAULT));
+            std::swap(g.x, g.x2);
+            cur = nxt;
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(e->pinned, g.cnt, sizeof(int) * (size_t)(3 * GS + n * GS), hipMemcpyDeviceToHost,
+                               e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (int k = 0; k < n; ++k) {
+            const int *f = e->pinned + 3 * GS + k * GS;
+            if (!any_left(f)) continue;
+            g.st.iterations++;
+            g.st.pull_iterations++;
+            for (int s = 0; s < GS; ++s) g.st.sum_F += f[s];
+            active_iters = it + k + 1;
+        }
+        more = any_left(e->pinned + cur * GS);
+        it += n;
+    }
+    g.iter_hint[phase] = active_iters;
+    HIP_TRY(hipMemsetAsync(g.x, 0, sizeof(D8) * (size_t)e->n_int, e->stream));
+    HIP_TRY(hipMemsetAsync(g.x2, 0, sizeof(D8) * (size_t)e->n_int, e->stream));
+    return DPPR_OK;
+}
+
+int group_stream_update(dppr_engine *e, Group &g, const Epoch &ep) {
+    const int L = ep.L;
+    if (L == 0) return DPPR_OK;
+    hipLaunchKernelGGL(k_su_keys, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->su_k[0], e->su_v[0]);
+    size_t tmp = e->su_tmp_bytes;
+    HIP_TRY(rocprim::radix_sort_pairs(e->su_tmp, tmp, e->su_k[0], e->su_k[1], e->su_v[0], e->su_v[1], (size_t)L, 0u,
+                                      (unsigned)e->bits, e->stream));
+    SuSources srcs{};
+    for (int s = 0; s < GS; ++s) srcs.s[s] = g.src.s[s];
+    // blockIdx.y = source lane; state element (v, lane) at base[v * 8 + lane]
+    hipLaunchKernelGGL(k_su_terms, dim3(grid_for(L), g.n), dim3(BLOCK), 0, e->stream, e->su_k[1], e->su_v[1], ep.b2,
+                       ep.ins, L, reinterpret_cast<const double *>(g.p), GS, e->su_term, e->su_ins);
+    hipLaunchKernelGGL(k_su_apply, dim3(grid_for(L), g.n), dim3(BLOCK), 0, e->stream, e->su_k[1], e->su_v[1], e->su_term,
+                       e->su_ins, ep.deg_after, L, reinterpret_cast<double *>(g.r), GS, srcs, 0.0, (int *)nullptr,
+                       (int *)nullptr, (int *)nullptr, (int *)nullptr);
+    HIP_TRY(hipGetLastError());
+    g.st.records += (int64_t)L * g.n;
     return DPPR_OK;
 }
 
@@ -512,7 +602,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     HIP_TRY_C(hipEventCreate(&e->ev0));
     HIP_TRY_C(hipEventCreate(&e->ev1));
     for (auto &ev : e->evpool) HIP_TRY_C(hipEventCreate(&ev));
-    HIP_TRY_C(hipHostMalloc((void **)&e->pinned, sizeof(int) * (MAX_CHUNK + 16), hipHostMallocDefault));
+    HIP_TRY_C(hipHostMalloc((void **)&e->pinned, sizeof(int) * (3 * GS + MAX_CHUNK * GS + 16), hipHostMallocDefault));
     const size_t Wn = (size_t)std::max(W, 1), Edn = (size_t)std::max(e->Ed, 1), Ln = (size_t)std::max(4 * c, 1);
     HIP_TRY_C(hipMalloc((void **)&e->w1, sizeof(int) * Wn));
     HIP_TRY_C(hipMalloc((void **)&e->w2, sizeof(int) * Wn));
@@ -551,7 +641,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
         HIP_TRY_C(hipMalloc((void **)&e->su_k[k], sizeof(uint32_t) * Ln));
         HIP_TRY_C(hipMalloc((void **)&e->su_v[k], sizeof(uint32_t) * Ln));
     }
-    HIP_TRY_C(hipMalloc((void **)&e->su_term, sizeof(double) * Ln));
+    HIP_TRY_C(hipMalloc((void **)&e->su_term, sizeof(double) * Ln * GS)); // one term array per source lane of a group
     HIP_TRY_C(hipMalloc((void **)&e->su_ins, Ln));
     HIP_TRY_C(rocprim::radix_sort_pairs(nullptr, e->su_tmp_bytes, e->su_k[0], e->su_k[1], e->su_v[0], e->su_v[1], Ln,
                                         0u, (unsigned)e->bits, e->stream));
@@ -582,6 +672,10 @@ void dppr_destroy(dppr_engine *e) {
         (void)hipFree(s.p); (void)hipFree(s.r); (void)hipFree(s.x); (void)hipFree(s.x2);
         (void)hipFree(s.ft[0]); (void)hipFree(s.ft[1]); (void)hipFree(s.neg);
         (void)hipFree(s.cnt); (void)hipFree(s.dstats); (void)hipFree(s.big);
+    }
+    for (auto &g : e->groups) {
+        (void)hipFree(g.p); (void)hipFree(g.r); (void)hipFree(g.x); (void)hipFree(g.x2);
+        (void)hipFree(g.cnt); (void)hipFree(g.dstats);
     }
     for (auto &ep : e->epochs) {
         (void)hipFree(ep.row_ptr); (void)hipFree(ep.adj); (void)hipFree(ep.out_row_ptr); (void)hipFree(ep.out_col); (void)hipFree(ep.b1); (void)hipFree(ep.b2);
@@ -1066,6 +1160,115 @@ int dppr_trace_get(dppr_engine *e, int32_t slot, int64_t *n_iters, int64_t *n_id
     if (n_ids) *n_ids = (int64_t)s.trace_ids.size();
     if (offsets && !s.trace_off.empty()) memcpy(offsets, s.trace_off.data(), sizeof(int64_t) * s.trace_off.size());
     if (ids && !s.trace_ids.empty()) memcpy(ids, s.trace_ids.data(), sizeof(int32_t) * s.trace_ids.size());
+    return DPPR_OK;
+}
+
+#define GET_GROUP(e, gid)                                                                             \
+    if (!(e) || (gid) < 0 || (gid) >= (int)(e)->groups.size()) return fail((e), DPPR_ERR_INVALID, "bad group"); \
+    Group &g = (e)->groups[(size_t)(gid)]
+
+int dppr_add_source_group(dppr_engine *e, const int32_t *sources, int32_t n, int32_t *out_group) {
+    if (!e || !sources || n < 1 || n > GS) return fail(e, DPPR_ERR_INVALID, "add_source_group: 1..8 sources");
+    HIP_TRY(hipSetDevice(e->device));
+    Group g;
+    g.n = n;
+    for (int s = 0; s < GS; ++s) g.src.s[s] = -1;
+    for (int s = 0; s < n; ++s) {
+        if (sources[s] < 0 || sources[s] >= e->V) return fail(e, DPPR_ERR_INVALID, "add_source_group: vertex out of range");
+        g.src_ext[s] = sources[s];
+        g.src.s[s] = to_int(e, sources[s]);
+    }
+    const size_t V = (size_t)e->V;
+    HIP_TRY(hipMalloc((void **)&g.p, sizeof(D8) * V));
+    HIP_TRY(hipMalloc((void **)&g.r, sizeof(D8) * V));
+    HIP_TRY(hipMalloc((void **)&g.x, sizeof(D8) * V));
+    HIP_TRY(hipMalloc((void **)&g.x2, sizeof(D8) * V));
+    HIP_TRY(hipMalloc((void **)&g.cnt, sizeof(int) * (3 * GS + MAX_CHUNK * GS)));
+    HIP_TRY(hipMalloc((void **)&g.dstats, sizeof(IterStats)));
+    HIP_TRY(hipMemsetAsync(g.x, 0, sizeof(D8) * V, e->stream));
+    HIP_TRY(hipMemsetAsync(g.x2, 0, sizeof(D8) * V, e->stream));
+    HIP_TRY(hipMemsetAsync(g.cnt, 0, sizeof(int) * (3 * GS + MAX_CHUNK * GS), e->stream));
+    HIP_TRY(hipMemsetAsync(g.dstats, 0, sizeof(IterStats), e->stream));
+    hipLaunchKernelGGL(k_ginit, dim3(grid_for(e->V)), dim3(BLOCK), 0, e->stream, g.p, g.r, e->V, g.src);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->groups.push_back(g);
+    if (out_group) *out_group = (int)e->groups.size() - 1;
+    return DPPR_OK;
+}
+
+int dppr_group_init_solve(dppr_engine *e, int32_t group, double eps, float *out_ms) {
+    GET_GROUP(e, group);
+    GET_EPOCH(e, -1);
+    if (!(eps > 0)) return fail(e, DPPR_ERR_INVALID, "eps must be positive");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    hipLaunchKernelGGL(k_ginit, dim3(grid_for(e->V)), dim3(BLOCK), 0, e->stream, g.p, g.r, e->V, g.src);
+    HIP_TRY(hipGetLastError());
+    int rc = group_loop(e, g, ep, 0, eps);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(hipEventSynchronize(e->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    if (out_ms) *out_ms = ms;
+    return DPPR_OK;
+}
+
+int dppr_group_update(dppr_engine *e, int32_t group, int32_t epoch, double eps, float *out_ms) {
+    GET_GROUP(e, group);
+    GET_EPOCH(e, epoch);
+    if (!(eps > 0)) return fail(e, DPPR_ERR_INVALID, "eps must be positive");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    int rc = group_stream_update(e, g, ep);
+    if (rc) return rc;
+    rc = group_loop(e, g, ep, 0, eps);
+    if (rc) return rc;
+    rc = group_loop(e, g, ep, 1, eps);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(hipEventSynchronize(e->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    if (out_ms) *out_ms = ms;
+    g.st.gpu_ms += ms;
+    g.st.batches++;
+    return DPPR_OK;
+}
+
+int dppr_group_read(dppr_engine *e, int32_t group, int32_t index, double *p, double *r) {
+    GET_GROUP(e, group);
+    if (index < 0 || index >= g.n) return fail(e, DPPR_ERR_INVALID, "group_read: bad source index");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = sync_map(e);
+    if (rc) return rc;
+    const D8 *src[2] = {g.p, g.r};
+    double *dst[2] = {p, r};
+    for (int k = 0; k < 2; ++k) {
+        if (!dst[k]) continue;
+        hipLaunchKernelGGL(k_gint_to_ext, dim3(grid_for(e->V)), dim3(BLOCK), 0, e->stream, src[k], index, e->d_ext2int,
+                           e->V, e->d_xfer);
+        HIP_TRY(hipMemcpyAsync(dst[k], e->d_xfer, sizeof(double) * (size_t)e->V, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    return DPPR_OK;
+}
+
+int dppr_group_stats(dppr_engine *e, int32_t group, dppr_stats_t *out) {
+    GET_GROUP(e, group);
+    if (!out) return DPPR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(e->device));
+    static thread_local IterStats h;
+    HIP_TRY(hipMemcpyAsync(&h, g.dstats, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    unsigned long long t = 0;
+    for (int i = 0; i < STAT_SLOTS; ++i) t += h.blk_E[i];
+    g.st.sum_E = (int64_t)t;
+    g.st.sum_N = g.st.sum_F;
+    g.st.algorithmic_bytes = 16ll * e->V * g.st.batches * g.n + 45ll * g.st.records + 72ll * g.st.sum_F +
+                             24ll * g.st.sum_E + 4ll * g.st.sum_N;
+    *out = g.st;
     return DPPR_OK;
 }
 

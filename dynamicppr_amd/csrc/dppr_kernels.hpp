@@ -816,25 +816,36 @@ __global__ __launch_bounds__(BLOCK) void k_su_keys(const int *__restrict__ e1, i
     }
 }
 
+// blockIdx.y = source lane of a group (0 for a single source); state element (v, lane) sits at
+// base[v * stride + lane]
 __global__ __launch_bounds__(BLOCK) void k_su_terms(const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ svals,
                                                     const int *__restrict__ e2, const uint8_t *__restrict__ ins, int L,
-                                                    const double *__restrict__ p, double *__restrict__ term,
-                                                    uint8_t *__restrict__ sins) {
+                                                    const double *__restrict__ p_base, int stride,
+                                                    double *__restrict__ term_base, uint8_t *__restrict__ sins) {
+    const double *p = p_base + blockIdx.y;
+    double *term = term_base + (size_t)blockIdx.y * (size_t)L;
     for (int j = blockIdx.x * BLOCK + threadIdx.x; j < L; j += gridDim.x * BLOCK) {
         const int u = (int)skeys[j];
         const int rec = (int)svals[j];
         const int v = e2[rec];
-        term[j] = ONE_MINUS_ALPHA * p[v] - p[u];
-        sins[j] = ins[rec];
+        term[j] = ONE_MINUS_ALPHA * p[(size_t)v * stride] - p[(size_t)u * stride];
+        if (blockIdx.y == 0) sins[j] = ins[rec];
     }
 }
 
+struct SuSources {
+    int s[8]; // source vertex per lane (blockIdx.y)
+};
 __global__ __launch_bounds__(BLOCK) void k_su_apply(const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ svals,
-                                                    const double *__restrict__ term, const uint8_t *__restrict__ sins,
-                                                    const int *__restrict__ deg_after, int L, double *__restrict__ r,
-                                                    int source, double eps, int *__restrict__ ft_pos,
+                                                    const double *__restrict__ term_base, const uint8_t *__restrict__ sins,
+                                                    const int *__restrict__ deg_after, int L, double *__restrict__ r_base,
+                                                    int stride, SuSources srcs, double eps, int *__restrict__ ft_pos,
                                                     int *__restrict__ cnt_pos, int *__restrict__ ft_neg,
                                                     int *__restrict__ cnt_neg) {
+    double *r = r_base + blockIdx.y;
+    const double *term = term_base + (size_t)blockIdx.y * (size_t)L;
+    const int source = srcs.s[blockIdx.y];
+    const bool seed = ft_pos != nullptr; // groups seed densely instead (k_gseed)
     const int nthreads = gridDim.x * BLOCK;
     for (int j0 = blockIdx.x * BLOCK; j0 < L; j0 += nthreads) {
         const int j = j0 + threadIdx.x;
@@ -851,7 +862,7 @@ __global__ __launch_bounds__(BLOCK) void k_su_apply(const uint32_t *__restrict__
                     ++end;
                 }
                 int d = deg_after[svals[j]] - delta; // RevertOutDegree (gpu/StreamUpdate.cuh:18-33)
-                double ru = r[u];
+                double ru = r[(size_t)u * stride];
                 const double src_term = ALPHA * (source == u ? 1.0 : 0.0);
                 for (int k = j; k < end; ++k) {
                     const double add = term[k] - ALPHA * ru + src_term;
@@ -863,9 +874,9 @@ __global__ __launch_bounds__(BLOCK) void k_su_apply(const uint32_t *__restrict__
                         ru -= add / (double)(d + 1) / ALPHA;
                     }
                 }
-                r[u] = ru;
-                pos = ru > eps;
-                neg = ru < -eps;
+                r[(size_t)u * stride] = ru;
+                pos = seed && ru > eps;
+                neg = seed && ru < -eps;
             }
         }
         // wave-aggregated appends

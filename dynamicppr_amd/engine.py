@@ -53,6 +53,7 @@ EXPORTS = [
     "dppr_incremental_batch_update", "dppr_execute_main_loop", "dppr_read", "dppr_write", "dppr_stats",
     "dppr_reset_stats", "dppr_inspect", "dppr_read_graph", "dppr_graph_edges", "dppr_read_out_graph", "dppr_trace_enable",
     "dppr_trace_get", "dppr_synchronize", "dppr_bench_atomics",
+    "dppr_add_source_group", "dppr_group_init_solve", "dppr_group_update", "dppr_group_read", "dppr_group_stats",
 ]
 
 
@@ -98,6 +99,11 @@ def lib():
     L.dppr_trace_enable.argtypes = [vp, C.c_int32, C.c_int]
     L.dppr_trace_get.argtypes = [vp, C.c_int32, i64p, i64p, i64p, ip]
     L.dppr_synchronize.argtypes = [vp]
+    L.dppr_add_source_group.argtypes = [vp, ip, C.c_int32, ip]
+    L.dppr_group_init_solve.argtypes = [vp, C.c_int32, C.c_double, fp]
+    L.dppr_group_update.argtypes = [vp, C.c_int32, C.c_int32, C.c_double, fp]
+    L.dppr_group_read.argtypes = [vp, C.c_int32, C.c_int32, dp, dp]
+    L.dppr_group_stats.argtypes = [vp, C.c_int32, C.POINTER(Stats)]
     L.dppr_bench_atomics.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, fp]
     for name in EXPORTS:
         if name not in ("dppr_strerror", "dppr_last_error", "dppr_destroy"):
@@ -259,6 +265,36 @@ class Engine:
         self._ck(self._L.dppr_trace_get(self._h, slot, None, None, off.ctypes.data_as(C.POINTER(C.c_int64)),
                                         ids.ctypes.data_as(C.POINTER(C.c_int32))), "trace_get")
         return [ids[off[i]:off[i + 1]].copy() for i in range(ni.value)]
+
+    # ---- source groups (multi-source batched sweeps) ----
+    def add_source_group(self, sources):
+        a, pa = _i32(sources)
+        gid = C.c_int32(-1)
+        self._ck(self._L.dppr_add_source_group(self._h, pa, len(a), C.byref(gid)), "add_source_group")
+        return gid.value
+
+    def group_init_solve(self, group, eps):
+        ms = C.c_float(0)
+        self._ck(self._L.dppr_group_init_solve(self._h, group, float(eps), C.byref(ms)), "group_init_solve")
+        return ms.value
+
+    def group_update(self, group, eps, epoch=-1):
+        ms = C.c_float(0)
+        self._ck(self._L.dppr_group_update(self._h, group, int(epoch), float(eps), C.byref(ms)), "group_update")
+        return ms.value
+
+    def group_read(self, group, index):
+        p = np.empty(self.V, dtype=np.float64)
+        r = np.empty(self.V, dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        self._ck(self._L.dppr_group_read(self._h, group, int(index), p.ctypes.data_as(dp), r.ctypes.data_as(dp)),
+                 "group_read")
+        return p, r
+
+    def group_stats(self, group):
+        st = Stats()
+        self._ck(self._L.dppr_group_stats(self._h, group, C.byref(st)), "group_stats")
+        return st.as_dict()
 
     def synchronize(self):
         self._ck(self._L.dppr_synchronize(self._h), "synchronize")

@@ -168,6 +168,19 @@ int dppr_write(dppr_engine *e, int32_t slot, const double *p, const double *r);
 int dppr_stats(dppr_engine *e, int32_t slot, dppr_stats_t *out);
 int dppr_reset_stats(dppr_engine *e, int32_t slot);
 
+/* ---- source groups (multi-source batched sweeps) ---------------------------------------
+ * Up to 8 sources that share the engine's graph are solved TOGETHER: their p / r / x vectors are
+ * interleaved 8-wide (one 64-byte sector per vertex), so one pass over the out-CSR serves all of
+ * them (BASELINE.json configs 3 and 5 run 10 sources over the same stream). Per source the
+ * arithmetic and the results are those of the single-source calls; group iterations are always
+ * dense sweeps. The reference has no counterpart (one source per process, gpu/PPRGPU.cuh:24). */
+int dppr_add_source_group(dppr_engine *e, const int32_t *sources, int32_t n /* 1..8 */, int32_t *out_group);
+int dppr_group_init_solve(dppr_engine *e, int32_t group, double eps, float *out_ms);
+/* timed region for all sources of the group at once (same scope as dppr_update) */
+int dppr_group_update(dppr_engine *e, int32_t group, int32_t epoch, double eps, float *out_ms);
+int dppr_group_read(dppr_engine *e, int32_t group, int32_t index, double *p, double *r);
+int dppr_group_stats(dppr_engine *e, int32_t group, dppr_stats_t *out); /* summed over the sources */
+
 /* ---- validation / test hooks -------------------------------------------- */
 
 /* Replaces: InspectPureRev alone (gpu/Inspect.cuh:8-48). Writes the legal vertices

@@ -499,3 +499,44 @@ def test_incremental_graph_equals_full_rebuild(directed):
             assert np.array_equal(ra, rb) and np.array_equal(ca, cb) and np.array_equal(da, db)
             oa, ob = a.e.read_out_graph(), b.e.read_out_graph()
             assert np.array_equal(oa[0], ob[0]) and np.array_equal(oa[1], ob[1])
+
+
+@pytest.mark.parametrize("big_row", [None, 4])
+@pytest.mark.parametrize("nsrc", [1, 3, 8])
+@pytest.mark.parametrize("directed", [1, 0])
+def test_source_group_matches_oracle_per_source(directed, nsrc, big_row):
+    """f2: up to 8 sources solved together on interleaved state. Every source's p/r must equal the
+    oracle's synchronous schedule for that source (group iterations are dense sweeps), and the
+    summed statistics must equal the sum of the per-source oracle runs."""
+    V, e1, e2 = datagen.rmat_stream(9, 6000, 11)
+    W, c, eps = 600, 20, 1e-9
+    sources = [int(s) for s in datagen.top_sources(V, e1, e2, W, directed, nsrc)]
+    tuning = dict(big_row_edges=big_row) if big_row else {}
+    e = eng.Engine(V, W, directed, c, **tuning)
+    g = orc.Graph(V, e1, e2, directed, W, c)
+    states = [orc.State(V, s, eps) for s in sources]
+    e.load_window(*g.window_edges())
+    gid = e.add_source_group(sources)
+    for s in states:
+        s.sync_execute(g)
+    e.group_init_solve(gid, eps)
+    for k in range(5):
+        if k:
+            assert not g.stream_updates()
+            g.inc_construct(1)
+            e.set_batch(*g.batch())
+            e.slide(*g.new_stream())
+            for s in states:
+                s.sync_inc_execute(g)
+            e.group_update(gid, eps)
+        for i, s in enumerate(states):
+            p, r = e.group_read(gid, i)
+            assert np.max(np.abs(p - s.p)) < SYNC_TOL and np.max(np.abs(r - s.r)) < SYNC_TOL, (k, i)
+    st = e.group_stats(gid)
+    assert st["sum_F"] == sum(s.stats()["F"] for s in states)
+    assert st["sum_E"] == sum(s.stats()["E"] for s in states)
+    assert st["iterations"] <= sum(s.stats()["iters"] for s in states)
+    with pytest.raises(eng.DpprError):
+        e.add_source_group(list(range(9)))
+    with pytest.raises(eng.DpprError):
+        e.group_read(gid, nsrc)
