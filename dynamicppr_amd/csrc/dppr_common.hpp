@@ -1,0 +1,107 @@
+// dppr_common.hpp -- shared device primitives of the hand-written gfx950 (CDNA4, wave64) kernels.
+// Compiled with -ffp-contract=off: the double arithmetic is the same sequence of IEEE operations
+// as the reference's expressions (cited per kernel).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dppr {
+
+constexpr double ALPHA = 0.15;                 // Meta.h:31
+constexpr double ONE_MINUS_ALPHA = 1.0 - ALPHA; // "(1.0 - ALPHA)" of gpu/ExpandRev.cuh:72
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256;
+constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
+constexpr int OUT_CAP = 1024; // per-wave staged next-frontier entries (4 KiB of LDS)
+
+struct Adj { // one in-CSR entry: edge src -> (row vertex)
+    int32_t v;      // tail of the edge (in-neighbour)
+    int32_t degp1;  // outdeg(v) + 1 at this epoch
+};
+
+// gpu/PPRCommon.cuh:6-11 IsLegalRevPush (strict inequalities)
+__device__ __forceinline__ bool legal(double r, int phase, double eps) {
+    return phase == 0 ? (r > eps) : (r < -eps);
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+__device__ __forceinline__ int wave_id() { return threadIdx.x / WAVE; }
+
+// number of set bits of mask strictly below this lane (v_mbcnt_lo/hi)
+__device__ __forceinline__ int mbcnt(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
+
+// wave64 inclusive scans on the DPP path (ALU latency, no LDS crossbar): Hillis-Steele inside each
+// row of 16 lanes (row_shr 1,2,4,8), then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3.
+// Lanes without a source keep `old` (the operation's identity).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_take(int identity, int x) {
+    return __builtin_amdgcn_update_dpp(identity, x, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int wave_inclusive_scan(int x) {
+    x += dpp_take<0x111, 0xf>(0, x);
+    x += dpp_take<0x112, 0xf>(0, x);
+    x += dpp_take<0x114, 0xf>(0, x);
+    x += dpp_take<0x118, 0xf>(0, x);
+    x += dpp_take<0x142, 0xa>(0, x);
+    x += dpp_take<0x143, 0xc>(0, x);
+    return x;
+}
+__device__ __forceinline__ int wave_inclusive_max(int x) { // for values >= -1
+    x = max(x, dpp_take<0x111, 0xf>(-1, x));
+    x = max(x, dpp_take<0x112, 0xf>(-1, x));
+    x = max(x, dpp_take<0x114, 0xf>(-1, x));
+    x = max(x, dpp_take<0x118, 0xf>(-1, x));
+    x = max(x, dpp_take<0x142, 0xa>(-1, x));
+    x = max(x, dpp_take<0x143, 0xc>(-1, x));
+    return x;
+}
+
+// device-scope returning f64 atomics (global_atomic_add_f64 / global_atomic_swap_x2)
+__device__ __forceinline__ double atomic_add_ret(double *p, double v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double atomic_exch(double *p, double v) {
+    unsigned long long o = __hip_atomic_exchange(reinterpret_cast<unsigned long long *>(p),
+                                                 __double_as_longlong(v), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+    return __longlong_as_double(o);
+}
+
+__device__ __forceinline__ void lds_add(double *p, double v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// wave-wide sum (butterfly; every lane gets the total, fixed order -> deterministic)
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int d = WAVE / 2; d >= 1; d >>= 1) x += __shfl_xor(x, d, WAVE);
+    return x;
+}
+
+// Device-side statistics. Same-address global atomics serialise at ~11 ns each, so one
+// atomic per wave (or per workgroup) on a shared counter would cost more than the kernels'
+// real work; every workgroup owns one slot instead (a slot stream runs one kernel at a
+// time) and the host sums the slots when statistics are read.
+constexpr int STAT_SLOTS = 4096; // >= the largest grid of the iteration kernels
+struct IterStats {
+    unsigned long long blk_E[STAT_SLOTS]; // traversed edges, per workgroup slot
+};
+// workgroup total of a wave-uniform per-wave value -> this workgroup's slot (call from all threads)
+template <int NWAVES>
+__device__ __forceinline__ void stat_add_edges(IterStats *stats, unsigned long long wave_edges,
+                                               unsigned long long *s_edges) {
+    if (lane_id() == 0) s_edges[wave_id()] = wave_edges;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+#pragma unroll
+        for (int k = 0; k < NWAVES; ++k) t += s_edges[k];
+        if (t) stats->blk_E[blockIdx.x] += t;
+    }
+}
+
+
+} // namespace dppr

@@ -1,0 +1,146 @@
+// dppr_update.hpp -- IncrementalBatchUpdate: lock-free grouped stream update and phase-1 filter.
+#pragma once
+
+#include "dppr_common.hpp"
+
+namespace dppr {
+
+// ---------------------------------------------------------------------------
+// a7  IncrementalBatchUpdate (gpu/PPRRevPushGPU.cuh:21-28; kernels
+// gpu/StreamUpdate.cuh:7-76), lock-free formulation.
+//
+// The reference serialises records that share a tail u with a per-vertex spin
+// lock taken inside a WarpAny loop; under wave64 lock-step that is a deadlock
+// hazard and its application order is arbitrary. Here the records are stably
+// grouped by tail (radix sort of (u, index)), and one lane applies each group in
+// batch-index order -- exactly the order cpu/PPRCPUMTCilkRev.h:108-124 applies them
+// at -t 1, so the updated residuals are bit-identical to that CPU path. Records of
+// different tails are independent (only r[u] and predeg[u] are written; p is
+// read-only during the update).
+//
+//  k_su_keys : keys = tail u, vals = record index
+//  k_su_terms: per record (parallel): t = (1-ALPHA)*p[v] - p[u]   (first two terms of
+//              the reference's add expression, evaluated left to right)
+//  k_su_apply: per group leader (sequential over the group):
+//              add = t - ALPHA*r[u] + ALPHA*[u==s]
+//              insert: d++; r[u] += add/(d+1)/ALPHA    delete: d--; r[u] -= add/(d+1)/ALPHA
+//              where d starts at the PRE-batch out-degree = post-batch degree reverted
+//              by the group's own records (CopyOutDegree + RevertOutDegree).
+//              Afterwards the leader seeds the phase-0 frontier (r[u] > eps) and the
+//              phase-1 candidate list (r[u] < -eps): only tails can leave [-eps, eps]
+//              (cpu/PPRCPUMTCilkRev.h:126-156 seeds from batch endpoints for the same reason).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_su_keys(const int *__restrict__ e1, int L, uint32_t *__restrict__ keys,
+                                                   uint32_t *__restrict__ vals) {
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < L; i += gridDim.x * BLOCK) {
+        keys[i] = (uint32_t)e1[i];
+        vals[i] = (uint32_t)i;
+    }
+}
+
+// blockIdx.y = source lane of a group (0 for a single source); state element (v, lane) sits at
+// base[v * stride + lane]
+__global__ __launch_bounds__(BLOCK) void k_su_terms(const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ svals,
+                                                    const int *__restrict__ e2, const uint8_t *__restrict__ ins, int L,
+                                                    const double *__restrict__ p_base, int stride,
+                                                    double *__restrict__ term_base, uint8_t *__restrict__ sins) {
+    const double *p = p_base + blockIdx.y;
+    double *term = term_base + (size_t)blockIdx.y * (size_t)L;
+    for (int j = blockIdx.x * BLOCK + threadIdx.x; j < L; j += gridDim.x * BLOCK) {
+        const int u = (int)skeys[j];
+        const int rec = (int)svals[j];
+        const int v = e2[rec];
+        term[j] = ONE_MINUS_ALPHA * p[(size_t)v * stride] - p[(size_t)u * stride];
+        if (blockIdx.y == 0) sins[j] = ins[rec];
+    }
+}
+
+struct SuSources {
+    int s[8]; // source vertex per lane (blockIdx.y)
+};
+__global__ __launch_bounds__(BLOCK) void k_su_apply(const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ svals,
+                                                    const double *__restrict__ term_base, const uint8_t *__restrict__ sins,
+                                                    const int *__restrict__ deg_after, int L, double *__restrict__ r_base,
+                                                    int stride, SuSources srcs, double eps, int *__restrict__ ft_pos,
+                                                    int *__restrict__ cnt_pos, int *__restrict__ ft_neg,
+                                                    int *__restrict__ cnt_neg) {
+    double *r = r_base + blockIdx.y;
+    const double *term = term_base + (size_t)blockIdx.y * (size_t)L;
+    const int source = srcs.s[blockIdx.y];
+    const bool seed = ft_pos != nullptr; // groups seed densely instead (k_gseed)
+    const int nthreads = gridDim.x * BLOCK;
+    for (int j0 = blockIdx.x * BLOCK; j0 < L; j0 += nthreads) {
+        const int j = j0 + threadIdx.x;
+        bool pos = false, neg = false;
+        int u = 0;
+        if (j < L) {
+            u = (int)skeys[j];
+            const bool leader = (j == 0) || ((int)skeys[j - 1] != u);
+            if (leader) {
+                int end = j;
+                int delta = 0; // post-batch degree minus pre-batch degree
+                while (end < L && (int)skeys[end] == u) {
+                    delta += sins[end] ? 1 : -1;
+                    ++end;
+                }
+                int d = deg_after[svals[j]] - delta; // RevertOutDegree (gpu/StreamUpdate.cuh:18-33)
+                double ru = r[(size_t)u * stride];
+                const double src_term = ALPHA * (source == u ? 1.0 : 0.0);
+                for (int k = j; k < end; ++k) {
+                    const double add = term[k] - ALPHA * ru + src_term;
+                    if (sins[k]) {
+                        d++;
+                        ru += add / (double)(d + 1) / ALPHA;
+                    } else {
+                        d--;
+                        ru -= add / (double)(d + 1) / ALPHA;
+                    }
+                }
+                r[(size_t)u * stride] = ru;
+                pos = seed && ru > eps;
+                neg = seed && ru < -eps;
+            }
+        }
+        // wave-aggregated appends
+        uint64_t m = __ballot(pos);
+        if (m) {
+            int gb = 0;
+            if (lane_id() == 0) gb = atomicAdd(cnt_pos, __popcll(m));
+            gb = __shfl(gb, 0, WAVE);
+            if (pos) ft_pos[gb + mbcnt(m)] = u;
+        }
+        m = __ballot(neg);
+        if (m) {
+            int gb = 0;
+            if (lane_id() == 0) gb = atomicAdd(cnt_neg, __popcll(m));
+            gb = __shfl(gb, 0, WAVE);
+            if (neg) ft_neg[gb + mbcnt(m)] = u;
+        }
+    }
+}
+
+// phase-1 seed: keep the candidates that are still below -eps after phase 0
+// (phase 0 only adds positive amounts, so no new vertex can have dropped below).
+__global__ __launch_bounds__(BLOCK) void k_filter(const int *__restrict__ cand, const int *__restrict__ cnt_cand,
+                                                  const double *__restrict__ r, int phase, double eps,
+                                                  int *__restrict__ ft, int *__restrict__ cnt) {
+    const int n = *cnt_cand;
+    for (int i0 = blockIdx.x * BLOCK; i0 < n; i0 += gridDim.x * BLOCK) {
+        const int i = i0 + threadIdx.x;
+        int u = 0;
+        bool hit = false;
+        if (i < n) {
+            u = cand[i];
+            hit = legal(r[u], phase, eps);
+        }
+        const uint64_t m = __ballot(hit);
+        if (m) {
+            int gb = 0;
+            if (lane_id() == 0) gb = atomicAdd(cnt, __popcll(m));
+            gb = __shfl(gb, 0, WAVE);
+            if (hit) ft[gb + mbcnt(m)] = u;
+        }
+    }
+}
+
+} // namespace dppr

@@ -38,7 +38,7 @@ class Stats(C.Structure):
 def build(force: bool = False) -> str:
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     csrc = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(csrc, f) for f in ("dppr_engine.hip", "dppr_kernels.hpp")]
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp"))]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "dppr.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
