@@ -73,7 +73,7 @@ int main(int argc, char *argv[]) {
         for (int d = 0; d < ngpu; ++d) {
             slowest = std::max(slowest, drivers[(size_t)d]->TotalPprTime());
             edges += (long long)gStreamUpdateCountPerBatch * (long long)drivers[(size_t)d]->batches_done *
-                     (long long)drivers[(size_t)d]->slots.size();
+                     (long long)drivers[(size_t)d]->source_vertex_ids.size();
         }
         std::cout << "gpus " << ngpu << " sources " << sources.size() << std::endl;
         std::cout << "aggregate_edge_num " << edges << std::endl;

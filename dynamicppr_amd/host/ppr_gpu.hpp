@@ -56,15 +56,35 @@ public:
             graph->SerializeEdgeStream(&init_stream);
             DPPR_CHECK(engine, dppr_load_window(engine, init_stream.edge1, init_stream.edge2, init_stream.length));
         }
-        slots.resize(source_vertex_ids.size());
-        for (size_t i = 0; i < slots.size(); ++i)
-            DPPR_CHECK(engine, dppr_add_source(engine, source_vertex_ids[i], &slots[i]));
+        // several sources on one device are solved together, 8 per group (multi-source batched
+        // sweeps); --split keeps the reference's one-source-at-a-time driver flow
+        use_groups = source_vertex_ids.size() > 1 && !gSplitInterface && !gNoGroups;
         if (!quiet_) std::cout << "start..." << std::endl;
-        for (size_t i = 0; i < slots.size(); ++i) { // Init + ExecuteMainLoop(0)
-            float ms = 0;
-            DPPR_CHECK(engine, dppr_init_solve(engine, slots[i], gTolerance, &ms));
-            if (!quiet_) std::cout << "elapsed time=" << ms << "ms" << std::endl;
-            if (gValidate) ValidateResult(i);
+        if (use_groups) {
+            for (size_t i = 0; i < source_vertex_ids.size(); i += 8) {
+                const int32_t n = (int32_t)std::min<size_t>(8, source_vertex_ids.size() - i);
+                int32_t gid = -1;
+                DPPR_CHECK(engine, dppr_add_source_group(engine, source_vertex_ids.data() + i, n, &gid));
+                groups.push_back(gid);
+            }
+            ppr_time.assign(groups.size(), 0.0f);
+            for (size_t k = 0; k < groups.size(); ++k) {
+                float ms = 0;
+                DPPR_CHECK(engine, dppr_group_init_solve(engine, groups[k], gTolerance, &ms));
+                if (!quiet_) std::cout << "elapsed time=" << ms << "ms" << std::endl;
+            }
+            if (gValidate)
+                for (size_t i = 0; i < source_vertex_ids.size(); ++i) ValidateResult(i);
+        } else {
+            slots.resize(source_vertex_ids.size());
+            for (size_t i = 0; i < slots.size(); ++i)
+                DPPR_CHECK(engine, dppr_add_source(engine, source_vertex_ids[i], &slots[i]));
+            for (size_t i = 0; i < slots.size(); ++i) { // Init + ExecuteMainLoop(0)
+                float ms = 0;
+                DPPR_CHECK(engine, dppr_init_solve(engine, slots[i], gTolerance, &ms));
+                if (!quiet_) std::cout << "elapsed time=" << ms << "ms" << std::endl;
+                if (gValidate) ValidateResult(i);
+            }
         }
         SlidingWindowExecuteMainLoop();
         if (!quiet_) std::cout << "finish!" << std::endl;
@@ -81,7 +101,14 @@ public:
             DPPR_CHECK(engine, dppr_set_batch(engine, graph->edge_batch->edge1, graph->edge_batch->edge2,
                                               graph->edge_batch->is_insert, graph->edge_batch->length));
             GPUBuildSlidingGraph();
-            // ---- timed: per source, IncrementalBatchUpdate + ExecuteMainLoop(0) + (1) ----
+            // ---- timed: IncrementalBatchUpdate + ExecuteMainLoop(0) + (1), per source or per group ----
+            for (size_t k = 0; k < groups.size(); ++k) {
+                float ms = 0;
+                DPPR_CHECK(engine, dppr_group_update(engine, groups[k], -1, gTolerance, &ms));
+                ppr_time[k] += ms;
+            }
+            if (use_groups && gValidate)
+                for (size_t i = 0; i < source_vertex_ids.size(); ++i) ValidateResult(i);
             for (size_t i = 0; i < slots.size(); ++i) {
                 float ms = 0;
                 if (gSplitInterface) {
@@ -116,10 +143,15 @@ public:
 
     // gpu/PPRRevPushGPU.cuh:134-164: residual bound, then |p - p_pow| < 100 eps with the
     // power iteration of cpu/PPRCPUPowVec.h:55-83 on the current window graph.
+    void ReadSource(size_t i, double *p, double *r) {
+        if (use_groups) DPPR_CHECK(engine, dppr_group_read(engine, groups[i / 8], (int32_t)(i % 8), p, r));
+        else DPPR_CHECK(engine, dppr_read(engine, slots[i], p, r));
+    }
+
     virtual void ValidateResult(size_t i) {
         const IndexType V = graph->vertex_count, s = source_vertex_ids[i];
         std::vector<double> p((size_t)V), r((size_t)V);
-        DPPR_CHECK(engine, dppr_read(engine, slots[i], p.data(), r.data()));
+        ReadSource(i, p.data(), r.data());
         for (IndexType u = 0; u < V; ++u) {
             if (!(r[u] < gTolerance && r[u] > -gTolerance)) {
                 std::cout << "VALIDATE FAILED: residual[" << u << "]=" << r[u] << std::endl;
@@ -162,8 +194,8 @@ public:
         if (!f) return;
         const IndexType V = graph->vertex_count;
         std::vector<double> p((size_t)V), r((size_t)V);
-        for (size_t i = 0; i < slots.size(); ++i) {
-            DPPR_CHECK(engine, dppr_read(engine, slots[i], p.data(), r.data()));
+        for (size_t i = 0; i < source_vertex_ids.size(); ++i) {
+            ReadSource(i, p.data(), r.data());
             std::fwrite(&source_vertex_ids[i], sizeof(IndexType), 1, f);
             std::fwrite(&V, sizeof(IndexType), 1, f);
             std::fwrite(p.data(), sizeof(double), (size_t)V, f);
@@ -182,8 +214,10 @@ public:
     dppr_engine *engine = nullptr;
     int device_id;
     std::vector<IndexType> source_vertex_ids;
-    std::vector<int32_t> slots;
-    std::vector<float> ppr_time; // ms per source, timed region only
+    std::vector<int32_t> slots;  // one per source (single-source mode)
+    std::vector<int32_t> groups; // one per 8 sources (group mode: several sources per device)
+    bool use_groups = false;
+    std::vector<float> ppr_time; // ms per source (single mode) or per group, timed region only
     size_t batches_done = 0;
 
 protected:
@@ -192,8 +226,8 @@ protected:
     void Report(size_t stream_batch_count) const {
         const double t = TotalPprTime();
         long long cur_edge_num = (long long)gStreamUpdateCountPerBatch * (long long)(stream_batch_count - 1) *
-                                 (long long)slots.size();
-        const size_t solves = (stream_batch_count - 1) * slots.size();
+                                 (long long)source_vertex_ids.size();
+        const size_t solves = (stream_batch_count - 1) * source_vertex_ids.size();
         std::cout << "coming stream_batch_count=" << stream_batch_count << std::endl;
         std::cout << "ppr_time " << t << std::endl;
         std::cout << "edge_num " << cur_edge_num << std::endl;
