@@ -160,7 +160,7 @@ def main():
             "algorithmic_bytes_per_launch": round(push_bytes / max(ps["push_launches"], 1), 1),
             "whole_batch_algorithmic_GBps": round(stats["algorithmic_bytes"] / (ev_ms * 1e-3) / 1e9, 2),
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # the CPU leg runs on rank 0 at N=1 only
             cpu = cpu_baseline(V, e1, e2, directed, W, c, source, a.eps, a.cpu_batches)
             bin_path = a.bin or (datagen.stand_in_path(a.config, a.data_dir) if a.data_dir else None)
             cpu["reference_fifo"] = reference_fifo_baseline(bin_path, directed, flags, source, a.eps, c)
