@@ -151,6 +151,15 @@ __global__ __launch_bounds__(BLOCK) void k_build_out_csr(const uint64_t *__restr
     for (int xx = last + 1 + blockIdx.x * BLOCK + threadIdx.x; xx <= V; xx += gridDim.x * BLOCK) row_ptr[xx] = Ed;
 }
 
+// tile_prefix[t] = out_row_ptr[min(64 t, V)]: edges before tile t (input of the host's group cut)
+__global__ __launch_bounds__(BLOCK) void k_tile_prefix(const int *__restrict__ out_row_ptr, int V, int n_tiles,
+                                                       int *__restrict__ tile_prefix) {
+    for (int t = blockIdx.x * BLOCK + threadIdx.x; t <= n_tiles; t += gridDim.x * BLOCK) {
+        const long long v = (long long)t * WAVE;
+        tile_prefix[t] = out_row_ptr[v < V ? (int)v : V];
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_gather_deg(const int *__restrict__ e1, int L, const int *__restrict__ outdeg,
                                                       int *__restrict__ deg_after) {
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < L; i += gridDim.x * BLOCK) deg_after[i] = outdeg[e1[i]];

@@ -37,6 +37,10 @@ struct Epoch {
     uint8_t *ins = nullptr;
     int L = 0;
     int id = -1; // global epoch number stored in this ring entry
+    // sweep groups: tiles [grp_tile[g], grp_tile[g+1]) per workgroup, about equal edges each
+    int *grp_tile = nullptr; // V/64 + 2
+    int n_groups = 0;
+    int grp_n_int = 0;       // internal ids covered by the table
     // hub directory of this epoch (vertices whose pushes are aggregated in LDS)
     int *hub_v = nullptr, *hub_degp1 = nullptr;
     int n_hubs = 0;
@@ -137,6 +141,7 @@ struct dppr_engine {
     bool map_dirty = true;
     double *d_xfer = nullptr;  // V doubles: staging of p / r in external order
     std::vector<int32_t> h_tmp1, h_tmp2;
+    std::vector<int32_t> h_tiles; // host copy of the tile edge prefix / group table
     int max_iters = 1 << 20;
     std::string err;
 };
@@ -185,6 +190,19 @@ bool translate(dppr_engine *e, const int32_t *src, int n, std::vector<int32_t> &
         dst[(size_t)i] = to_int(e, v);
     }
     return true;
+}
+
+int cut_sweep_groups(dppr_engine *e, Epoch &ep);
+
+// A vertex that got its internal id AFTER an epoch was built (a source outside the window, a
+// dppr_write to an unseen vertex) is not covered by that epoch's sweep groups: re-cut them.
+int recut_stale_groups(dppr_engine *e) {
+    for (auto &ep : e->epochs)
+        if (ep.id >= 0 && ep.grp_n_int != e->n_int) {
+            int rc = cut_sweep_groups(e, ep);
+            if (rc) return rc;
+        }
+    return DPPR_OK;
 }
 
 int sync_map(dppr_engine *e) {
@@ -246,6 +264,50 @@ int merge_batch_keys(dppr_engine *e, uint64_t *&sorted, uint64_t *del_unsorted, 
     return DPPR_OK;
 }
 
+int sweep_block(const dppr_engine *e) { return e->pull_block ? e->pull_block : 1024; }
+
+// Cut the vertex range into sweep groups of at most (workgroup size / 64) consecutive tiles with
+// about equal weight (edges + a per-vertex term), so that no workgroup of k_pull_iter is the
+// straggler because a hub's long row happens to sit in its range. Host greedy over the tile
+// prefix; part of the (untimed) graph build.
+int cut_sweep_groups(dppr_engine *e, Epoch &ep) {
+    const int NV = e->n_int;
+    const int n_tiles = (NV + WAVE - 1) / WAVE;
+    const int max_tiles = sweep_block(e) / WAVE;
+    e->h_tiles.resize((size_t)n_tiles + 2);
+    if (n_tiles > 0) {
+        int *scratch = reinterpret_cast<int *>(e->keys_a); // Ed * 8 bytes >= (n_tiles + 1) * 4 unless the graph is tiny
+        const bool fits = (size_t)e->Ed * sizeof(uint64_t) >= ((size_t)n_tiles + 1) * sizeof(int);
+        if (!fits) scratch = e->hub_slot_of;               // V ints: always large enough
+        hipLaunchKernelGGL(k_tile_prefix, dim3(grid_for(n_tiles + 1)), dim3(BLOCK), 0, e->stream, ep.out_row_ptr, NV,
+                           n_tiles, scratch);
+        HIP_TRY(hipMemcpyAsync(e->h_tiles.data(), scratch, sizeof(int) * ((size_t)n_tiles + 1), hipMemcpyDeviceToHost,
+                               e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    const long long total_w = (n_tiles ? (long long)e->h_tiles[(size_t)n_tiles] : 0) + 2ll * WAVE * n_tiles;
+    const long long want_groups = std::max<long long>(252, (n_tiles + max_tiles * 3 / 4 - 1) / std::max(1, max_tiles * 3 / 4));
+    const long long target = std::max<long long>(1, total_w / want_groups);
+    std::vector<int32_t> cut;
+    cut.push_back(0);
+    long long acc = 0;
+    int first = 0;
+    for (int t = 0; t < n_tiles; ++t) {
+        acc += (long long)(e->h_tiles[(size_t)t + 1] - e->h_tiles[(size_t)t]) + 2 * WAVE;
+        if (acc >= target || t + 1 - first == max_tiles) {
+            cut.push_back(t + 1);
+            first = t + 1;
+            acc = 0;
+        }
+    }
+    if (cut.back() != n_tiles) cut.push_back(n_tiles);
+    ep.n_groups = (int)cut.size() - 1;
+    ep.grp_n_int = NV;
+    HIP_TRY(hipMemcpyAsync(ep.grp_tile, cut.data(), sizeof(int) * cut.size(), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream)); // `cut` is a local
+    return DPPR_OK;
+}
+
 // Hub directory + in-CSR + out-CSR of `ep` from the persistent sorted keys and outdeg.
 int build_epoch(dppr_engine *e, Epoch &ep) {
     const int Ed = e->Ed;
@@ -279,7 +341,7 @@ int build_epoch(dppr_engine *e, Epoch &ep) {
                        e->directed ? e->out_sorted : e->in_sorted, Ed, e->V, e->bits, ep.out_row_ptr, ep.out_col);
     HIP_TRY(hipGetLastError());
     ep.Ed = Ed;
-    return DPPR_OK;
+    return cut_sweep_groups(e, ep);
 }
 
 int read_count(dppr_engine *e, const int *dptr, int *out) {
@@ -346,28 +408,21 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             const int nxt = (cur + 1) % 3, zer = (cur + 2) % 3;
             int *log_slot = s.log + k;
             if ((pull || sync_sched) && !dense_valid) {
-                hipLaunchKernelGGL(k_snapshot_dense, dim3(std::min(grid_for(std::max(F, pull_min == 0x7fffffff ? F : pull_min)), 1024)),
-                                   dim3(BLOCK), 0, e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x);
+                // grid-stride over a frontier whose size is only known on the device (k > 0): sized for
+                // the last size the host saw, capped
+                hipLaunchKernelGGL(k_snapshot_dense, dim3(std::min(grid_for(std::max(F, 1 << 14)), 1024)), dim3(BLOCK), 0,
+                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x);
                 dense_valid = true;
             }
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k], e->stream));
             if (pull) {
-                // workgroup size = vertices per group: the smallest size that puts ONE group on each of
-                // (at most) 256 CUs; larger graphs take 1024 and stride
-                int pb = e->pull_block;
-                if (!pb) {
-                    static const int sizes[] = {256, 384, 512, 576, 640, 768, 896, 1024};
-                    pb = 1024;
-                    for (int sz : sizes)
-                        if ((e->n_int + sz - 1) / sz <= 256) {
-                            pb = sz;
-                            break;
-                        }
-                }
-#define DPPR_LAUNCH_PULL(PB)                                                                                        \
-    hipLaunchKernelGGL(k_pull_iter<PB>, dim3(grid_for(e->n_int, PB, 1024)), dim3(PB), 0, e->stream, e->n_int,       \
-                       s.cnt + cur, ep.out_row_ptr, ep.out_col, s.x, s.x2, s.r, s.p, s.cnt + nxt, s.cnt + zer, phase, \
-                       eps, s.dstats, log_slot, std::min(e->big_row, PULL_BIG_ROW_DEFAULT))
+                // workgroup size = max tiles per group x 64 (the groups themselves were cut by the builder)
+                const int pb = sweep_block(e);
+#define DPPR_LAUNCH_PULL(PB)                                                                                          \
+    hipLaunchKernelGGL(k_pull_iter<PB>, dim3(std::min(std::max(ep.n_groups, 1), 1024)), dim3(PB), 0, e->stream,        \
+                       ep.grp_n_int, ep.grp_tile, ep.n_groups, s.cnt + cur, ep.out_row_ptr, ep.out_col, s.x, s.x2, s.r, \
+                       s.p, s.cnt + nxt, s.cnt + zer, phase, eps, s.dstats, log_slot,                                   \
+                       std::min(e->big_row, PULL_BIG_ROW_DEFAULT))
                 switch (pb) {
                 case 256: DPPR_LAUNCH_PULL(256); break;
                 case 384: DPPR_LAUNCH_PULL(384); break;
@@ -656,6 +711,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
         HIP_TRY_C(hipMalloc((void **)&ep.b2, sizeof(int) * Ln));
         HIP_TRY_C(hipMalloc((void **)&ep.deg_after, sizeof(int) * Ln));
         HIP_TRY_C(hipMalloc((void **)&ep.ins, Ln));
+        HIP_TRY_C(hipMalloc((void **)&ep.grp_tile, sizeof(int) * ((size_t)V / WAVE + 3)));
         HIP_TRY_C(hipMalloc((void **)&ep.hub_v, sizeof(int) * HUB_CAP));
         HIP_TRY_C(hipMalloc((void **)&ep.hub_degp1, sizeof(int) * HUB_CAP));
     }
@@ -679,7 +735,7 @@ void dppr_destroy(dppr_engine *e) {
     }
     for (auto &ep : e->epochs) {
         (void)hipFree(ep.row_ptr); (void)hipFree(ep.adj); (void)hipFree(ep.out_row_ptr); (void)hipFree(ep.out_col); (void)hipFree(ep.b1); (void)hipFree(ep.b2);
-        (void)hipFree(ep.deg_after); (void)hipFree(ep.ins); (void)hipFree(ep.hub_v); (void)hipFree(ep.hub_degp1);
+        (void)hipFree(ep.deg_after); (void)hipFree(ep.ins); (void)hipFree(ep.hub_v); (void)hipFree(ep.hub_degp1); (void)hipFree(ep.grp_tile);
     }
     (void)hipFree(e->w1); (void)hipFree(e->w2); (void)hipFree(e->outdeg);
     (void)hipFree(e->hub_slot_of); (void)hipFree(e->hub_hist); (void)hipFree(e->d_ext2int); (void)hipFree(e->d_xfer);
@@ -898,6 +954,7 @@ int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->slots.push_back(std::move(s));
+    if (int rc = recut_stale_groups(e)) return rc; // the source may have received a fresh internal id
     if (out_slot) *out_slot = (int)e->slots.size() - 1;
     return DPPR_OK;
 }
@@ -1024,6 +1081,8 @@ int dppr_write(dppr_engine *e, int32_t slot, const double *p, const double *r) {
     for (int v = 0; v < e->V; ++v)
         if ((p && p[v] != 0.0) || (r && r[v] != 0.0)) (void)to_int(e, v);
     int rc = sync_map(e);
+    if (rc) return rc;
+    rc = recut_stale_groups(e);
     if (rc) return rc;
     const double *src[2] = {p, r};
     double *dst[2] = {s.p, s.r};
@@ -1193,6 +1252,7 @@ int dppr_add_source_group(dppr_engine *e, const int32_t *sources, int32_t n, int
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->groups.push_back(g);
+    if (int rc = recut_stale_groups(e)) return rc;
     if (out_group) *out_group = (int)e->groups.size() - 1;
     return DPPR_OK;
 }

@@ -55,7 +55,8 @@ __device__ unsigned long long g_stamps[4096 * 8];
 #endif
 
 template <int PULL_BLOCK>
-__global__ __launch_bounds__(PULL_BLOCK) void k_pull_iter(int V, const int *__restrict__ cnt_in,
+__global__ __launch_bounds__(PULL_BLOCK) void k_pull_iter(int V, const int *__restrict__ grp_tile, int n_groups,
+                                                          const int *__restrict__ cnt_in,
                                                           const int *__restrict__ out_row_ptr,
                                                           const int *__restrict__ out_col,
                                                           const double *__restrict__ x, double *__restrict__ x_new,
@@ -75,15 +76,23 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_pull_iter(int V, const int *__re
     __shared__ int s_chunk0[PULL_WAVES][WAVE + 1]; // per wave copy: first chunk id of each long row
     __shared__ int s_nbig;
     const int lane = lane_id(), w = wave_id();
-    const int n_groups = (V + PULL_BLOCK - 1) / PULL_BLOCK; // PULL_BLOCK consecutive vertices per pass
+    // Work is dealt in GROUPS of consecutive 64-vertex tiles: group g = tiles [grp_tile[g],
+    // grp_tile[g+1]), at most PULL_WAVES of them, cut by the graph builder so that every group
+    // carries about the same number of edges (a hub's group has few tiles, and all the
+    // workgroup's waves share its long rows). Wave w takes the group's w-th tile.
     const int F = *cnt_in;
     // the first group's tile loads are issued BEFORE F is consumed: the (cold) read of the
     // frontier size overlaps them instead of heading the dependent chain
     int rs = 0, d = 0;
     double rv = 0.0, xv = 0.0, pv = 0.0;
+    int t0 = 0, t1 = 0;
+    if ((int)blockIdx.x < n_groups) {
+        t0 = grp_tile[blockIdx.x];
+        t1 = grp_tile[blockIdx.x + 1];
+    }
     {
-        const int v0 = ((int)blockIdx.x * PULL_WAVES + w) * WAVE + lane;
-        if ((int)blockIdx.x < n_groups && v0 < V) {
+        const int v0 = (t0 + w) * WAVE + lane;
+        if (t0 + w < t1 && v0 < V) {
             rs = out_row_ptr[v0];
             d = out_row_ptr[v0 + 1] - rs;
             rv = r[v0];
@@ -116,8 +125,12 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_pull_iter(int V, const int *__re
     for (int g = blockIdx.x; g < n_groups; g += gridDim.x) { // workgroup-uniform loop
         if (threadIdx.x == 0) s_nbig = 0;
         __syncthreads();
-        const int v = (g * PULL_WAVES + w) * WAVE + lane;
-        const bool valid = v < V;
+        if (g != (int)blockIdx.x) {
+            t0 = grp_tile[g];
+            t1 = grp_tile[g + 1];
+        }
+        const int v = (t0 + w) * WAVE + lane;
+        const bool valid = t0 + w < t1 && v < V; // waves beyond the group's tiles only help with long rows
         if (g != (int)blockIdx.x) { // later groups (the first one was loaded above)
             rs = 0; d = 0; rv = 0.0; xv = 0.0; pv = 0.0;
             if (valid) {

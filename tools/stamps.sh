@@ -17,7 +17,7 @@ ss = st.SlidingStream(V, e1, e2, 0, wl)
 e.load_window(*ss.serialize_edge_stream()); slot = e.add_source(src); e.init_solve(slot, 1e-9)
 L = eng.lib()
 L.dppr_debug_stamps.argtypes = [C.POINTER(C.c_uint64), C.c_int]
-rows = 284
+rows = 252
 for b in range(3):
     ss.stream_updates(); e.set_batch(*ss.batch_arrays()); e.slide(*ss.new_arrays()); e.update(slot, 1e-9)
 buf = np.zeros(rows * 8, dtype=np.uint64)
