@@ -90,10 +90,7 @@ inline void ArgumentsChecker() {
         std::cout << "-y 0 (static mode) is deprecated in the reference (README.md:82) and not supported" << std::endl;
         ok = false;
     }
-    if (gVariant != OPTIMIZED) {
-        std::cout << "only -o 0 (OPTIMIZED) is built; variants 1-3 are ablations of the reference" << std::endl;
-        ok = false;
-    }
+    if (gVariant < 0 || gVariant >= kVariantTypeSize) ok = false;
     if (!ok) {
         std::cout << "invalid arguments" << std::endl;
         PrintUsage();
@@ -124,5 +121,11 @@ inline void ArgumentsParser(int argc, char **argv) {
     gSplitInterface = has(argc, argv, "--split");
     gSchedule = has(argc, argv, "--sync") ? 1 : 0;
     gNoGroups = has(argc, argv, "--no-groups");
+    // -o: the reference's four variants are implementation ablations (eager vs pre-extracted residuals,
+    // threshold-crossing vs status-array dedup, gpu/PPRRevPushGPUVariants.cuh); all of them enqueue a
+    // vertex exactly when its residual ends the iteration legal. This engine has two schedules: the
+    // variants that read residuals eagerly (0 OPTIMIZED, 2 EAGER) run the eager schedule, the ones that
+    // pre-extract them with InspectExtra (1 FAST_FRONTIER, 3 VANILLA) run the synchronous one.
+    if (gVariant == FAST_FRONTIER || gVariant == VANILLA) gSchedule = 1;
     ArgumentsChecker();
 }

@@ -37,7 +37,7 @@ def test_invalid_arguments_print_usage_and_exit(pagerank, small_bin):
                 ["-d", path, "-a", "1", "-i", "1", "-y", "1", "-r", "0.01", "-b", "5"],  # gAppType out of range
                 ["-d", path, "-a", "0", "-i", "1", "-y", "1", "-n", "1", "-c", "0", "-l", "10"],
                 ["-d", path, "-a", "0", "-i", "1", "-y", "0", "-r", "0.01", "-b", "5"],   # static mode
-                ["-d", path, "-a", "0", "-i", "1", "-y", "1", "-r", "0.01", "-b", "5", "-o", "2"]):
+                ["-d", path, "-a", "0", "-i", "1", "-y", "1", "-r", "0.01", "-b", "5", "-o", "4"]):   # no such variant
         r = run([pagerank] + bad)
         assert r.returncode != 0
         assert "invalid arguments" in r.stdout and "[USAGE]" in r.stdout
@@ -69,7 +69,7 @@ def read_dump(path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("directed", [1, 0])
-@pytest.mark.parametrize("extra", [[], ["--split"], ["--sync"]])
+@pytest.mark.parametrize("extra", [[], ["--split"], ["--sync"], ["-o", "1"], ["-o", "2"], ["-o", "3"]])
 def test_cli_end_to_end_matches_oracle(pagerank, small_bin, tmp_path, directed, extra):
     path, V, e1, e2 = small_bin
     W, c = 600, 6
@@ -120,3 +120,19 @@ def test_cli_multiple_sources_one_gpu(pagerank, small_bin, tmp_path, extra):
             g.inc_construct(1)
             s.cilk_inc_execute(g)
         assert np.max(np.abs(got[sv][0] - s.p)) < 1e-9
+
+
+@pytest.mark.gpu
+def test_sweep_tool_scrapes_the_stdout_contract(pagerank, small_bin, tmp_path):
+    """tools/sweep.py = scripts/gpu.sh + scripts/extract_gpu.py: runs the variant sweep and scrapes
+    ppr_latency / ppr_throughput from the logs."""
+    import json
+    path, V, e1, e2 = small_bin
+    src = int(datagen.top_sources(V, e1, e2, 600, 1, 1)[0])
+    r = run(["python3", os.path.join(ROOT, "tools", "sweep.py"), "variant", "--data", path, "--directed", "1",
+             "--source", str(src), "--log-dir", str(tmp_path / "log")])
+    assert r.returncode == 0, r.stdout
+    rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert [x["variant"] for x in rows] == [0, 1, 2, 3]
+    assert all(x["ppr_latency_ms"] and x["ppr_throughput"] and x["ppr_throughput"] > 0 for x in rows)
+    assert len(os.listdir(tmp_path / "log")) == 4
