@@ -72,7 +72,16 @@ def main():
         sys.exit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL (backend "nccl") carries only the barrier and two scalar reductions; if it cannot come up
+        # on this node the same three calls work over gloo -- the data path has no collective either way
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+        except Exception as exc:  # noqa: BLE001
+            print(f"[rank {rank}] RCCL init failed ({exc}); falling back to gloo", file=sys.stderr, flush=True)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            dist.init_process_group("gloo")
 
     # ---------------- workload (untimed) ----------------
     if a.bin:
