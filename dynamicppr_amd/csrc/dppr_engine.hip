@@ -95,6 +95,12 @@ struct dppr_engine {
     bool profiling = false;
     int pull_block = 0;   // sweep workgroup size (0: by graph size; 256 / 512 / 1024)
     int chunk_iters = 24; // iterations enqueued between two host read-backs of the frontier size
+    // resident sweeps (dppr_persist.hpp)
+    int persist_mode = 1;              // 1: use k_pull_persist when an epoch's groups fit the chip at once
+    bool persist_ok = true;            // cleared after a grid-barrier time-out: per-iteration launches from then on
+    int persist_cap = 0;               // co-resident workgroups of k_pull_persist at the sweep's block size
+    unsigned long long persist_ticks = 5000000ull; // barrier time limit in 100 MHz ticks (50 ms)
+    GridBar *bar = nullptr;
     // window ring, stream order
     int *w1 = nullptr, *w2 = nullptr;
     int head = 0;
@@ -266,6 +272,30 @@ int merge_batch_keys(dppr_engine *e, uint64_t *&sorted, uint64_t *del_unsorted, 
 
 int sweep_block(const dppr_engine *e) { return e->pull_block ? e->pull_block : 1024; }
 
+// workgroups of the resident sweep that the device holds at once (0: resident sweeps are off)
+int persist_capacity(const dppr_engine *e) {
+    const int pb = sweep_block(e);
+    if (!e->persist_mode || !e->persist_ok || (pb != 256 && pb != 512 && pb != 1024)) return 0;
+    return e->persist_cap;
+}
+
+// How many workgroups of the resident sweep the device holds at once, from the runtime's occupancy
+// figure for the instantiation the engine will launch.
+int query_persist_cap(dppr_engine *e) {
+    e->persist_cap = 0;
+    int per_cu = 0;
+    switch (sweep_block(e)) {
+    case 256: HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pull_persist<256>, 256, 0)); break;
+    case 512: HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pull_persist<512>, 512, 0)); break;
+    case 1024: HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pull_persist<1024>, 1024, 0)); break;
+    default: return DPPR_OK; // other block sizes (tuning only) always use per-iteration launches
+    }
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+    e->persist_cap = std::min(per_cu * cus, STAT_SLOTS);
+    return DPPR_OK;
+}
+
 // Cut the vertex range into sweep groups of at most (workgroup size / 64) consecutive tiles with
 // about equal weight (edges + a per-vertex term), so that no workgroup of k_pull_iter is the
 // straggler because a hub's long row happens to sit in its range. Host greedy over the tile
@@ -286,21 +316,36 @@ int cut_sweep_groups(dppr_engine *e, Epoch &ep) {
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
     const long long total_w = (n_tiles ? (long long)e->h_tiles[(size_t)n_tiles] : 0) + 2ll * WAVE * n_tiles;
-    const long long want_groups = std::max<long long>(252, (n_tiles + max_tiles * 3 / 4 - 1) / std::max(1, max_tiles * 3 / 4));
-    const long long target = std::max<long long>(1, total_w / want_groups);
     std::vector<int32_t> cut;
-    cut.push_back(0);
-    long long acc = 0;
-    int first = 0;
-    for (int t = 0; t < n_tiles; ++t) {
-        acc += (long long)(e->h_tiles[(size_t)t + 1] - e->h_tiles[(size_t)t]) + 2 * WAVE;
-        if (acc >= target || t + 1 - first == max_tiles) {
-            cut.push_back(t + 1);
-            first = t + 1;
-            acc = 0;
+    auto greedy = [&](long long want_groups) {
+        const long long target = std::max<long long>(1, total_w / std::max<long long>(1, want_groups));
+        cut.clear();
+        cut.push_back(0);
+        long long acc = 0;
+        int first = 0;
+        for (int t = 0; t < n_tiles; ++t) {
+            acc += (long long)(e->h_tiles[(size_t)t + 1] - e->h_tiles[(size_t)t]) + 2 * WAVE;
+            if (acc >= target || t + 1 - first == max_tiles) {
+                cut.push_back(t + 1);
+                first = t + 1;
+                acc = 0;
+            }
+        }
+        if (cut.back() != n_tiles) cut.push_back(n_tiles);
+    };
+    // A window small enough for one workgroup per group to be resident at once gets at most that
+    // many groups (then runs of dense iterations are single launches, dppr_persist.hpp); the greedy
+    // cut can overshoot its aim by a few groups, so aim a little lower until it fits.
+    const int cap = persist_capacity(e);
+    bool fitted = false;
+    if (cap > 0 && (long long)n_tiles <= (long long)cap * max_tiles * 7 / 8) {
+        for (long long want = cap; want >= cap * 3 / 4 && !fitted; want -= std::max(1, cap / 64)) {
+            greedy(want);
+            fitted = (int)cut.size() - 1 <= cap;
         }
     }
-    if (cut.back() != n_tiles) cut.push_back(n_tiles);
+    if (!fitted)
+        greedy(std::max<long long>(252, (n_tiles + max_tiles * 3 / 4 - 1) / std::max(1, max_tiles * 3 / 4)));
     ep.n_groups = (int)cut.size() - 1;
     ep.grp_n_int = NV;
     HIP_TRY(hipMemcpyAsync(ep.grp_tile, cut.data(), sizeof(int) * cut.size(), hipMemcpyHostToDevice, e->stream));
@@ -404,6 +449,67 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
         else n = F > prevF ? 2 : e->chunk_iters;                // growing: short chunks; decaying tail: long
         n = std::min(n, MAX_CHUNK);
         if (!pull && !list_valid && (rc = make_list())) return rc;
+        const int pcap = persist_capacity(e);
+        if (pull && n >= 2 && !s.trace && pcap > 0 && ep.n_groups > 0 && ep.n_groups <= pcap) {
+            // ---- a run of dense iterations as ONE resident launch (dppr_persist.hpp)
+            if (!dense_valid) {
+                hipLaunchKernelGGL(k_snapshot_dense, dim3(std::min(grid_for(std::max(F, 1 << 14)), 1024)), dim3(BLOCK), 0,
+                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x);
+                dense_valid = true;
+            }
+            HIP_TRY(hipMemsetAsync(e->bar, 0, sizeof(GridBar), e->stream));
+            if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
+#define DPPR_LAUNCH_PERSIST(PB)                                                                                       \
+    hipLaunchKernelGGL(k_pull_persist<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,        \
+                       ep.out_row_ptr, ep.out_col, s.x, s.x2, s.r, s.p, s.cnt, cur, phase, eps, s.dstats, s.log, n,     \
+                       e->bar, s.cnt + 7, e->persist_ticks)
+            switch (sweep_block(e)) {
+            case 256: DPPR_LAUNCH_PERSIST(256); break;
+            case 512: DPPR_LAUNCH_PERSIST(512); break;
+            default: DPPR_LAUNCH_PERSIST(1024); break;
+            }
+#undef DPPR_LAUNCH_PERSIST
+            if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[1], e->stream));
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(e->pinned, s.cnt, sizeof(int) * (size_t)(8 + n), hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            const int sweeps = e->pinned[7] & (PERSIST_ABORTED - 1);
+            const bool aborted = (e->pinned[7] & PERSIST_ABORTED) != 0;
+            for (int k = 0; k < n; ++k) {
+                const int f = e->pinned[8 + k];
+                if (f <= 0) continue;
+                s.st.iterations++;
+                s.st.pull_iterations++;
+                s.st.sum_F += f;
+                active_iters = it + k + 1;
+            }
+            if (e->profiling) {
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, e->evpool[0], e->evpool[1]));
+                s.st.push_ms += ms;
+                s.st.push_launches++;
+            }
+            s.st.persist_launches++;
+            if (sweeps & 1) std::swap(s.x, s.x2); // s.x = the snapshot the last sweep wrote
+            cur = 0;                              // the launch leaves the live count in cnt[0]
+            list_valid = false;
+            any_pull = true;
+            prevF = F;
+            F = e->pinned[0];
+            it += aborted ? sweeps : n;
+            if (aborted) {
+                // a workgroup waited too long at a grid barrier (the grid was not co-resident): the
+                // state is that of `sweeps` complete iterations; count the frontier it left and go on
+                // with per-iteration launches
+                s.st.persist_aborts++;
+                e->persist_ok = false;
+                HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(s.cnt + 0), 1, 1, e->stream));
+                if ((rc = make_list())) return rc; // list + its size (cnt[7]) from the dense snapshot
+                HIP_TRY(hipMemcpyAsync(s.cnt + 0, s.cnt + 7, sizeof(int), hipMemcpyDeviceToDevice, e->stream));
+                if ((rc = read_count(e, s.cnt + 0, &F))) return rc;
+            }
+            continue;
+        }
         for (int k = 0; k < n; ++k) {
             const int nxt = (cur + 1) % 3, zer = (cur + 2) % 3;
             int *log_slot = s.log + k;
@@ -671,6 +777,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     e->ext2int.assign((size_t)V, -1);
     e->int2ext.reserve(1024);
     HIP_TRY_C(hipMalloc((void **)&e->hub_hist, sizeof(int) * 64));
+    HIP_TRY_C(hipMalloc((void **)&e->bar, sizeof(GridBar)));
     HIP_TRY_C(hipMalloc((void **)&e->keys_a, sizeof(uint64_t) * Edn));
     HIP_TRY_C(hipMalloc((void **)&e->keys_b, sizeof(uint64_t) * Edn));
     HIP_TRY_C(hipMalloc((void **)&e->in_sorted, sizeof(uint64_t) * Edn));
@@ -738,6 +845,7 @@ void dppr_destroy(dppr_engine *e) {
         (void)hipFree(ep.deg_after); (void)hipFree(ep.ins); (void)hipFree(ep.hub_v); (void)hipFree(ep.hub_degp1); (void)hipFree(ep.grp_tile);
     }
     (void)hipFree(e->w1); (void)hipFree(e->w2); (void)hipFree(e->outdeg);
+    (void)hipFree(e->bar);
     (void)hipFree(e->hub_slot_of); (void)hipFree(e->hub_hist); (void)hipFree(e->d_ext2int); (void)hipFree(e->d_xfer);
     (void)hipFree(e->keys_a); (void)hipFree(e->keys_b); (void)hipFree(e->sort_tmp);
     (void)hipFree(e->in_sorted); (void)hipFree(e->out_sorted); (void)hipFree(e->keep); (void)hipFree(e->inc_tmp);
@@ -762,6 +870,15 @@ int dppr_set_schedule(dppr_engine *e, int schedule) {
 int dppr_set_profiling(dppr_engine *e, int on) {
     if (!e) return DPPR_ERR_INVALID;
     e->profiling = on != 0;
+    return DPPR_OK;
+}
+
+int dppr_set_persistent(dppr_engine *e, int mode, int64_t timeout_us) {
+    if (!e || (mode != 0 && mode != 1) || e->loaded || !e->slots.empty())
+        return fail(e, DPPR_ERR_INVALID, "set_persistent: call right after dppr_create, mode 0 or 1");
+    e->persist_mode = mode;
+    if (timeout_us > 0) e->persist_ticks = (unsigned long long)timeout_us * 100ull; // wall_clock64 runs at 100 MHz
+    if (timeout_us < 0) e->persist_ticks = 0;
     return DPPR_OK;
 }
 
@@ -834,7 +951,9 @@ int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32
     for (auto &ep : e->epochs) ep.id = -1;
     Epoch &ep = e->epochs[0];
     ep.L = 0;
-    int rc = sort_window_full(e);
+    int rc = query_persist_cap(e);
+    if (rc) return rc;
+    rc = sort_window_full(e);
     if (rc) return rc;
     rc = build_epoch(e, ep);
     if (rc) return rc;

@@ -29,7 +29,7 @@ class Stats(C.Structure):
                 ("records", C.c_int64), ("inspected", C.c_int64), ("batches", C.c_int64),
                 ("pull_iterations", C.c_int64),
                 ("algorithmic_bytes", C.c_int64), ("gpu_ms", C.c_double), ("push_ms", C.c_double),
-                ("push_launches", C.c_int64)]
+                ("push_launches", C.c_int64), ("persist_launches", C.c_int64), ("persist_aborts", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -48,7 +48,7 @@ def build(force: bool = False) -> str:
 
 _lib = None
 EXPORTS = [
-    "dppr_abi_version", "dppr_strerror", "dppr_last_error", "dppr_create", "dppr_destroy", "dppr_set_schedule", "dppr_set_profiling", "dppr_set_tuning", "dppr_set_incremental_graph",
+    "dppr_abi_version", "dppr_strerror", "dppr_last_error", "dppr_create", "dppr_destroy", "dppr_set_schedule", "dppr_set_profiling", "dppr_set_tuning", "dppr_set_persistent", "dppr_set_incremental_graph",
     "dppr_load_window", "dppr_set_batch", "dppr_slide", "dppr_add_source", "dppr_init_solve", "dppr_update",
     "dppr_incremental_batch_update", "dppr_execute_main_loop", "dppr_read", "dppr_write", "dppr_stats",
     "dppr_reset_stats", "dppr_inspect", "dppr_read_graph", "dppr_graph_edges", "dppr_read_out_graph", "dppr_trace_enable",
@@ -80,6 +80,7 @@ def lib():
     L.dppr_set_profiling.argtypes = [vp, C.c_int]
     L.dppr_set_incremental_graph.argtypes = [vp, C.c_int]
     L.dppr_set_tuning.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.dppr_set_persistent.argtypes = [vp, C.c_int, C.c_int64]
     L.dppr_load_window.argtypes = [vp, ip, ip, C.c_int32]
     L.dppr_set_batch.argtypes = [vp, ip, ip, u8p, C.c_int32]
     L.dppr_slide.argtypes = [vp, ip, ip, C.c_int32, ip]
@@ -128,7 +129,8 @@ class Engine:
     """
 
     def __init__(self, V, W, directed, max_batch, n_epochs=1, device=0, schedule=SCHEDULE_EAGER,
-                 hub_min_degree=None, big_row_edges=None, pull_min_frontier=None, chunk_iters=None, pull_block=None):
+                 hub_min_degree=None, big_row_edges=None, pull_min_frontier=None, chunk_iters=None, pull_block=None,
+                 persistent=None, persist_timeout_us=None):
         self._L = lib()
         self._h = C.c_void_p()
         self.V, self.W, self.directed, self.c = int(V), int(W), int(directed), int(max_batch)
@@ -141,6 +143,9 @@ class Engine:
             self._ck(self._L.dppr_set_tuning(self._h, int(hub_min_degree or 256), int(big_row_edges or 512),
                                              int(pull_min_frontier or 0), int(chunk_iters or 0),
                                              int(pull_block or 0)), "set_tuning")
+        if persistent is not None or persist_timeout_us is not None:
+            self._ck(self._L.dppr_set_persistent(self._h, 1 if persistent is None else int(persistent),
+                                                 int(persist_timeout_us or 0)), "set_persistent")
 
     def _ck(self, rc, what):
         if rc:

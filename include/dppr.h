@@ -67,6 +67,8 @@ typedef struct dppr_stats_t {
     double gpu_ms;        /* sum of event-timed regions */
     double push_ms;       /* sum of per-launch event times of the push kernel (profiling on only) */
     int64_t push_launches; /* push-kernel launches timed into push_ms */
+    int64_t persist_launches; /* launches of the resident multi-iteration sweep (k_pull_persist) */
+    int64_t persist_aborts;   /* of those, launches that stopped at a grid-barrier time-out */
 } dppr_stats_t;
 
 /* ---- lifetime ----------------------------------------------------------- */
@@ -104,6 +106,16 @@ int dppr_set_profiling(dppr_engine *e, int on);
  * small graphs exercise every path. */
 int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges, int pull_min_frontier,
                     int chunk_iters, int pull_block);
+/* Resident sweeps: when a window's sweep groups all fit on the chip at once, a run of dense
+ * iterations is ONE launch that keeps the per-vertex state on chip and separates iterations
+ * with a grid barrier (no counterpart in the reference, whose loop reads the frontier size back
+ * after every iteration, gpu/PPRRevPushGPU.cuh:107). mode 1 = automatic (default), 0 = never
+ * (every iteration its own launch). timeout_us: how long a workgroup waits at a grid barrier
+ * before the launch is abandoned at that iteration boundary and the engine continues with
+ * per-iteration launches (0 keeps the default, 50 ms; negative = give up at the first wait, which
+ * tests use to exercise that path; the results are the same either way).
+ * Only valid right after dppr_create. */
+int dppr_set_persistent(dppr_engine *e, int mode, int64_t timeout_us);
 
 /* ---- graph side (UNTIMED in the reference's metric) --------------------- */
 
