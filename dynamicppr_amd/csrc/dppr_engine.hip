@@ -23,6 +23,10 @@
 using namespace dppr;
 
 static constexpr int MAX_CHUNK = 64;
+// Slot::cnt: [0..2] rotating frontier counters, [3] phase-1 candidates, [4] scratch, [5..6] big-row
+// counters, [7] list scratch / status of a resident launch, [8] status of a second resident launch
+// enqueued ahead; the per-launch logs (2 x MAX_CHUNK) follow the header
+static constexpr int CNT_HDR = 16;
 
 namespace {
 
@@ -58,6 +62,8 @@ struct Slot {
     int *log = nullptr;     // per-chunk log: frontier size seen by each enqueued iteration
     long long iter_seq = 0; // running iteration number (selects the big-row counter)
     int iter_hint[2] = {0, 0}; // iterations the last loop of each phase took (sizes the next chunks)
+    bool start_dense[2] = {false, false}; // the last loop of each phase began with a frontier worth a sweep
+    int last_F0[2] = {0, 0};   // ... and its size
     IterStats *dstats = nullptr;
     bool converged = false; // |r| <= eps everywhere (state after a completed solve)
     double conv_eps = 0.0;
@@ -99,7 +105,8 @@ struct dppr_engine {
     int persist_mode = 1;              // 1: use k_pull_persist when an epoch's groups fit the chip at once
     bool persist_ok = true;            // cleared after a grid-barrier time-out: per-iteration launches from then on
     int persist_cap = 0;               // co-resident workgroups of k_pull_persist at the sweep's block size
-    unsigned long long persist_ticks = 5000000ull; // barrier time limit in 100 MHz ticks (50 ms)
+    unsigned long long persist_ticks = 5000000ull; // roll-call time limit in 100 MHz ticks (50 ms)
+    int persist_rollcall_extra = 0;    // tests: the roll-call waits for a workgroup that does not exist
     GridBar *bar = nullptr;
     // window ring, stream order
     int *w1 = nullptr, *w2 = nullptr;
@@ -406,17 +413,32 @@ int read_count(dppr_engine *e, const int *dptr, int *out) {
 // the count (and the per-iteration log of F) once per chunk. The host also picks, per chunk,
 // how the iterations are evaluated: SPARSE (push kernels, atomics) or DENSE (pull sweep, no
 // atomics) -- the same sums either way.
-int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, double eps, int buf, int cur) {
-    const int pull_min = e->pull_min_frontier > 0   ? e->pull_min_frontier
-                         : e->pull_min_frontier < 0 ? 0x7fffffff
-                                                    : std::max(1024, e->Ed / 192);
+//
+// `entry` describes a loop that is picked up in the middle (after launches that batch_ahead
+// enqueued without waiting): iterations already done, the frontier size if the host knows it,
+// and whether s.x already holds the frontier's dense snapshot.
+struct LoopEntry {
+    int it = 0;
+    int F = -1; // -1: read cnt[cur]
+    bool dense = false;
+    bool any_pull = false;
+};
+
+int pull_min_frontier(const dppr_engine *e) {
+    return e->pull_min_frontier > 0 ? e->pull_min_frontier : e->pull_min_frontier < 0 ? 0x7fffffff : std::max(1024, e->Ed / 192);
+}
+
+int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, double eps, int buf, int cur,
+                      LoopEntry entry = LoopEntry()) {
+    const int pull_min = pull_min_frontier(e);
     const bool sync_sched = e->schedule == DPPR_SCHEDULE_SYNC;
     const HubTable hubs{ep.hub_v, ep.hub_degp1, ep.n_hubs};
     // the sparse grid must cover the largest frontier a push chunk can meet
     const int push_grid = pull_min == 0x7fffffff ? 2048 : std::min(2048, std::max(64, (pull_min * 4 / WAVE + 3) / 4));
-    bool dense_valid = false; // s.x holds the snapshot of the current frontier (p already updated)
-    bool list_valid = true;   // s.ft[buf] holds the frontier as a list (sweeps only count it)
-    bool any_pull = false;
+    bool dense_valid = entry.dense; // s.x holds the snapshot of the current frontier (p already updated)
+    bool list_valid = !entry.dense; // s.ft[buf] holds the frontier as a list (sweeps only count it)
+    bool any_pull = entry.any_pull;
+    bool x_clean = false;           // a resident launch ended the loop and left s.x / s.x2 all zero
     auto make_list = [&]() -> int { // dense snapshot -> sparse list (after a sweep)
         HIP_TRY(hipMemsetAsync(s.cnt + 7, 0, sizeof(int), e->stream));
         hipLaunchKernelGGL(k_list_from_dense, dim3(grid_for(e->n_int, BLOCK * INSPECT_ITEMS)), dim3(BLOCK), 0, e->stream,
@@ -425,10 +447,14 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
         list_valid = true;
         return DPPR_OK;
     };
-    int F = 0, prevF = 0, active_iters = 0;
-    int rc = read_count(e, s.cnt + cur, &F);
-    if (rc) return rc;
-    for (int it = 0; F > 0;) {
+    int F = entry.F, prevF = 0, active_iters = entry.it;
+    int rc = DPPR_OK;
+    if (F < 0 && (rc = read_count(e, s.cnt + cur, &F))) return rc;
+    if (entry.it == 0) {
+        s.start_dense[phase] = F >= pull_min;
+        s.last_F0[phase] = F;
+    }
+    for (int it = entry.it; F > 0;) {
         if (it >= e->max_iters) return fail(e, DPPR_ERR_NOT_CONVERGED, "iteration cap hit");
         if (s.trace) {
             if (!list_valid && (rc = make_list())) return rc;
@@ -454,7 +480,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             // ---- a run of dense iterations as ONE resident launch (dppr_persist.hpp)
             if (!dense_valid) {
                 hipLaunchKernelGGL(k_snapshot_dense, dim3(std::min(grid_for(std::max(F, 1 << 14)), 1024)), dim3(BLOCK), 0,
-                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x);
+                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x, (const int *)nullptr, 0);
                 dense_valid = true;
             }
             HIP_TRY(hipMemsetAsync(e->bar, 0, sizeof(GridBar), e->stream));
@@ -462,7 +488,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                       \
     hipLaunchKernelGGL(k_pull_persist<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,        \
                        ep.out_row_ptr, ep.out_col, s.x, s.x2, s.r, s.p, s.cnt, cur, phase, eps, s.dstats, s.log, n,     \
-                       e->bar, s.cnt + 7, e->persist_ticks)
+                       e->bar, s.cnt + 7, e->persist_ticks, e->persist_rollcall_extra, (const int *)nullptr)
             switch (sweep_block(e)) {
             case 256: DPPR_LAUNCH_PERSIST(256); break;
             case 512: DPPR_LAUNCH_PERSIST(512); break;
@@ -471,12 +497,21 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
 #undef DPPR_LAUNCH_PERSIST
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[1], e->stream));
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(e->pinned, s.cnt, sizeof(int) * (size_t)(8 + n), hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipMemcpyAsync(e->pinned, s.cnt, sizeof(int) * (size_t)(CNT_HDR + n), hipMemcpyDeviceToHost, e->stream));
             HIP_TRY(hipStreamSynchronize(e->stream));
-            const int sweeps = e->pinned[7] & (PERSIST_ABORTED - 1);
-            const bool aborted = (e->pinned[7] & PERSIST_ABORTED) != 0;
+            const int status = e->pinned[7];
+            s.st.persist_launches++;
+            if (status & PERSIST_FAULT) return fail(e, DPPR_ERR_HIP, "grid barrier of the resident sweep timed out");
+            if (status & PERSIST_ABORTED) {
+                // the roll-call failed (the grid was not co-resident): nothing was changed; this engine
+                // goes on with per-iteration launches
+                s.st.persist_aborts++;
+                e->persist_ok = false;
+                continue;
+            }
+            const int sweeps = status & PERSIST_SWEEPS;
             for (int k = 0; k < n; ++k) {
-                const int f = e->pinned[8 + k];
+                const int f = e->pinned[CNT_HDR + k];
                 if (f <= 0) continue;
                 s.st.iterations++;
                 s.st.pull_iterations++;
@@ -489,25 +524,14 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 s.st.push_ms += ms;
                 s.st.push_launches++;
             }
-            s.st.persist_launches++;
             if (sweeps & 1) std::swap(s.x, s.x2); // s.x = the snapshot the last sweep wrote
             cur = 0;                              // the launch leaves the live count in cnt[0]
             list_valid = false;
             any_pull = true;
+            x_clean = (status & PERSIST_CONVERGED) != 0;
             prevF = F;
             F = e->pinned[0];
-            it += aborted ? sweeps : n;
-            if (aborted) {
-                // a workgroup waited too long at a grid barrier (the grid was not co-resident): the
-                // state is that of `sweeps` complete iterations; count the frontier it left and go on
-                // with per-iteration launches
-                s.st.persist_aborts++;
-                e->persist_ok = false;
-                HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(s.cnt + 0), 1, 1, e->stream));
-                if ((rc = make_list())) return rc; // list + its size (cnt[7]) from the dense snapshot
-                HIP_TRY(hipMemcpyAsync(s.cnt + 0, s.cnt + 7, sizeof(int), hipMemcpyDeviceToDevice, e->stream));
-                if ((rc = read_count(e, s.cnt + 0, &F))) return rc;
-            }
+            it += n;
             continue;
         }
         for (int k = 0; k < n; ++k) {
@@ -517,7 +541,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 // grid-stride over a frontier whose size is only known on the device (k > 0): sized for
                 // the last size the host saw, capped
                 hipLaunchKernelGGL(k_snapshot_dense, dim3(std::min(grid_for(std::max(F, 1 << 14)), 1024)), dim3(BLOCK), 0,
-                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x);
+                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x, (const int *)nullptr, 0);
                 dense_valid = true;
             }
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k], e->stream));
@@ -566,10 +590,10 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
         }
         HIP_TRY(hipGetLastError());
         // one read-back per chunk: the new frontier size and the F of each iteration just run
-        HIP_TRY(hipMemcpyAsync(e->pinned, s.cnt, sizeof(int) * (size_t)(8 + n), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->pinned, s.cnt, sizeof(int) * (size_t)(CNT_HDR + n), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
         for (int k = 0; k < n; ++k) {
-            const int f = e->pinned[8 + k];
+            const int f = e->pinned[CNT_HDR + k];
             if (f <= 0) continue; // the frontier emptied inside the chunk: the rest were no-ops
             s.st.iterations++;
             s.st.sum_F += f;
@@ -587,11 +611,142 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
         it += n;
     }
     s.iter_hint[phase] = active_iters;
-    if (any_pull) { // leave both dense vectors all-zero for the next loop
+    if (any_pull && !x_clean) { // leave both dense vectors all-zero for the next loop
         // only internal ids below n_int are ever written
         HIP_TRY(hipMemsetAsync(s.x, 0, sizeof(double) * (size_t)e->n_int, e->stream));
         HIP_TRY(hipMemsetAsync(s.x2, 0, sizeof(double) * (size_t)e->n_int, e->stream));
     }
+    return DPPR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The frontier loops of one batch enqueued AHEAD, without a single read-back in between.
+//
+// When consecutive batches behave alike (both phases start with a frontier worth a sweep and take
+// about as many iterations as last time -- the steady state of a sliding-window stream), the host
+// knows what it will launch before it has seen any count: snapshot, one resident launch for
+// phase 0, the phase-1 filter, snapshot, one resident launch for phase 1. They are enqueued back
+// to back; the three that belong to phase 1 carry a GUARD (the status word of the phase-0
+// launch) and do nothing unless phase 0 really converged inside its launch. One copy of the
+// counters, both status words and both logs comes back at the end. Whatever did not go as
+// expected (phase 0 needed more sweeps, a roll-call failed) leaves the state at a well-defined
+// point from which the ordinary host-driven loop resumes (`stage`, `en0`, `en1`).
+// The reference pays a blocking read-back per ITERATION (gpu/PPRRevPushGPU.cuh:107).
+// ---------------------------------------------------------------------------------------------
+bool can_batch_ahead(const dppr_engine *e, const Slot &s, const Epoch &ep) {
+    const int cap = persist_capacity(e);
+    return e->persist_mode == 1 && cap > 0 && ep.n_groups > 0 && ep.n_groups <= cap && !s.trace && e->chunk_iters > 1 && ep.L > 0 &&
+           s.iter_hint[0] > 0 && s.iter_hint[1] > 0 && s.start_dense[0] && s.start_dense[1];
+}
+
+// stage (out): 0 = phase 0 still open (resume with en0), 1 = phase 0 done, phase 1 open (resume with
+// en1; *p1_seeded tells whether its frontier list / snapshot exist), 2 = both phases done
+int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage, LoopEntry *en0, LoopEntry *en1,
+                bool *p1_seeded) {
+    const int pull_min = pull_min_frontier(e);
+    const int n0 = std::min(s.iter_hint[0] + 2, MAX_CHUNK), n1 = std::min(s.iter_hint[1] + 2, MAX_CHUNK);
+    int *stat_a = s.cnt + 7, *stat_b = s.cnt + 8;
+    HIP_TRY(hipMemsetAsync(e->bar, 0, 2 * sizeof(GridBar), e->stream));
+    auto snapshot = [&](int phase, const int *guard) {
+        hipLaunchKernelGGL(k_snapshot_dense, dim3(std::min(grid_for(std::max(s.last_F0[phase], 1 << 14)), 1024)),
+                           dim3(BLOCK), 0, e->stream, s.ft[0], s.cnt + 0, s.r, s.p, s.x, guard, PERSIST_CONVERGED);
+    };
+    auto resident = [&](int phase, int n, int *log, GridBar *bar, int *status, const int *guard) {
+#define DPPR_LAUNCH_PERSIST(PB)                                                                                        \
+    hipLaunchKernelGGL(k_pull_persist<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,         \
+                       ep.out_row_ptr, ep.out_col, s.x, s.x2, s.r, s.p, s.cnt, 0, phase, eps, s.dstats, log, n, bar,     \
+                       status, e->persist_ticks, e->persist_rollcall_extra, guard)
+        switch (sweep_block(e)) {
+        case 256: DPPR_LAUNCH_PERSIST(256); break;
+        case 512: DPPR_LAUNCH_PERSIST(512); break;
+        default: DPPR_LAUNCH_PERSIST(1024); break;
+        }
+#undef DPPR_LAUNCH_PERSIST
+    };
+    snapshot(0, nullptr);
+    if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
+    resident(0, n0, s.log, e->bar, stat_a, nullptr);
+    if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[1], e->stream));
+    // phase 1, guarded by "phase 0 converged" (which also left cnt[0..2] zero and x / x2 clean)
+    hipLaunchKernelGGL(k_filter, dim3(grid_for(std::max(ep.L, 1))), dim3(BLOCK), 0, e->stream, s.neg, s.cnt + 3, s.r, 1,
+                       eps, s.ft[0], s.cnt + 0, (const int *)stat_a, PERSIST_CONVERGED);
+    snapshot(1, stat_a);
+    if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2], e->stream));
+    resident(1, n1, s.log + n0, e->bar + 1, stat_b, stat_a);
+    if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[3], e->stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(e->pinned, s.cnt, sizeof(int) * (size_t)(CNT_HDR + n0 + n1), hipMemcpyDeviceToHost,
+                           e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+
+    const int st_a = e->pinned[7], st_b = e->pinned[8];
+    // what a launch did, from its log: iterations, frontier sizes; returns the active iterations
+    auto account = [&](const int *log, int n, int ev) {
+        int active = 0;
+        for (int k = 0; k < n; ++k) {
+            if (log[k] <= 0) continue;
+            s.st.iterations++;
+            s.st.pull_iterations++;
+            s.st.sum_F += log[k];
+            active = k + 1;
+        }
+        if (e->profiling) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, e->evpool[ev], e->evpool[ev + 1]) == hipSuccess) {
+                s.st.push_ms += ms;
+                s.st.push_launches++;
+            }
+        }
+        return active;
+    };
+    *stage = 0;
+    *p1_seeded = false;
+    *en0 = LoopEntry();
+    *en1 = LoopEntry();
+    s.st.persist_launches++;
+    if (st_a & PERSIST_FAULT) return fail(e, DPPR_ERR_HIP, "grid barrier of the resident sweep timed out");
+    if (st_a & PERSIST_ABORTED) { // roll-call failed: only the snapshot was taken
+        s.st.persist_aborts++;
+        e->persist_ok = false;
+        en0->dense = true;
+        return DPPR_OK;
+    }
+    const int *log_a = e->pinned + CNT_HDR, *log_b = log_a + n0;
+    s.start_dense[0] = log_a[0] >= pull_min;
+    s.last_F0[0] = log_a[0];
+    const int act_a = account(log_a, n0, 0);
+    if (!(st_a & PERSIST_CONVERGED)) { // phase 0 needs more sweeps than it was given; phase 1 did not start
+        if ((st_a & PERSIST_SWEEPS) & 1) std::swap(s.x, s.x2);
+        en0->it = n0;
+        en0->F = e->pinned[0];
+        en0->dense = true;
+        en0->any_pull = true;
+        return DPPR_OK;
+    }
+    s.iter_hint[0] = act_a;
+    *stage = 1;
+    *p1_seeded = true; // the guard let the filter and the snapshot run
+    s.st.persist_launches++;
+    if (st_b & PERSIST_FAULT) return fail(e, DPPR_ERR_HIP, "grid barrier of the resident sweep timed out");
+    if (st_b & PERSIST_ABORTED) {
+        s.st.persist_aborts++;
+        e->persist_ok = false;
+        en1->dense = true;
+        return DPPR_OK;
+    }
+    s.start_dense[1] = log_b[0] >= pull_min;
+    s.last_F0[1] = log_b[0];
+    const int act_b = account(log_b, n1, 2);
+    if (!(st_b & PERSIST_CONVERGED)) {
+        if ((st_b & PERSIST_SWEEPS) & 1) std::swap(s.x, s.x2);
+        en1->it = n1;
+        en1->F = e->pinned[0];
+        en1->dense = true;
+        en1->any_pull = true;
+        return DPPR_OK;
+    }
+    s.iter_hint[1] = act_b;
+    *stage = 2;
     return DPPR_OK;
 }
 
@@ -777,7 +932,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     e->ext2int.assign((size_t)V, -1);
     e->int2ext.reserve(1024);
     HIP_TRY_C(hipMalloc((void **)&e->hub_hist, sizeof(int) * 64));
-    HIP_TRY_C(hipMalloc((void **)&e->bar, sizeof(GridBar)));
+    HIP_TRY_C(hipMalloc((void **)&e->bar, 2 * sizeof(GridBar))); // [1]: the second launch of a batch enqueued ahead
     HIP_TRY_C(hipMalloc((void **)&e->keys_a, sizeof(uint64_t) * Edn));
     HIP_TRY_C(hipMalloc((void **)&e->keys_b, sizeof(uint64_t) * Edn));
     HIP_TRY_C(hipMalloc((void **)&e->in_sorted, sizeof(uint64_t) * Edn));
@@ -874,11 +1029,14 @@ int dppr_set_profiling(dppr_engine *e, int on) {
 }
 
 int dppr_set_persistent(dppr_engine *e, int mode, int64_t timeout_us) {
-    if (!e || (mode != 0 && mode != 1) || e->loaded || !e->slots.empty())
-        return fail(e, DPPR_ERR_INVALID, "set_persistent: call right after dppr_create, mode 0 or 1");
+    if (!e || mode < 0 || mode > 2 || e->loaded || !e->slots.empty())
+        return fail(e, DPPR_ERR_INVALID, "set_persistent: call right after dppr_create, mode 0, 1 or 2");
     e->persist_mode = mode;
     if (timeout_us > 0) e->persist_ticks = (unsigned long long)timeout_us * 100ull; // wall_clock64 runs at 100 MHz
-    if (timeout_us < 0) e->persist_ticks = 0;
+    if (timeout_us < 0) { // tests: a roll-call that cannot succeed, given up after 200 us
+        e->persist_ticks = 20000ull;
+        e->persist_rollcall_extra = 1;
+    }
     return DPPR_OK;
 }
 
@@ -1062,12 +1220,12 @@ int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
     HIP_TRY(hipMalloc((void **)&s.ft[0], sizeof(int) * V));
     HIP_TRY(hipMalloc((void **)&s.ft[1], sizeof(int) * V));
     HIP_TRY(hipMalloc((void **)&s.neg, sizeof(int) * (size_t)std::max(4 * e->c, 1)));
-    HIP_TRY(hipMalloc((void **)&s.cnt, sizeof(int) * (8 + MAX_CHUNK)));
-    s.log = s.cnt + 8; // the per-chunk log sits right behind the counters: one read-back fetches both
+    HIP_TRY(hipMalloc((void **)&s.cnt, sizeof(int) * (CNT_HDR + 2 * MAX_CHUNK)));
+    s.log = s.cnt + CNT_HDR; // the per-chunk log sits right behind the counters: one read-back fetches both
     // a row is deferred only if it has >= big_row edges, so at most Ed / big_row of them exist
     HIP_TRY(hipMalloc((void **)&s.big, sizeof(BigItem) * ((size_t)e->Ed / (size_t)std::max(e->big_row, 1) + 64)));
     HIP_TRY(hipMalloc((void **)&s.dstats, sizeof(IterStats)));
-    HIP_TRY(hipMemsetAsync(s.cnt, 0, sizeof(int) * (8 + MAX_CHUNK), e->stream));
+    HIP_TRY(hipMemsetAsync(s.cnt, 0, sizeof(int) * (CNT_HDR + 2 * MAX_CHUNK), e->stream));
     HIP_TRY(hipMemsetAsync(s.dstats, 0, sizeof(IterStats), e->stream));
     hipLaunchKernelGGL(k_init, dim3(grid_for(e->V)), dim3(BLOCK), 0, e->stream, s.p, s.r, e->V, source);
     HIP_TRY(hipGetLastError());
@@ -1149,15 +1307,27 @@ int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *
     if (rc) return rc;
     s.converged = false;
     if (seeded) {
-        rc = run_frontier_loop(e, s, ep, 0, eps, 0, 0);
-        if (rc) return rc;
-        // phase 1: candidates recorded by the update, re-checked now
-        HIP_TRY(hipMemsetAsync(s.cnt, 0, sizeof(int) * 3, e->stream));
-        hipLaunchKernelGGL(k_filter, dim3(grid_for(std::max(ep.L, 1))), dim3(BLOCK), 0, e->stream, s.neg, s.cnt + 3,
-                           s.r, 1, eps, s.ft[0], s.cnt + 0);
-        HIP_TRY(hipGetLastError());
-        rc = run_frontier_loop(e, s, ep, 1, eps, 0, 0);
-        if (rc) return rc;
+        int stage = 0;
+        bool p1_seeded = false;
+        LoopEntry en0, en1;
+        if (can_batch_ahead(e, s, ep)) {
+            rc = batch_ahead(e, s, ep, eps, &stage, &en0, &en1, &p1_seeded);
+            if (rc) return rc;
+        }
+        if (stage == 0) {
+            rc = run_frontier_loop(e, s, ep, 0, eps, 0, 0, en0);
+            if (rc) return rc;
+        }
+        if (stage <= 1) {
+            if (!p1_seeded) { // phase 1: candidates recorded by the update, re-checked now
+                HIP_TRY(hipMemsetAsync(s.cnt, 0, sizeof(int) * 3, e->stream));
+                hipLaunchKernelGGL(k_filter, dim3(grid_for(std::max(ep.L, 1))), dim3(BLOCK), 0, e->stream, s.neg,
+                                   s.cnt + 3, s.r, 1, eps, s.ft[0], s.cnt + 0, (const int *)nullptr, 0);
+                HIP_TRY(hipGetLastError());
+            }
+            rc = run_frontier_loop(e, s, ep, 1, eps, 0, 0, en1);
+            if (rc) return rc;
+        }
     } else {
         rc = main_loop_inspect(e, s, ep, 0, eps);
         if (rc) return rc;

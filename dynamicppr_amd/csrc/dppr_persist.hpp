@@ -2,8 +2,14 @@
 #pragma once
 
 #include "dppr_common.hpp"
+#include "dppr_pull.hpp" // STAMP (diagnostic builds)
 
 namespace dppr {
+
+#define PSTAMP(i)                \
+    do {                         \
+        if (it == 10) STAMP(i);  \
+    } while (0)
 
 // ---------------------------------------------------------------------------
 // a4+a5, DENSE iterations on graphs whose sweep fits the chip in one wave of workgroups.
@@ -29,18 +35,24 @@ namespace dppr {
 // The arithmetic per vertex is k_pull_iter's: the same terms (1-ALPHA)*x[u]/(outdeg(v)+1), summed
 // into residual[v] (gpu/ExpandRev.cuh:70-73), the same repair (:708-743) and legal-push test.
 //
-// Grid barrier: workgroups arrive on one of BAR_SUBS counters (64-bit: arrivals << 32 | running
-// sum of next-frontier counts); workgroup 0 watches the counters and publishes
-// {generation, cumulative count} with ONE compare-and-swap on the word everybody polls. A
-// workgroup that waits longer than the time limit swaps the same word to BAR_ABORT instead, so
-// "barrier g completed" and "launch aborted at barrier g" are decided at a single point: either
-// way every workgroup has finished exactly g sweeps and the state in memory is that of g complete
-// iterations. The host then continues with per-iteration launches (dppr_engine.hip). The limit
-// only matters if the grid is not co-resident (another context holding CUs): the engine sizes the
-// grid to the occupancy the runtime reports, so it is a safety net, not a code path that is
-// expected to run.
+// Co-residency and the grid barrier. A grid barrier only terminates if every workgroup of the
+// launch is resident. The engine sizes the grid to the occupancy the runtime reports, and the
+// kernel verifies it with a ROLL-CALL before it changes anything: every workgroup checks in on
+// entry, workgroup 0 watches the check-ins and publishes READY with one compare-and-swap on the
+// word everybody reads after their set-up; a workgroup that waits longer than the time limit swaps
+// that word to BAR_ABORT instead. One word decides, so all workgroups agree, and an aborted launch
+// has not touched the state (the host goes on with per-iteration launches, dppr_engine.hip).
+// After a successful roll-call all workgroups are running and stay resident, so the per-iteration
+// barriers always complete and can be the cheap all-to-all kind: a workgroup adds
+// (1 << 32 | its next-frontier count) to one of BAR_SUBS counters -- there are two sets, used by
+// odd and even iterations, so a fast workgroup's next arrival never mixes into the sums a slow one
+// is still reading -- and then 16 lanes of its first wave poll the 16 counters of that parity until
+// all arrivals are in: one memory-side atomic and one read, and the sum of the low halves is the
+// size of the next frontier. A time-out there cannot be a residency problem; it is reported as a
+// device fault (DPPR_ERR_HIP), never silently survived.
 // ---------------------------------------------------------------------------
 constexpr int BAR_SUBS = 16;
+constexpr int BAR_REPS = 16;
 constexpr unsigned long long BAR_ABORT = ~0ull;
 constexpr int PERSIST_SLOTS = 4; // edge slots per thread kept in registers (PB * 4 edges per group)
 
@@ -48,19 +60,32 @@ struct alignas(128) BarWord {
     unsigned long long w;
     unsigned long long pad[15];
 };
-struct GridBar {            // zeroed by the host before every launch
-    BarWord gen;            // generation << 32 | cumulative next-frontier count; BAR_ABORT after a time-out
-    BarWord sub[BAR_SUBS];  // arrivals << 32 | cumulative count of the workgroups with blockIdx % BAR_SUBS == s
+struct GridBar {                // zeroed by the host before every launch
+    BarWord gen;                // roll-call outcome: 0 pending, BAR_READY, BAR_ABORT
+    BarWord roll[BAR_SUBS];     // roll-call check-ins of the workgroups with blockIdx % BAR_SUBS == s
+    // per iteration parity and replica: arrivals << 32 | cumulative next-frontier count. Accesses to
+    // ONE address serialise at the memory side (~10 ns each, measured: 242 workgroups polling the
+    // same 16 words made the barrier take 4 us), so every workgroup arrives on all BAR_REPS replicas
+    // of its counter (one 16-lane atomic instruction) and polls only the replica of its own
+    // sixteen: no word sees more than ~16 arrivals or ~16 pollers.
+    BarWord sub[2][BAR_REPS][BAR_SUBS];
 };
-constexpr int PERSIST_ABORTED = 1 << 30; // flag in the launch's status word (low bits: complete sweeps)
+constexpr unsigned long long BAR_READY = 1ull;
+constexpr int PERSIST_ABORTED = 1 << 30; // status word: the roll-call failed, nothing was changed (low bits: complete sweeps)
+constexpr int PERSIST_FAULT = 1 << 29;   // status word: a grid barrier timed out after a successful roll-call
+constexpr int PERSIST_CONVERGED = 1 << 28; // status word: the frontier emptied; both snapshot vectors are all zero again
+constexpr int PERSIST_SKIPPED = 1 << 27;   // status word: the launch was enqueued ahead and its guard said no
+constexpr int PERSIST_SWEEPS = (1 << 16) - 1;
 
 __device__ __forceinline__ unsigned long long bar_load(unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // The snapshot vectors are exchanged between workgroups on different XCDs (each XCD has its own
 // L2) once per iteration. They are read and written with agent-scope accesses (sc1: through the
-// L2 to the memory side), so an iteration needs no L2 write-back / invalidate at all; a full
-// "release" per wave (buffer_wbl2) was measured at ~75 us per iteration for the 4096 waves.
+// L2 to the memory side) and every wave waits for its stores to complete (s_waitcnt vmcnt(0))
+// before its workgroup arrives at the grid barrier, so an iteration needs no L2 write-back /
+// invalidate: a full agent-scope release per wave (buffer_wbl2) was measured at ~75 us per
+// iteration for the 4096 waves, one per workgroup at ~2.7 us.
 __device__ __forceinline__ double x_load(const double *p) {
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -80,7 +105,8 @@ __global__ __launch_bounds__(PB) void k_pull_persist(int V, const int *__restric
                                                      const int *__restrict__ out_col, double *xa, double *xb, double *r,
                                                      double *p, int *cnt, int cur0, int phase, double eps,
                                                      IterStats *stats, int *log, int n_iter, GridBar *bar,
-                                                     int *status, unsigned long long limit_ticks) {
+                                                     int *status, unsigned long long limit_ticks, int rollcall_extra,
+                                                     const int *guard) {
     constexpr int NW = PB / WAVE;
     constexpr int S = PERSIST_SLOTS;
     __shared__ int s_scan[PB + 1];
@@ -91,6 +117,18 @@ __global__ __launch_bounds__(PB) void k_pull_persist(int V, const int *__restric
     __shared__ unsigned long long s_edges[NW];
     __shared__ unsigned s_next[2]; // barrier outcome: {completed, size of the next frontier}
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    // a launch enqueued ahead of time runs only if the one before it converged (dppr_engine.hip, batch_ahead)
+    if (guard && !(__hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & PERSIST_CONVERGED)) {
+        if (blockIdx.x == 0 && tid == 0) *status = PERSIST_SKIPPED;
+        return;
+    }
+    const unsigned G = gridDim.x;
+    const unsigned subs_used = G < (unsigned)BAR_SUBS ? G : (unsigned)BAR_SUBS;
+    // workgroups that share counter `lane` (lanes >= subs_used watch nothing)
+    const unsigned long long n_sub = lane < (int)subs_used ? (G - lane + BAR_SUBS - 1) / BAR_SUBS : 0;
+    const unsigned long long t_entry = wall_clock64();
+    if (tid == 0) // roll-call: this workgroup is running
+        __hip_atomic_fetch_add(&bar->roll[blockIdx.x % BAR_SUBS].w, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // ---- static part: the group's vertices and edge slots
     const int t0 = grp_tile[blockIdx.x], t1 = grp_tile[blockIdx.x + 1];
@@ -151,10 +189,44 @@ __global__ __launch_bounds__(PB) void k_pull_persist(int V, const int *__restric
         uni[k] = __ballot(own[k] >= 0 && own[k] == first) == ~0ull;
     }
 
+    // ---- roll-call outcome (the set-up above ran while the other workgroups were starting)
+    if (w == 0) {
+        if (blockIdx.x == 0) { // lane s watches check-in counter s
+            unsigned polls = 0;
+            bool all_here = false;
+            for (;;) {
+                const unsigned long long word = lane < (int)subs_used ? bar_load(&bar->roll[lane].w) : 0;
+                // rollcall_extra > 0 (tests only) makes the roll-call wait for a workgroup that does not exist
+                if (__ballot(word >= n_sub + (lane == 0 ? (unsigned long long)rollcall_extra : 0ull)) == ~0ull) {
+                    all_here = true;
+                    break;
+                }
+                if ((polls++ & 31u) == 0 && (bar_load(&bar->gen.w) != 0 || wall_clock64() - t_entry > limit_ticks)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0) (void)bar_cas(&bar->gen.w, 0ull, all_here ? BAR_READY : BAR_ABORT);
+        }
+        if (lane == 0) {
+            unsigned long long word;
+            unsigned polls = 0;
+            while ((word = bar_load(&bar->gen.w)) == 0) {
+                if ((polls++ & 31u) == 0 && wall_clock64() - t_entry > limit_ticks)
+                    (void)bar_cas(&bar->gen.w, 0ull, BAR_ABORT); // decided here or by workgroup 0, never both
+                __builtin_amdgcn_s_sleep(1);
+            }
+            s_next[0] = word == BAR_READY;
+        }
+    }
+    __syncthreads();
+    if (!s_next[0]) { // not co-resident: leave everything as it was
+        if (blockIdx.x == 0 && tid == 0) *status = PERSIST_ABORTED;
+        return;
+    }
+
     unsigned long long edges = 0;
-    unsigned Cprev = 0; // cumulative next-frontier count published by the barriers so far
+    unsigned Cpar[2] = {0u, 0u}; // (first wave) cumulative counts read from the two counter sets so far
     int sweeps = 0, logged = 0;
-    bool aborted = false;
+    bool fault = false, converged = false;
     for (int it = 0; it < n_iter; ++it) {
         const double *xin = (it & 1) ? xb : xa;
         double *xout = (it & 1) ? xa : xb;
@@ -164,7 +236,14 @@ __global__ __launch_bounds__(PB) void k_pull_persist(int V, const int *__restric
         for (int k = 0; k < S; ++k) xg[k] = own[k] >= 0 ? x_load(xin + col[k]) : 0.0;
         if (blockIdx.x == 0 && tid == 0) log[it] = (int)F;
         logged = it + 1;
-        if (F == 0) break; // every workgroup sees the same F
+        if (F == 0) { // every workgroup sees the same F
+            // the frontier is empty: the last sweep wrote an all-zero snapshot (xin); zero the one
+            // before it too, so both vectors are clean for the next loop
+            if (valid) x_store(xout + v, 0.0);
+            converged = true;
+            break;
+        }
+        PSTAMP(0);
         double *acc = s_acc[it & 1];
 #pragma unroll
         for (int k = 0; k < S; ++k) {
@@ -186,7 +265,9 @@ __global__ __launch_bounds__(PB) void k_pull_persist(int V, const int *__restric
             if (nz) lds_add(&acc[o], ONE_MINUS_ALPHA * xe / (double)(s_scan[o + 1] - s_scan[o] + 1));
             edges += (unsigned long long)__popcll(__ballot(nz));
         }
+        PSTAMP(1);
         __syncthreads();
+        PSTAMP(2);
         // repair, threshold, next snapshot (k_pull_iter::finish), on registers
         double rn = acc[tid];
         if (xv != 0.0) rn -= xv;
@@ -203,60 +284,55 @@ __global__ __launch_bounds__(PB) void k_pull_persist(int V, const int *__restric
         ++sweeps;
 
         // ---- grid barrier #sweeps, carrying the next frontier's size
-        __syncthreads(); // (workgroup release: every wave's xout stores are complete before wave 0 arrives)
+        PSTAMP(3);
+        // every wave's xout stores must be COMPLETE before wave 0 arrives for the workgroup. The
+        // barrier alone does not wait for them (a workgroup-scope release on gfx942/950 omits
+        // vmcnt: the waves of a workgroup share their CU's L1), and a remote workgroup would read
+        // last iteration's value.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        PSTAMP(4);
         if (w == 0) {
-            const unsigned gen = (unsigned)sweeps;
-            const unsigned G = gridDim.x;
-            const unsigned subs_used = G < (unsigned)BAR_SUBS ? G : (unsigned)BAR_SUBS;
-            const unsigned long long old_word = ((unsigned long long)(gen - 1) << 32) | Cprev;
+            const int par = sweeps & 1;
+            const unsigned long long rounds = (unsigned long long)((sweeps + 1) >> 1); // barriers of this parity so far
             const unsigned long long t_start = wall_clock64();
             const int part = lane < NW ? s_cnt[lane] : 0;
             const int tot = __builtin_amdgcn_readlane(wave_inclusive_scan(part), WAVE - 1);
-            if (lane == 0)
-                __hip_atomic_fetch_add(&bar->sub[blockIdx.x % BAR_SUBS].w, (1ull << 32) | (unsigned)tot, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-            if (blockIdx.x == 0) { // the deciding workgroup: lane s watches counter s
-                const unsigned long long n_sub = lane < (int)subs_used ? (G - lane + BAR_SUBS - 1) / BAR_SUBS : 0;
-                unsigned long long word = 0;
-                unsigned polls = 0;
-                bool gave_up = false;
-                for (;;) {
-                    if (lane < (int)subs_used) word = bar_load(&bar->sub[lane].w);
-                    const bool here = lane >= (int)subs_used || (word >> 32) >= n_sub * gen;
-                    if (__ballot(here) == ~0ull) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    if ((polls++ & 31u) == 0 && (bar_load(&bar->gen.w) == BAR_ABORT || wall_clock64() - t_start > limit_ticks)) {
-                        gave_up = true;
-                        break;
-                    }
+            if (lane < BAR_REPS)
+                __hip_atomic_fetch_add(&bar->sub[par][lane][blockIdx.x % BAR_SUBS].w, (1ull << 32) | (unsigned)tot,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int my_rep = (blockIdx.x / BAR_SUBS) % BAR_REPS;
+            unsigned long long word = 0;
+            unsigned polls = 0;
+            bool ok = true;
+            for (;;) {
+                if (lane < (int)subs_used) word = bar_load(&bar->sub[par][my_rep][lane].w);
+                if (__ballot((word >> 32) >= n_sub * rounds) == ~0ull) break;
+                if ((polls++ & 63u) == 63u && wall_clock64() - t_start > limit_ticks + 100000000ull) { // + 1 s
+                    ok = false;
+                    break;
                 }
-                if (!gave_up) {
-                    const unsigned mine = lane < (int)subs_used ? (unsigned)word : 0u;
-                    const unsigned C = (unsigned)__builtin_amdgcn_readlane(wave_inclusive_scan((int)mine), WAVE - 1);
-                    if (lane == 0) (void)bar_cas(&bar->gen.w, old_word, ((unsigned long long)gen << 32) | C);
-                } else if (lane == 0) {
-                    (void)bar_cas(&bar->gen.w, old_word, BAR_ABORT);
-                }
+                __builtin_amdgcn_s_sleep(1);
             }
+            const unsigned C = (unsigned)__builtin_amdgcn_readlane(wave_inclusive_scan((int)(unsigned)word), WAVE - 1);
             if (lane == 0) {
-                unsigned long long word;
-                unsigned polls = 0;
-                while ((word = bar_load(&bar->gen.w)) == old_word) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if ((polls++ & 31u) == 0 && wall_clock64() - t_start > limit_ticks)
-                        (void)bar_cas(&bar->gen.w, old_word, BAR_ABORT); // decided here or by the publisher, never both
-                }
-                s_next[0] = word != BAR_ABORT;
-                s_next[1] = (unsigned)word - Cprev;
+                s_next[0] = ok;
+                s_next[1] = C - Cpar[par];
             }
+            Cpar[par] = C;
         }
         __syncthreads();
+        PSTAMP(5);
         if (!s_next[0]) {
-            aborted = true;
+            fault = true;
             break;
         }
         F = s_next[1];
-        Cprev += F;
+    }
+
+    if (!fault && !converged && F == 0) { // emptied exactly at the last sweep this launch was given
+        if (valid) x_store(((sweeps & 1) ? xa : xb) + v, 0.0);
+        converged = true;
     }
 
     // ---- the launch ends: registers back to memory, counters in the state the per-iteration
@@ -267,10 +343,10 @@ __global__ __launch_bounds__(PB) void k_pull_persist(int V, const int *__restric
     }
     if (blockIdx.x == 0 && tid == 0) {
         for (int k = logged; k < n_iter; ++k) log[k] = 0; // iterations this launch did not get to
-        cnt[0] = aborted ? 0 : (int)F;
+        cnt[0] = (int)F;
         cnt[1] = 0;
         cnt[2] = 0;
-        *status = sweeps | (aborted ? PERSIST_ABORTED : 0);
+        *status = sweeps | (fault ? PERSIST_FAULT : 0) | (converged ? PERSIST_CONVERGED : 0);
     }
     stat_add_edges<NW>(stats, edges, s_edges);
 }

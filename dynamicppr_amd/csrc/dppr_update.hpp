@@ -123,7 +123,11 @@ __global__ __launch_bounds__(BLOCK) void k_su_apply(const uint32_t *__restrict__
 // (phase 0 only adds positive amounts, so no new vertex can have dropped below).
 __global__ __launch_bounds__(BLOCK) void k_filter(const int *__restrict__ cand, const int *__restrict__ cnt_cand,
                                                   const double *__restrict__ r, int phase, double eps,
-                                                  int *__restrict__ ft, int *__restrict__ cnt) {
+                                                  int *__restrict__ ft, int *__restrict__ cnt,
+                                                  const int *__restrict__ guard, int guard_mask) {
+    // enqueued ahead of time (dppr_engine.hip, batch_ahead): only runs if the launch before it
+    // ended the way the host expected
+    if (guard && !(*guard & guard_mask)) return;
     const int n = *cnt_cand;
     for (int i0 = blockIdx.x * BLOCK; i0 < n; i0 += gridDim.x * BLOCK) {
         const int i = i0 + threadIdx.x;

@@ -109,11 +109,14 @@ int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges, int p
 /* Resident sweeps: when a window's sweep groups all fit on the chip at once, a run of dense
  * iterations is ONE launch that keeps the per-vertex state on chip and separates iterations
  * with a grid barrier (no counterpart in the reference, whose loop reads the frontier size back
- * after every iteration, gpu/PPRRevPushGPU.cuh:107). mode 1 = automatic (default), 0 = never
- * (every iteration its own launch). timeout_us: how long a workgroup waits at a grid barrier
- * before the launch is abandoned at that iteration boundary and the engine continues with
- * per-iteration launches (0 keeps the default, 50 ms; negative = give up at the first wait, which
- * tests use to exercise that path; the results are the same either way).
+ * after every iteration, gpu/PPRRevPushGPU.cuh:107). mode 1 = automatic (default; in the steady
+ * state of a stream the launches of BOTH phases of a batch are enqueued ahead, without a
+ * read-back in between), 2 = resident launches but one host read-back per launch, 0 = never
+ * (every iteration its own launch). Such a launch first checks that all its workgroups are
+ * running (a grid barrier needs that); timeout_us is how long that roll-call may take before the
+ * launch gives up WITHOUT having changed anything and the engine continues with per-iteration
+ * launches (0 keeps the default, 50 ms; negative = a roll-call that cannot succeed, which tests
+ * use to exercise that path; the results are the same either way).
  * Only valid right after dppr_create. */
 int dppr_set_persistent(dppr_engine *e, int mode, int64_t timeout_us);
 

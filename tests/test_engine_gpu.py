@@ -33,13 +33,13 @@ TUNINGS = [dict(pull_min_frontier=-1), dict(hub_min_degree=3, big_row_edges=8, p
            dict(pull_min_frontier=40, chunk_iters=1), dict(hub_min_degree=3, pull_min_frontier=60, chunk_iters=3),
            dict(pull_min_frontier=1, pull_block=512, big_row_edges=8), dict(pull_min_frontier=30, pull_block=1024, big_row_edges=4),
            # resident sweeps (one launch per run of dense iterations) are on by default: also run
-           # without them, with small workgroups (several groups), and with the grid barrier giving
-           # up at once (the launch is abandoned after its first sweep, per-iteration launches go on)
+           # without them, with small workgroups (several groups), and with a roll-call that cannot
+           # succeed (the first resident launch gives up untouched, per-iteration launches go on)
            dict(pull_min_frontier=1, persistent=0), dict(pull_min_frontier=1, pull_block=256),
            dict(pull_min_frontier=1, pull_block=256, persist_timeout_us=-1)]
 TUNING_IDS = ["push-only", "push-hubs+bigrows", "push-all-hub-all-big", "pull-only", "mixed-pull>=40", "default",
               "mixed-chunk1", "mixed-chunk3", "pull-wg512", "mixed-wg1024", "pull-no-persist", "pull-wg256",
-              "pull-barrier-gives-up"]
+              "pull-rollcall-fails"]
 
 
 def make(directed, schedule=eng.SCHEDULE_EAGER, scale=9, edges=6000, seed=11, W=600, c=6, eps=1e-9, n_epochs=1,
@@ -391,18 +391,19 @@ def test_full_size_livejournal_standin_two_sources():
     assert st0["batches"] == 2 and st0["pull_iterations"] > 0 and st0["sum_E"] > 10 * len(w1)
 
 
-@pytest.mark.parametrize("mode", ["resident", "per-iteration", "barrier-gives-up", "heavy-groups"])
+@pytest.mark.parametrize("mode", ["resident", "per-iteration", "rollcall-fails", "heavy-groups"])
 @pytest.mark.parametrize("directed", [1, 0])
 def test_resident_sweeps_same_work_as_per_iteration_launches(directed, mode):
     """Runs of dense iterations as ONE resident launch (k_pull_persist) do exactly the oracle's
     synchronous work -- iterations, sum of frontier sizes, traversed edges, p/r to rounding -- as do
-    per-iteration launches, a launch abandoned at a grid-barrier time-out, and groups with more
-    edges than the kernel keeps in registers (edge slots beyond PERSIST_SLOTS)."""
+    per-iteration launches, a resident launch whose roll-call fails (not co-resident: it gives up
+    before touching anything), and groups with more edges than the kernel keeps in registers (edge
+    slots beyond PERSIST_SLOTS)."""
     tuning = dict(pull_min_frontier=1)
     scale, edges, W, c = 10, 30000, 3000, 60
     if mode == "per-iteration":
         tuning["persistent"] = 0
-    elif mode == "barrier-gives-up":
+    elif mode == "rollcall-fails":
         tuning["persist_timeout_us"] = -1
     elif mode == "heavy-groups":
         tuning["pull_block"] = 256
@@ -425,8 +426,8 @@ def test_resident_sweeps_same_work_as_per_iteration_launches(directed, mode):
     assert stats["sum_F"] == want["F"] and stats["sum_E"] == want["E"]
     if mode == "per-iteration":
         assert stats["persist_launches"] == 0
-    elif mode == "barrier-gives-up":
-        # the first resident launch is abandoned at its first barrier; none is tried after that
+    elif mode == "rollcall-fails":
+        # the first resident launch gives up at its roll-call; none is tried after that
         assert stats["persist_launches"] == 1 and stats["persist_aborts"] == 1
     else:
         assert stats["persist_launches"] >= 4 and stats["persist_aborts"] == 0
