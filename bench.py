@@ -162,9 +162,13 @@ def main():
         push_bytes = 72 * ps["sum_F"] + 24 * ps["sum_E"] + 4 * ps["sum_N"]
         achieved = push_bytes / (ps["push_ms"] * 1e-3) / 1e9 if ps["push_ms"] > 0 else 0.0
         roof = {
-            "bound": "hbm", "kernel": "k_pull_iter / k_push_iter (one frontier iteration)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+            "bound": "hbm",
+            "kernel": ("k_pull_persist (one launch = a run of frontier iterations, state kept on chip)"
+                       if ps["persist_launches"] else "k_pull_iter / k_push_iter (one frontier iteration)"),
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
-            "traffic": pmc_traffic_per_iteration() if (a.config == "youtube" and not a.bin) else None,
+            "traffic": pmc_traffic_per_launch(bool(ps["persist_launches"])) if (a.config == "youtube" and not a.bin) else None,
+            "iterations_per_launch": round(ps["iterations"] / max(ps["push_launches"], 1), 2),
             "launches": ps["push_launches"], "avg_launch_us": round(1e3 * ps["push_ms"] / max(ps["push_launches"], 1), 3),
             "algorithmic_bytes_per_launch": round(push_bytes / max(ps["push_launches"], 1), 1),
             "whole_batch_algorithmic_GBps": round(stats["algorithmic_bytes"] / (ev_ms * 1e-3) / 1e9, 2),
@@ -254,20 +258,21 @@ def bench_group(a, e, ss, sources, rank, world, W, c, n_steps, V, e1, name, flag
         dist.destroy_process_group()
 
 
-def pmc_traffic_per_iteration():
-    """HBM bytes per frontier iteration from the committed rocprofv3 --pmc summary of this same
-    workload (tools/prof_pmc.sh -> profiles/r01_final_pmc_traffic_youtube.json; FETCH_SIZE and
-    WRITE_SIZE in separate passes, 2 x FETCH + WRITE per the gfx950 correction of
+def pmc_traffic_per_launch(resident):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of
+    this same workload (tools/prof_pmc.sh -> profiles/r01_final_pmc_traffic_youtube.json; FETCH_SIZE
+    and WRITE_SIZE in separate passes, 2 x FETCH + WRITE per the gfx950 correction of
     MI355X_MICROARCH.md). bench.py cannot run the profiler on itself, so this is read back;
-    None when the file is missing or the workload differs."""
+    None when the file is missing or was taken with the other kind of launch."""
     path = os.path.join(ROOT, "profiles", "r01_final_pmc_traffic_youtube.json")
     if not os.path.exists(path):
         return None
     d = json.load(open(path))
-    iters = sum(v["launches"] for k, v in d.items() if k.startswith(("k_pull_iter", "k_push_iter")))
-    total = sum(v["launches"] * v["hbm_bytes_per_launch_corrected"] for k, v in d.items()
-                if k.startswith(("k_pull_iter", "k_push_iter", "k_push_big")))
-    return round(total / iters, 1) if iters else None
+    heads = ("k_pull_persist",) if resident else ("k_pull_iter", "k_push_iter")
+    tails = heads if resident else heads + ("k_push_big",)
+    launches = sum(v["launches"] for k, v in d.items() if k.startswith(heads))
+    total = sum(v["launches"] * v["hbm_bytes_per_launch_corrected"] for k, v in d.items() if k.startswith(tails))
+    return round(total / launches, 1) if launches else None
 
 
 def _force_converged(e, slot, eps):

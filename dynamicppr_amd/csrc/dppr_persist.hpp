@@ -52,7 +52,14 @@ namespace dppr {
 // device fault (DPPR_ERR_HIP), never silently survived.
 // ---------------------------------------------------------------------------
 constexpr int BAR_SUBS = 16;
-constexpr int BAR_REPS = 16;
+#ifndef DPPR_BAR_REPS
+#define DPPR_BAR_REPS 16
+#endif
+#ifndef DPPR_BAR_SLEEP
+#define DPPR_BAR_SLEEP 4
+#endif
+constexpr int BAR_REPS = DPPR_BAR_REPS;       // replicas of every arrival counter
+constexpr int BAR_POLL_SLEEP = DPPR_BAR_SLEEP; // s_sleep units (64 clocks) between two polls
 constexpr unsigned long long BAR_ABORT = ~0ull;
 constexpr int PERSIST_SLOTS = 4; // edge slots per thread kept in registers (PB * 4 edges per group)
 
@@ -305,6 +312,8 @@ __global__ __launch_bounds__(PB) void k_pull_persist(int V, const int *__restric
             unsigned long long word = 0;
             unsigned polls = 0;
             bool ok = true;
+            // (more polls in flight make the barrier SLOWER: four per workgroup took it from 5.4 K to
+            // 8.3 K cycles -- reads of one word serialise at the memory side like atomics do)
             for (;;) {
                 if (lane < (int)subs_used) word = bar_load(&bar->sub[par][my_rep][lane].w);
                 if (__ballot((word >> 32) >= n_sub * rounds) == ~0ull) break;
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(PB) void k_pull_persist(int V, const int *__restric
                     ok = false;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(BAR_POLL_SLEEP);
             }
             const unsigned C = (unsigned)__builtin_amdgcn_readlane(wave_inclusive_scan((int)(unsigned)word), WAVE - 1);
             if (lane == 0) {
