@@ -55,6 +55,7 @@ struct Slot {
     int source_ext = 0; // id the caller gave
     double *p = nullptr, *r = nullptr;
     double *x = nullptr, *x2 = nullptr; // dense per-iteration push amounts (x) and pull output (x2)
+    double *x3 = nullptr;               // third snapshot vector of the data-flow resident sweep (all zero outside it)
     int *ft[2] = {nullptr, nullptr};
     int *neg = nullptr;     // phase-1 candidates
     int *cnt = nullptr;     // [0..2] rotating frontier counters, [3] neg candidates, [4] scratch, [5..6] big-row counters
@@ -102,7 +103,8 @@ struct dppr_engine {
     int pull_block = 0;   // sweep workgroup size (0: by graph size; 256 / 512 / 1024)
     int chunk_iters = 24; // iterations enqueued between two host read-backs of the frontier size
     // resident sweeps (dppr_persist.hpp)
-    int persist_mode = 1;              // 1: use k_pull_persist when an epoch's groups fit the chip at once
+    int persist_mode = 1;              // 1: use resident sweeps when an epoch's groups fit the chip at once
+    bool persist_flow = true;          // resident sweeps synchronise by data flow (k_pull_flow) / by grid barrier
     bool persist_ok = true;            // cleared after a grid-barrier time-out: per-iteration launches from then on
     int persist_cap = 0;               // co-resident workgroups of k_pull_persist at the sweep's block size
     unsigned long long persist_ticks = 5000000ull; // roll-call time limit in 100 MHz ticks (50 ms)
@@ -291,12 +293,15 @@ int persist_capacity(const dppr_engine *e) {
 int query_persist_cap(dppr_engine *e) {
     e->persist_cap = 0;
     int per_cu = 0;
-    switch (sweep_block(e)) {
-    case 256: HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pull_persist<256>, 256, 0)); break;
-    case 512: HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pull_persist<512>, 512, 0)); break;
-    case 1024: HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pull_persist<1024>, 1024, 0)); break;
-    default: return DPPR_OK; // other block sizes (tuning only) always use per-iteration launches
+    const int pb = sweep_block(e);
+    if (pb != 256 && pb != 512 && pb != 1024) return DPPR_OK; // other block sizes (tuning only): per-iteration launches
+#define DPPR_OCC(K, PB) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, K<PB>, PB, 0))
+    if (e->persist_flow) {
+        if (pb == 256) DPPR_OCC(k_pull_flow, 256); else if (pb == 512) DPPR_OCC(k_pull_flow, 512); else DPPR_OCC(k_pull_flow, 1024);
+    } else {
+        if (pb == 256) DPPR_OCC(k_pull_persist, 256); else if (pb == 512) DPPR_OCC(k_pull_persist, 512); else DPPR_OCC(k_pull_persist, 1024);
     }
+#undef DPPR_OCC
     int cus = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
     e->persist_cap = std::min(per_cu * cus, STAT_SLOTS);
@@ -428,6 +433,19 @@ int pull_min_frontier(const dppr_engine *e) {
     return e->pull_min_frontier > 0 ? e->pull_min_frontier : e->pull_min_frontier < 0 ? 0x7fffffff : std::max(1024, e->Ed / 192);
 }
 
+// after a resident launch of `sweeps` sweeps: make s.x the vector that holds the live snapshot
+// (the other vectors are all zero again)
+void rotate_snapshots(const dppr_engine *e, Slot &s, int sweeps) {
+    if (e->persist_flow) { // three vectors, x_g lives in vector g % 3
+        double *b[3] = {s.x, s.x2, s.x3};
+        s.x = b[sweeps % 3];
+        s.x2 = b[(sweeps + 1) % 3];
+        s.x3 = b[(sweeps + 2) % 3];
+    } else if (sweeps & 1) {
+        std::swap(s.x, s.x2);
+    }
+}
+
 int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, double eps, int buf, int cur,
                       LoopEntry entry = LoopEntry()) {
     const int pull_min = pull_min_frontier(e);
@@ -486,9 +504,15 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             HIP_TRY(hipMemsetAsync(e->bar, 0, sizeof(GridBar), e->stream));
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                       \
-    hipLaunchKernelGGL(k_pull_persist<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,        \
-                       ep.out_row_ptr, ep.out_col, s.x, s.x2, s.r, s.p, s.cnt, cur, phase, eps, s.dstats, s.log, n,     \
-                       e->bar, s.cnt + 7, e->persist_ticks, e->persist_rollcall_extra, (const int *)nullptr)
+    if (e->persist_flow)                                                                                              \
+        hipLaunchKernelGGL(k_pull_flow<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,       \
+                           ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.r, s.p, s.cnt, cur, phase, eps, s.dstats,     \
+                           s.log, n, e->bar, s.cnt + 7, e->persist_ticks, e->persist_rollcall_extra,                    \
+                           (const int *)nullptr);                                                                       \
+    else                                                                                                              \
+        hipLaunchKernelGGL(k_pull_persist<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,    \
+                           ep.out_row_ptr, ep.out_col, s.x, s.x2, s.r, s.p, s.cnt, cur, phase, eps, s.dstats, s.log, n, \
+                           e->bar, s.cnt + 7, e->persist_ticks, e->persist_rollcall_extra, (const int *)nullptr)
             switch (sweep_block(e)) {
             case 256: DPPR_LAUNCH_PERSIST(256); break;
             case 512: DPPR_LAUNCH_PERSIST(512); break;
@@ -524,7 +548,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 s.st.push_ms += ms;
                 s.st.push_launches++;
             }
-            if (sweeps & 1) std::swap(s.x, s.x2); // s.x = the snapshot the last sweep wrote
+            rotate_snapshots(e, s, sweeps);       // s.x = the snapshot the last sweep wrote
             cur = 0;                              // the launch leaves the live count in cnt[0]
             list_valid = false;
             any_pull = true;
@@ -653,9 +677,14 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
     };
     auto resident = [&](int phase, int n, int *log, GridBar *bar, int *status, const int *guard) {
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                        \
-    hipLaunchKernelGGL(k_pull_persist<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,         \
-                       ep.out_row_ptr, ep.out_col, s.x, s.x2, s.r, s.p, s.cnt, 0, phase, eps, s.dstats, log, n, bar,     \
-                       status, e->persist_ticks, e->persist_rollcall_extra, guard)
+    if (e->persist_flow)                                                                                               \
+        hipLaunchKernelGGL(k_pull_flow<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,        \
+                           ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.r, s.p, s.cnt, 0, phase, eps, s.dstats, log,   \
+                           n, bar, status, e->persist_ticks, e->persist_rollcall_extra, guard);                          \
+    else                                                                                                               \
+        hipLaunchKernelGGL(k_pull_persist<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,     \
+                           ep.out_row_ptr, ep.out_col, s.x, s.x2, s.r, s.p, s.cnt, 0, phase, eps, s.dstats, log, n, bar, \
+                           status, e->persist_ticks, e->persist_rollcall_extra, guard)
         switch (sweep_block(e)) {
         case 256: DPPR_LAUNCH_PERSIST(256); break;
         case 512: DPPR_LAUNCH_PERSIST(512); break;
@@ -716,7 +745,7 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
     s.last_F0[0] = log_a[0];
     const int act_a = account(log_a, n0, 0);
     if (!(st_a & PERSIST_CONVERGED)) { // phase 0 needs more sweeps than it was given; phase 1 did not start
-        if ((st_a & PERSIST_SWEEPS) & 1) std::swap(s.x, s.x2);
+        rotate_snapshots(e, s, st_a & PERSIST_SWEEPS);
         en0->it = n0;
         en0->F = e->pinned[0];
         en0->dense = true;
@@ -738,7 +767,7 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
     s.last_F0[1] = log_b[0];
     const int act_b = account(log_b, n1, 2);
     if (!(st_b & PERSIST_CONVERGED)) {
-        if ((st_b & PERSIST_SWEEPS) & 1) std::swap(s.x, s.x2);
+        rotate_snapshots(e, s, st_b & PERSIST_SWEEPS);
         en1->it = n1;
         en1->F = e->pinned[0];
         en1->dense = true;
@@ -987,7 +1016,7 @@ void dppr_destroy(dppr_engine *e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto &s : e->slots) {
-        (void)hipFree(s.p); (void)hipFree(s.r); (void)hipFree(s.x); (void)hipFree(s.x2);
+        (void)hipFree(s.p); (void)hipFree(s.r); (void)hipFree(s.x); (void)hipFree(s.x2); (void)hipFree(s.x3);
         (void)hipFree(s.ft[0]); (void)hipFree(s.ft[1]); (void)hipFree(s.neg);
         (void)hipFree(s.cnt); (void)hipFree(s.dstats); (void)hipFree(s.big);
     }
@@ -1029,9 +1058,10 @@ int dppr_set_profiling(dppr_engine *e, int on) {
 }
 
 int dppr_set_persistent(dppr_engine *e, int mode, int64_t timeout_us) {
-    if (!e || mode < 0 || mode > 2 || e->loaded || !e->slots.empty())
-        return fail(e, DPPR_ERR_INVALID, "set_persistent: call right after dppr_create, mode 0, 1 or 2");
-    e->persist_mode = mode;
+    if (!e || mode < 0 || mode > 3 || e->loaded || !e->slots.empty())
+        return fail(e, DPPR_ERR_INVALID, "set_persistent: call right after dppr_create, mode 0..3");
+    e->persist_mode = mode == 3 ? 1 : mode;
+    e->persist_flow = mode != 3;
     if (timeout_us > 0) e->persist_ticks = (unsigned long long)timeout_us * 100ull; // wall_clock64 runs at 100 MHz
     if (timeout_us < 0) { // tests: a roll-call that cannot succeed, given up after 200 us
         e->persist_ticks = 20000ull;
@@ -1215,8 +1245,10 @@ int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
     HIP_TRY(hipMalloc((void **)&s.r, sizeof(double) * V));
     HIP_TRY(hipMalloc((void **)&s.x, sizeof(double) * V));
     HIP_TRY(hipMalloc((void **)&s.x2, sizeof(double) * V));
+    HIP_TRY(hipMalloc((void **)&s.x3, sizeof(double) * V));
     HIP_TRY(hipMemsetAsync(s.x, 0, sizeof(double) * V, e->stream));
     HIP_TRY(hipMemsetAsync(s.x2, 0, sizeof(double) * V, e->stream));
+    HIP_TRY(hipMemsetAsync(s.x3, 0, sizeof(double) * V, e->stream));
     HIP_TRY(hipMalloc((void **)&s.ft[0], sizeof(int) * V));
     HIP_TRY(hipMalloc((void **)&s.ft[1], sizeof(int) * V));
     HIP_TRY(hipMalloc((void **)&s.neg, sizeof(int) * (size_t)std::max(4 * e->c, 1)));

@@ -1,0 +1,370 @@
+// dppr_flow.hpp -- resident sweeps without a grid barrier on the critical path.
+#pragma once
+
+#include "dppr_persist.hpp"
+
+namespace dppr {
+
+// ---------------------------------------------------------------------------
+// a4+a5, DENSE iterations, resident launch, DATA-FLOW synchronisation.
+//
+// k_pull_persist separates iterations with a grid barrier: stores complete (~1.7 K clocks) ->
+// arrive -> everybody has arrived (~5.4 K) -> only then the next gathers start (~8 K): three
+// memory-side round trips in a row, 45 % of an iteration spent waiting. Here an iteration's
+// gathers wait for exactly what they need -- the values themselves:
+//
+//   * three snapshot vectors B[0..2]; sweep g reads x_g from B[g % 3], writes x_{g+1} to
+//     B[(g+1) % 3], and B[(g+2) % 3] (which held x_{g-1}) is RESET for the sweep after;
+//   * a reset entry holds X_EMPTY, a NaN bit pattern no computed value has; a gather that
+//     reads X_EMPTY is simply repeated until the owner has stored this round's value. A value
+//     needs one store and is seen by the next poll of whoever waits for it: no barrier between
+//     "stored" and "may be read";
+//   * the arrival counters of k_pull_persist remain, but nobody waits on them in the common case:
+//     a workgroup arrives (fire and forget) when it has finished sweep g; during sweep g+1 its
+//     first wave looks at the arrivals of sweep g -- a whole gather phase later, so normally
+//     complete -- to learn (1) that every workgroup is done READING x_g... more precisely done
+//     with sweep g, so that B[(g+2) % 3] may be reset, and (2) how many vertices are legal in
+//     x_{g+1}, i.e. whether the loop is over. Every workgroup evaluates the same sums at the
+//     same iteration number, so all of them stop together.
+//
+// Ordering argument (why a gather never sees a stale value instead of X_EMPTY or the right one):
+// the owner's first wave resets B[(g+2) % 3] for the whole group, waits for those stores to
+// complete (s_waitcnt vmcnt(0)), and only then the workgroup passes the __syncthreads after
+// which any of its waves stores x_{g+1}. A consumer reads B[(g+2) % 3] as x_{g+2} no earlier
+// than its sweep g+2, which it starts after it consumed x_{g+1} of every vertex it depends on
+// -- stored after the reset completed. The reset itself waits for "all workgroups finished
+// sweep g-1" (arrivals), so nobody still needs x_{g-1}. Progress: sweep g of any workgroup needs
+// only values of sweep g-1 and arrivals of sweep g-1, never anything of sweep g.
+// The launch starts with the roll-call barrier of k_pull_persist (all workgroups resident, and
+// all X_EMPTY initialisations in place) and ends with one real barrier.
+// The arithmetic is k_pull_persist's, term for term.
+// ---------------------------------------------------------------------------
+constexpr unsigned long long X_EMPTY = 0x7FF8DEADBEEFCAFEull;
+
+__device__ __forceinline__ unsigned long long xb_load(const double *p) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void xb_store(double *p, unsigned long long bits) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int PB>
+__global__ __launch_bounds__(PB) void k_pull_flow(int V, const int *__restrict__ grp_tile,
+                                                  const int *__restrict__ out_row_ptr, const int *__restrict__ out_col,
+                                                  double *b0, double *b1, double *b2, double *r, double *p, int *cnt,
+                                                  int cur0, int phase, double eps, IterStats *stats, int *log, int n_iter,
+                                                  GridBar *bar, int *status, unsigned long long limit_ticks,
+                                                  int rollcall_extra, const int *guard) {
+    constexpr int NW = PB / WAVE;
+    constexpr int S = PERSIST_SLOTS;
+    __shared__ int s_scan[PB + 1];
+    __shared__ int s_rs[PB];
+    __shared__ double s_acc[2][PB];
+    __shared__ int s_wtot[NW];
+    __shared__ int s_cnt[NW];
+    __shared__ unsigned long long s_edges[NW];
+    __shared__ unsigned s_next[2]; // {roll-call outcome / no fault, size of the frontier of the current sweep}
+    __shared__ int s_fault;
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    if (guard && !(__hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & PERSIST_CONVERGED)) {
+        if (blockIdx.x == 0 && tid == 0) *status = PERSIST_SKIPPED;
+        return;
+    }
+    const unsigned G = gridDim.x;
+    const unsigned subs_used = G < (unsigned)BAR_SUBS ? G : (unsigned)BAR_SUBS;
+    const unsigned long long n_sub = lane < (int)subs_used ? (G - lane + BAR_SUBS - 1) / BAR_SUBS : 0;
+    const int my_rep = (blockIdx.x / BAR_SUBS) % BAR_REPS;
+    const unsigned long long t_entry = wall_clock64();
+
+    // ---- static part (as k_pull_persist), plus: the two vectors that are not the input start EMPTY
+    const int t0 = grp_tile[blockIdx.x], t1 = grp_tile[blockIdx.x + 1];
+    const int v = t0 * WAVE + tid;
+    const bool valid = tid < (t1 - t0) * WAVE && v < V;
+    if (valid) {
+        xb_store(b1 + v, X_EMPTY);
+        xb_store(b2 + v, X_EMPTY);
+    }
+    if (tid == 0) s_fault = 0;
+    int rs = 0, d = 0;
+    double rv = 0.0, xv = 0.0, pv = 0.0;
+    if (valid) {
+        rs = out_row_ptr[v];
+        d = out_row_ptr[v + 1] - rs;
+        rv = r[v];
+        xv = b0[v];
+        pv = p[v];
+    }
+    unsigned F = (unsigned)__hip_atomic_load(cnt + cur0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int incl = wave_inclusive_scan(d);
+    if (lane == WAVE - 1) s_wtot[w] = incl;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the EMPTY marks are in place before this workgroup checks in
+    __syncthreads();
+    if (tid == 0) // roll-call: this workgroup is running and has initialised its entries
+        __hip_atomic_fetch_add(&bar->roll[blockIdx.x % BAR_SUBS].w, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int woff = 0, Eg = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int t = s_wtot[k];
+        woff += k < w ? t : 0;
+        Eg += t;
+    }
+    s_scan[tid] = woff + incl - d;
+    s_rs[tid] = rs;
+    if (tid == 0) s_scan[PB] = Eg;
+    s_acc[0][tid] = rv;
+    __syncthreads();
+    auto owner_of = [&](int e) {
+        int lo = 0, hi = PB;
+#pragma unroll
+        for (int st = PB; st > 1; st >>= 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_scan[mid] <= e) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
+    int own[S], col[S];
+    double den[S];
+    bool uni[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        const int e = tid + k * PB;
+        own[k] = -1;
+        col[k] = 0;
+        den[k] = 1.0;
+        if (e < Eg) {
+            const int o = owner_of(e);
+            own[k] = o;
+            col[k] = out_col[s_rs[o] + (e - s_scan[o])];
+            den[k] = (double)(s_scan[o + 1] - s_scan[o] + 1);
+        }
+        const int first = __builtin_amdgcn_readfirstlane(own[k]);
+        uni[k] = __ballot(own[k] >= 0 && own[k] == first) == ~0ull;
+    }
+
+    // ---- roll-call outcome
+    if (w == 0) {
+        if (blockIdx.x == 0) {
+            unsigned polls = 0;
+            bool all_here = false;
+            for (;;) {
+                const unsigned long long word = lane < (int)subs_used ? bar_load(&bar->roll[lane].w) : 0;
+                if (__ballot(word >= n_sub + (lane == 0 ? (unsigned long long)rollcall_extra : 0ull)) == ~0ull) {
+                    all_here = true;
+                    break;
+                }
+                if ((polls++ & 31u) == 0 && (bar_load(&bar->gen.w) != 0 || wall_clock64() - t_entry > limit_ticks)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0) (void)bar_cas(&bar->gen.w, 0ull, all_here ? BAR_READY : BAR_ABORT);
+        }
+        if (lane == 0) {
+            unsigned long long word;
+            unsigned polls = 0;
+            while ((word = bar_load(&bar->gen.w)) == 0) {
+                if ((polls++ & 31u) == 0 && wall_clock64() - t_entry > limit_ticks)
+                    (void)bar_cas(&bar->gen.w, 0ull, BAR_ABORT);
+                __builtin_amdgcn_s_sleep(1);
+            }
+            s_next[0] = word == BAR_READY;
+            s_next[1] = F;
+        }
+    }
+    __syncthreads();
+    if (!s_next[0]) { // not co-resident: put the two vectors back to all-zero and leave
+        if (valid) {
+            xb_store(b1 + v, 0ull);
+            xb_store(b2 + v, 0ull);
+        }
+        if (blockIdx.x == 0 && tid == 0) *status = PERSIST_ABORTED;
+        return;
+    }
+
+    // arrivals of sweep h: counter set h & 1, (h >> 1) + 1 rounds of that set so far. Returns false on a
+    // time-out; on success *count = legal vertices summed over all workgroups, cumulative for the set.
+    auto wait_arrivals = [&](int h, unsigned long long first_word, unsigned *cum) {
+        const unsigned long long rounds = (unsigned long long)((h >> 1) + 1);
+        unsigned long long word = first_word;
+        unsigned polls = 0;
+        const unsigned long long t_start = wall_clock64();
+        for (;;) {
+            if (__ballot((word >> 32) >= n_sub * rounds) == ~0ull) break;
+            if ((polls++ & 63u) == 63u && wall_clock64() - t_start > limit_ticks + 100000000ull) return false;
+            __builtin_amdgcn_s_sleep(BAR_POLL_SLEEP);
+            if (lane < (int)subs_used) word = bar_load(&bar->sub[h & 1][my_rep][lane].w);
+        }
+        *cum = (unsigned)__builtin_amdgcn_readlane(wave_inclusive_scan((int)(unsigned)word), WAVE - 1);
+        return true;
+    };
+
+    unsigned long long edges = 0;
+    unsigned Cpar[2] = {0u, 0u};
+    int sweeps = 0, logged = 0;
+    bool fault = false, converged = false;
+    int g = 0;
+    for (; g < n_iter; ++g) {
+        const int ri = g % 3;
+        const double *xin = ri == 0 ? b0 : ri == 1 ? b1 : b2;
+        double *xout = ri == 0 ? b1 : ri == 1 ? b2 : b0;
+        double *xrst = ri == 0 ? b2 : ri == 1 ? b0 : b1;
+        const int it = g; // (PSTAMP)
+        PSTAMP(0);
+        // first wave: the arrivals of sweep g-1, read BEFORE the gathers are issued (loads return in
+        // order, so this is back long before they are)
+        unsigned long long fw = 0;
+        if (w == 0 && g >= 1 && lane < (int)subs_used) fw = bar_load(&bar->sub[(g - 1) & 1][my_rep][lane].w);
+#ifdef DPPR_FLOW_PACE
+        if (g >= 1) __builtin_amdgcn_s_sleep(DPPR_FLOW_PACE); // let the values of the sweep before land first
+#endif
+        unsigned long long gb[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) gb[k] = own[k] >= 0 ? xb_load(xin + col[k]) : 0ull;
+        if (w == 0 && g >= 1) {
+            unsigned cum = 0;
+            const bool ok = wait_arrivals(g - 1, fw, &cum);
+            const unsigned fsz = cum - Cpar[(g - 1) & 1];
+            Cpar[(g - 1) & 1] = cum;
+            if (lane == 0) {
+                s_next[1] = fsz;
+                if (!ok) s_fault = 1;
+            }
+            if (ok && fsz != 0) { // every workgroup is done with sweep g-1: nobody reads x_{g-1} any more
+                for (int i = lane; i < (t1 - t0) * WAVE; i += WAVE) {
+                    const int vv = t0 * WAVE + i;
+                    if (vv < V) xb_store(xrst + vv, X_EMPTY);
+                }
+            }
+        }
+        // gathers whose owner has not stored this round's value yet are repeated
+        {
+            unsigned polls = 0;
+            const unsigned long long t_start = wall_clock64();
+            for (;;) {
+                bool pend = false;
+#pragma unroll
+                for (int k = 0; k < S; ++k) pend |= gb[k] == X_EMPTY;
+                if (__ballot(pend) == 0) break;
+                if ((polls++ & 63u) == 63u && (s_fault || wall_clock64() - t_start > limit_ticks + 100000000ull)) {
+                    s_fault = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int k = 0; k < S; ++k)
+                    if (gb[k] == X_EMPTY) gb[k] = xb_load(xin + col[k]);
+            }
+        }
+        PSTAMP(1);
+        double *acc = s_acc[g & 1];
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            const double xg = __longlong_as_double((long long)gb[k]);
+            const bool nz = xg != 0.0;
+            const double term = ONE_MINUS_ALPHA * xg / den[k];
+            if (uni[k]) {
+                const double sum = wave_sum(nz ? term : 0.0);
+                if (lane == 0 && sum != 0.0) lds_add(&acc[own[k]], sum);
+            } else if (nz) {
+                lds_add(&acc[own[k]], term);
+            }
+            edges += (unsigned long long)__popcll(__ballot(nz));
+        }
+        for (int e0 = S * PB; e0 < Eg; e0 += PB) { // edges beyond the register slots
+            const int e = e0 + tid;
+            double xe = 0.0;
+            int o = 0;
+            if (e < Eg) {
+                o = owner_of(e);
+                const double *src = xin + out_col[s_rs[o] + (e - s_scan[o])];
+                unsigned long long bits = xb_load(src);
+                unsigned polls = 0;
+                while (bits == X_EMPTY && !s_fault) {
+                    if ((polls++ & 1023u) == 1023u) s_fault = 1; // ~ seconds: a device fault, reported below
+                    __builtin_amdgcn_s_sleep(8);
+                    bits = xb_load(src);
+                }
+                xe = __longlong_as_double((long long)bits);
+            }
+            const bool nz = xe != 0.0 && !(xe != xe);
+            if (nz) lds_add(&acc[o], ONE_MINUS_ALPHA * xe / (double)(s_scan[o + 1] - s_scan[o] + 1));
+            edges += (unsigned long long)__popcll(__ballot(nz));
+        }
+        // (first wave: its reset stores are complete before the workgroup goes on to store x_{g+1})
+        PSTAMP(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        PSTAMP(3);
+        if (s_fault) {
+            fault = true;
+            break;
+        }
+        F = s_next[1]; // size of the frontier this sweep consumed
+        if (blockIdx.x == 0 && tid == 0) log[g] = (int)F;
+        logged = g + 1;
+        if (F == 0) { // the loop is over; this sweep had nothing to do (every workgroup sees the same F)
+            converged = true;
+            break;
+        }
+        double rn = acc[tid];
+        if (xv != 0.0) rn -= xv;
+        const bool lg = valid && legal(rn, phase, eps);
+        if (valid) {
+            rv = rn;
+            xv = lg ? rn : 0.0;
+            xb_store(xout + v, (unsigned long long)__double_as_longlong(xv));
+            if (lg) pv = pv + ALPHA * rn;
+        }
+        s_acc[(g + 1) & 1][tid] = rv;
+        const int wl = __popcll(__ballot(lg));
+        if (lane == 0) s_cnt[w] = wl;
+        ++sweeps;
+        PSTAMP(4);
+        __syncthreads();
+        PSTAMP(5);
+        if (w == 0) { // arrive for sweep g (nobody waits for this now)
+            const int part = lane < NW ? s_cnt[lane] : 0;
+            const int tot = __builtin_amdgcn_readlane(wave_inclusive_scan(part), WAVE - 1);
+            if (lane < BAR_REPS)
+                __hip_atomic_fetch_add(&bar->sub[g & 1][lane][blockIdx.x % BAR_SUBS].w, (1ull << 32) | (unsigned)tot,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
+    // ---- the launch ends. Converged: x_g is all zero, the other two vectors are cleaned. Out of
+    // sweeps: one real barrier (everybody finished the last sweep), its count is the live frontier
+    // size; the vector with x_{n_iter} stays, the other two are cleaned.
+    if (!fault && !converged) {
+        if (w == 0) {
+            unsigned cum = 0;
+            unsigned long long fw = lane < (int)subs_used ? bar_load(&bar->sub[(g - 1) & 1][my_rep][lane].w) : 0;
+            const bool ok = wait_arrivals(g - 1, fw, &cum);
+            if (lane == 0) {
+                s_next[1] = cum - Cpar[(g - 1) & 1];
+                if (!ok) s_fault = 1;
+            }
+        }
+        __syncthreads();
+        fault = s_fault != 0;
+        F = s_next[1];
+    }
+    if (!fault && valid) {
+        const int ri = g % 3; // B[ri] holds x_g (all zero if converged)
+        double *o1 = ri == 0 ? b1 : ri == 1 ? b2 : b0;
+        double *o2 = ri == 0 ? b2 : ri == 1 ? b0 : b1;
+        xb_store(o1 + v, 0ull);
+        xb_store(o2 + v, 0ull);
+    }
+    if (valid) {
+        r[v] = rv;
+        p[v] = pv;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        for (int k = logged; k < n_iter; ++k) log[k] = 0;
+        cnt[0] = (int)F;
+        cnt[1] = 0;
+        cnt[2] = 0;
+        *status = sweeps | (fault ? PERSIST_FAULT : 0) | ((converged || (!fault && F == 0)) ? PERSIST_CONVERGED : 0);
+    }
+    stat_add_edges<NW>(stats, edges, s_edges);
+}
+
+} // namespace dppr

@@ -20,6 +20,7 @@
 //   dppr_push.hpp     Init, Inspect, dense snapshot, sparse frontier iteration (push atomics)
 //   dppr_pull.hpp     dense frontier iteration (pull sweep, no global atomics)
 //   dppr_persist.hpp  a run of dense iterations as one resident launch (grid barrier, state on chip)
+//   dppr_flow.hpp     the same with data-flow synchronisation (no barrier on the critical path)
 //   dppr_update.hpp   IncrementalBatchUpdate (lock-free, batch-index order)
 //   dppr_builder.hpp  sliding-window graph builder (full sort / incremental merge), id translation
 //   dppr_multi.hpp    multi-source batched sweeps (included separately by the engine)
@@ -29,5 +30,6 @@
 #include "dppr_push.hpp"
 #include "dppr_pull.hpp"
 #include "dppr_persist.hpp"
+#include "dppr_flow.hpp"
 #include "dppr_update.hpp"
 #include "dppr_builder.hpp"

@@ -357,6 +357,39 @@ def test_full_size_youtube_standin_properties():
     assert st["batches"] == 3 and st["sum_E"] > 0 and st["algorithmic_bytes"] > 16 * V * 3
 
 
+def test_full_size_resident_sweeps_match_per_iteration_launches():
+    """configs[1] size, 242 workgroups on all XCDs: resident launches (data-flow synchronised sweeps,
+    both phases of a batch enqueued ahead) against per-iteration launches of the same engine code,
+    batch by batch. The two evaluate the same sums in different orders, so p / r agree to rounding;
+    a value read one iteration too early or too late would show up at ~1e-7."""
+    V, e1, e2, cfg = datagen.stand_in_stream("youtube", "/tmp/dppr_data")
+    W, c, _, _ = orc.workload_config(len(e1), 0.1, 0, 0.01, 100, 0, 0)
+    src = int(datagen.top_sources(V, e1, e2, W, cfg.directed, 1)[0])
+    eps = 1e-9
+    engines = [eng.Engine(V, W, cfg.directed, c, persistent=m) for m in (0, 1)]
+    slots = []
+    for e in engines:
+        e.load_window(e1[:W], e2[:W])
+        slots.append(e.add_source(src))
+        e.init_solve(slots[-1], eps)
+    pos = W
+    for k in range(16):
+        if k:
+            b1 = np.concatenate([e1[pos - W:pos - W + c], e1[pos:pos + c]])
+            b2 = np.concatenate([e2[pos - W:pos - W + c], e2[pos:pos + c]])
+            ins = np.concatenate([np.zeros(c, np.uint8), np.ones(c, np.uint8)])
+            for e, sl in zip(engines, slots):
+                e.set_batch(np.concatenate([b1, b2]), np.concatenate([b2, b1]), np.concatenate([ins, ins]))
+                e.slide(e1[pos:pos + c], e2[pos:pos + c])
+                e.update(sl, eps)
+            pos += c
+        (p0, r0), (p1, r1) = (e.read(sl) for e, sl in zip(engines, slots))
+        assert np.max(np.abs(p0 - p1)) < 1e-13 and np.max(np.abs(r0 - r1)) < 1e-13, k
+    st0, st1 = (e.stats(sl) for e, sl in zip(engines, slots))
+    assert (st0["iterations"], st0["sum_F"], st0["sum_E"]) == (st1["iterations"], st1["sum_F"], st1["sum_E"])
+    assert st0["persist_launches"] == 0 and st1["persist_launches"] >= 30 and st1["persist_aborts"] == 0
+
+
 def test_full_size_livejournal_standin_two_sources():
     """BASELINE.json configs[2] size (soc-LiveJournal1 stand-in, directed, 69 M stream edges):
     two sources drawn from degree ranks [10, 1000) share one device graph; size-independent
