@@ -163,7 +163,7 @@ def main():
         achieved = push_bytes / (ps["push_ms"] * 1e-3) / 1e9 if ps["push_ms"] > 0 else 0.0
         roof = {
             "bound": "hbm",
-            "kernel": ("k_pull_persist (one launch = a run of frontier iterations, state kept on chip)"
+            "kernel": ("k_pull_resident (one launch = a run of frontier iterations, state kept on chip)"
                        if ps["persist_launches"] else "k_pull_iter / k_push_iter (one frontier iteration)"),
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
@@ -268,7 +268,7 @@ def pmc_traffic_per_launch(resident):
     if not os.path.exists(path):
         return None
     d = json.load(open(path))
-    heads = ("k_pull_persist",) if resident else ("k_pull_iter", "k_push_iter")
+    heads = ("k_pull_resident",) if resident else ("k_pull_iter", "k_push_iter")
     tails = heads if resident else heads + ("k_push_big",)
     launches = sum(v["launches"] for k, v in d.items() if k.startswith(heads))
     total = sum(v["launches"] * v["hbm_bytes_per_launch_corrected"] for k, v in d.items() if k.startswith(tails))

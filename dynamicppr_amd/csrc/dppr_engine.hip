@@ -102,11 +102,10 @@ struct dppr_engine {
     bool profiling = false;
     int pull_block = 0;   // sweep workgroup size (0: by graph size; 256 / 512 / 1024)
     int chunk_iters = 24; // iterations enqueued between two host read-backs of the frontier size
-    // resident sweeps (dppr_persist.hpp)
+    // resident sweeps (dppr_resident.hpp)
     int persist_mode = 1;              // 1: use resident sweeps when an epoch's groups fit the chip at once
-    bool persist_flow = true;          // resident sweeps synchronise by data flow (k_pull_flow) / by grid barrier
     bool persist_ok = true;            // cleared after a grid-barrier time-out: per-iteration launches from then on
-    int persist_cap = 0;               // co-resident workgroups of k_pull_persist at the sweep's block size
+    int persist_cap = 0;               // co-resident workgroups of k_pull_resident at the sweep's block size
     unsigned long long persist_ticks = 5000000ull; // roll-call time limit in 100 MHz ticks (50 ms)
     int persist_rollcall_extra = 0;    // tests: the roll-call waits for a workgroup that does not exist
     GridBar *bar = nullptr;
@@ -295,13 +294,9 @@ int query_persist_cap(dppr_engine *e) {
     int per_cu = 0;
     const int pb = sweep_block(e);
     if (pb != 256 && pb != 512 && pb != 1024) return DPPR_OK; // other block sizes (tuning only): per-iteration launches
-#define DPPR_OCC(K, PB) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, K<PB>, PB, 0))
-    if (e->persist_flow) {
-        if (pb == 256) DPPR_OCC(k_pull_flow, 256); else if (pb == 512) DPPR_OCC(k_pull_flow, 512); else DPPR_OCC(k_pull_flow, 1024);
-    } else {
-        if (pb == 256) DPPR_OCC(k_pull_persist, 256); else if (pb == 512) DPPR_OCC(k_pull_persist, 512); else DPPR_OCC(k_pull_persist, 1024);
-    }
-#undef DPPR_OCC
+    if (pb == 256) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pull_resident<256>, 256, 0));
+    else if (pb == 512) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pull_resident<512>, 512, 0));
+    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pull_resident<1024>, 1024, 0));
     int cus = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
     e->persist_cap = std::min(per_cu * cus, STAT_SLOTS);
@@ -346,7 +341,7 @@ int cut_sweep_groups(dppr_engine *e, Epoch &ep) {
         if (cut.back() != n_tiles) cut.push_back(n_tiles);
     };
     // A window small enough for one workgroup per group to be resident at once gets at most that
-    // many groups (then runs of dense iterations are single launches, dppr_persist.hpp); the greedy
+    // many groups (then runs of dense iterations are single launches, dppr_resident.hpp); the greedy
     // cut can overshoot its aim by a few groups, so aim a little lower until it fits.
     const int cap = persist_capacity(e);
     bool fitted = false;
@@ -435,15 +430,11 @@ int pull_min_frontier(const dppr_engine *e) {
 
 // after a resident launch of `sweeps` sweeps: make s.x the vector that holds the live snapshot
 // (the other vectors are all zero again)
-void rotate_snapshots(const dppr_engine *e, Slot &s, int sweeps) {
-    if (e->persist_flow) { // three vectors, x_g lives in vector g % 3
-        double *b[3] = {s.x, s.x2, s.x3};
-        s.x = b[sweeps % 3];
-        s.x2 = b[(sweeps + 1) % 3];
-        s.x3 = b[(sweeps + 2) % 3];
-    } else if (sweeps & 1) {
-        std::swap(s.x, s.x2);
-    }
+void rotate_snapshots(Slot &s, int sweeps) { // three vectors, x_g lives in vector g % 3
+    double *b[3] = {s.x, s.x2, s.x3};
+    s.x = b[sweeps % 3];
+    s.x2 = b[(sweeps + 1) % 3];
+    s.x3 = b[(sweeps + 2) % 3];
 }
 
 int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, double eps, int buf, int cur,
@@ -495,7 +486,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
         if (!pull && !list_valid && (rc = make_list())) return rc;
         const int pcap = persist_capacity(e);
         if (pull && n >= 2 && !s.trace && pcap > 0 && ep.n_groups > 0 && ep.n_groups <= pcap) {
-            // ---- a run of dense iterations as ONE resident launch (dppr_persist.hpp)
+            // ---- a run of dense iterations as ONE resident launch (dppr_resident.hpp)
             if (!dense_valid) {
                 hipLaunchKernelGGL(k_snapshot_dense, dim3(std::min(grid_for(std::max(F, 1 << 14)), 1024)), dim3(BLOCK), 0,
                                    e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x, (const int *)nullptr, 0);
@@ -504,15 +495,9 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             HIP_TRY(hipMemsetAsync(e->bar, 0, sizeof(GridBar), e->stream));
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                       \
-    if (e->persist_flow)                                                                                              \
-        hipLaunchKernelGGL(k_pull_flow<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,       \
-                           ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.r, s.p, s.cnt, cur, phase, eps, s.dstats,     \
-                           s.log, n, e->bar, s.cnt + 7, e->persist_ticks, e->persist_rollcall_extra,                    \
-                           (const int *)nullptr);                                                                       \
-    else                                                                                                              \
-        hipLaunchKernelGGL(k_pull_persist<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,    \
-                           ep.out_row_ptr, ep.out_col, s.x, s.x2, s.r, s.p, s.cnt, cur, phase, eps, s.dstats, s.log, n, \
-                           e->bar, s.cnt + 7, e->persist_ticks, e->persist_rollcall_extra, (const int *)nullptr)
+    hipLaunchKernelGGL(k_pull_resident<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,       \
+                       ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.r, s.p, s.cnt, cur, phase, eps, s.dstats, s.log,  \
+                       n, e->bar, s.cnt + 7, e->persist_ticks, e->persist_rollcall_extra, (const int *)nullptr)
             switch (sweep_block(e)) {
             case 256: DPPR_LAUNCH_PERSIST(256); break;
             case 512: DPPR_LAUNCH_PERSIST(512); break;
@@ -548,7 +533,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 s.st.push_ms += ms;
                 s.st.push_launches++;
             }
-            rotate_snapshots(e, s, sweeps);       // s.x = the snapshot the last sweep wrote
+            rotate_snapshots(s, sweeps);       // s.x = the snapshot the last sweep wrote
             cur = 0;                              // the launch leaves the live count in cnt[0]
             list_valid = false;
             any_pull = true;
@@ -677,14 +662,9 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
     };
     auto resident = [&](int phase, int n, int *log, GridBar *bar, int *status, const int *guard) {
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                        \
-    if (e->persist_flow)                                                                                               \
-        hipLaunchKernelGGL(k_pull_flow<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,        \
-                           ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.r, s.p, s.cnt, 0, phase, eps, s.dstats, log,   \
-                           n, bar, status, e->persist_ticks, e->persist_rollcall_extra, guard);                          \
-    else                                                                                                               \
-        hipLaunchKernelGGL(k_pull_persist<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,     \
-                           ep.out_row_ptr, ep.out_col, s.x, s.x2, s.r, s.p, s.cnt, 0, phase, eps, s.dstats, log, n, bar, \
-                           status, e->persist_ticks, e->persist_rollcall_extra, guard)
+    hipLaunchKernelGGL(k_pull_resident<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,        \
+                       ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.r, s.p, s.cnt, 0, phase, eps, s.dstats, log, n,    \
+                       bar, status, e->persist_ticks, e->persist_rollcall_extra, guard)
         switch (sweep_block(e)) {
         case 256: DPPR_LAUNCH_PERSIST(256); break;
         case 512: DPPR_LAUNCH_PERSIST(512); break;
@@ -745,7 +725,7 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
     s.last_F0[0] = log_a[0];
     const int act_a = account(log_a, n0, 0);
     if (!(st_a & PERSIST_CONVERGED)) { // phase 0 needs more sweeps than it was given; phase 1 did not start
-        rotate_snapshots(e, s, st_a & PERSIST_SWEEPS);
+        rotate_snapshots(s, st_a & PERSIST_SWEEPS);
         en0->it = n0;
         en0->F = e->pinned[0];
         en0->dense = true;
@@ -767,7 +747,7 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
     s.last_F0[1] = log_b[0];
     const int act_b = account(log_b, n1, 2);
     if (!(st_b & PERSIST_CONVERGED)) {
-        rotate_snapshots(e, s, st_b & PERSIST_SWEEPS);
+        rotate_snapshots(s, st_b & PERSIST_SWEEPS);
         en1->it = n1;
         en1->F = e->pinned[0];
         en1->dense = true;
@@ -1058,10 +1038,9 @@ int dppr_set_profiling(dppr_engine *e, int on) {
 }
 
 int dppr_set_persistent(dppr_engine *e, int mode, int64_t timeout_us) {
-    if (!e || mode < 0 || mode > 3 || e->loaded || !e->slots.empty())
-        return fail(e, DPPR_ERR_INVALID, "set_persistent: call right after dppr_create, mode 0..3");
-    e->persist_mode = mode == 3 ? 1 : mode;
-    e->persist_flow = mode != 3;
+    if (!e || mode < 0 || mode > 2 || e->loaded || !e->slots.empty())
+        return fail(e, DPPR_ERR_INVALID, "set_persistent: call right after dppr_create, mode 0, 1 or 2");
+    e->persist_mode = mode;
     if (timeout_us > 0) e->persist_ticks = (unsigned long long)timeout_us * 100ull; // wall_clock64 runs at 100 MHz
     if (timeout_us < 0) { // tests: a roll-call that cannot succeed, given up after 200 us
         e->persist_ticks = 20000ull;

@@ -19,8 +19,7 @@
 //   dppr_common.hpp   wave64 primitives (ballot/mbcnt ranks, DPP scans, f64 atomics), statistics slots
 //   dppr_push.hpp     Init, Inspect, dense snapshot, sparse frontier iteration (push atomics)
 //   dppr_pull.hpp     dense frontier iteration (pull sweep, no global atomics)
-//   dppr_persist.hpp  a run of dense iterations as one resident launch (grid barrier, state on chip)
-//   dppr_flow.hpp     the same with data-flow synchronisation (no barrier on the critical path)
+//   dppr_resident.hpp a run of dense iterations as one resident launch (state on chip, data-flow synchronisation)
 //   dppr_update.hpp   IncrementalBatchUpdate (lock-free, batch-index order)
 //   dppr_builder.hpp  sliding-window graph builder (full sort / incremental merge), id translation
 //   dppr_multi.hpp    multi-source batched sweeps (included separately by the engine)
@@ -29,7 +28,6 @@
 #include "dppr_common.hpp"
 #include "dppr_push.hpp"
 #include "dppr_pull.hpp"
-#include "dppr_persist.hpp"
-#include "dppr_flow.hpp"
+#include "dppr_resident.hpp"
 #include "dppr_update.hpp"
 #include "dppr_builder.hpp"

@@ -1,46 +1,112 @@
-// dppr_flow.hpp -- resident sweeps without a grid barrier on the critical path.
+// dppr_resident.hpp -- a run of dense frontier iterations as ONE resident launch.
 #pragma once
 
-#include "dppr_persist.hpp"
+#include "dppr_common.hpp"
+#include "dppr_pull.hpp" // STAMP (diagnostic builds)
 
 namespace dppr {
 
+#define PSTAMP(i)                \
+    do {                         \
+        if (it == 10) STAMP(i);  \
+    } while (0)
+
 // ---------------------------------------------------------------------------
-// a4+a5, DENSE iterations, resident launch, DATA-FLOW synchronisation.
+// a4+a5, DENSE iterations on graphs whose sweep fits the chip in one wave of workgroups.
 //
-// k_pull_persist separates iterations with a grid barrier: stores complete (~1.7 K clocks) ->
-// arrive -> everybody has arrived (~5.4 K) -> only then the next gathers start (~8 K): three
-// memory-side round trips in a row, 45 % of an iteration spent waiting. Here an iteration's
+// On a small window (configs[1]: ~0.6 M edges) one sweep of k_pull_iter moves ~18 MB and is not
+// bandwidth bound at all: its time is the dependent chain  grp_tile -> out_row_ptr -> out_col ->
+// x[col] -> stores, plus the launch ramp, the kernel-end cache write-back and the gap to the next
+// dispatch -- and a batch needs ~80 such iterations (gpu/PPRRevPushGPU.cuh:106-130 pays a blocking
+// D2H on top of every one of them).
+//
+// k_pull_resident runs up to n_iter consecutive sweeps in one launch. Every workgroup owns ONE
+// sweep group (<= PB consecutive vertices, cut by the graph builder) for the whole launch, so
+// everything that does not change between iterations is computed once and kept on chip:
+//   * row starts / lengths and their workgroup-wide prefix (LDS),
+//   * the owner row, the out_col entry and the divisor (outdeg+1) of every edge slot (registers;
+//     the group's concatenated edge list is dealt to the PB threads with stride PB, so long rows
+//     are spread over all waves and out_col is read coalesced -- once),
+//   * residual / pagerank / snapshot value of the thread's own vertex (registers; r and p go back
+//     to memory when the launch ends).
+// One iteration is then: gather x[col] (the only dependent memory hop), LDS-atomic the terms
+// into the owners' sums, repair + threshold + next snapshot exactly as k_pull_iter::finish does,
+// and store x_new[v]. The arithmetic per vertex is k_pull_iter's: the same terms
+// (1-ALPHA)*x[u]/(outdeg(v)+1), summed into residual[v] (gpu/ExpandRev.cuh:70-73), the same repair
+// (:708-743) and legal-push test.
+//
+// SYNCHRONISATION BETWEEN ITERATIONS IS BY DATA FLOW. (A first version separated iterations with a
+// grid barrier: stores complete ~1.7 K clocks -> arrive -> everybody has arrived ~5.4 K -> only
+// then the next gathers ~8 K; three memory-side round trips in a row.) Here an iteration's
 // gathers wait for exactly what they need -- the values themselves:
-//
 //   * three snapshot vectors B[0..2]; sweep g reads x_g from B[g % 3], writes x_{g+1} to
 //     B[(g+1) % 3], and B[(g+2) % 3] (which held x_{g-1}) is RESET for the sweep after;
-//   * a reset entry holds X_EMPTY, a NaN bit pattern no computed value has; a gather that
-//     reads X_EMPTY is simply repeated until the owner has stored this round's value. A value
-//     needs one store and is seen by the next poll of whoever waits for it: no barrier between
-//     "stored" and "may be read";
-//   * the arrival counters of k_pull_persist remain, but nobody waits on them in the common case:
-//     a workgroup arrives (fire and forget) when it has finished sweep g; during sweep g+1 its
-//     first wave looks at the arrivals of sweep g -- a whole gather phase later, so normally
-//     complete -- to learn (1) that every workgroup is done READING x_g... more precisely done
-//     with sweep g, so that B[(g+2) % 3] may be reset, and (2) how many vertices are legal in
-//     x_{g+1}, i.e. whether the loop is over. Every workgroup evaluates the same sums at the
-//     same iteration number, so all of them stop together.
+//   * a reset entry holds X_EMPTY, a NaN bit pattern no computed value has; a gather that reads
+//     X_EMPTY is simply repeated until the owner has stored this round's value;
+//   * arrival counters (one memory-side atomic per workgroup and sweep, fire and forget) tell
+//     "every workgroup has finished sweep h" and carry the number of legal vertices it produced.
+//     Nobody waits on them in the common case: during sweep g the first wave of a workgroup looks
+//     at the arrivals of sweep g-1 -- issued a whole gather phase earlier, so normally complete --
+//     to learn (1) that nobody reads x_{g-1} any more, so B[(g+2) % 3] may be reset, and (2) the
+//     size of the frontier sweep g consumes, i.e. whether the loop is over. Every workgroup
+//     evaluates the same sums at the same iteration number, so all of them stop together.
+// Why a gather never sees a stale value instead of X_EMPTY or the right one: the owner's first
+// wave resets B[(g+2) % 3] for the whole group, waits for those stores to complete (s_waitcnt
+// vmcnt(0)), and only then the workgroup passes the __syncthreads after which any of its waves
+// stores x_{g+1}. A consumer reads B[(g+2) % 3] as x_{g+2} no earlier than its sweep g+2, which it
+// starts after it consumed x_{g+1} of every vertex it depends on -- stored after the reset
+// completed. Progress: sweep g of any workgroup needs only values and arrivals of sweep g-1.
+// Accesses to ONE address serialise at the memory side (~10 ns each; 242 workgroups polling the
+// same 16 words took 4 us), so every counter exists BAR_REPS times: a workgroup arrives on all
+// replicas (one 16-lane atomic instruction) and reads only the replica of its own sixteen. Two
+// counter sets, for odd and even sweeps, keep a fast workgroup's next arrival out of the sums a
+// slow one is still reading.
+// The snapshot vectors are exchanged between XCDs (each has its own L2) with agent-scope
+// accesses (sc1) and explicit waits for store completion; a workgroup barrier alone does NOT wait
+// for outstanding stores on gfx942/950 (workgroup-scope release omits vmcnt), and an agent-scope
+// release per wave (buffer_wbl2) costs ~75 us per iteration for the 4096 waves.
 //
-// Ordering argument (why a gather never sees a stale value instead of X_EMPTY or the right one):
-// the owner's first wave resets B[(g+2) % 3] for the whole group, waits for those stores to
-// complete (s_waitcnt vmcnt(0)), and only then the workgroup passes the __syncthreads after
-// which any of its waves stores x_{g+1}. A consumer reads B[(g+2) % 3] as x_{g+2} no earlier
-// than its sweep g+2, which it starts after it consumed x_{g+1} of every vertex it depends on
-// -- stored after the reset completed. The reset itself waits for "all workgroups finished
-// sweep g-1" (arrivals), so nobody still needs x_{g-1}. Progress: sweep g of any workgroup needs
-// only values of sweep g-1 and arrivals of sweep g-1, never anything of sweep g.
-// The launch starts with the roll-call barrier of k_pull_persist (all workgroups resident, and
-// all X_EMPTY initialisations in place) and ends with one real barrier.
-// The arithmetic is k_pull_persist's, term for term.
+// CO-RESIDENCY. Waiting on other workgroups only terminates if every workgroup of the launch is
+// resident. The engine sizes the grid to the occupancy the runtime reports, and the kernel verifies
+// it with a ROLL-CALL before it changes anything that matters: every workgroup checks in on entry,
+// workgroup 0 watches the check-ins and publishes READY with one compare-and-swap on the word
+// everybody reads after their set-up; a workgroup that waits longer than the time limit swaps that
+// word to BAR_ABORT instead. One word decides, so all workgroups agree; an aborted launch leaves
+// the state as it found it and the host goes on with per-iteration launches (dppr_engine.hip).
+// After a successful roll-call all workgroups are running and stay resident; a time-out later on
+// cannot be a residency problem and is reported as a device fault (DPPR_ERR_HIP).
 // ---------------------------------------------------------------------------
+constexpr int BAR_SUBS = 16;
+constexpr int BAR_REPS = 16;       // replicas of every arrival counter
+constexpr int BAR_POLL_SLEEP = 4;  // s_sleep units (64 clocks) between two polls of the arrivals
+constexpr unsigned long long BAR_ABORT = ~0ull;
+constexpr unsigned long long BAR_READY = 1ull;
+constexpr int PERSIST_SLOTS = 4; // edge slots per thread kept in registers (PB * 4 edges per group)
 constexpr unsigned long long X_EMPTY = 0x7FF8DEADBEEFCAFEull;
 
+struct alignas(128) BarWord {
+    unsigned long long w;
+    unsigned long long pad[15];
+};
+struct GridBar {                          // zeroed by the host before every launch
+    BarWord gen;                          // roll-call outcome: 0 pending, BAR_READY, BAR_ABORT
+    BarWord roll[BAR_SUBS];               // roll-call check-ins of the workgroups with blockIdx % BAR_SUBS == s
+    BarWord sub[2][BAR_REPS][BAR_SUBS];   // per sweep parity and replica: arrivals << 32 | cumulative legal count
+};
+// status word of a launch (low bits: complete sweeps)
+constexpr int PERSIST_ABORTED = 1 << 30;   // the roll-call failed, nothing was changed
+constexpr int PERSIST_FAULT = 1 << 29;     // a wait timed out after a successful roll-call
+constexpr int PERSIST_CONVERGED = 1 << 28; // the frontier emptied; all snapshot vectors are all zero again
+constexpr int PERSIST_SKIPPED = 1 << 27;   // the launch was enqueued ahead and its guard said no
+constexpr int PERSIST_SWEEPS = (1 << 16) - 1;
+
+__device__ __forceinline__ unsigned long long bar_load(unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool bar_cas(unsigned long long *p, unsigned long long expect, unsigned long long desired) {
+    return __hip_atomic_compare_exchange_strong(p, &expect, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ unsigned long long xb_load(const double *p) {
     return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -49,7 +115,7 @@ __device__ __forceinline__ void xb_store(double *p, unsigned long long bits) {
 }
 
 template <int PB>
-__global__ __launch_bounds__(PB) void k_pull_flow(int V, const int *__restrict__ grp_tile,
+__global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restrict__ grp_tile,
                                                   const int *__restrict__ out_row_ptr, const int *__restrict__ out_col,
                                                   double *b0, double *b1, double *b2, double *r, double *p, int *cnt,
                                                   int cur0, int phase, double eps, IterStats *stats, int *log, int n_iter,
@@ -76,7 +142,8 @@ __global__ __launch_bounds__(PB) void k_pull_flow(int V, const int *__restrict__
     const int my_rep = (blockIdx.x / BAR_SUBS) % BAR_REPS;
     const unsigned long long t_entry = wall_clock64();
 
-    // ---- static part (as k_pull_persist), plus: the two vectors that are not the input start EMPTY
+    // ---- static part: the group's vertices and edge slots; the two vectors that are not the input
+    // start EMPTY
     const int t0 = grp_tile[blockIdx.x], t1 = grp_tile[blockIdx.x + 1];
     const int v = t0 * WAVE + tid;
     const bool valid = tid < (t1 - t0) * WAVE && v < V;
@@ -212,9 +279,6 @@ __global__ __launch_bounds__(PB) void k_pull_flow(int V, const int *__restrict__
         // order, so this is back long before they are)
         unsigned long long fw = 0;
         if (w == 0 && g >= 1 && lane < (int)subs_used) fw = bar_load(&bar->sub[(g - 1) & 1][my_rep][lane].w);
-#ifdef DPPR_FLOW_PACE
-        if (g >= 1) __builtin_amdgcn_s_sleep(DPPR_FLOW_PACE); // let the values of the sweep before land first
-#endif
         unsigned long long gb[S];
 #pragma unroll
         for (int k = 0; k < S; ++k) gb[k] = own[k] >= 0 ? xb_load(xin + col[k]) : 0ull;

@@ -67,7 +67,7 @@ typedef struct dppr_stats_t {
     double gpu_ms;        /* sum of event-timed regions */
     double push_ms;       /* sum of per-launch event times of the push kernel (profiling on only) */
     int64_t push_launches; /* push-kernel launches timed into push_ms */
-    int64_t persist_launches; /* launches of the resident multi-iteration sweep (k_pull_persist) */
+    int64_t persist_launches; /* launches of the resident multi-iteration sweep (k_pull_resident) */
     int64_t persist_aborts;   /* of those, launches that stopped at a grid-barrier time-out */
 } dppr_stats_t;
 
@@ -107,13 +107,14 @@ int dppr_set_profiling(dppr_engine *e, int on);
 int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges, int pull_min_frontier,
                     int chunk_iters, int pull_block);
 /* Resident sweeps: when a window's sweep groups all fit on the chip at once, a run of dense
- * iterations is ONE launch that keeps the per-vertex state on chip and separates iterations
- * with a grid barrier (no counterpart in the reference, whose loop reads the frontier size back
- * after every iteration, gpu/PPRRevPushGPU.cuh:107). mode 1 = automatic (default; in the steady
+ * iterations is ONE launch that keeps the per-vertex state on chip; workgroups exchange the
+ * per-iteration snapshot through memory and wait for each other's values, not for the host (no
+ * counterpart in the reference, whose loop reads the frontier size back after every iteration,
+ * gpu/PPRRevPushGPU.cuh:107). mode 1 = automatic (default; in the steady
  * state of a stream the launches of BOTH phases of a batch are enqueued ahead, without a
  * read-back in between), 2 = resident launches but one host read-back per launch, 0 = never
  * (every iteration its own launch). Such a launch first checks that all its workgroups are
- * running (a grid barrier needs that); timeout_us is how long that roll-call may take before the
+ * running (waiting on one another needs that); timeout_us is how long that roll-call may take before the
  * launch gives up WITHOUT having changed anything and the engine continues with per-iteration
  * launches (0 keeps the default, 50 ms; negative = a roll-call that cannot succeed, which tests
  * use to exercise that path; the results are the same either way).

@@ -427,7 +427,7 @@ def test_full_size_livejournal_standin_two_sources():
 @pytest.mark.parametrize("mode", ["resident", "per-iteration", "rollcall-fails", "heavy-groups"])
 @pytest.mark.parametrize("directed", [1, 0])
 def test_resident_sweeps_same_work_as_per_iteration_launches(directed, mode):
-    """Runs of dense iterations as ONE resident launch (k_pull_persist) do exactly the oracle's
+    """Runs of dense iterations as ONE resident launch (k_pull_resident) do exactly the oracle's
     synchronous work -- iterations, sum of frontier sizes, traversed edges, p/r to rounding -- as do
     per-iteration launches, a resident launch whose roll-call fails (not co-resident: it gives up
     before touching anything), and groups with more edges than the kernel keeps in registers (edge

@@ -25,7 +25,7 @@ assert L.dppr_debug_stamps(buf.ctypes.data_as(C.POINTER(C.c_uint64)), rows) == 0
 s = buf.reshape(rows, 8).astype(np.int64)
 s = s[s[:, 0] > 0]
 print("workgroups with stamps:", len(s))
-names = ["gathers (incl. repeats, arrivals poll)", "LDS adds", "sync (all adds in)", "finish + x store issued", "sync (counts)"] if os.environ.get("DPPR_STAMP_FLOW", "1") == "1" else ["gathers + LDS adds", "sync (all adds in)", "finish + x store issued", "sync (stores complete)", "grid barrier (arrive..published)"]
+names = ["gathers (incl. repeats, arrivals poll)", "LDS adds", "sync (all adds in)", "finish + x store issued", "sync (counts)"]
 t0 = s[:, 0].min()
 print("iteration start spread (cycles): median", int(np.median(s[:, 0] - t0)), "max", int((s[:, 0] - t0).max()))
 for i, n in enumerate(names):
