@@ -341,15 +341,36 @@ int cut_sweep_groups(dppr_engine *e, Epoch &ep) {
         if (cut.back() != n_tiles) cut.push_back(n_tiles);
     };
     // A window small enough for one workgroup per group to be resident at once gets at most that
-    // many groups (then runs of dense iterations are single launches, dppr_resident.hpp); the greedy
-    // cut can overshoot its aim by a few groups, so aim a little lower until it fits.
+    // many groups (then runs of dense iterations are single launches, dppr_resident.hpp). A resident
+    // workgroup's time is its edge count (every iteration all workgroups wait for the slowest one's
+    // values), so this cut MINIMISES THE LARGEST group: bisection on the bound, first-fit inside.
     const int cap = persist_capacity(e);
     bool fitted = false;
     if (cap > 0 && (long long)n_tiles <= (long long)cap * max_tiles * 7 / 8) {
-        for (long long want = cap; want >= cap * 3 / 4 && !fitted; want -= std::max(1, cap / 64)) {
-            greedy(want);
-            fitted = (int)cut.size() - 1 <= cap;
+        const long long vterm = 8; // per tile: the per-vertex work of a resident workgroup is small and fixed
+        auto pack = [&](long long bound) { // first-fit with groups of weight <= bound; false if a tile alone exceeds it
+            cut.clear();
+            cut.push_back(0);
+            long long acc = 0;
+            int first = 0;
+            for (int t = 0; t < n_tiles; ++t) {
+                const long long wt = (long long)(e->h_tiles[(size_t)t + 1] - e->h_tiles[(size_t)t]) + vterm;
+                if (t > first && (acc + wt > bound || t - first == max_tiles)) {
+                    cut.push_back(t);
+                    first = t;
+                    acc = 0;
+                }
+                acc += wt;
+            }
+            cut.push_back(n_tiles);
+            return (int)cut.size() - 1;
+        };
+        long long lo = 1, hi = (long long)e->h_tiles[(size_t)n_tiles] + vterm * n_tiles + 1;
+        while (lo < hi) { // smallest bound that needs at most cap groups
+            const long long mid = (lo + hi) / 2;
+            if (pack(mid) <= cap) hi = mid; else lo = mid + 1;
         }
+        fitted = pack(lo) <= cap;
     }
     if (!fitted)
         greedy(std::max<long long>(252, (n_tiles + max_tiles * 3 / 4 - 1) / std::max(1, max_tiles * 3 / 4)));
