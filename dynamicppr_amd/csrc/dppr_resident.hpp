@@ -26,7 +26,8 @@ namespace dppr {
 //   * row starts / lengths and their workgroup-wide prefix (LDS),
 //   * the owner row, the out_col entry and the divisor (outdeg+1) of every edge slot (registers;
 //     the group's concatenated edge list is dealt to the PB threads with stride PB, so long rows
-//     are spread over all waves and out_col is read coalesced -- once),
+//     are spread over all waves and out_col is read coalesced -- once; pre-reducing the stretches of
+//     a long row inside a wave before the LDS atomics was measured and is slower than the atomics),
 //   * residual / pagerank / snapshot value of the thread's own vertex (registers; r and p go back
 //     to memory when the launch ends).
 // One iteration is then: gather x[col] (the only dependent memory hop), LDS-atomic the terms
@@ -191,7 +192,6 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
     };
     int own[S], col[S];
     double den[S];
-    bool uni[S];
 #pragma unroll
     for (int k = 0; k < S; ++k) {
         const int e = tid + k * PB;
@@ -204,8 +204,6 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
             col[k] = out_col[s_rs[o] + (e - s_scan[o])];
             den[k] = (double)(s_scan[o + 1] - s_scan[o] + 1);
         }
-        const int first = __builtin_amdgcn_readfirstlane(own[k]);
-        uni[k] = __ballot(own[k] >= 0 && own[k] == first) == ~0ull;
     }
 
     // ---- roll-call outcome
@@ -324,12 +322,7 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
             const double xg = __longlong_as_double((long long)gb[k]);
             const bool nz = xg != 0.0;
             const double term = ONE_MINUS_ALPHA * xg / den[k];
-            if (uni[k]) {
-                const double sum = wave_sum(nz ? term : 0.0);
-                if (lane == 0 && sum != 0.0) lds_add(&acc[own[k]], sum);
-            } else if (nz) {
-                lds_add(&acc[own[k]], term);
-            }
+            if (nz) lds_add(&acc[own[k]], term);
             edges += (unsigned long long)__popcll(__ballot(nz));
         }
         for (int e0 = S * PB; e0 < Eg; e0 += PB) { // edges beyond the register slots
