@@ -675,8 +675,7 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
                 bool *p1_seeded) {
     const int pull_min = pull_min_frontier(e);
     const int n0 = std::min(s.iter_hint[0] + 2, MAX_CHUNK), n1 = std::min(s.iter_hint[1] + 2, MAX_CHUNK);
-    int *stat_a = s.cnt + 7, *stat_b = s.cnt + 8;
-    HIP_TRY(hipMemsetAsync(e->bar, 0, 2 * sizeof(GridBar), e->stream));
+    int *stat_a = s.cnt + 7, *stat_b = s.cnt + 8; // (both GridBars were zeroed by the batch's first kernel, k_su_keys)
     auto snapshot = [&](int phase, const int *guard) {
         hipLaunchKernelGGL(k_snapshot_dense, dim3(std::min(grid_for(std::max(s.last_F0[phase], 1 << 14)), 1024)),
                            dim3(BLOCK), 0, e->stream, s.ft[0], s.cnt + 0, s.r, s.p, s.x, guard, PERSIST_CONVERGED);
@@ -698,9 +697,8 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
     resident(0, n0, s.log, e->bar, stat_a, nullptr);
     if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[1], e->stream));
     // phase 1, guarded by "phase 0 converged" (which also left cnt[0..2] zero and x / x2 clean)
-    hipLaunchKernelGGL(k_filter, dim3(grid_for(std::max(ep.L, 1))), dim3(BLOCK), 0, e->stream, s.neg, s.cnt + 3, s.r, 1,
-                       eps, s.ft[0], s.cnt + 0, (const int *)stat_a, PERSIST_CONVERGED);
-    snapshot(1, stat_a);
+    hipLaunchKernelGGL(k_filter_snapshot, dim3(grid_for(std::max(ep.L, 1))), dim3(BLOCK), 0, e->stream, s.neg, s.cnt + 3,
+                       s.r, s.p, s.x, 1, eps, s.ft[0], s.cnt + 0, (const int *)stat_a, PERSIST_CONVERGED);
     if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2], e->stream));
     resident(1, n1, s.log + n0, e->bar + 1, stat_b, stat_a);
     if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[3], e->stream));
@@ -791,22 +789,19 @@ int main_loop_inspect(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
 }
 
 // IncrementalBatchUpdate; when seed != 0 also seeds ft[0]/cnt[0] (phase 0) and neg/cnt[3].
-int stream_update(dppr_engine *e, Slot &s, const Epoch &ep, double eps, bool seed) {
+int stream_update(dppr_engine *e, Slot &s, const Epoch &ep, double eps, bool seed, bool zero_bars = false) {
     const int L = ep.L;
     HIP_TRY(hipMemsetAsync(s.cnt, 0, sizeof(int) * 5, e->stream));
     if (L == 0) return DPPR_OK;
-    hipLaunchKernelGGL(k_su_keys, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->su_k[0], e->su_v[0]);
+    hipLaunchKernelGGL(k_su_keys, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->su_k[0], e->su_v[0],
+                       zero_bars ? reinterpret_cast<unsigned long long *>(e->bar) : nullptr,
+                       zero_bars ? (int)(2 * sizeof(GridBar) / sizeof(unsigned long long)) : 0);
     size_t tmp = e->su_tmp_bytes;
     HIP_TRY(rocprim::radix_sort_pairs(e->su_tmp, tmp, e->su_k[0], e->su_k[1], e->su_v[0], e->su_v[1], (size_t)L, 0u,
                                       (unsigned)e->bits, e->stream));
-    hipLaunchKernelGGL(k_su_terms, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, e->su_k[1], e->su_v[1], ep.b2, ep.ins,
-                       L, s.p, 1, e->su_term, e->su_ins);
     // without seeding the lists go to scratch space (cnt[4] / neg) and are ignored
-    SuSources one{};
-    one.s[0] = s.source;
-    hipLaunchKernelGGL(k_su_apply, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, e->su_k[1], e->su_v[1], e->su_term,
-                       e->su_ins, ep.deg_after, L, s.r, 1, one, seed ? eps : 1e300, s.ft[0], s.cnt + 0, s.neg,
-                       s.cnt + 3);
+    hipLaunchKernelGGL(k_su_apply_fused, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, e->su_k[1], e->su_v[1], ep.b2, ep.ins,
+                       ep.deg_after, L, s.p, s.r, s.source, seed ? eps : 1e300, s.ft[0], s.cnt + 0, s.neg, s.cnt + 3);
     HIP_TRY(hipGetLastError());
     s.st.records += L;
     return DPPR_OK;
@@ -879,7 +874,8 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps)
 int group_stream_update(dppr_engine *e, Group &g, const Epoch &ep) {
     const int L = ep.L;
     if (L == 0) return DPPR_OK;
-    hipLaunchKernelGGL(k_su_keys, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->su_k[0], e->su_v[0]);
+    hipLaunchKernelGGL(k_su_keys, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->su_k[0], e->su_v[0],
+                       (unsigned long long *)nullptr, 0);
     size_t tmp = e->su_tmp_bytes;
     HIP_TRY(rocprim::radix_sort_pairs(e->su_tmp, tmp, e->su_k[0], e->su_k[1], e->su_v[0], e->su_v[1], (size_t)L, 0u,
                                       (unsigned)e->bits, e->stream));
@@ -1334,15 +1330,16 @@ int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *
     // Seeding from the batch tails is exact only if every |r| <= eps beforehand
     // (the state a completed solve leaves). Otherwise fall back to full Inspect passes.
     const bool seeded = s.converged && s.conv_eps <= eps;
+    const bool ahead = seeded && can_batch_ahead(e, s, ep);
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    int rc = stream_update(e, s, ep, eps, seeded);
+    int rc = stream_update(e, s, ep, eps, seeded, ahead);
     if (rc) return rc;
     s.converged = false;
     if (seeded) {
         int stage = 0;
         bool p1_seeded = false;
         LoopEntry en0, en1;
-        if (can_batch_ahead(e, s, ep)) {
+        if (ahead) {
             rc = batch_ahead(e, s, ep, eps, &stage, &en0, &en1, &p1_seeded);
             if (rc) return rc;
         }

@@ -30,8 +30,12 @@ namespace dppr {
 //              phase-1 candidate list (r[u] < -eps): only tails can leave [-eps, eps]
 //              (cpu/PPRCPUMTCilkRev.h:126-156 seeds from batch endpoints for the same reason).
 // ---------------------------------------------------------------------------
+// (also zeroes `nz` 8-byte words at `zero` when given: the first kernel of a batch clears the counters
+// of the resident launches that follow instead of a separate fill)
 __global__ __launch_bounds__(BLOCK) void k_su_keys(const int *__restrict__ e1, int L, uint32_t *__restrict__ keys,
-                                                   uint32_t *__restrict__ vals) {
+                                                   uint32_t *__restrict__ vals, unsigned long long *__restrict__ zero,
+                                                   int nz) {
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nz; i += gridDim.x * BLOCK) zero[i] = 0ull;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < L; i += gridDim.x * BLOCK) {
         keys[i] = (uint32_t)e1[i];
         vals[i] = (uint32_t)i;
@@ -115,6 +119,125 @@ __global__ __launch_bounds__(BLOCK) void k_su_apply(const uint32_t *__restrict__
             if (lane_id() == 0) gb = atomicAdd(cnt_neg, __popcll(m));
             gb = __shfl(gb, 0, WAVE);
             if (neg) ft_neg[gb + mbcnt(m)] = u;
+        }
+    }
+}
+
+// Single-source form of k_su_terms + k_su_apply in one launch. The group leaders walk their records
+// one after the other (the order is the point), so what they walk must not be a chain of global
+// loads: every workgroup stages a window of SU_WIN sorted records -- tail, insert flag and the
+// term t, computed here in parallel -- in LDS, its own BLOCK records plus a halo for groups that
+// run past them; a group that outgrows even the window finishes from global memory.
+constexpr int SU_WIN = 1024;
+__global__ __launch_bounds__(BLOCK) void k_su_apply_fused(const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ svals,
+                                                          const int *__restrict__ e2, const uint8_t *__restrict__ ins,
+                                                          const int *__restrict__ deg_after, int L,
+                                                          const double *__restrict__ p, double *__restrict__ r, int source,
+                                                          double eps, int *__restrict__ ft_pos, int *__restrict__ cnt_pos,
+                                                          int *__restrict__ ft_neg, int *__restrict__ cnt_neg) {
+    __shared__ uint32_t s_key[SU_WIN];
+    __shared__ double s_term[SU_WIN];
+    __shared__ uint8_t s_ins[SU_WIN];
+    auto term_of = [&](int u, int rec) { return ONE_MINUS_ALPHA * p[e2[rec]] - p[u]; };
+    for (int j0 = blockIdx.x * BLOCK; j0 < L; j0 += gridDim.x * BLOCK) {
+        __syncthreads(); // the window of the previous pass is no longer read
+        const int wn = min(SU_WIN, L - j0);
+        for (int i = threadIdx.x; i < wn; i += BLOCK) {
+            const int u = (int)skeys[j0 + i], rec = (int)svals[j0 + i];
+            s_key[i] = (uint32_t)u;
+            s_ins[i] = ins[rec];
+            s_term[i] = term_of(u, rec);
+        }
+        __syncthreads();
+        const int j = j0 + threadIdx.x;
+        bool pos = false, neg = false;
+        int u = 0;
+        if (j < L) {
+            u = (int)s_key[threadIdx.x];
+            const bool leader = (j == 0) || ((int)skeys[j - 1] != u);
+            if (leader) {
+                // extent of the group and its net degree change (post-batch minus pre-batch)
+                int end = threadIdx.x, delta = 0;
+                while (end < wn && (int)s_key[end] == u) {
+                    delta += s_ins[end] ? 1 : -1;
+                    ++end;
+                }
+                int gend = j0 + end; // the part beyond the window, if any
+                if (end == wn)
+                    while (gend < L && (int)skeys[gend] == u) {
+                        delta += ins[svals[gend]] ? 1 : -1;
+                        ++gend;
+                    }
+                int d = deg_after[svals[j]] - delta; // RevertOutDegree (gpu/StreamUpdate.cuh:18-33)
+                double ru = r[u];
+                const double src_term = ALPHA * (source == u ? 1.0 : 0.0);
+                auto apply = [&](double t, bool is_ins) {
+                    const double add = t - ALPHA * ru + src_term;
+                    if (is_ins) {
+                        d++;
+                        ru += add / (double)(d + 1) / ALPHA;
+                    } else {
+                        d--;
+                        ru -= add / (double)(d + 1) / ALPHA;
+                    }
+                };
+                for (int k = threadIdx.x; k < end; ++k) apply(s_term[k], s_ins[k] != 0);
+                for (int k = j0 + end; k < gend; ++k) {
+                    const int rec = (int)svals[k];
+                    apply(term_of(u, rec), ins[rec] != 0);
+                }
+                r[u] = ru;
+                pos = ru > eps;
+                neg = ru < -eps;
+            }
+        }
+        uint64_t m = __ballot(pos);
+        if (m) {
+            int gb = 0;
+            if (lane_id() == 0) gb = atomicAdd(cnt_pos, __popcll(m));
+            gb = __shfl(gb, 0, WAVE);
+            if (pos) ft_pos[gb + mbcnt(m)] = u;
+        }
+        m = __ballot(neg);
+        if (m) {
+            int gb = 0;
+            if (lane_id() == 0) gb = atomicAdd(cnt_neg, __popcll(m));
+            gb = __shfl(gb, 0, WAVE);
+            if (neg) ft_neg[gb + mbcnt(m)] = u;
+        }
+    }
+}
+
+// phase-1 seeding and dense snapshot in one pass (batch_ahead): the candidates that are still
+// below -eps enter the frontier list AND the snapshot (x[u] = r[u], pagerank[u] += ALPHA * r[u],
+// the head of ExpandUnifiedRev, gpu/ExpandRev.cuh:34-42). Candidates are distinct vertices.
+__global__ __launch_bounds__(BLOCK) void k_filter_snapshot(const int *__restrict__ cand, const int *__restrict__ cnt_cand,
+                                                           const double *__restrict__ r, double *__restrict__ p,
+                                                           double *__restrict__ x, int phase, double eps,
+                                                           int *__restrict__ ft, int *__restrict__ cnt,
+                                                           const int *__restrict__ guard, int guard_mask) {
+    if (guard && !(*guard & guard_mask)) return; // see k_filter
+    const int n = *cnt_cand;
+    for (int i0 = blockIdx.x * BLOCK; i0 < n; i0 += gridDim.x * BLOCK) {
+        const int i = i0 + threadIdx.x;
+        int u = 0;
+        bool hit = false;
+        double ru = 0.0;
+        if (i < n) {
+            u = cand[i];
+            ru = r[u];
+            hit = legal(ru, phase, eps);
+        }
+        if (hit) {
+            x[u] = ru;
+            p[u] += ALPHA * ru;
+        }
+        const uint64_t m = __ballot(hit);
+        if (m) {
+            int gb = 0;
+            if (lane_id() == 0) gb = atomicAdd(cnt, __popcll(m));
+            gb = __shfl(gb, 0, WAVE);
+            if (hit) ft[gb + mbcnt(m)] = u;
         }
     }
 }
