@@ -27,6 +27,7 @@ static constexpr int MAX_CHUNK = 64;
 // counters, [7] list scratch / status of a resident launch, [8] status of a second resident launch
 // enqueued ahead; the per-launch logs (2 x MAX_CHUNK) follow the header
 static constexpr int CNT_HDR = 16;
+static constexpr int RESIDENT_MARGIN = 8; // sweeps a resident launch is given beyond what the last batch needed
 
 namespace {
 
@@ -503,10 +504,12 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             n = s.iter_hint[phase] > it ? s.iter_hint[phase] - it + 1 : e->chunk_iters;
         else if ((long long)F * 4 >= pull_min) n = 1;          // about to turn dense: re-decide next iteration
         else n = F > prevF ? 2 : e->chunk_iters;                // growing: short chunks; decaying tail: long
+        const int pcap = persist_capacity(e);
+        const bool resident = pull && n >= 2 && !s.trace && pcap > 0 && ep.n_groups > 0 && ep.n_groups <= pcap;
+        if (resident && s.iter_hint[phase] > it) n += RESIDENT_MARGIN - 1;
         n = std::min(n, MAX_CHUNK);
         if (!pull && !list_valid && (rc = make_list())) return rc;
-        const int pcap = persist_capacity(e);
-        if (pull && n >= 2 && !s.trace && pcap > 0 && ep.n_groups > 0 && ep.n_groups <= pcap) {
+        if (resident) {
             // ---- a run of dense iterations as ONE resident launch (dppr_resident.hpp)
             if (!dense_valid) {
                 hipLaunchKernelGGL(k_snapshot_dense, dim3(std::min(grid_for(std::max(F, 1 << 14)), 1024)), dim3(BLOCK), 0,
@@ -674,7 +677,9 @@ bool can_batch_ahead(const dppr_engine *e, const Slot &s, const Epoch &ep) {
 int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage, LoopEntry *en0, LoopEntry *en1,
                 bool *p1_seeded) {
     const int pull_min = pull_min_frontier(e);
-    const int n0 = std::min(s.iter_hint[0] + 2, MAX_CHUNK), n1 = std::min(s.iter_hint[1] + 2, MAX_CHUNK);
+    // a resident launch stops by itself when the frontier empties: a generous allowance costs nothing,
+    // a short one costs a read-back and another launch
+    const int n0 = std::min(s.iter_hint[0] + RESIDENT_MARGIN, MAX_CHUNK), n1 = std::min(s.iter_hint[1] + RESIDENT_MARGIN, MAX_CHUNK);
     int *stat_a = s.cnt + 7, *stat_b = s.cnt + 8; // (both GridBars were zeroed by the batch's first kernel, k_su_keys)
     auto snapshot = [&](int phase, const int *guard) {
         hipLaunchKernelGGL(k_snapshot_dense, dim3(std::min(grid_for(std::max(s.last_F0[phase], 1 << 14)), 1024)),
