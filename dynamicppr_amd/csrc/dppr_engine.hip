@@ -521,7 +521,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                       \
     hipLaunchKernelGGL(k_pull_resident<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,       \
                        ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.r, s.p, s.cnt, cur, phase, eps, s.dstats, s.log,  \
-                       n, e->bar, s.cnt + 7, e->persist_ticks, e->persist_rollcall_extra, (const int *)nullptr)
+                       n, e->bar, s.cnt + 7, e->persist_ticks, e->persist_rollcall_extra, (const int *)nullptr, 0)
             switch (sweep_block(e)) {
             case 256: DPPR_LAUNCH_PERSIST(256); break;
             case 512: DPPR_LAUNCH_PERSIST(512); break;
@@ -653,17 +653,17 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
 }
 
 // ---------------------------------------------------------------------------------------------
-// The frontier loops of one batch enqueued AHEAD, without a single read-back in between.
+// Both frontier loops of one batch as ONE resident launch, without a read-back in between.
 //
-// When consecutive batches behave alike (both phases start with a frontier worth a sweep and take
-// about as many iterations as last time -- the steady state of a sliding-window stream), the host
-// knows what it will launch before it has seen any count: snapshot, one resident launch for
-// phase 0, the phase-1 filter, snapshot, one resident launch for phase 1. They are enqueued back
-// to back; the three that belong to phase 1 carry a GUARD (the status word of the phase-0
-// launch) and do nothing unless phase 0 really converged inside its launch. One copy of the
-// counters, both status words and both logs comes back at the end. Whatever did not go as
-// expected (phase 0 needed more sweeps, a roll-call failed) leaves the state at a well-defined
-// point from which the ordinary host-driven loop resumes (`stage`, `en0`, `en1`).
+// When consecutive batches behave alike (both phases start with a frontier worth a sweep -- the
+// steady state of a sliding-window stream), the host knows what it will launch before it has seen
+// any count. After a converged solve the frontier of a phase is {v : legal(residual[v])}, which the
+// resident kernel reads off its registers (PLAN_SEED), and when phase 0 is over it seeds phase 1
+// the same way and goes on (PLAN_BOTH): Inspect / snapshot / phase 0 / Inspect / snapshot / phase 1
+// of gpu/PPRGPU.cuh:138-164 are one kernel. One copy of the counters, the status word and the log
+// comes back at the end. Whatever did not go as expected (a phase needed more sweeps than the
+// launch was given, the roll-call failed) leaves the state at a well-defined point from which the
+// ordinary host-driven loop resumes (`stage`, `en0`, `en1`).
 // The reference pays a blocking read-back per ITERATION (gpu/PPRRevPushGPU.cuh:107).
 // ---------------------------------------------------------------------------------------------
 bool can_batch_ahead(const dppr_engine *e, const Slot &s, const Epoch &ep) {
@@ -673,112 +673,88 @@ bool can_batch_ahead(const dppr_engine *e, const Slot &s, const Epoch &ep) {
 }
 
 // stage (out): 0 = phase 0 still open (resume with en0), 1 = phase 0 done, phase 1 open (resume with
-// en1; *p1_seeded tells whether its frontier list / snapshot exist), 2 = both phases done
+// en1; *p1_seeded tells whether its snapshot exists), 2 = both phases done
 int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage, LoopEntry *en0, LoopEntry *en1,
                 bool *p1_seeded) {
     const int pull_min = pull_min_frontier(e);
     // a resident launch stops by itself when the frontier empties: a generous allowance costs nothing,
-    // a short one costs a read-back and another launch
-    const int n0 = std::min(s.iter_hint[0] + RESIDENT_MARGIN, MAX_CHUNK), n1 = std::min(s.iter_hint[1] + RESIDENT_MARGIN, MAX_CHUNK);
-    int *stat_a = s.cnt + 7, *stat_b = s.cnt + 8; // (both GridBars were zeroed by the batch's first kernel, k_su_keys)
-    auto snapshot = [&](int phase, const int *guard) {
-        hipLaunchKernelGGL(k_snapshot_dense, dim3(std::min(grid_for(std::max(s.last_F0[phase], 1 << 14)), 1024)),
-                           dim3(BLOCK), 0, e->stream, s.ft[0], s.cnt + 0, s.r, s.p, s.x, guard, PERSIST_CONVERGED);
-    };
-    auto resident = [&](int phase, int n, int *log, GridBar *bar, int *status, const int *guard) {
+    // a short one costs a read-back and another launch (+1: the step that seeds phase 1)
+    const int n = std::min(s.iter_hint[0] + s.iter_hint[1] + 1 + 2 * RESIDENT_MARGIN, 2 * MAX_CHUNK);
+    int *status = s.cnt + 7; // (the GridBar was zeroed by the batch's first kernel, k_su_keys)
+    if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                        \
     hipLaunchKernelGGL(k_pull_resident<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,        \
-                       ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.r, s.p, s.cnt, 0, phase, eps, s.dstats, log, n,    \
-                       bar, status, e->persist_ticks, e->persist_rollcall_extra, guard)
-        switch (sweep_block(e)) {
-        case 256: DPPR_LAUNCH_PERSIST(256); break;
-        case 512: DPPR_LAUNCH_PERSIST(512); break;
-        default: DPPR_LAUNCH_PERSIST(1024); break;
-        }
+                       ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.r, s.p, s.cnt, 0, 0, eps, s.dstats, s.log, n,      \
+                       e->bar, status, e->persist_ticks, e->persist_rollcall_extra, (const int *)nullptr,                \
+                       PLAN_SEED | PLAN_BOTH)
+    switch (sweep_block(e)) {
+    case 256: DPPR_LAUNCH_PERSIST(256); break;
+    case 512: DPPR_LAUNCH_PERSIST(512); break;
+    default: DPPR_LAUNCH_PERSIST(1024); break;
+    }
 #undef DPPR_LAUNCH_PERSIST
-    };
-    snapshot(0, nullptr);
-    if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
-    resident(0, n0, s.log, e->bar, stat_a, nullptr);
     if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[1], e->stream));
-    // phase 1, guarded by "phase 0 converged" (which also left cnt[0..2] zero and x / x2 clean)
-    hipLaunchKernelGGL(k_filter_snapshot, dim3(grid_for(std::max(ep.L, 1))), dim3(BLOCK), 0, e->stream, s.neg, s.cnt + 3,
-                       s.r, s.p, s.x, 1, eps, s.ft[0], s.cnt + 0, (const int *)stat_a, PERSIST_CONVERGED);
-    if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2], e->stream));
-    resident(1, n1, s.log + n0, e->bar + 1, stat_b, stat_a);
-    if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[3], e->stream));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(e->pinned, s.cnt, sizeof(int) * (size_t)(CNT_HDR + n0 + n1), hipMemcpyDeviceToHost,
-                           e->stream));
+    HIP_TRY(hipMemcpyAsync(e->pinned, s.cnt, sizeof(int) * (size_t)(CNT_HDR + n), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
 
-    const int st_a = e->pinned[7], st_b = e->pinned[8];
-    // what a launch did, from its log: iterations, frontier sizes; returns the active iterations
-    auto account = [&](const int *log, int n, int ev) {
-        int active = 0;
-        for (int k = 0; k < n; ++k) {
-            if (log[k] <= 0) continue;
-            s.st.iterations++;
-            s.st.pull_iterations++;
-            s.st.sum_F += log[k];
-            active = k + 1;
-        }
-        if (e->profiling) {
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, e->evpool[ev], e->evpool[ev + 1]) == hipSuccess) {
-                s.st.push_ms += ms;
-                s.st.push_launches++;
-            }
-        }
-        return active;
-    };
+    const int st = e->pinned[7];
     *stage = 0;
     *p1_seeded = false;
     *en0 = LoopEntry();
     *en1 = LoopEntry();
     s.st.persist_launches++;
-    if (st_a & PERSIST_FAULT) return fail(e, DPPR_ERR_HIP, "grid barrier of the resident sweep timed out");
-    if (st_a & PERSIST_ABORTED) { // roll-call failed: only the snapshot was taken
+    if (st & PERSIST_FAULT) return fail(e, DPPR_ERR_HIP, "a wait inside the resident sweep timed out");
+    if (st & PERSIST_ABORTED) { // roll-call failed: nothing was changed, the lists of the stream update stand
         s.st.persist_aborts++;
         e->persist_ok = false;
-        en0->dense = true;
         return DPPR_OK;
     }
-    const int *log_a = e->pinned + CNT_HDR, *log_b = log_a + n0;
-    s.start_dense[0] = log_a[0] >= pull_min;
-    s.last_F0[0] = log_a[0];
-    const int act_a = account(log_a, n0, 0);
-    if (!(st_a & PERSIST_CONVERGED)) { // phase 0 needs more sweeps than it was given; phase 1 did not start
-        rotate_snapshots(s, st_a & PERSIST_SWEEPS);
-        en0->it = n0;
+    if (e->profiling) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e->evpool[0], e->evpool[1]));
+        s.st.push_ms += ms;
+        s.st.push_launches++;
+    }
+    // the log: frontier sizes of phase 0, a zero (phase 0 over), those of phase 1, a zero
+    const int *log = e->pinned + CNT_HDR;
+    const int pos = st & PERSIST_SWEEPS; // loop position the launch stopped at
+    int act[2] = {0, 0}, ph = 0;
+    for (int k = 0; k < std::min(pos + 1, n) && ph < 2; ++k) {
+        if (log[k] <= 0) {
+            ++ph;
+            continue;
+        }
+        if (act[ph] == 0) {
+            s.start_dense[ph] = log[k] >= pull_min;
+            s.last_F0[ph] = log[k];
+        }
+        s.st.iterations++;
+        s.st.pull_iterations++;
+        s.st.sum_F += log[k];
+        act[ph]++;
+    }
+    rotate_snapshots(s, pos);
+    if (!(st & PERSIST_PHASE1)) { // phase 0 needs more sweeps than the launch had; phase 1 has not started
+        en0->it = act[0];
         en0->F = e->pinned[0];
         en0->dense = true;
         en0->any_pull = true;
         return DPPR_OK;
     }
-    s.iter_hint[0] = act_a;
+    s.iter_hint[0] = act[0];
+    if (act[0] == 0) s.start_dense[0] = false;
     *stage = 1;
-    *p1_seeded = true; // the guard let the filter and the snapshot run
-    s.st.persist_launches++;
-    if (st_b & PERSIST_FAULT) return fail(e, DPPR_ERR_HIP, "grid barrier of the resident sweep timed out");
-    if (st_b & PERSIST_ABORTED) {
-        s.st.persist_aborts++;
-        e->persist_ok = false;
-        en1->dense = true;
-        return DPPR_OK;
-    }
-    s.start_dense[1] = log_b[0] >= pull_min;
-    s.last_F0[1] = log_b[0];
-    const int act_b = account(log_b, n1, 2);
-    if (!(st_b & PERSIST_CONVERGED)) {
-        rotate_snapshots(s, st_b & PERSIST_SWEEPS);
-        en1->it = n1;
+    *p1_seeded = true;
+    if (!(st & PERSIST_CONVERGED)) {
+        en1->it = act[1];
         en1->F = e->pinned[0];
         en1->dense = true;
         en1->any_pull = true;
         return DPPR_OK;
     }
-    s.iter_hint[1] = act_b;
+    s.iter_hint[1] = act[1];
+    if (act[1] == 0) s.start_dense[1] = false;
     *stage = 2;
     return DPPR_OK;
 }

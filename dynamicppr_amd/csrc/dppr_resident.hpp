@@ -94,12 +94,16 @@ struct GridBar {                          // zeroed by the host before every lau
     BarWord roll[BAR_SUBS];               // roll-call check-ins of the workgroups with blockIdx % BAR_SUBS == s
     BarWord sub[2][BAR_REPS][BAR_SUBS];   // per sweep parity and replica: arrivals << 32 | cumulative legal count
 };
-// status word of a launch (low bits: complete sweeps)
+// status word of a launch
 constexpr int PERSIST_ABORTED = 1 << 30;   // the roll-call failed, nothing was changed
 constexpr int PERSIST_FAULT = 1 << 29;     // a wait timed out after a successful roll-call
 constexpr int PERSIST_CONVERGED = 1 << 28; // the frontier emptied; all snapshot vectors are all zero again
 constexpr int PERSIST_SKIPPED = 1 << 27;   // the launch was enqueued ahead and its guard said no
-constexpr int PERSIST_SWEEPS = (1 << 16) - 1;
+constexpr int PERSIST_PHASE1 = 1 << 26;    // a launch that runs both phases had started phase 1
+constexpr int PERSIST_SWEEPS = (1 << 16) - 1; // low bits: loop position g; the live snapshot is vector g % 3
+// plan of a launch
+constexpr int PLAN_SEED = 1;  // take the first snapshot from the registers: {v : legal(residual[v])} (valid after a converged solve)
+constexpr int PLAN_BOTH = 2;  // when phase 0 is over, seed phase 1 the same way and go on
 
 __device__ __forceinline__ unsigned long long bar_load(unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
                                                   double *b0, double *b1, double *b2, double *r, double *p, int *cnt,
                                                   int cur0, int phase, double eps, IterStats *stats, int *log, int n_iter,
                                                   GridBar *bar, int *status, unsigned long long limit_ticks,
-                                                  int rollcall_extra, const int *guard) {
+                                                  int rollcall_extra, const int *guard, int plan) {
     constexpr int NW = PB / WAVE;
     constexpr int S = PERSIST_SLOTS;
     __shared__ int s_scan[PB + 1];
@@ -159,16 +163,33 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
         rs = out_row_ptr[v];
         d = out_row_ptr[v + 1] - rs;
         rv = r[v];
-        xv = b0[v];
         pv = p[v];
+        if (!(plan & PLAN_SEED)) xv = b0[v];
     }
     unsigned F = (unsigned)__hip_atomic_load(cnt + cur0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (plan & PLAN_SEED) {
+        // Inspect + the head of ExpandUnifiedRev (gpu/PPRRevPushGPU.cuh:97-104, gpu/ExpandRev.cuh:34-42) on
+        // the registers: the frontier is {v : legal(residual[v])}, x_0[v] = residual[v] for those,
+        // pagerank[v] += ALPHA * residual[v]. After a converged solve plus a stream update these are the
+        // vertices k_su_apply listed.
+        const bool lg0 = valid && legal(rv, phase, eps);
+        xv = lg0 ? rv : 0.0;
+        if (lg0) pv = pv + ALPHA * rv;
+        if (valid) xb_store(b0 + v, (unsigned long long)__double_as_longlong(xv));
+        const int wl = __popcll(__ballot(lg0));
+        if (lane == 0) s_cnt[w] = wl;
+    }
     const int incl = wave_inclusive_scan(d);
     if (lane == WAVE - 1) s_wtot[w] = incl;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the EMPTY marks are in place before this workgroup checks in
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the EMPTY marks (and seeds) are in place before this workgroup checks in
     __syncthreads();
-    if (tid == 0) // roll-call: this workgroup is running and has initialised its entries
-        __hip_atomic_fetch_add(&bar->roll[blockIdx.x % BAR_SUBS].w, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) { // roll-call: this workgroup is running and has initialised its entries
+        unsigned long long seeds = 0;
+        if (plan & PLAN_SEED)
+            for (int k = 0; k < NW; ++k) seeds += (unsigned)s_cnt[k];
+        __hip_atomic_fetch_add(&bar->roll[blockIdx.x % BAR_SUBS].w, (1ull << 32) | seeds, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
     int woff = 0, Eg = 0;
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
@@ -211,16 +232,21 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
         if (blockIdx.x == 0) {
             unsigned polls = 0;
             bool all_here = false;
+            unsigned long long word = 0;
             for (;;) {
-                const unsigned long long word = lane < (int)subs_used ? bar_load(&bar->roll[lane].w) : 0;
-                if (__ballot(word >= n_sub + (lane == 0 ? (unsigned long long)rollcall_extra : 0ull)) == ~0ull) {
+                word = lane < (int)subs_used ? bar_load(&bar->roll[lane].w) : 0;
+                // rollcall_extra > 0 (tests only) makes the roll-call wait for a workgroup that does not exist
+                if (__ballot((word >> 32) >= n_sub + (lane == 0 ? (unsigned long long)rollcall_extra : 0ull)) == ~0ull) {
                     all_here = true;
                     break;
                 }
                 if ((polls++ & 31u) == 0 && (bar_load(&bar->gen.w) != 0 || wall_clock64() - t_entry > limit_ticks)) break;
                 __builtin_amdgcn_s_sleep(1);
             }
-            if (lane == 0) (void)bar_cas(&bar->gen.w, 0ull, all_here ? BAR_READY : BAR_ABORT);
+            // READY carries the seed count of all workgroups (PLAN_SEED) in its high half
+            const unsigned seeds = (unsigned)__builtin_amdgcn_readlane(wave_inclusive_scan((int)(unsigned)word), WAVE - 1);
+            if (lane == 0)
+                (void)bar_cas(&bar->gen.w, 0ull, all_here ? (BAR_READY | ((unsigned long long)seeds << 32)) : BAR_ABORT);
         }
         if (lane == 0) {
             unsigned long long word;
@@ -230,13 +256,14 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
                     (void)bar_cas(&bar->gen.w, 0ull, BAR_ABORT);
                 __builtin_amdgcn_s_sleep(1);
             }
-            s_next[0] = word == BAR_READY;
-            s_next[1] = F;
+            s_next[0] = word != BAR_ABORT;
+            s_next[1] = (plan & PLAN_SEED) ? (unsigned)(word >> 32) : F;
         }
     }
     __syncthreads();
-    if (!s_next[0]) { // not co-resident: put the two vectors back to all-zero and leave
+    if (!s_next[0]) { // not co-resident: put the vectors back to what they were and leave
         if (valid) {
+            if (plan & PLAN_SEED) xb_store(b0 + v, 0ull);
             xb_store(b1 + v, 0ull);
             xb_store(b2 + v, 0ull);
         }
@@ -263,8 +290,10 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
 
     unsigned long long edges = 0;
     unsigned Cpar[2] = {0u, 0u};
-    int sweeps = 0, logged = 0;
+    int logged = 0;
     bool fault = false, converged = false;
+    int cur_phase = phase;
+    const int last_phase = (plan & PLAN_BOTH) ? 1 : phase;
     int g = 0;
     for (; g < n_iter; ++g) {
         const int ri = g % 3;
@@ -357,13 +386,30 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
         F = s_next[1]; // size of the frontier this sweep consumed
         if (blockIdx.x == 0 && tid == 0) log[g] = (int)F;
         logged = g + 1;
-        if (F == 0) { // the loop is over; this sweep had nothing to do (every workgroup sees the same F)
+        if (F == 0 && cur_phase == last_phase) { // the loop is over; this sweep had nothing to do (every workgroup sees the same F)
             converged = true;
             break;
         }
         double rn = acc[tid];
-        if (xv != 0.0) rn -= xv;
-        const bool lg = valid && legal(rn, phase, eps);
+        if (F == 0) {
+            // phase 0 is over (x_g is all zero, the gathers above found nothing) and the launch goes on
+            // with phase 1: this step seeds it from the registers the way PLAN_SEED does, in place of a
+            // sweep. The vector after next still holds x_{g-1}: the first wave skipped its reset when it
+            // saw the empty frontier, so do it now (everybody is past sweep g-1).
+            cur_phase = 1;
+            if (w == 0) {
+                for (int i = lane; i < (t1 - t0) * WAVE; i += WAVE) {
+                    const int vv = t0 * WAVE + i;
+                    if (vv < V) xb_store(xrst + vv, X_EMPTY);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            rn = rv;
+        } else if (xv != 0.0) {
+            rn -= xv;
+        }
+        const bool lg = valid && legal(rn, cur_phase, eps);
         if (valid) {
             rv = rn;
             xv = lg ? rn : 0.0;
@@ -373,7 +419,6 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
         s_acc[(g + 1) & 1][tid] = rv;
         const int wl = __popcll(__ballot(lg));
         if (lane == 0) s_cnt[w] = wl;
-        ++sweeps;
         PSTAMP(4);
         __syncthreads();
         PSTAMP(5);
@@ -419,7 +464,8 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
         cnt[0] = (int)F;
         cnt[1] = 0;
         cnt[2] = 0;
-        *status = sweeps | (fault ? PERSIST_FAULT : 0) | ((converged || (!fault && F == 0)) ? PERSIST_CONVERGED : 0);
+        *status = g | (fault ? PERSIST_FAULT : 0) | (cur_phase != phase ? PERSIST_PHASE1 : 0) |
+                  ((converged || (!fault && F == 0 && cur_phase == last_phase)) ? PERSIST_CONVERGED : 0);
     }
     stat_add_edges<NW>(stats, edges, s_edges);
 }
