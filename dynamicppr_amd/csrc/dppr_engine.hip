@@ -772,11 +772,14 @@ int main_loop_inspect(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
 // IncrementalBatchUpdate; when seed != 0 also seeds ft[0]/cnt[0] (phase 0) and neg/cnt[3].
 int stream_update(dppr_engine *e, Slot &s, const Epoch &ep, double eps, bool seed, bool zero_bars = false) {
     const int L = ep.L;
-    HIP_TRY(hipMemsetAsync(s.cnt, 0, sizeof(int) * 5, e->stream));
-    if (L == 0) return DPPR_OK;
+    if (L == 0) {
+        HIP_TRY(hipMemsetAsync(s.cnt, 0, sizeof(int) * 5, e->stream));
+        return DPPR_OK;
+    }
+    // (the batch's first kernel also clears cnt[0..4] and, for a resident launch enqueued ahead, its GridBar)
     hipLaunchKernelGGL(k_su_keys, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->su_k[0], e->su_v[0],
                        zero_bars ? reinterpret_cast<unsigned long long *>(e->bar) : nullptr,
-                       zero_bars ? (int)(2 * sizeof(GridBar) / sizeof(unsigned long long)) : 0);
+                       zero_bars ? (int)(sizeof(GridBar) / sizeof(unsigned long long)) : 0, s.cnt, 5);
     size_t tmp = e->su_tmp_bytes;
     HIP_TRY(rocprim::radix_sort_pairs(e->su_tmp, tmp, e->su_k[0], e->su_k[1], e->su_v[0], e->su_v[1], (size_t)L, 0u,
                                       (unsigned)e->bits, e->stream));
@@ -856,7 +859,7 @@ int group_stream_update(dppr_engine *e, Group &g, const Epoch &ep) {
     const int L = ep.L;
     if (L == 0) return DPPR_OK;
     hipLaunchKernelGGL(k_su_keys, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->su_k[0], e->su_v[0],
-                       (unsigned long long *)nullptr, 0);
+                       (unsigned long long *)nullptr, 0, (int *)nullptr, 0);
     size_t tmp = e->su_tmp_bytes;
     HIP_TRY(rocprim::radix_sort_pairs(e->su_tmp, tmp, e->su_k[0], e->su_k[1], e->su_v[0], e->su_v[1], (size_t)L, 0u,
                                       (unsigned)e->bits, e->stream));

@@ -30,12 +30,14 @@ namespace dppr {
 //              phase-1 candidate list (r[u] < -eps): only tails can leave [-eps, eps]
 //              (cpu/PPRCPUMTCilkRev.h:126-156 seeds from batch endpoints for the same reason).
 // ---------------------------------------------------------------------------
-// (also zeroes `nz` 8-byte words at `zero` when given: the first kernel of a batch clears the counters
-// of the resident launches that follow instead of a separate fill)
+// (also zeroes `nz` 8-byte words at `zero` and `nzi` ints at `zero_ints` when given: the first kernel of a
+// batch clears the counters of what follows instead of separate fills; one workgroup's bitonic sort in
+// LDS was tried for the grouping of small batches and is 3x slower than the device radix sort)
 __global__ __launch_bounds__(BLOCK) void k_su_keys(const int *__restrict__ e1, int L, uint32_t *__restrict__ keys,
                                                    uint32_t *__restrict__ vals, unsigned long long *__restrict__ zero,
-                                                   int nz) {
+                                                   int nz, int *__restrict__ zero_ints, int nzi) {
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nz; i += gridDim.x * BLOCK) zero[i] = 0ull;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < nzi; i += gridDim.x * BLOCK) zero_ints[i] = 0;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < L; i += gridDim.x * BLOCK) {
         keys[i] = (uint32_t)e1[i];
         vals[i] = (uint32_t)i;
