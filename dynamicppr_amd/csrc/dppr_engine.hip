@@ -513,7 +513,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             // ---- a run of dense iterations as ONE resident launch (dppr_resident.hpp)
             if (!dense_valid) {
                 hipLaunchKernelGGL(k_snapshot_dense, dim3(std::min(grid_for(std::max(F, 1 << 14)), 1024)), dim3(BLOCK), 0,
-                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x, (const int *)nullptr, 0);
+                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x);
                 dense_valid = true;
             }
             HIP_TRY(hipMemsetAsync(e->bar, 0, sizeof(GridBar), e->stream));
@@ -521,7 +521,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                       \
     hipLaunchKernelGGL(k_pull_resident<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,       \
                        ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.r, s.p, s.cnt, cur, phase, eps, s.dstats, s.log,  \
-                       n, e->bar, s.cnt + 7, e->persist_ticks, e->persist_rollcall_extra, (const int *)nullptr, 0)
+                       n, e->bar, s.cnt + 7, e->persist_ticks, e->persist_rollcall_extra, 0)
             switch (sweep_block(e)) {
             case 256: DPPR_LAUNCH_PERSIST(256); break;
             case 512: DPPR_LAUNCH_PERSIST(512); break;
@@ -574,7 +574,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 // grid-stride over a frontier whose size is only known on the device (k > 0): sized for
                 // the last size the host saw, capped
                 hipLaunchKernelGGL(k_snapshot_dense, dim3(std::min(grid_for(std::max(F, 1 << 14)), 1024)), dim3(BLOCK), 0,
-                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x, (const int *)nullptr, 0);
+                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x);
                 dense_valid = true;
             }
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k], e->stream));
@@ -685,8 +685,7 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                        \
     hipLaunchKernelGGL(k_pull_resident<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,        \
                        ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.r, s.p, s.cnt, 0, 0, eps, s.dstats, s.log, n,      \
-                       e->bar, status, e->persist_ticks, e->persist_rollcall_extra, (const int *)nullptr,                \
-                       PLAN_SEED | PLAN_BOTH)
+                       e->bar, status, e->persist_ticks, e->persist_rollcall_extra, PLAN_SEED | PLAN_BOTH)
     switch (sweep_block(e)) {
     case 256: DPPR_LAUNCH_PERSIST(256); break;
     case 512: DPPR_LAUNCH_PERSIST(512); break;
@@ -1335,7 +1334,7 @@ int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *
             if (!p1_seeded) { // phase 1: candidates recorded by the update, re-checked now
                 HIP_TRY(hipMemsetAsync(s.cnt, 0, sizeof(int) * 3, e->stream));
                 hipLaunchKernelGGL(k_filter, dim3(grid_for(std::max(ep.L, 1))), dim3(BLOCK), 0, e->stream, s.neg,
-                                   s.cnt + 3, s.r, 1, eps, s.ft[0], s.cnt + 0, (const int *)nullptr, 0);
+                                   s.cnt + 3, s.r, 1, eps, s.ft[0], s.cnt + 0);
                 HIP_TRY(hipGetLastError());
             }
             rc = run_frontier_loop(e, s, ep, 1, eps, 0, 0, en1);

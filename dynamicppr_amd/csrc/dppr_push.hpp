@@ -66,9 +66,7 @@ __global__ __launch_bounds__(BLOCK) void k_inspect(const double *__restrict__ r,
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_snapshot_dense(const int *__restrict__ ft, const int *__restrict__ cnt_in,
                                                           const double *__restrict__ r, double *__restrict__ p,
-                                                          double *__restrict__ x, const int *__restrict__ guard,
-                                                          int guard_mask) {
-    if (guard && !(*guard & guard_mask)) return; // see k_filter
+                                                          double *__restrict__ x) {
     const int F = *cnt_in;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < F; i += gridDim.x * BLOCK) {
         const int u = ft[i];

@@ -98,7 +98,6 @@ struct GridBar {                          // zeroed by the host before every lau
 constexpr int PERSIST_ABORTED = 1 << 30;   // the roll-call failed, nothing was changed
 constexpr int PERSIST_FAULT = 1 << 29;     // a wait timed out after a successful roll-call
 constexpr int PERSIST_CONVERGED = 1 << 28; // the frontier emptied; all snapshot vectors are all zero again
-constexpr int PERSIST_SKIPPED = 1 << 27;   // the launch was enqueued ahead and its guard said no
 constexpr int PERSIST_PHASE1 = 1 << 26;    // a launch that runs both phases had started phase 1
 constexpr int PERSIST_SWEEPS = (1 << 16) - 1; // low bits: loop position g; the live snapshot is vector g % 3
 // plan of a launch
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
                                                   double *b0, double *b1, double *b2, double *r, double *p, int *cnt,
                                                   int cur0, int phase, double eps, IterStats *stats, int *log, int n_iter,
                                                   GridBar *bar, int *status, unsigned long long limit_ticks,
-                                                  int rollcall_extra, const int *guard, int plan) {
+                                                  int rollcall_extra, int plan) {
     constexpr int NW = PB / WAVE;
     constexpr int S = PERSIST_SLOTS;
     __shared__ int s_scan[PB + 1];
@@ -137,10 +136,6 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
     __shared__ unsigned s_next[2]; // {roll-call outcome / no fault, size of the frontier of the current sweep}
     __shared__ int s_fault;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
-    if (guard && !(__hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & PERSIST_CONVERGED)) {
-        if (blockIdx.x == 0 && tid == 0) *status = PERSIST_SKIPPED;
-        return;
-    }
     const unsigned G = gridDim.x;
     const unsigned subs_used = G < (unsigned)BAR_SUBS ? G : (unsigned)BAR_SUBS;
     const unsigned long long n_sub = lane < (int)subs_used ? (G - lane + BAR_SUBS - 1) / BAR_SUBS : 0;

@@ -210,49 +210,11 @@ __global__ __launch_bounds__(BLOCK) void k_su_apply_fused(const uint32_t *__rest
     }
 }
 
-// phase-1 seeding and dense snapshot in one pass (batch_ahead): the candidates that are still
-// below -eps enter the frontier list AND the snapshot (x[u] = r[u], pagerank[u] += ALPHA * r[u],
-// the head of ExpandUnifiedRev, gpu/ExpandRev.cuh:34-42). Candidates are distinct vertices.
-__global__ __launch_bounds__(BLOCK) void k_filter_snapshot(const int *__restrict__ cand, const int *__restrict__ cnt_cand,
-                                                           const double *__restrict__ r, double *__restrict__ p,
-                                                           double *__restrict__ x, int phase, double eps,
-                                                           int *__restrict__ ft, int *__restrict__ cnt,
-                                                           const int *__restrict__ guard, int guard_mask) {
-    if (guard && !(*guard & guard_mask)) return; // see k_filter
-    const int n = *cnt_cand;
-    for (int i0 = blockIdx.x * BLOCK; i0 < n; i0 += gridDim.x * BLOCK) {
-        const int i = i0 + threadIdx.x;
-        int u = 0;
-        bool hit = false;
-        double ru = 0.0;
-        if (i < n) {
-            u = cand[i];
-            ru = r[u];
-            hit = legal(ru, phase, eps);
-        }
-        if (hit) {
-            x[u] = ru;
-            p[u] += ALPHA * ru;
-        }
-        const uint64_t m = __ballot(hit);
-        if (m) {
-            int gb = 0;
-            if (lane_id() == 0) gb = atomicAdd(cnt, __popcll(m));
-            gb = __shfl(gb, 0, WAVE);
-            if (hit) ft[gb + mbcnt(m)] = u;
-        }
-    }
-}
-
 // phase-1 seed: keep the candidates that are still below -eps after phase 0
 // (phase 0 only adds positive amounts, so no new vertex can have dropped below).
 __global__ __launch_bounds__(BLOCK) void k_filter(const int *__restrict__ cand, const int *__restrict__ cnt_cand,
                                                   const double *__restrict__ r, int phase, double eps,
-                                                  int *__restrict__ ft, int *__restrict__ cnt,
-                                                  const int *__restrict__ guard, int guard_mask) {
-    // enqueued ahead of time (dppr_engine.hip, batch_ahead): only runs if the launch before it
-    // ended the way the host expected
-    if (guard && !(*guard & guard_mask)) return;
+                                                  int *__restrict__ ft, int *__restrict__ cnt) {
     const int n = *cnt_cand;
     for (int i0 = blockIdx.x * BLOCK; i0 < n; i0 += gridDim.x * BLOCK) {
         const int i = i0 + threadIdx.x;
