@@ -668,8 +668,13 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
 // ---------------------------------------------------------------------------------------------
 bool can_batch_ahead(const dppr_engine *e, const Slot &s, const Epoch &ep) {
     const int cap = persist_capacity(e);
-    return e->persist_mode == 1 && cap > 0 && ep.n_groups > 0 && ep.n_groups <= cap && !s.trace && e->chunk_iters > 1 && ep.L > 0 &&
-           s.iter_hint[0] > 0 && s.iter_hint[1] > 0 && s.start_dense[0] && s.start_dense[1];
+    if (e->persist_mode != 1 || cap <= 0 || ep.n_groups <= 0 || ep.n_groups > cap || s.trace || e->chunk_iters <= 1 || ep.L <= 0)
+        return false;
+    // A resident sweep costs the same ~5 us whatever the frontier size, less than one push iteration's
+    // launches: with the automatic push/pull threshold a window that can run resident always does.
+    // With an explicit threshold (tests) only if the last batch's phases both started above it.
+    return e->pull_min_frontier == 0 ||
+           (s.iter_hint[0] > 0 && s.iter_hint[1] > 0 && s.start_dense[0] && s.start_dense[1]);
 }
 
 // stage (out): 0 = phase 0 still open (resume with en0), 1 = phase 0 done, phase 1 open (resume with
@@ -679,7 +684,9 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
     const int pull_min = pull_min_frontier(e);
     // a resident launch stops by itself when the frontier empties: a generous allowance costs nothing,
     // a short one costs a read-back and another launch (+1: the step that seeds phase 1)
-    const int n = std::min(s.iter_hint[0] + s.iter_hint[1] + 1 + 2 * RESIDENT_MARGIN, 2 * MAX_CHUNK);
+    const int n = s.iter_hint[0] > 0 && s.iter_hint[1] > 0
+                      ? std::min(s.iter_hint[0] + s.iter_hint[1] + 1 + 2 * RESIDENT_MARGIN, 2 * MAX_CHUNK)
+                      : 2 * MAX_CHUNK; // no history yet
     int *status = s.cnt + 7; // (the GridBar was zeroed by the batch's first kernel, k_su_keys)
     if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                        \

@@ -621,3 +621,38 @@ def test_source_group_matches_oracle_per_source(directed, nsrc, big_row):
         e.add_source_group(list(range(9)))
     with pytest.raises(eng.DpprError):
         e.group_read(gid, nsrc)
+
+
+def test_two_engines_on_one_device_from_two_threads():
+    """Two engines share device 0 and are driven from two host threads at once: their resident
+    launches compete for the same CUs (each wants all of them). Whatever the interleaving -- one
+    waits for the other, or a roll-call gives up and that engine goes on with per-iteration
+    launches -- both must finish and match the oracle."""
+    import threading
+    V, e1, e2 = datagen.rmat_stream(12, 60000, 31)
+    W, c, eps = 6000, 60, 1e-9
+    srcs = [int(x) for x in datagen.top_sources(V, e1, e2, W, 0, 2)]
+    scs = [Scenario(V, e1, e2, 0, W, c, s_, eps, schedule=eng.SCHEDULE_SYNC, pull_min_frontier=1) for s_ in srcs]
+    errors = []
+
+    def drive(sc):
+        try:
+            sc.s.sync_execute(sc.g)
+            sc.e.init_solve(sc.slot, eps)
+            for _ in range(12):
+                assert sc.advance_graphs()
+                sc.s.sync_inc_execute(sc.g)
+                sc.e.update(sc.slot, eps)
+                p, r = sc.e.read(sc.slot)
+                assert np.max(np.abs(p - sc.s.p)) < SYNC_TOL and np.max(np.abs(r - sc.s.r)) < SYNC_TOL
+        except BaseException as ex:  # noqa: BLE001 - reported by the main thread
+            errors.append(repr(ex))
+
+    threads = [threading.Thread(target=drive, args=(sc,)) for sc in scs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a driver thread hangs"
+    assert not errors, errors
+    assert sum(sc.e.stats(sc.slot)["persist_launches"] for sc in scs) > 0
