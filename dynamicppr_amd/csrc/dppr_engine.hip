@@ -427,17 +427,19 @@ int read_count(dppr_engine *e, const int *dptr, int *out) {
 
 // Frontier loop: PPRRevPushGPU::ExecuteOptimized's while(1) (gpu/PPRRevPushGPU.cuh:106-130).
 // On entry s.ft[buf] holds the frontier and s.cnt[cur] its size; cnt[(cur+1)%3] is zero and
-// both dense vectors s.x / s.x2 are all zero (no snapshot taken yet).
+// the dense vectors s.x / s.x2 / s.x3 are all zero (no snapshot taken yet) -- unless `entry` says
+// otherwise.
 //
 // The reference reads the frontier count back after EVERY iteration (blocking 4-byte D2H,
 // :107). Here iterations are enqueued in CHUNKS: every kernel takes F from device memory,
 // rotates the three counters itself and exits at once when F == 0, so the host only reads
 // the count (and the per-iteration log of F) once per chunk. The host also picks, per chunk,
 // how the iterations are evaluated: SPARSE (push kernels, atomics) or DENSE (pull sweep, no
-// atomics) -- the same sums either way.
+// atomics; as ONE resident launch for the whole chunk when the epoch's sweep groups fit the chip,
+// dppr_resident.hpp) -- the same sums either way.
 //
-// `entry` describes a loop that is picked up in the middle (after launches that batch_ahead
-// enqueued without waiting): iterations already done, the frontier size if the host knows it,
+// `entry` describes a loop that is picked up in the middle (after a launch of batch_ahead that
+// ended before the loop did): iterations already done, the frontier size if the host knows it,
 // and whether s.x already holds the frontier's dense snapshot.
 struct LoopEntry {
     int it = 0;
