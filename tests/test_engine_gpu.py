@@ -135,6 +135,31 @@ def test_incremental_batch_update_hub_tail_many_records():
     assert np.array_equal(r, sc.s.r)
 
 
+@pytest.mark.parametrize("shape", ["group-beyond-lds-window", "more-records-than-one-grid-pass"])
+def test_incremental_batch_update_large_batches(shape):
+    """k_su_apply_fused stages 1024 sorted records per workgroup in LDS and covers 2048 x 256
+    records per grid pass: a tail group longer than the window finishes from global memory, and a
+    batch longer than one pass loops -- both still bit-identical to the CPU order."""
+    rng = np.random.default_rng(7)
+    if shape == "group-beyond-lds-window":
+        V, W, c, n = 64, 4000, 3000, 12000          # 70 % of the records share tail 5: a ~4000-record group
+        e1 = np.where(rng.random(n) < 0.7, 5, rng.integers(0, V, n)).astype(np.int32)
+    else:
+        V, W, c, n = 4096, 300000, 270000, 900000   # L = 2c = 540 000 > 524 288
+        e1 = rng.integers(0, V, n).astype(np.int32)
+    e2 = rng.integers(0, V, n).astype(np.int32)
+    e2 = np.where(e2 == e1, (e2 + 1) % V, e2).astype(np.int32)
+    sc = Scenario(V, e1, e2, 1, W, c, 5, 1e-9)
+    sc.s.cilk_execute(sc.g)
+    sc.e.write(sc.slot, sc.s.p.copy(), sc.s.r.copy())
+    assert sc.advance_graphs()
+    sc.s.copy_revert_out_degree(sc.g)
+    sc.s.stream_update(sc.g)
+    sc.e.incremental_batch_update(sc.slot)
+    _, r = sc.e.read(sc.slot)
+    assert np.array_equal(r, sc.s.r)
+
+
 @pytest.mark.parametrize("tuning", TUNINGS, ids=TUNING_IDS)
 @pytest.mark.parametrize("directed", [1, 0])
 def test_sync_schedule_frontier_sets_bit_exact(directed, tuning):
