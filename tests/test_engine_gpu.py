@@ -449,7 +449,7 @@ def test_full_size_livejournal_standin_two_sources():
     assert st0["batches"] == 2 and st0["pull_iterations"] > 0 and st0["sum_E"] > 10 * len(w1)
 
 
-@pytest.mark.parametrize("mode", ["resident", "per-iteration", "rollcall-fails", "heavy-groups"])
+@pytest.mark.parametrize("mode", ["resident", "per-iteration", "rollcall-fails", "rollcall-fails-whole-batch", "heavy-groups"])
 @pytest.mark.parametrize("directed", [1, 0])
 def test_resident_sweeps_same_work_as_per_iteration_launches(directed, mode):
     """Runs of dense iterations as ONE resident launch (k_pull_resident) do exactly the oracle's
@@ -463,6 +463,11 @@ def test_resident_sweeps_same_work_as_per_iteration_launches(directed, mode):
         tuning["persistent"] = 0
     elif mode == "rollcall-fails":
         tuning["persist_timeout_us"] = -1
+    elif mode == "rollcall-fails-whole-batch":
+        # automatic push/pull threshold: the from-scratch solve stays sparse on this small graph, so the
+        # first resident launch is a whole batch (seeding inside the kernel) -- and it has to put back
+        # what it seeded when its roll-call fails
+        tuning = dict(persist_timeout_us=-1)
     elif mode == "heavy-groups":
         tuning["pull_block"] = 256
         edges, W, c = 200000, 40000, 400 # ~80 edges per vertex: a 256-vertex group carries > 4 * 256 edges
@@ -484,7 +489,7 @@ def test_resident_sweeps_same_work_as_per_iteration_launches(directed, mode):
     assert stats["sum_F"] == want["F"] and stats["sum_E"] == want["E"]
     if mode == "per-iteration":
         assert stats["persist_launches"] == 0
-    elif mode == "rollcall-fails":
+    elif mode.startswith("rollcall-fails"):
         # the first resident launch gives up at its roll-call; none is tried after that
         assert stats["persist_launches"] == 1 and stats["persist_aborts"] == 1
     else:
