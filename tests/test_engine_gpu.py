@@ -496,6 +496,31 @@ def test_resident_sweeps_same_work_as_per_iteration_launches(directed, mode):
         assert stats["persist_launches"] >= 4 and stats["persist_aborts"] == 0
 
 
+@pytest.mark.parametrize("directed", [1, 0])
+def test_whole_batch_launch_that_runs_out_of_sweeps_is_resumed(directed):
+    """eps = 1e-13 needs ~140 sweeps per batch, more than one resident launch is ever given (128):
+    the launch stops mid-phase, the host reads where it stands and resumes -- same work as the
+    oracle's synchronous schedule."""
+    V, e1, e2 = datagen.rmat_stream(10, 30000, 5)
+    W, c, eps = 3000, 60, 1e-13
+    src = int(datagen.top_sources(V, e1, e2, W, directed, 1)[0])
+    sc = Scenario(V, e1, e2, directed, W, c, src, eps, schedule=eng.SCHEDULE_SYNC)
+    sc.s.sync_execute(sc.g)
+    sc.e.init_solve(sc.slot, eps)
+    it0 = sc.e.stats(sc.slot)["iterations"]
+    for k in range(4):
+        if k:
+            assert sc.advance_graphs()
+            sc.s.sync_inc_execute(sc.g)
+            sc.e.update(sc.slot, eps)
+        p, r = sc.e.read(sc.slot)
+        assert np.max(np.abs(p - sc.s.p)) < SYNC_TOL and np.max(np.abs(r - sc.s.r)) < SYNC_TOL
+    st, want = sc.e.stats(sc.slot), sc.s.stats()
+    assert (st["iterations"], st["sum_F"], st["sum_E"]) == (want["iters"], want["F"], want["E"])
+    # every batch needed more iterations than its launch could run (and one step for the phase switch)
+    assert (st["iterations"] - it0) / 3 > 128 and st["persist_launches"] >= 3 and st["persist_aborts"] == 0
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_randomised_streams_sync_frontiers(seed):
     """Different seeded streams / shapes, each with the path thresholds lowered in a different way:
