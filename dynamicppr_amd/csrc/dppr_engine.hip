@@ -103,6 +103,7 @@ struct dppr_engine {
     bool profiling = false;
     int pull_block = 0;   // sweep workgroup size (0: by graph size; 256 / 512 / 1024)
     int chunk_iters = 24; // iterations enqueued between two host read-backs of the frontier size
+    bool chunk_explicit = false; // set by dppr_set_tuning: then it also caps what a resident launch is given
     // resident sweeps (dppr_resident.hpp)
     int persist_mode = 1;              // 1: use resident sweeps when an epoch's groups fit the chip at once
     bool persist_ok = true;            // cleared after a grid-barrier time-out: per-iteration launches from then on
@@ -510,6 +511,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
         const bool resident = pull && n >= 2 && !s.trace && pcap > 0 && ep.n_groups > 0 && ep.n_groups <= pcap;
         if (resident && s.iter_hint[phase] > it) n += RESIDENT_MARGIN - 1;
         n = std::min(n, MAX_CHUNK);
+        if (e->chunk_explicit) n = std::min(n, std::max(e->chunk_iters, 1));
         if (!pull && !list_valid && (rc = make_list())) return rc;
         if (resident) {
             // ---- a run of dense iterations as ONE resident launch (dppr_resident.hpp)
@@ -686,9 +688,10 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
     const int pull_min = pull_min_frontier(e);
     // a resident launch stops by itself when the frontier empties: a generous allowance costs nothing,
     // a short one costs a read-back and another launch (+1: the step that seeds phase 1)
-    const int n = s.iter_hint[0] > 0 && s.iter_hint[1] > 0
+    int n = s.iter_hint[0] > 0 && s.iter_hint[1] > 0
                       ? std::min(s.iter_hint[0] + s.iter_hint[1] + 1 + 2 * RESIDENT_MARGIN, 2 * MAX_CHUNK)
                       : 2 * MAX_CHUNK; // no history yet
+    if (e->chunk_explicit) n = std::min(n, e->chunk_iters); // (tests: launches that stop mid-phase and are resumed)
     int *status = s.cnt + 7; // (the GridBar was zeroed by the batch's first kernel, k_su_keys)
     if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                        \
@@ -1065,7 +1068,10 @@ int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges, int p
     e->hub_min_degree = hub_min_degree;
     e->big_row = big_row_edges;
     e->pull_min_frontier = pull_min_frontier;
-    if (chunk_iters > 0) e->chunk_iters = std::min(chunk_iters, MAX_CHUNK);
+    if (chunk_iters > 0) {
+        e->chunk_iters = std::min(chunk_iters, MAX_CHUNK);
+        e->chunk_explicit = true;
+    }
     if (pull_block >= 256 && pull_block <= 1024 && pull_block % 64 == 0) e->pull_block = pull_block;
     return DPPR_OK;
 }

@@ -100,7 +100,8 @@ int dppr_set_profiling(dppr_engine *e, int on);
  * expanded by the whole grid; pull_min_frontier: frontier size from which an iteration is
  * evaluated as a dense pull sweep instead of push atomics (0 = auto: max(1024, edges/192),
  * negative = never); chunk_iters: iterations enqueued per host read-back of the frontier size
- * (default 24, 1 = read back every iteration like the reference, <= 0 keeps the default);
+ * (default 24, 1 = read back every iteration like the reference, <= 0 keeps the default; an
+ * explicit value also caps the sweeps a resident launch may run before the host looks);
  * pull_block: workgroup size of the sweep, 256 / 512 / 1024 (0 = chosen from the graph size).
  * Results never depend on them beyond floating-point summation order; tests set them so
  * small graphs exercise every path. */

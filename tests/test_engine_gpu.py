@@ -36,10 +36,12 @@ TUNINGS = [dict(pull_min_frontier=-1), dict(hub_min_degree=3, big_row_edges=8, p
            # without them, with small workgroups (several groups), and with a roll-call that cannot
            # succeed (the first resident launch gives up untouched, per-iteration launches go on)
            dict(pull_min_frontier=1, persistent=0), dict(pull_min_frontier=1, pull_block=256),
-           dict(pull_min_frontier=1, pull_block=256, persist_timeout_us=-1)]
+           dict(pull_min_frontier=1, pull_block=256, persist_timeout_us=-1),
+           # resident launches that may run only 3 sweeps at a time: every one stops mid-phase and is resumed
+           dict(pull_min_frontier=1, chunk_iters=3)]
 TUNING_IDS = ["push-only", "push-hubs+bigrows", "push-all-hub-all-big", "pull-only", "mixed-pull>=40", "default",
               "mixed-chunk1", "mixed-chunk3", "pull-wg512", "mixed-wg1024", "pull-no-persist", "pull-wg256",
-              "pull-rollcall-fails"]
+              "pull-rollcall-fails", "pull-resident-3-sweeps"]
 
 
 def make(directed, schedule=eng.SCHEDULE_EAGER, scale=9, edges=6000, seed=11, W=600, c=6, eps=1e-9, n_epochs=1,
