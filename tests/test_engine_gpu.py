@@ -498,6 +498,40 @@ def test_resident_sweeps_same_work_as_per_iteration_launches(directed, mode):
         assert stats["persist_launches"] >= 4 and stats["persist_aborts"] == 0
 
 
+@pytest.mark.parametrize("seed", list(range(1, 11)))
+def test_randomised_streams_whole_batch_resident_launches(seed):
+    """Different seeded streams / shapes / workgroup sizes with the engine left to itself (automatic
+    threshold: every batch after the first solve is one resident launch, both phases seeded inside
+    the kernel): same iterations, frontier sizes and traversed edges as the oracle's synchronous
+    schedule, p / r to rounding."""
+    rng = np.random.default_rng(1000 + seed)
+    scale = int(rng.integers(7, 13))
+    edges = int(rng.integers(3000, 40000))
+    directed = int(seed % 2)
+    W = int(edges * rng.uniform(0.05, 0.3))
+    c = int(max(1, W * rng.uniform(0.005, 0.08)))
+    eps = float(rng.choice([1e-9, 1e-7, 1e-11]))
+    tuning = dict(pull_block=int(rng.choice([256, 512, 1024]))) if seed % 3 else {}
+    V, e1, e2 = datagen.rmat_stream(scale, edges, 500 + seed)
+    src = int(datagen.top_sources(V, e1, e2, W, directed, 3)[seed % 3])
+    sc = Scenario(V, e1, e2, directed, W, c, src, eps, schedule=eng.SCHEDULE_SYNC, **tuning)
+    sc.s.sync_execute(sc.g)
+    sc.e.init_solve(sc.slot, eps)
+    n_batches = 0
+    for k in range(7):
+        if k:
+            if not sc.advance_graphs():
+                break
+            n_batches += 1
+            sc.s.sync_inc_execute(sc.g)
+            sc.e.update(sc.slot, eps)
+        p, r = sc.e.read(sc.slot)
+        assert np.max(np.abs(p - sc.s.p)) < SYNC_TOL and np.max(np.abs(r - sc.s.r)) < SYNC_TOL, k
+    st, want = sc.e.stats(sc.slot), sc.s.stats()
+    assert (st["iterations"], st["sum_F"], st["sum_E"]) == (want["iters"], want["F"], want["E"])
+    assert st["persist_launches"] >= n_batches and st["persist_aborts"] == 0
+
+
 @pytest.mark.parametrize("directed", [1, 0])
 def test_whole_batch_launch_that_runs_out_of_sweeps_is_resumed(directed):
     """eps = 1e-13 needs ~140 sweeps per batch, more than one resident launch is ever given (128):
