@@ -9,15 +9,15 @@ DPPR_LIB=/tmp/libdppr_hip_stamps.so python3 - <<'PY'
 import ctypes as C, numpy as np, os, sys
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
 from dynamicppr_amd import datagen, engine as eng, stream as st
-V, e1, e2, cfg = datagen.stand_in_stream("youtube", "/tmp/dppr_data")
-wl = st.workload_config(len(e1), 0.1, 0, 0.01, 100)
-src = int(datagen.top_sources(V, e1, e2, wl.window, 0, 1)[0])
-e = eng.Engine(V, wl.window, 0, wl.per_batch)
-ss = st.SlidingStream(V, e1, e2, 0, wl)
+V, e1, e2, cfg = datagen.stand_in_stream(os.environ.get("DPPR_STAMP_CONFIG", "youtube"), "/tmp/dppr_data")
+wl = st.workload_config(len(e1), 0.1, 0, 0.01, 100); directed = cfg.directed
+src = int(datagen.top_sources(V, e1, e2, wl.window, directed, 1)[0])
+e = eng.Engine(V, wl.window, directed, wl.per_batch, persistent=0)
+ss = st.SlidingStream(V, e1, e2, directed, wl)
 e.load_window(*ss.serialize_edge_stream()); slot = e.add_source(src); e.init_solve(slot, 1e-9)
 L = eng.lib()
 L.dppr_debug_stamps.argtypes = [C.POINTER(C.c_uint64), C.c_int]
-rows = 252
+rows = int(os.environ.get("DPPR_STAMP_ROWS", "252"))
 for b in range(3):
     ss.stream_updates(); e.set_batch(*ss.batch_arrays()); e.slide(*ss.new_arrays()); e.update(slot, 1e-9)
 buf = np.zeros(rows * 8, dtype=np.uint64)
