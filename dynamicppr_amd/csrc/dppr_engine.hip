@@ -282,9 +282,11 @@ int merge_batch_keys(dppr_engine *e, uint64_t *&sorted, uint64_t *del_unsorted, 
 }
 
 // Workgroup size of the sweeps. Unless pinned (dppr_set_tuning): 1024 for a window that can run
-// resident (one 1024-vertex group per CU, <= 256 groups), 512 for larger ones -- the per-iteration
+// resident (one 1024-vertex group per CU, <= 256 groups); 512 for mid-size ones -- the per-iteration
 // sweep is latency-bound per group there, and three 512-thread workgroups fit a CU where one
-// 1024-thread workgroup does (72 VGPRs): 7.7 -> 7.2 ms per batch on the LiveJournal stand-in.
+// 1024-thread workgroup does (72 VGPRs): 7.7 -> 7.2 ms per batch on the LiveJournal stand-in; 1024
+// again beyond 4 M active vertices, where a sweep takes milliseconds and is bound by the gathers'
+// traffic (twitter stand-in: 222 ms per batch with 1024, 229 with 512).
 int sweep_block(const dppr_engine *e) { return e->pull_block ? e->pull_block : e->auto_block; }
 
 // workgroups of the resident sweep that the device holds at once (0: resident sweeps are off)
@@ -1138,7 +1140,10 @@ int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32
     for (auto &ep : e->epochs) ep.id = -1;
     Epoch &ep = e->epochs[0];
     ep.L = 0;
-    e->auto_block = (e->n_int + WAVE - 1) / WAVE <= 256 * 16 * 7 / 8 ? 1024 : 512; // (see sweep_block)
+    {
+        const int tiles = (e->n_int + WAVE - 1) / WAVE; // (see sweep_block)
+        e->auto_block = tiles <= 256 * 16 * 7 / 8 || tiles > 65536 ? 1024 : 512;
+    }
     int rc = query_persist_cap(e);
     if (rc) return rc;
     rc = sort_window_full(e);
