@@ -101,8 +101,7 @@ struct dppr_engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t evpool[2 * 64] = {};
     bool profiling = false;
-    int pull_block = 0;   // sweep workgroup size pinned by dppr_set_tuning (0: auto_block)
-    int auto_block = 1024; // chosen at dppr_load_window from the number of active vertices
+    int pull_block = 0;   // sweep workgroup size pinned by dppr_set_tuning (0: 1024)
     int chunk_iters = 24; // iterations enqueued between two host read-backs of the frontier size
     bool chunk_explicit = false; // set by dppr_set_tuning: then it also caps what a resident launch is given
     // resident sweeps (dppr_resident.hpp)
@@ -281,13 +280,9 @@ int merge_batch_keys(dppr_engine *e, uint64_t *&sorted, uint64_t *del_unsorted, 
     return DPPR_OK;
 }
 
-// Workgroup size of the sweeps. Unless pinned (dppr_set_tuning): 1024 for a window that can run
-// resident (one 1024-vertex group per CU, <= 256 groups); 512 for mid-size ones -- the per-iteration
-// sweep is latency-bound per group there, and three 512-thread workgroups fit a CU where one
-// 1024-thread workgroup does (72 VGPRs): 7.7 -> 7.2 ms per batch on the LiveJournal stand-in; 1024
-// again beyond 4 M active vertices, where a sweep takes milliseconds and is bound by the gathers'
-// traffic (twitter stand-in: 222 ms per batch with 1024, 229 with 512).
-int sweep_block(const dppr_engine *e) { return e->pull_block ? e->pull_block : e->auto_block; }
+// Workgroup size of the sweeps: 1024 unless pinned (dppr_set_tuning; 512 was measured on the LiveJournal
+// and twitter stand-ins and is not better once two 1024-thread workgroups fit a CU).
+int sweep_block(const dppr_engine *e) { return e->pull_block ? e->pull_block : 1024; }
 
 // workgroups of the resident sweep that the device holds at once (0: resident sweeps are off)
 int persist_capacity(const dppr_engine *e) {
@@ -1140,10 +1135,6 @@ int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32
     for (auto &ep : e->epochs) ep.id = -1;
     Epoch &ep = e->epochs[0];
     ep.L = 0;
-    {
-        const int tiles = (e->n_int + WAVE - 1) / WAVE; // (see sweep_block)
-        e->auto_block = tiles <= 256 * 16 * 7 / 8 || tiles > 65536 ? 1024 : 512;
-    }
     int rc = query_persist_cap(e);
     if (rc) return rc;
     rc = sort_window_full(e);

@@ -54,8 +54,12 @@ __device__ unsigned long long g_stamps[4096 * 8];
 #define STAMP(i) ((void)0)
 #endif
 
+// 8 waves per SIMD (<= 64 VGPRs, a handful of spilled registers): two 1024-thread workgroups per CU
+// instead of one. On windows that run this kernel per iteration the sweep is latency-bound per group
+// (DESIGN.md section 6), and the second resident workgroup is worth 12 % (LiveJournal stand-in:
+// 88 -> 77 us per sweep). The block sizes that are not powers of two exist for tests only.
 template <int PULL_BLOCK>
-__global__ __launch_bounds__(PULL_BLOCK) void k_pull_iter(int V, const int *__restrict__ grp_tile, int n_groups,
+__global__ __launch_bounds__(PULL_BLOCK, (PULL_BLOCK & (PULL_BLOCK - 1)) == 0 ? 8 : 1) void k_pull_iter(int V, const int *__restrict__ grp_tile, int n_groups,
                                                           const int *__restrict__ cnt_in,
                                                           const int *__restrict__ out_row_ptr,
                                                           const int *__restrict__ out_col,
