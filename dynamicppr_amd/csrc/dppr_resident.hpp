@@ -120,11 +120,12 @@ __device__ __forceinline__ void xb_store(double *p, unsigned long long bits) {
 
 template <int PB>
 __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restrict__ grp_tile,
-                                                  const int *__restrict__ out_row_ptr, const int *__restrict__ out_col,
-                                                  double *b0, double *b1, double *b2, double *r, double *p, int *cnt,
-                                                  int cur0, int phase, double eps, IterStats *stats, int *log, int n_iter,
-                                                  GridBar *bar, int *status, unsigned long long limit_ticks,
-                                                  int rollcall_extra, int plan) {
+                                                      const int *__restrict__ out_row_ptr,
+                                                      const int *__restrict__ out_col, double *b0, double *b1,
+                                                      double *b2, double *r, double *p, int *cnt, int cur0, int phase,
+                                                      double eps, IterStats *stats, int *log, int n_iter, GridBar *bar,
+                                                      int *status, unsigned long long limit_ticks, int rollcall_extra,
+                                                      int plan) {
     constexpr int NW = PB / WAVE;
     constexpr int S = PERSIST_SLOTS;
     __shared__ int s_scan[PB + 1];
