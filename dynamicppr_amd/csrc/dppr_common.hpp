@@ -74,11 +74,25 @@ __device__ __forceinline__ void lds_add(double *p, double v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// wave-wide sum (butterfly; every lane gets the total, fixed order -> deterministic)
+// wave-wide sum; every lane gets the total. Same DPP ladder as the integer scans (two 32-bit DPP moves
+// + one v_add_f64 per step; the xor-butterfly over ds_bpermute it replaces cost ~10x the cycles), fixed
+// order -> deterministic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take_f64(double x) { // 0.0 where the lane has no source
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-    for (int d = WAVE / 2; d >= 1; d >>= 1) x += __shfl_xor(x, d, WAVE);
-    return x;
+    x += dpp_take_f64<0x111, 0xf>(x);
+    x += dpp_take_f64<0x112, 0xf>(x);
+    x += dpp_take_f64<0x114, 0xf>(x);
+    x += dpp_take_f64<0x118, 0xf>(x);
+    x += dpp_take_f64<0x142, 0xa>(x);
+    x += dpp_take_f64<0x143, 0xc>(x);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), WAVE - 1);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), WAVE - 1);
+    return __hiloint2double(hi, lo);
 }
 
 // Device-side statistics. Same-address global atomics serialise at ~11 ns each, so one
