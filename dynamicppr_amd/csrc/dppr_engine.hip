@@ -1113,6 +1113,27 @@ int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32
                 }
             }
         }
+        // Large windows: the x[u] gathers of a sweep are random 8-byte reads, and what an XCD's 4 MB L2
+        // keeps of them saves 64-byte sectors on the fabric. Gathers follow the in-degree, which is
+        // heavily skewed (LiveJournal stand-in: the top 524 K of 1.18 M vertices take 95 % of them), so
+        // the HOT_SET vertices of highest in-degree get the first ids -- 4 MB of x, densely packed -- and
+        // everybody else follows; inside both sets the order stays hashed, so long rows are still spread
+        // over the tiles (and a window of at most HOT_SET vertices is numbered exactly as before).
+        // Measured on that stand-in: 73 -> 67 us per sweep (262 K: 68 us, 131 K: no gain).
+        constexpr size_t HOT_SET = 524288;
+        if (fresh.size() > HOT_SET) {
+            std::vector<int32_t> indeg((size_t)e->V, 0);
+            for (int i = 0; i < n; ++i) {
+                indeg[(size_t)e2[i]]++;
+                if (!e->directed) indeg[(size_t)e1[i]]++;
+            }
+            std::vector<int32_t> d;
+            d.reserve(fresh.size());
+            for (auto &kv : fresh) d.push_back(indeg[(size_t)kv.second]);
+            std::nth_element(d.begin(), d.begin() + (std::ptrdiff_t)HOT_SET, d.end(), std::greater<int32_t>());
+            const int32_t thr = d[HOT_SET]; // vertices with a larger in-degree are hot (at most HOT_SET of them)
+            for (auto &kv : fresh) kv.first = (kv.first >> 1) | (indeg[(size_t)kv.second] > thr ? 0ull : 1ull << 63);
+        }
         std::sort(fresh.begin(), fresh.end());
         for (auto &kv : fresh) {
             e->ext2int[(size_t)kv.second] = -1;
