@@ -24,8 +24,8 @@ using namespace dppr;
 
 static constexpr int MAX_CHUNK = 64;
 // Slot::cnt: [0..2] rotating frontier counters, [3] phase-1 candidates, [4] scratch, [5..6] big-row
-// counters, [7] list scratch / status of a resident launch, [8] status of a second resident launch
-// enqueued ahead; the per-launch logs (2 x MAX_CHUNK) follow the header
+// counters, [7] list scratch / status word of a resident launch; the log of a launch (up to
+// 2 x MAX_CHUNK entries: a whole batch) follows the header
 static constexpr int CNT_HDR = 16;
 static constexpr int RESIDENT_MARGIN = 8; // sweeps a resident launch is given beyond what the last batch needed
 
@@ -955,7 +955,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     e->ext2int.assign((size_t)V, -1);
     e->int2ext.reserve(1024);
     HIP_TRY_C(hipMalloc((void **)&e->hub_hist, sizeof(int) * 64));
-    HIP_TRY_C(hipMalloc((void **)&e->bar, 2 * sizeof(GridBar))); // [1]: the second launch of a batch enqueued ahead
+    HIP_TRY_C(hipMalloc((void **)&e->bar, sizeof(GridBar)));
     HIP_TRY_C(hipMalloc((void **)&e->keys_a, sizeof(uint64_t) * Edn));
     HIP_TRY_C(hipMalloc((void **)&e->keys_b, sizeof(uint64_t) * Edn));
     HIP_TRY_C(hipMalloc((void **)&e->in_sorted, sizeof(uint64_t) * Edn));
