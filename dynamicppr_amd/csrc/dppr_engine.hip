@@ -27,7 +27,6 @@ static constexpr int MAX_CHUNK = 64;
 // counters, [7] list scratch / status word of a resident launch; the log of a launch (up to
 // 2 x MAX_CHUNK entries: a whole batch) follows the header
 static constexpr int CNT_HDR = 16;
-static_assert(2 * MAX_CHUNK <= RESIDENT_LOG_MAX, "a resident launch logs at most RESIDENT_LOG_MAX sweeps");
 static constexpr int RESIDENT_MARGIN = 8; // sweeps a resident launch is given beyond what the last batch needed
 
 namespace {
@@ -151,7 +150,6 @@ struct dppr_engine {
     std::vector<Slot> slots;
     std::vector<Group> groups;
     int *pinned = nullptr; // host-pinned readback words
-    int *pinned_dev = nullptr; // the same block as the device addresses it
     // vertex compaction: external id <-> internal id (assigned on first appearance)
     std::vector<int32_t> ext2int, int2ext;
     int n_int = 0;
@@ -529,7 +527,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                       \
     hipLaunchKernelGGL(k_pull_resident<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,       \
                        ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.r, s.p, s.cnt, cur, phase, eps, s.dstats, s.log,  \
-                       n, e->bar, s.cnt + 7, e->persist_ticks, e->persist_rollcall_extra, 0, (int *)nullptr)
+                       n, e->bar, s.cnt + 7, e->persist_ticks, e->persist_rollcall_extra, 0)
             switch (sweep_block(e)) {
             case 256: DPPR_LAUNCH_PERSIST(256); break;
             case 512: DPPR_LAUNCH_PERSIST(512); break;
@@ -696,16 +694,12 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
                       ? std::min(s.iter_hint[0] + s.iter_hint[1] + 1 + 2 * RESIDENT_MARGIN, 2 * MAX_CHUNK)
                       : 2 * MAX_CHUNK; // no history yet
     if (e->chunk_explicit) n = std::min(n, e->chunk_iters); // (tests: launches that stop mid-phase and are resumed)
-    // The launch writes its status word, its log and the live frontier size straight into the pinned
-    // host block (same layout as a copy of s.cnt would have): no copy-back dispatch after the kernel.
-    // (the GridBar was zeroed by the batch's first kernel, k_su_keys)
-    int *host = e->pinned_dev;
+    int *status = s.cnt + 7; // (the GridBar was zeroed by the batch's first kernel, k_su_keys)
     if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                        \
     hipLaunchKernelGGL(k_pull_resident<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,        \
-                       ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.r, s.p, s.cnt, 0, 0, eps, s.dstats,                \
-                       host + CNT_HDR, n, e->bar, host + 7, e->persist_ticks, e->persist_rollcall_extra,                 \
-                       PLAN_SEED | PLAN_BOTH, host + 0)
+                       ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.r, s.p, s.cnt, 0, 0, eps, s.dstats, s.log, n,      \
+                       e->bar, status, e->persist_ticks, e->persist_rollcall_extra, PLAN_SEED | PLAN_BOTH)
     switch (sweep_block(e)) {
     case 256: DPPR_LAUNCH_PERSIST(256); break;
     case 512: DPPR_LAUNCH_PERSIST(512); break;
@@ -714,6 +708,7 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
 #undef DPPR_LAUNCH_PERSIST
     if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[1], e->stream));
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(e->pinned, s.cnt, sizeof(int) * (size_t)(CNT_HDR + n), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
 
     const int st = e->pinned[7];
@@ -947,7 +942,6 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     HIP_TRY_C(hipEventCreate(&e->ev1));
     for (auto &ev : e->evpool) HIP_TRY_C(hipEventCreate(&ev));
     HIP_TRY_C(hipHostMalloc((void **)&e->pinned, sizeof(int) * (3 * GS + MAX_CHUNK * GS + 16), hipHostMallocDefault));
-    HIP_TRY_C(hipHostGetDevicePointer((void **)&e->pinned_dev, e->pinned, 0));
     const size_t Wn = (size_t)std::max(W, 1), Edn = (size_t)std::max(e->Ed, 1), Ln = (size_t)std::max(4 * c, 1);
     HIP_TRY_C(hipMalloc((void **)&e->w1, sizeof(int) * Wn));
     HIP_TRY_C(hipMalloc((void **)&e->w2, sizeof(int) * Wn));

@@ -84,7 +84,6 @@ constexpr unsigned long long BAR_ABORT = ~0ull;
 constexpr unsigned long long BAR_READY = 1ull;
 constexpr int PERSIST_SLOTS = 4; // edge slots per thread kept in registers (PB * 4 edges per group)
 constexpr unsigned long long X_EMPTY = 0x7FF8DEADBEEFCAFEull;
-constexpr int RESIDENT_LOG_MAX = 128; // most sweeps one launch may be given
 
 struct alignas(128) BarWord {
     unsigned long long w;
@@ -126,7 +125,7 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
                                                       double *b2, double *r, double *p, int *cnt, int cur0, int phase,
                                                       double eps, IterStats *stats, int *log, int n_iter, GridBar *bar,
                                                       int *status, unsigned long long limit_ticks, int rollcall_extra,
-                                                      int plan, int *live_out) {
+                                                      int plan) {
     constexpr int NW = PB / WAVE;
     constexpr int S = PERSIST_SLOTS;
     __shared__ int s_scan[PB + 1];
@@ -137,7 +136,6 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
     __shared__ unsigned long long s_edges[NW];
     __shared__ unsigned s_next[2]; // {roll-call outcome / no fault, size of the frontier of the current sweep}
     __shared__ int s_fault;
-    __shared__ int s_log[RESIDENT_LOG_MAX]; // (workgroup 0) frontier sizes; written out when the launch ends
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const unsigned G = gridDim.x;
     const unsigned subs_used = G < (unsigned)BAR_SUBS ? G : (unsigned)BAR_SUBS;
@@ -382,7 +380,7 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
             break;
         }
         F = s_next[1]; // size of the frontier this sweep consumed
-        if (blockIdx.x == 0 && tid == 0 && g < RESIDENT_LOG_MAX) s_log[g] = (int)F;
+        if (blockIdx.x == 0 && tid == 0) log[g] = (int)F;
         logged = g + 1;
         if (F == 0 && cur_phase == last_phase) { // the loop is over; this sweep had nothing to do (every workgroup sees the same F)
             converged = true;
@@ -457,15 +455,11 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
         r[v] = rv;
         p[v] = pv;
     }
-    if (blockIdx.x == 0) { // the log goes out in one piece (it may live in pinned host memory)
-        __syncthreads();
-        for (int k = tid; k < n_iter; k += PB) log[k] = k < logged && k < RESIDENT_LOG_MAX ? s_log[k] : 0;
-    }
     if (blockIdx.x == 0 && tid == 0) {
+        for (int k = logged; k < n_iter; ++k) log[k] = 0;
         cnt[0] = (int)F;
         cnt[1] = 0;
         cnt[2] = 0;
-        if (live_out) *live_out = (int)F; // (log / status / live_out may be pinned host memory: no copy-back kernel)
         *status = g | (fault ? PERSIST_FAULT : 0) | (cur_phase != phase ? PERSIST_PHASE1 : 0) |
                   ((converged || (!fault && F == 0 && cur_phase == last_phase)) ? PERSIST_CONVERGED : 0);
     }
