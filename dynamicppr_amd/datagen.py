@@ -93,7 +93,7 @@ def write_bin(path: str, V: int, e1: np.ndarray, e2: np.ndarray) -> None:
 
 def read_bin(path: str):
     """Read a reference ``.bin``: returns ``(V, e1, e2)`` (``GraphVec.h:43-70``)."""
-    raw = np.fromfile(path, dtype="<i4")
+    raw = np.memmap(path, dtype="<i4", mode="r")   # no second copy of a multi-GB file
     V = int(raw[0])
     body = raw[1:]
     n = len(body) // 2
@@ -120,27 +120,99 @@ STAND_INS = {
 }
 
 
-def stand_in_path(key: str, cache_dir: str) -> str:
+def stand_in_path(key: str, cache_dir: str, limit: int | None = None) -> str:
     cfg = STAND_INS[key]
-    return os.path.join(cache_dir, f"{cfg.name}.rmat{cfg.scale}.s{cfg.seed}.bin")
+    tag = "" if limit is None or limit >= cfg.edges else f".first{limit}"
+    return os.path.join(cache_dir, f"{cfg.name}.rmat{cfg.scale}.s{cfg.seed}{tag}.bin")
 
 
-def stand_in_stream(key: str, cache_dir: str | None = None):
-    """``(V, e1, e2, StandIn)`` for a named config; cached as ``.bin`` when asked."""
-    cfg = STAND_INS[key]
-    if cache_dir:
-        os.makedirs(cache_dir, exist_ok=True)
-        path = stand_in_path(key, cache_dir)
-        if os.path.exists(path):
-            V, e1, e2 = read_bin(path)
-            return V, e1, e2, cfg
-    V, e1, e2 = rmat_stream(cfg.scale, cfg.edges, cfg.seed)
-    if cache_dir:
-        # several ranks may generate the same file at once: write privately, publish atomically
-        tmp = f"{path}.{os.getpid()}.tmp"
+GENERATOR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host", "rmat_gen")
+PROVENANCE: dict = {}   # path -> {"origin": "generated (...)" | "cached", "checksum": ..., "edges": ...}
+
+
+def file_checksum(path: str) -> str:
+    """Fast content checksum of a stream file (xxh3-64 when xxhash is importable, else CRC32)."""
+    try:
+        import xxhash
+        h = xxhash.xxh3_64()
+        kind = "xxh3_64"
+    except ImportError:  # pragma: no cover
+        import zlib
+
+        class _Crc:
+            def __init__(self):
+                self.v = 0
+
+            def update(self, b):
+                self.v = zlib.crc32(b, self.v)
+
+            def hexdigest(self):
+                return f"{self.v:08x}"
+        h, kind = _Crc(), "crc32"
+    with open(path, "rb") as f:
+        while True:
+            b = f.read(1 << 24)
+            if not b:
+                break
+            h.update(b)
+    return f"{kind}:{h.hexdigest()}"
+
+
+def generate_bin(path: str, scale: int, edges: int, seed: int, limit: int | None = None) -> str:
+    """Write the first ``limit`` (default: all) edges of the seeded stream to ``path``. Uses the
+    compiled multi-threaded generator (host/rmat_gen, byte-identical output, tests/test_datagen.py)
+    when it has been built, the numpy one otherwise. Returns which one ran."""
+    limit = edges if limit is None else min(limit, edges)
+    tmp = f"{path}.{os.getpid()}.tmp"   # several processes may generate the same file: publish atomically
+    if os.path.exists(GENERATOR):
+        import subprocess
+        subprocess.check_call([GENERATOR, "--scale", str(scale), "--edges", str(edges), "--seed", str(seed),
+                               "--limit", str(limit), "--out", tmp], stdout=subprocess.DEVNULL)
+        how = "compiled generator host/rmat_gen"
+    else:
+        V, e1, e2 = rmat_stream(scale, limit, seed)   # the stream is prefix-stable: first `limit` edges
         write_bin(tmp, V, e1, e2)
-        os.replace(tmp, path)
+        how = "numpy generator datagen.rmat_stream"
+    os.replace(tmp, path)
+    return how
+
+
+def ensure_stand_in(key: str, cache_dir: str, limit: int | None = None) -> str:
+    """Make sure the stand-in file (or its ``limit``-edge prefix) exists; returns its path and records
+    whether it was generated now or found cached, with a checksum (``PROVENANCE[path]``)."""
+    cfg = STAND_INS[key]
+    os.makedirs(cache_dir, exist_ok=True)
+    path = stand_in_path(key, cache_dir, limit)
+    n = cfg.edges if limit is None else min(limit, cfg.edges)
+    if os.path.exists(path) and os.path.getsize(path) == 4 + 8 * n:
+        origin = "cached"
+    else:
+        origin = "generated (" + generate_bin(path, cfg.scale, cfg.edges, cfg.seed, limit) + ")"
+    PROVENANCE[path] = {"origin": origin, "checksum": file_checksum(path), "edges": n, "path": path}
+    return path
+
+
+def stand_in_stream(key: str, cache_dir: str | None = None, limit: int | None = None):
+    """``(V, e1, e2, StandIn)`` for a named config; cached as ``.bin`` when asked. With ``limit`` only
+    the first ``limit`` stream edges are produced (a sliding-window run reads W + batches*c of them);
+    ``StandIn.edges`` stays the full stream length, which the workload derivation needs."""
+    cfg = STAND_INS[key]
+    if cache_dir:
+        V, e1, e2 = read_bin(ensure_stand_in(key, cache_dir, limit))
+        return V, e1, e2, cfg
+    V, e1, e2 = rmat_stream(cfg.scale, cfg.edges if limit is None else min(limit, cfg.edges), cfg.seed)
     return V, e1, e2, cfg
+
+
+def ranked_sources(V: int, e1: np.ndarray, e2: np.ndarray, W: int, directed: int, lo: int, hi: int, k: int = 10,
+                   seed: int = 1) -> np.ndarray:
+    """``k`` source vertices sampled from out-degree ranks ``[lo, hi)`` of the initial window -- what
+    ``workload/Workload.cpp:45-55`` writes as the "top1000" file (``lo, hi = 10, 1000``). The
+    reference samples with unseeded ``rand()``; here the draw is a seeded permutation of the rank
+    range so that every run and every rank picks the same ids."""
+    ranked = top_sources(V, e1, e2, W, directed, hi)
+    pick = np.sort(_permutation(hi - lo, seed)[:k]) + lo
+    return ranked[pick].astype(np.int32)
 
 
 def top_sources(V: int, e1: np.ndarray, e2: np.ndarray, W: int, directed: int, k: int = 10) -> np.ndarray:
