@@ -8,12 +8,23 @@ ExecuteMainLoop(1). Batch upload and CSR rebuild are untimed there, so here all
 W+K graph epochs are pre-staged in HBM (dppr_slide) before the timed region and
 the K timed steps run back to back.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config youtube]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config livejournal] [--sources S]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU: independent source vertices shard one per GPU (BASELINE.json
-north_star; no data-path collective), every rank streams the same batches over its
-own replica of the window graph -> weak scaling; value = N * c * K / max-rank time.
+Default workload = BASELINE.json configs[2], the largest single-GPU configuration:
+soc-LiveJournal1 stand-in, directed, -r 0.01 -b 100, the 10 sources of a "top1000" file (ranks
+[10, 1000) of the window out-degree, workload/Workload.cpp:49-51) streamed together over ONE
+replica of the window graph (a source group, dppr_group_update). Other configs by name:
+youtube (configs[1], one top-10 source, the resident single-source path), twitter (configs[3],
+one top-10 source per GPU), friendster (configs[4]), dblp (configs[0]).
+
+Multi-GPU: independent source vertices shard across GPUs (BASELINE.json north_star; no data-path
+collective), every rank streams the same batches over its own replica of the window graph and
+solves ITS sources -> weak scaling; value = (sources summed over ranks) * c * K / max-rank time.
+
+The line also carries `parity` (checked in this very run: |r| < eps and the loop invariant for
+every source at the end of the timed region, max |p_gpu - p_cpu| against the CPU leg's batches),
+`roofline` (dominant kernel, hipEvent-bracketed launches) and `cpu_baseline`.
 """
 from __future__ import annotations
 
@@ -29,24 +40,37 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+NORTH_STAR_TOL = 1e-9   # BASELINE.json: "within the repo's 1e-9 tolerance"
+
+# per config: (sources per GPU, how they are picked)
+PLANS = {
+    "dblp": (1, "top10"), "youtube": (1, "top10"), "livejournal": (10, "top1000"),
+    "twitter": (1, "top10"), "friendster": (2, "top1000"),
+}
+# committed rocprofv3 --pmc summaries (tools/prof_pmc.sh) of the dominant kernel per workload
+PMC_FILES = {
+    ("youtube", 1): ("profiles/r01_final_pmc_traffic_youtube.json", ("k_pull_resident",)),
+    ("livejournal", 10): ("profiles/r02_pmc_traffic_livejournal_group10.json", ("k_gsweep",)),
+}
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="youtube", help="stand-in name (dynamicppr_amd/datagen.py STAND_INS)")
+    ap.add_argument("--config", default="livejournal", help="stand-in name (dynamicppr_amd/datagen.py STAND_INS)")
+    ap.add_argument("--sources", type=int, default=None, metavar="S",
+                    help="sources per GPU (1 = single-source path, 2..16 = one source group); default per config")
+    ap.add_argument("--pick", default=None, choices=["top10", "top1000"], help="source ranks: [0,10) or [10,1000)")
     ap.add_argument("--eps", type=float, default=1e-9)
     ap.add_argument("--schedule", default="eager", choices=["eager", "sync"])
     ap.add_argument("--data-dir", default=os.environ.get("DPPR_DATA", "/tmp/dppr_data"))
     ap.add_argument("--bin", default=None, help="real reference .bin file to use instead of the stand-in")
     ap.add_argument("--directed", type=int, default=None)
-    ap.add_argument("--cpu-batches", type=int, default=12, help="batches timed on the CPU oracle (bounded sample)")
+    ap.add_argument("--cpu-batches", type=int, default=None, help="batches timed on the CPU oracle (bounded sample)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--group", type=int, default=1, metavar="S",
-                    help="solve S (1..8) top-degree sources per GPU together as one source group (multi-source "
-                         "batched sweeps, BASELINE.json configs 3 and 5 style); value counts c*K per source")
+    ap.add_argument("--group", type=int, default=None, help=argparse.SUPPRESS)  # old spelling of --sources
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
                     help="engine tuning knob (hub_min_degree, big_row_edges, pull_min_frontier, chunk_iters, pull_block)")
     return ap.parse_args()
@@ -82,133 +106,56 @@ def main():
             if dist.is_initialized():
                 dist.destroy_process_group()
             dist.init_process_group("gloo")
+    D = dist if world > 1 else None
 
     # ---------------- workload (untimed) ----------------
+    n_steps = a.warmup + a.steps
+    S, pick = PLANS.get(a.config, (1, "top10"))
+    S = a.sources or a.group or S
+    pick = a.pick or pick
     if a.bin:
         V, e1, e2 = datagen.read_bin(a.bin)
+        stream_len = len(e1)
         directed = 1 if a.directed is None else a.directed
-        name, flags = os.path.basename(a.bin), "-n 0 -r 0.01 -b 100"
+        name, flags, provenance = os.path.basename(a.bin), "-n 0 -r 0.01 -b 100", {"origin": "file", "path": a.bin}
     else:
-        V, e1, e2, cfg = datagen.stand_in_stream(a.config, a.data_dir or None)
+        cfg = datagen.STAND_INS[a.config]
+        stream_len = cfg.edges
         directed = cfg.directed if a.directed is None else a.directed
         name, flags = f"{cfg.name} stand-in (R-MAT scale {cfg.scale}, seed {cfg.seed})", cfg.flags
     f = flags.split()
     opt = {f[i]: f[i + 1] for i in range(0, len(f), 2)}
-    cfg_type = int(opt.get("-n", 0))
-    wl = st.workload_config(len(e1), 0.1, cfg_type, float(opt.get("-r", -1.0)), int(opt.get("-b", 0)),
+    wl = st.workload_config(stream_len, 0.1, int(opt.get("-n", 0)), float(opt.get("-r", -1.0)), int(opt.get("-b", 0)),
                             int(opt.get("-c", 0)), int(opt.get("-l", 0)))
     W, c = wl.window, wl.per_batch
-    n_steps = a.warmup + a.steps
-    max_batches = (len(e1) - W) // max(c, 1)
+    max_batches = (stream_len - W) // max(c, 1)
     if n_steps > max_batches:
         sys.exit(f"stream too short for {n_steps} batches (max {max_batches})")
-    sources = datagen.top_sources(V, e1, e2, W, directed, 10)
-    source = shard.assign_sources(sources, rank, world, per_rank=1)[0]   # one top-10 source per GPU
+    if not a.bin:
+        # the run reads W + n_steps * c stream edges: only that prefix of the seeded stream is generated
+        # (rank 0 writes the file, the others wait and read it)
+        need = min(stream_len, W + (n_steps + 1) * c)
+        if rank == 0:
+            datagen.ensure_stand_in(a.config, a.data_dir, need)
+        if D:
+            D.barrier()
+        path = datagen.ensure_stand_in(a.config, a.data_dir, need)
+        provenance = datagen.PROVENANCE[path]
+        V, e1, e2 = datagen.read_bin(path)
+    if pick == "top1000":   # 10 ids sampled from degree ranks [10, 1000): a "top1000" file; every rank its own draw
+        sources = [int(s) for s in datagen.ranked_sources(V, e1, e2, W, directed, 10, 1000, max(S, 10), seed=1 + rank)[:S]]
+    else:                   # the top-10 file, dealt round-robin over the ranks
+        sources = shard.assign_sources(datagen.top_sources(V, e1, e2, W, directed, 10), rank, world, per_rank=S)
 
     schedule = eng.SCHEDULE_EAGER if a.schedule == "eager" else eng.SCHEDULE_SYNC
     tune = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.tune}
     e = eng.Engine(V, W, directed, c, n_epochs=n_steps + 1, device=local_rank, schedule=schedule, **tune)
     ss = st.SlidingStream(V, e1, e2, directed, wl)
-    w1, w2 = ss.serialize_edge_stream()
-    e.load_window(w1, w2)
-    if a.group > 1:
-        return bench_group(a, e, ss, sources, rank, world, W, c, n_steps, V, e1, name, flags, directed, dist, shard, torch)
-    slot = e.add_source(source)
-    init_ms = e.init_solve(slot, a.eps)
+    e.load_window(*ss.serialize_edge_stream())
+    solver = GroupSolver(e, sources) if S > 1 else SingleSolver(e, sources[0])
+    init_ms = solver.init_solve(a.eps)
     L = 0
     for _ in range(n_steps):                      # pre-stage every epoch in HBM
-        assert not ss.stream_updates()
-        b1, b2, ins = ss.batch_arrays()
-        L = len(b1)
-        e.set_batch(b1, b2, ins)
-        n1, n2 = ss.new_arrays()
-        e.slide(n1, n2)
-
-    def device_sync():
-        torch.cuda.synchronize()
-        e.synchronize()
-
-    # ---------------- warmup ----------------
-    for k in range(1, a.warmup + 1):
-        e.update(slot, a.eps, epoch=k)
-    p0, r0 = e.read(slot)                         # state at the start of the timed region
-    e.reset_stats(slot)
-
-    # ---------------- timed region: exactly K steps, barrier + synchronize on both sides ----------------
-    ev = [0.0]
-
-    def run_steps():
-        for k in range(a.warmup + 1, n_steps + 1):
-            ev[0] += e.update(slot, a.eps, epoch=k)
-
-    dt, _ = shard.timed_region(run_steps, device_sync, dist if world > 1 else None)
-    ev_ms = ev[0]
-    stats = e.stats(slot)
-    units = shard.aggregate_units(c * a.steps, dist if world > 1 else None)
-
-    # ---------------- roofline of the dominant kernel (profiled replay of the same K steps) ----------------
-    roof = None
-    cpu = None
-    if rank == 0:
-        e.write(slot, p0, r0)
-        e.reset_stats(slot)
-        e.set_profiling(True)
-        # replay starts from the same converged state, so the batch-tail seeding is valid
-        _force_converged(e, slot, a.eps)
-        for k in range(a.warmup + 1, n_steps + 1):
-            e.update(slot, a.eps, epoch=k)
-        e.set_profiling(False)
-        ps = e.stats(slot)
-        push_bytes = 72 * ps["sum_F"] + 24 * ps["sum_E"] + 4 * ps["sum_N"]
-        achieved = push_bytes / (ps["push_ms"] * 1e-3) / 1e9 if ps["push_ms"] > 0 else 0.0
-        roof = {
-            "bound": "hbm",
-            "kernel": ("k_pull_resident (one launch = a run of frontier iterations, state kept on chip)"
-                       if ps["persist_launches"] else "k_pull_iter / k_push_iter (one frontier iteration)"),
-            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
-            "traffic": pmc_traffic_per_launch(bool(ps["persist_launches"])) if (a.config == "youtube" and not a.bin) else None,
-            "iterations_per_launch": round(ps["iterations"] / max(ps["push_launches"], 1), 2),
-            "launches": ps["push_launches"], "avg_launch_us": round(1e3 * ps["push_ms"] / max(ps["push_launches"], 1), 3),
-            "algorithmic_bytes_per_launch": round(push_bytes / max(ps["push_launches"], 1), 1),
-            "whole_batch_algorithmic_GBps": round(stats["algorithmic_bytes"] / (ev_ms * 1e-3) / 1e9, 2),
-        }
-        if not a.no_cpu_baseline and world == 1:   # the CPU leg runs on rank 0 at N=1 only
-            cpu = cpu_baseline(V, e1, e2, directed, W, c, source, a.eps, a.cpu_batches)
-            bin_path = a.bin or (datagen.stand_in_path(a.config, a.data_dir) if a.data_dir else None)
-            cpu["reference_fifo"] = reference_fifo_baseline(bin_path, directed, flags, source, a.eps, c)
-
-    if rank == 0:
-        value = units / dt
-        line = {
-            "metric": "edge-updates/sec (ppr_throughput); ms_per_step = mean per-batch PPR update time",
-            "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{name}, {'directed' if directed else 'undirected'}, -a 0 -y 1 -w 0.1 {flags} "
-                                   f"-e {a.eps:g}, one top-10 source per GPU",
-                       "V": V, "stream_edges": int(len(e1)), "window": W, "batch_c": c, "records_L": L,
-                       "source": source, "schedule": a.schedule, "parallelism": f"sources x{world} (replicated graph)"},
-            "event_ms_per_step": round(ev_ms / a.steps, 4), "init_solve_ms": round(init_ms, 3),
-            "iterations_per_step": round(stats["iterations"] / a.steps, 2),
-            "pull_iterations_per_step": round(stats["pull_iterations"] / a.steps, 2),
-            "edges_pushed_per_step": round(stats["sum_E"] / a.steps, 1),
-            "roofline": roof, "cpu_baseline": cpu,
-        }
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-
-
-def bench_group(a, e, ss, sources, rank, world, W, c, n_steps, V, e1, name, flags, directed, dist, shard, torch):
-    """--group S: the S top-degree sources of this rank are solved together (dppr_group_*)."""
-    S = a.group
-    mine = [int(sources[(rank * S + k) % len(sources)]) for k in range(S)]
-    gid = e.add_source_group(mine)
-    init_ms = e.group_init_solve(gid, a.eps)
-    L = 0
-    for _ in range(n_steps):
         assert not ss.stream_updates()
         b1, b2, ins = ss.batch_arrays()
         L = len(b1)
@@ -219,86 +166,216 @@ def bench_group(a, e, ss, sources, rank, world, W, c, n_steps, V, e1, name, flag
         torch.cuda.synchronize()
         e.synchronize()
 
+    # ---------------- warmup (untimed); the first batches' results are kept for the parity block ----------------
+    cpu_batches = a.cpu_batches if a.cpu_batches is not None else (12 if stream_len < 10_000_000 else 2)
+    want_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline
+    snaps = []
     for k in range(1, a.warmup + 1):
-        e.group_update(gid, a.eps, epoch=k)
-    base = e.group_stats(gid)
+        solver.update(a.eps, k)
+        if want_cpu and k <= cpu_batches:
+            snaps.append(solver.read(0)[0])
+    solver.begin_timed()
+
+    # ---------------- timed region: exactly K steps, barrier + synchronize on both sides ----------------
     ev = [0.0]
 
     def run_steps():
         for k in range(a.warmup + 1, n_steps + 1):
-            ev[0] += e.group_update(gid, a.eps, epoch=k)
+            ev[0] += solver.update(a.eps, k)
 
-    dt, _ = shard.timed_region(run_steps, device_sync, dist if world > 1 else None)
-    st = e.group_stats(gid)
-    units = shard.aggregate_units(S * c * a.steps, dist if world > 1 else None)
+    dt, _ = shard.timed_region(run_steps, device_sync, D)
+    ev_ms = ev[0]
+    stats = solver.stats()
+    units = shard.aggregate_units(S * c * a.steps, D)
+
+    # ---------------- parity at the end of the timed region: every source of this rank ----------------
+    w1, w2 = ss.serialize_edge_stream()
+    src_e, dst_e = (w1, w2) if directed else (np.concatenate([w1, w2]), np.concatenate([w2, w1]))
+    max_r, max_inv = 0.0, 0.0
+    for i, s in enumerate(sources):
+        p, r = solver.read(i)
+        max_r = max(max_r, float(np.max(np.abs(r))))
+        max_inv = max(max_inv, invariant_max_err(p, r, src_e, dst_e, V, s))
+    parity = {"eps": a.eps, "max_abs_residual": max_r, "invariant_max_err": max_inv, "sources_checked": len(sources),
+              "max_abs_dp_vs_cpu_t1": None, "tolerance": NORTH_STAR_TOL,
+              "ok": bool(max_r < a.eps and max_inv < 1e-12)}
+
+    # ---------------- roofline of the dominant kernel ----------------
+    roof = cpu = None
     if rank == 0:
-        algo = st["algorithmic_bytes"] - base["algorithmic_bytes"]
-        iters = st["iterations"] - base["iterations"]
+        ps = solver.profile(a, n_steps)
+        push_bytes = 72 * ps["sum_F"] + 24 * ps["sum_E"] + 4 * ps["sum_N"]
+        achieved = push_bytes / (ps["push_ms"] * 1e-3) / 1e9 if ps["push_ms"] > 0 else 0.0
+        traffic, traffic_src = pmc_traffic_per_launch(a.config if not a.bin else None, S)
+        roof = {
+            "bound": "hbm", "kernel": solver.kernel_name(ps),
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 5),
+            "traffic": traffic, "traffic_source": traffic_src,
+            "iterations_per_launch": round(ps["iterations"] / max(ps["push_launches"], 1), 2),
+            "launches": ps["push_launches"], "avg_launch_us": round(1e3 * ps["push_ms"] / max(ps["push_launches"], 1), 3),
+            "algorithmic_bytes_per_launch": round(push_bytes / max(ps["push_launches"], 1), 1),
+            "whole_batch_algorithmic_GBps": round(stats["algorithmic_bytes"] / (ev_ms * 1e-3) / 1e9, 2),
+            "note": "achieved = SURVEY.md 8(d) bytes (72 F + 24 E + 4 N, summed over the sources) of the hipEvent-"
+                    "bracketed launches / their time; sparse random 8-byte traffic: the kernel is bound by random-"
+                    "sector throughput of L2 / Infinity Cache / HBM, not by streaming bandwidth (DESIGN.md section 6)",
+        }
+        if want_cpu:
+            cpu = cpu_baseline(V, e1, e2, directed, W, c, sources[0], a.eps, cpu_batches, snaps, stream_len)
+            if cpu.get("max_abs_dp") is not None:
+                parity["max_abs_dp_vs_cpu_t1"] = cpu.pop("max_abs_dp")
+                parity["cpu_batches_compared"] = cpu.pop("compared")
+                parity["ok"] = bool(parity["ok"] and parity["max_abs_dp_vs_cpu_t1"] < NORTH_STAR_TOL)
+            if stream_len < 10_000_000 and not a.bin:   # the reference's own FIFO binary needs the whole file
+                full = datagen.ensure_stand_in(a.config, a.data_dir)
+                cpu["reference_fifo"] = reference_fifo_baseline(full, directed, flags, sources[0], a.eps, c)
+
+    if rank == 0:
+        value = units / dt
         line = {
-            "metric": "edge-updates/sec (ppr_throughput, summed over sources); ms_per_step = per-batch update time of the group",
-            "value": round(units / dt, 1), "unit": "edges/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "metric": "edge-updates/sec (ppr_throughput, summed over sources); ms_per_step = mean per-batch PPR update time",
+            "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{name}, {'directed' if directed else 'undirected'}, -a 0 -y 1 -w 0.1 {flags} "
-                                   f"-e {a.eps:g}, {S} top-degree sources per GPU solved as one group",
-                       "V": V, "stream_edges": int(len(e1)), "window": W, "batch_c": c, "records_L": L,
-                       "sources": mine, "parallelism": f"source groups of {S} x{world} GPUs (replicated graph)"},
-            "event_ms_per_step": round(ev[0] / a.steps, 4), "init_solve_ms": round(init_ms, 3),
-            "iterations_per_step": round(iters / a.steps, 2),
-            "edges_pushed_per_step": round((st["sum_E"] - base["sum_E"]) / a.steps, 1),
-            "roofline": {"bound": "hbm", "kernel": "k_pull_multi (one sweep for all sources)",
-                         "achieved": round(algo / (ev[0] * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(algo / (ev[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None,
-                         "note": "whole timed region (stream update + seeding + sweeps), algorithmic bytes summed over sources"},
-            "cpu_baseline": None,
+                                   f"-e {a.eps:g}, {S} source(s) per GPU from degree ranks "
+                                   f"{'[10,1000) (a top1000 file)' if pick == 'top1000' else '[0,10) (the top10 file)'}"
+                                   + (", streamed together as one source group over one graph replica" if S > 1 else ""),
+                       "V": V, "stream_edges": int(stream_len), "window": W, "batch_c": c, "records_L": L,
+                       "sources": sources, "schedule": a.schedule,
+                       "parallelism": f"{S} source(s) per GPU x {world} GPU(s), replicated graph, no collective",
+                       "stream_file": provenance},
+            "event_ms_per_step": round(ev_ms / a.steps, 4), "init_solve_ms": round(init_ms, 3),
+            "per_source_edges_per_s": round(value / (S * world), 1),
+            "iterations_per_step": round(stats["iterations"] / a.steps, 2),
+            "pull_iterations_per_step": round(stats["pull_iterations"] / a.steps, 2),
+            "edges_pushed_per_step": round(stats["sum_E"] / a.steps, 1),
+            "parity": parity, "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and not parity["ok"]:
+        print(f"PARITY FAILED: {parity}", file=sys.stderr, flush=True)
+        sys.exit(3)
 
 
-def pmc_traffic_per_launch(resident):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of
-    this same workload (tools/prof_pmc.sh -> profiles/r01_final_pmc_traffic_youtube.json; FETCH_SIZE
-    and WRITE_SIZE in separate passes, 2 x FETCH + WRITE per the gfx950 correction of
-    MI355X_MICROARCH.md). bench.py cannot run the profiler on itself, so this is read back;
-    None when the file is missing or was taken with the other kind of launch."""
-    path = os.path.join(ROOT, "profiles", "r01_final_pmc_traffic_youtube.json")
-    if not os.path.exists(path):
-        return None
+class SingleSolver:
+    """One source on the single-source path (dppr_update: resident / per-iteration sweeps, push)."""
+
+    def __init__(self, e, source):
+        self.e, self.source = e, source
+        self.slot = e.add_source(source)
+
+    def init_solve(self, eps):
+        return self.e.init_solve(self.slot, eps)
+
+    def update(self, eps, epoch):
+        return self.e.update(self.slot, eps, epoch=epoch)
+
+    def read(self, i):
+        return self.e.read(self.slot)
+
+    def begin_timed(self):
+        self.p0, self.r0 = self.e.read(self.slot)     # state at the start of the timed region
+        self.e.reset_stats(self.slot)
+
+    def stats(self):
+        return self.e.stats(self.slot)
+
+    def profile(self, a, n_steps):
+        """Replay of the same K steps from the saved state with a hipEvent pair around every launch of
+        the dominant kernel (the extra events would perturb a sub-millisecond timed batch)."""
+        e, slot = self.e, self.slot
+        e.write(slot, self.p0, self.r0)
+        # after dppr_write the engine no longer trusts |r| <= eps; the restored state IS a converged one, so
+        # re-establish that with an empty main-loop pass per phase (a full Inspect that finds nothing)
+        e.execute_main_loop(slot, 0, a.eps)
+        e.execute_main_loop(slot, 1, a.eps)
+        e.reset_stats(slot)
+        e.set_profiling(True)
+        for k in range(a.warmup + 1, n_steps + 1):
+            e.update(slot, a.eps, epoch=k)
+        e.set_profiling(False)
+        return e.stats(slot)
+
+    def kernel_name(self, ps):
+        return ("k_pull_resident (one launch = a run of frontier iterations, state kept on chip)"
+                if ps["persist_launches"] else "k_pull_iter / k_push_iter (one frontier iteration)")
+
+
+class GroupSolver:
+    """2..16 sources solved together (dppr_group_update: multi-source sweeps, k_gsweep)."""
+
+    def __init__(self, e, sources):
+        self.e, self.sources = e, sources
+        self.gid = e.add_source_group(sources)
+
+    def init_solve(self, eps):
+        return self.e.group_init_solve(self.gid, eps)
+
+    def update(self, eps, epoch):
+        return self.e.group_update(self.gid, eps, epoch=epoch)
+
+    def read(self, i):
+        return self.e.group_read(self.gid, i)
+
+    def begin_timed(self):
+        self.e.group_reset_stats(self.gid)
+        self.e.set_profiling(True)    # a sweep takes ~100 us: its event pair does not move the batch time
+
+    def stats(self):
+        return self.e.group_stats(self.gid)
+
+    def profile(self, a, n_steps):
+        self.e.set_profiling(False)
+        return self.e.group_stats(self.gid)    # the timed region's own launches were bracketed
+
+    def kernel_name(self, ps):
+        return "k_gsweep (one frontier iteration of all sources of the group)"
+
+
+def invariant_max_err(p, r, src, dst, V, source, alpha=0.15):
+    """p[u] + a r[u] == a [u==s] + (1-a)/(outdeg(u)+1) * sum_{v in out(u)} p[v]."""
+    outdeg = np.bincount(src, minlength=V)
+    acc = np.bincount(src, weights=p[dst], minlength=V)
+    rhs = (1.0 - alpha) / (outdeg + 1.0) * acc
+    rhs[source] += alpha
+    return float(np.max(np.abs(p + alpha * r - rhs)))
+
+
+def pmc_traffic_per_launch(config, S):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this
+    same workload (tools/prof_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate passes, 2 x FETCH + WRITE
+    per the gfx950 correction of MI355X_MICROARCH.md). bench.py cannot run the profiler on itself, so
+    the figure is read back from profiles/ and labelled with its file; (None, None) when there is none
+    for this workload."""
+    rel, heads = PMC_FILES.get((config, S), (None, ()))
+    path = os.path.join(ROOT, rel) if rel else None
+    if not path or not os.path.exists(path):
+        return None, None
     d = json.load(open(path))
-    heads = ("k_pull_resident",) if resident else ("k_pull_iter", "k_push_iter")
-    tails = heads if resident else heads + ("k_push_big",)
     launches = sum(v["launches"] for k, v in d.items() if k.startswith(heads))
-    total = sum(v["launches"] * v["hbm_bytes_per_launch_corrected"] for k, v in d.items() if k.startswith(tails))
-    return round(total / launches, 1) if launches else None
+    total = sum(v["launches"] * v["hbm_bytes_per_launch_corrected"] for k, v in d.items() if k.startswith(heads))
+    return (round(total / launches, 1), f"committed profile {rel}") if launches else (None, None)
 
 
-def _force_converged(e, slot, eps):
-    """After dppr_write the engine no longer trusts |r| <= eps; the restored state IS a
-    converged one (it was read after a completed update), so re-establish that with an empty
-    main loop pass (a full Inspect that finds nothing)."""
-    e.execute_main_loop(slot, 0, eps)
-    e.execute_main_loop(slot, 1, eps)
-    e.reset_stats(slot)
-
-
-def cpu_baseline(V, e1, e2, directed, W, c, source, eps, batches):
+def cpu_baseline(V, e1, e2, directed, W, c, source, eps, batches, snaps, stream_len):
     """CPU leg (kind "port"): the oracle's restatement of cpu/PPRCPUMTCilkRev, timed with the
     reference's scope (IncExecuteImpl only, cpu/PPRCPUMTCilk.h:131-137) on a bounded sample of
-    the same workload. Headline = all host cores (OpenMP in place of Cilk Plus, which this
-    toolchain lacks); the -t 1 figure is reported beside it."""
+    the same workload: one source, the first `batches` batches after the from-scratch solve, at
+    -t 1 and with OpenMP workers (in place of Cilk Plus, which this toolchain lacks). The -t 1 run's
+    p after every batch is compared with the GPU's (parity block)."""
     from oracle import oracle as orc
     threads = max(1, min(orc.max_threads(), os.cpu_count() or 1))
 
-    def run(nthreads):
-        nonlocal batches
+    def run(nthreads, nb, compare=False):
         g = orc.Graph(V, e1, e2, directed, W, c)
         s = orc.State(V, source, eps)
         s.cilk_execute(g)
-        total, done = 0.0, 0
-        for _ in range(batches):
+        total, done, worst = 0.0, 0, None
+        for k in range(nb):
             if g.stream_updates():
                 break
             g.inc_construct(1)
@@ -309,28 +386,29 @@ def cpu_baseline(V, e1, e2, directed, W, c, source, eps, batches):
                 s.cilk_inc_execute_mt(g, nthreads)
             total += time.perf_counter() - t
             done += 1
-        return total, done
+            if compare and k < len(snaps):
+                worst = max(worst or 0.0, float(np.max(np.abs(snaps[k] - s.p))))
+        return total, done, worst
 
-    t1, n1 = run(1)
-    # the parallel schedule does not scale monotonically (CAS contention on hub vertices, tiny
-    # per-iteration work): try a few worker counts on a short sample and time the best one
-    cands = sorted({t for t in (8, 16, 32, 40, 64) if t <= threads} | ({threads} if threads <= 16 else set()))
-    best, best_rate = 1, n1 / t1 if t1 > 0 else 0.0
-    short = max(2, batches // 4)
-    full = batches
-    for t in cands:
-        batches = short
-        tt, nn = run(t)
-        if tt > 0 and nn / tt > best_rate:
-            best, best_rate = t, nn / tt
-    batches = full
-    threads = best
-    tm, nm = run(threads) if threads > 1 else (t1, n1)
-    return {"value": round(c * nm / tm, 1) if tm > 0 else None, "unit": "edges/s", "cores": threads,
+    t1, n1, worst = run(1, batches, compare=True)
+    # the parallel schedule does not scale monotonically (CAS contention on hub vertices, tiny per-iteration
+    # work on small windows): on small streams try a few worker counts on a short sample and time the best
+    best = min(threads, 16)
+    if stream_len < 10_000_000:
+        cands = sorted({t for t in (8, 16, 32, 40, 64) if t <= threads} | ({threads} if threads <= 16 else set()))
+        best, best_rate = 1, n1 / t1 if t1 > 0 else 0.0
+        for t in cands:
+            tt, nn, _ = run(t, max(2, batches // 4))
+            if tt > 0 and nn / tt > best_rate:
+                best, best_rate = t, nn / tt
+    tm, nm, _ = run(best, batches) if best > 1 else (t1, n1, None)
+    return {"value": round(c * nm / tm, 1) if tm > 0 else None, "unit": "edges/s", "cores": best,
             "kind": "port", "ms_per_step": round(1e3 * tm / max(nm, 1), 2),
             "t1_value": round(c * n1 / t1, 1) if t1 > 0 else None, "t1_ms_per_step": round(1e3 * t1 / max(n1, 1), 2),
-            "sample": f"first {nm} batches of the same stream/source after the from-scratch solve; oracle "
-                      f"restatement of cpu/PPRCPUMTCilkRev with OpenMP workers ({threads} threads) and at -t 1, gcc -O2"}
+            "max_abs_dp": worst, "compared": min(n1, len(snaps)),
+            "sample": f"ONE source ({source}; the GPU value sums all of a rank's sources), first {nm} batches of the same "
+                      f"stream after the from-scratch solve; oracle restatement of cpu/PPRCPUMTCilkRev with OpenMP "
+                      f"workers ({best} threads) and at -t 1, gcc -O2"}
 
 
 def reference_fifo_baseline(bin_path, directed, flags, source, eps, c, batches=4):

@@ -27,6 +27,7 @@ static constexpr int MAX_CHUNK = 64;
 // counters, [7] list scratch / status word of a resident launch; the log of a launch (up to
 // 2 x MAX_CHUNK entries: a whole batch) follows the header
 static constexpr int CNT_HDR = 16;
+static constexpr int PERSIST_RETRY_BATCHES = 64; // after a failed roll-call: batches on per-iteration launches before the next try
 static constexpr int RESIDENT_MARGIN = 8; // sweeps a resident launch is given beyond what the last batch needed
 
 namespace {
@@ -46,6 +47,10 @@ struct Epoch {
     int *grp_tile = nullptr; // V/64 + 2
     int n_groups = 0;
     int grp_n_int = 0;       // internal ids covered by the table
+    // the same for the 16-wide source-group sweep, whose groups hold at most 512 vertices (cut only
+    // once such a group exists)
+    int *ggrp_tile = nullptr;
+    int n_ggroups = 0;
     // hub directory of this epoch (vertices whose pushes are aggregated in LDS)
     int *hub_v = nullptr, *hub_degp1 = nullptr;
     int n_hubs = 0;
@@ -69,6 +74,8 @@ struct Slot {
     IterStats *dstats = nullptr;
     bool converged = false; // |r| <= eps everywhere (state after a completed solve)
     double conv_eps = 0.0;
+    int last_epoch = -2;    // epoch whose batch was applied last (-2: unknown, e.g. after dppr_write: anything goes)
+    bool seed_lists_valid = false; // ft[0]/cnt[0] and neg/cnt[3] hold the lists of the last dppr_incremental_batch_update
     bool phase0_done = false; // ExecuteMainLoop(0) completed since the last modification
     double phase0_eps = 0.0;
     dppr_stats_t st{};
@@ -77,16 +84,23 @@ struct Slot {
     std::vector<int32_t> trace_ids;
 };
 
-// f2: up to 8 sources solved together on interleaved state (dppr_multi.hpp)
+// f2: up to 16 sources solved together on interleaved state (dppr_multi.hpp)
 struct Group {
-    int n = 0;             // sources in use (1..8)
-    int src_ext[GS] = {0}; // ids the caller gave
-    Src8 src{};            // internal ids, -1 = unused lane
-    D8 *p = nullptr, *r = nullptr, *x = nullptr, *x2 = nullptr;
-    int *cnt = nullptr;    // [3][8] rotating frontier sizes, then the per-chunk log [MAX][8]
+    int n = 0;                 // sources in use (1..16)
+    int spl = 1;               // sources per state lane: 1 (<= 8 sources, 64-byte vertex state) or 2 (128-byte)
+    int gw = OCT;              // doubles per vertex = 8 * spl
+    int src_ext[GS_MAX] = {0}; // ids the caller gave
+    SrcN src{};                // internal ids, -1 = unused lane
+    double *p = nullptr, *r = nullptr, *x = nullptr, *x2 = nullptr; // [V][gw]
+    uint32_t *act[2] = {nullptr, nullptr}; // activity bitmaps that go with x / x2
+    size_t act_bytes = 0;
+    int *cnt = nullptr;        // [3][GS_MAX] rotating frontier sizes, then the per-chunk log [MAX][GS_MAX]
     IterStats *dstats = nullptr;
     dppr_stats_t st{};
     int iter_hint[2] = {0, 0};
+    bool converged = false;    // |r| <= conv_eps for every source (state after a completed solve)
+    double conv_eps = 0.0;
+    int last_epoch = -2;       // epoch whose batch was applied last (-2: unknown)
 };
 
 } // namespace
@@ -106,7 +120,8 @@ struct dppr_engine {
     bool chunk_explicit = false; // set by dppr_set_tuning: then it also caps what a resident launch is given
     // resident sweeps (dppr_resident.hpp)
     int persist_mode = 1;              // 1: use resident sweeps when an epoch's groups fit the chip at once
-    bool persist_ok = true;            // cleared after a grid-barrier time-out: per-iteration launches from then on
+    bool persist_ok = true;            // cleared when a roll-call gives up: per-iteration launches until re-armed
+    int persist_retry = 0;             // dppr_update calls until resident launches are tried again (0: not pending)
     int persist_cap = 0;               // co-resident workgroups of k_pull_resident at the sweep's block size
     unsigned long long persist_ticks = 5000000ull; // roll-call time limit in 100 MHz ticks (50 ms)
     int persist_rollcall_extra = 0;    // tests: the roll-call waits for a workgroup that does not exist
@@ -134,6 +149,8 @@ struct dppr_engine {
     void *inc_tmp = nullptr;
     size_t inc_tmp_bytes = 0;
     bool incremental = true; // dppr_slide merges the batch into the sorted keys (false: full re-sort)
+    bool wide_groups = false;       // a source group of more than 8 sources exists: epochs carry the second group table
+    bool group_tail_seeding = true; // source groups seed from the batch tails after a converged solve (false: dense Inspect)
     // stream-update scratch
     uint32_t *su_k[2] = {nullptr, nullptr}, *su_v[2] = {nullptr, nullptr};
     double *su_term = nullptr;
@@ -214,7 +231,7 @@ int cut_sweep_groups(dppr_engine *e, Epoch &ep);
 // dppr_write to an unseen vertex) is not covered by that epoch's sweep groups: re-cut them.
 int recut_stale_groups(dppr_engine *e) {
     for (auto &ep : e->epochs)
-        if (ep.id >= 0 && ep.grp_n_int != e->n_int) {
+        if (ep.id >= 0 && (ep.grp_n_int != e->n_int || (e->wide_groups && ep.n_ggroups == 0))) {
             int rc = cut_sweep_groups(e, ep);
             if (rc) return rc;
         }
@@ -228,6 +245,11 @@ int sync_map(dppr_engine *e) {
     e->map_dirty = false;
     return DPPR_OK;
 }
+
+// A state that has seen the batches up to epoch `last` can only take epoch last + 1 next: skipping or
+// replaying one would leave the batch delta of a whole epoch out of (or twice in) p / r and still
+// "converge" (n_epochs > 1 keeps many epochs resident, so nothing else would notice).
+bool epoch_in_sequence(int last, int id) { return last < 0 || id == last + 1; }
 
 Epoch *find_epoch(dppr_engine *e, int epoch) {
     if (e->newest < 0) return nullptr;
@@ -382,6 +404,28 @@ int cut_sweep_groups(dppr_engine *e, Epoch &ep) {
     ep.grp_n_int = NV;
     HIP_TRY(hipMemcpyAsync(ep.grp_tile, cut.data(), sizeof(int) * cut.size(), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream)); // `cut` is a local
+    ep.n_ggroups = 0;
+    if (e->wide_groups) { // groups of at most 8 tiles for k_gsweep<2, 512>
+        const int gmax = 512 / WAVE;
+        const long long want = std::max<long long>(504, (n_tiles + gmax * 3 / 4 - 1) / std::max(1, gmax * 3 / 4));
+        const long long target = std::max<long long>(1, total_w / want);
+        cut.clear();
+        cut.push_back(0);
+        long long acc = 0;
+        int first = 0;
+        for (int t = 0; t < n_tiles; ++t) {
+            acc += (long long)(e->h_tiles[(size_t)t + 1] - e->h_tiles[(size_t)t]) + 2 * WAVE;
+            if (acc >= target || t + 1 - first == gmax) {
+                cut.push_back(t + 1);
+                first = t + 1;
+                acc = 0;
+            }
+        }
+        if (cut.back() != n_tiles) cut.push_back(n_tiles);
+        ep.n_ggroups = (int)cut.size() - 1;
+        HIP_TRY(hipMemcpyAsync(ep.ggrp_tile, cut.data(), sizeof(int) * cut.size(), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
     return DPPR_OK;
 }
 
@@ -546,6 +590,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 // goes on with per-iteration launches
                 s.st.persist_aborts++;
                 e->persist_ok = false;
+                e->persist_retry = PERSIST_RETRY_BATCHES;
                 continue;
             }
             const int sweeps = status & PERSIST_SWEEPS;
@@ -721,6 +766,7 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
     if (st & PERSIST_ABORTED) { // roll-call failed: nothing was changed, the lists of the stream update stand
         s.st.persist_aborts++;
         e->persist_ok = false;
+        e->persist_retry = PERSIST_RETRY_BATCHES;
         return DPPR_OK;
     }
     if (e->profiling) {
@@ -774,6 +820,7 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
 
 // full Inspect seeding + loop = ExecuteMainLoop(phase)
 int main_loop_inspect(dppr_engine *e, Slot &s, const Epoch &ep, int phase, double eps) {
+    s.seed_lists_valid = false;
     HIP_TRY(hipMemsetAsync(s.cnt, 0, sizeof(int) * 3, e->stream));
     hipLaunchKernelGGL(k_inspect, dim3(grid_for(e->n_int, BLOCK * INSPECT_ITEMS)), dim3(BLOCK), 0, e->stream, s.r,
                        e->n_int, phase, eps, s.ft[0], s.cnt + 0);
@@ -815,56 +862,86 @@ int pull_device_stats(dppr_engine *e, Slot &s) {
 }
 
 // ---------------------------------------------------------------------------- f2: groups
-int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps) {
-    // dense seeding: every legal vertex of every source enters, snapshot taken (k_gseed)
+// One frontier loop of a source group. `tails`: the state was converged before the batch's stream
+// update, so only the batch tails (sorted in su_k[1]) can be legal -- no pass over all vertices.
+int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps, bool tails) {
     int cur = 0;
-    HIP_TRY(hipMemsetAsync(g.cnt, 0, sizeof(int) * 3 * GS, e->stream));
-    hipLaunchKernelGGL(k_gseed, dim3(grid_for(e->n_int)), dim3(BLOCK), 0, e->stream, e->n_int, g.r, g.x, g.p, phase, eps,
-                       g.cnt + cur * GS);
+    const int GWM = GS_MAX;
+    HIP_TRY(hipMemsetAsync(g.cnt, 0, sizeof(int) * 3 * GWM, e->stream));
+    if (tails) {
+        HIP_TRY(hipMemsetAsync(g.act[0], 0, g.act_bytes, e->stream));
+        if (ep.L > 0) {
+            if (g.spl == 1)
+                hipLaunchKernelGGL(k_gseed_tails<1>, dim3(grid_for(ep.L, BLOCK / OCT)), dim3(BLOCK), 0, e->stream, e->su_k[1],
+                                   ep.L, g.r, g.x, g.p, g.act[0], phase, eps, g.cnt + cur * GWM);
+            else
+                hipLaunchKernelGGL(k_gseed_tails<2>, dim3(grid_for(ep.L, BLOCK / OCT)), dim3(BLOCK), 0, e->stream, e->su_k[1],
+                                   ep.L, g.r, g.x, g.p, g.act[0], phase, eps, g.cnt + cur * GWM);
+        }
+    } else {
+        // dense seeding: every legal vertex of every source enters, snapshot taken
+        if (g.spl == 1)
+            hipLaunchKernelGGL(k_gseed_dense<1>, dim3(grid_for(e->n_int, BLOCK / OCT)), dim3(BLOCK), 0, e->stream, e->n_int,
+                               g.r, g.x, g.p, g.act[0], phase, eps, g.cnt + cur * GWM);
+        else
+            hipLaunchKernelGGL(k_gseed_dense<2>, dim3(grid_for(e->n_int, BLOCK / OCT)), dim3(BLOCK), 0, e->stream, e->n_int,
+                               g.r, g.x, g.p, g.act[0], phase, eps, g.cnt + cur * GWM);
+        g.st.inspected += (int64_t)e->n_int * g.n;
+    }
     HIP_TRY(hipGetLastError());
-    g.st.inspected += (int64_t)e->n_int * g.n;
-    int *log = g.cnt + 3 * GS;
+    int *log = g.cnt + 3 * GWM;
     auto any_left = [&](const int *c) {
-        for (int s = 0; s < GS; ++s)
+        for (int s = 0; s < GWM; ++s)
             if (c[s] > 0) return true;
         return false;
     };
-    HIP_TRY(hipMemcpyAsync(e->pinned, g.cnt + cur * GS, sizeof(int) * GS, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->pinned, g.cnt + cur * GWM, sizeof(int) * GWM, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     bool more = any_left(e->pinned);
     int active_iters = 0;
-    const int max_chunk = MAX_CHUNK;
+    const int sweep_grid = std::min(std::max(g.spl == 1 ? ep.n_groups : ep.n_ggroups, 1), 2048);
     for (int it = 0; more;) {
         if (it >= e->max_iters) return fail(e, DPPR_ERR_NOT_CONVERGED, "iteration cap hit");
         int n = g.iter_hint[phase] > it ? g.iter_hint[phase] - it + 1 : e->chunk_iters;
-        n = std::max(1, std::min(n, max_chunk));
+        n = std::max(1, std::min(n, MAX_CHUNK));
         for (int k = 0; k < n; ++k) {
             const int nxt = (cur + 1) % 3, zer = (cur + 2) % 3;
-            hipLaunchKernelGGL(k_pull_multi, dim3(grid_for(e->n_int, GPB, 1024)), dim3(GPB), 0, e->stream, e->n_int,
-                               g.cnt + cur * GS, ep.out_row_ptr, ep.out_col, g.x, g.x2, g.r, g.p, g.cnt + nxt * GS,
-                               g.cnt + zer * GS, phase, eps, g.dstats, log + k * GS,
-                               std::min(e->big_row, PULL_BIG_ROW_DEFAULT));
+            if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k], e->stream));
+            if (g.spl == 1)
+                hipLaunchKernelGGL((k_gsweep<1, 1024>), dim3(sweep_grid), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.grp_tile,
+                                   ep.n_groups, g.cnt + cur * GWM, ep.out_row_ptr, ep.out_col, g.x, g.x2, g.act[0], g.act[1],
+                                   g.r, g.p, g.cnt + nxt * GWM, g.cnt + zer * GWM, phase, eps, g.dstats, log + k * GWM);
+            else
+                hipLaunchKernelGGL((k_gsweep<2, 512>), dim3(sweep_grid), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.ggrp_tile,
+                                   ep.n_ggroups, g.cnt + cur * GWM, ep.out_row_ptr, ep.out_col, g.x, g.x2, g.act[0], g.act[1],
+                                   g.r, g.p, g.cnt + nxt * GWM, g.cnt + zer * GWM, phase, eps, g.dstats, log + k * GWM);
+            if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k + 1], e->stream));
             std::swap(g.x, g.x2);
+            std::swap(g.act[0], g.act[1]);
             cur = nxt;
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(e->pinned, g.cnt, sizeof(int) * (size_t)(3 * GS + n * GS), hipMemcpyDeviceToHost,
+        HIP_TRY(hipMemcpyAsync(e->pinned, g.cnt, sizeof(int) * (size_t)(3 * GWM + n * GWM), hipMemcpyDeviceToHost,
                                e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
         for (int k = 0; k < n; ++k) {
-            const int *f = e->pinned + 3 * GS + k * GS;
+            const int *f = e->pinned + 3 * GWM + k * GWM;
             if (!any_left(f)) continue;
             g.st.iterations++;
             g.st.pull_iterations++;
-            for (int s = 0; s < GS; ++s) g.st.sum_F += f[s];
+            for (int s = 0; s < GWM; ++s) g.st.sum_F += f[s];
             active_iters = it + k + 1;
+            if (e->profiling) {
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, e->evpool[2 * k], e->evpool[2 * k + 1]));
+                g.st.push_ms += ms;
+                g.st.push_launches++;
+            }
         }
-        more = any_left(e->pinned + cur * GS);
+        more = any_left(e->pinned + cur * GWM);
         it += n;
     }
     g.iter_hint[phase] = active_iters;
-    HIP_TRY(hipMemsetAsync(g.x, 0, sizeof(D8) * (size_t)e->n_int, e->stream));
-    HIP_TRY(hipMemsetAsync(g.x2, 0, sizeof(D8) * (size_t)e->n_int, e->stream));
     return DPPR_OK;
 }
 
@@ -877,13 +954,13 @@ int group_stream_update(dppr_engine *e, Group &g, const Epoch &ep) {
     HIP_TRY(rocprim::radix_sort_pairs(e->su_tmp, tmp, e->su_k[0], e->su_k[1], e->su_v[0], e->su_v[1], (size_t)L, 0u,
                                       (unsigned)e->bits, e->stream));
     SuSources srcs{};
-    for (int s = 0; s < GS; ++s) srcs.s[s] = g.src.s[s];
-    // blockIdx.y = source lane; state element (v, lane) at base[v * 8 + lane]
+    for (int s = 0; s < GS_MAX; ++s) srcs.s[s] = g.src.s[s];
+    // blockIdx.y = source lane; state element (v, lane) at base[v * gw + lane]
     hipLaunchKernelGGL(k_su_terms, dim3(grid_for(L), g.n), dim3(BLOCK), 0, e->stream, e->su_k[1], e->su_v[1], ep.b2,
-                       ep.ins, L, reinterpret_cast<const double *>(g.p), GS, e->su_term, e->su_ins);
+                       ep.ins, L, g.p, g.gw, e->su_term, e->su_ins);
     hipLaunchKernelGGL(k_su_apply, dim3(grid_for(L), g.n), dim3(BLOCK), 0, e->stream, e->su_k[1], e->su_v[1], e->su_term,
-                       e->su_ins, ep.deg_after, L, reinterpret_cast<double *>(g.r), GS, srcs, 0.0, (int *)nullptr,
-                       (int *)nullptr, (int *)nullptr, (int *)nullptr);
+                       e->su_ins, ep.deg_after, L, g.r, g.gw, srcs, 0.0, (int *)nullptr, (int *)nullptr, (int *)nullptr,
+                       (int *)nullptr);
     HIP_TRY(hipGetLastError());
     g.st.records += (int64_t)L * g.n;
     return DPPR_OK;
@@ -941,7 +1018,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     HIP_TRY_C(hipEventCreate(&e->ev0));
     HIP_TRY_C(hipEventCreate(&e->ev1));
     for (auto &ev : e->evpool) HIP_TRY_C(hipEventCreate(&ev));
-    HIP_TRY_C(hipHostMalloc((void **)&e->pinned, sizeof(int) * (3 * GS + MAX_CHUNK * GS + 16), hipHostMallocDefault));
+    HIP_TRY_C(hipHostMalloc((void **)&e->pinned, sizeof(int) * (3 * GS_MAX + MAX_CHUNK * GS_MAX + 16), hipHostMallocDefault));
     const size_t Wn = (size_t)std::max(W, 1), Edn = (size_t)std::max(e->Ed, 1), Ln = (size_t)std::max(4 * c, 1);
     HIP_TRY_C(hipMalloc((void **)&e->w1, sizeof(int) * Wn));
     HIP_TRY_C(hipMalloc((void **)&e->w2, sizeof(int) * Wn));
@@ -981,7 +1058,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
         HIP_TRY_C(hipMalloc((void **)&e->su_k[k], sizeof(uint32_t) * Ln));
         HIP_TRY_C(hipMalloc((void **)&e->su_v[k], sizeof(uint32_t) * Ln));
     }
-    HIP_TRY_C(hipMalloc((void **)&e->su_term, sizeof(double) * Ln * GS)); // one term array per source lane of a group
+    HIP_TRY_C(hipMalloc((void **)&e->su_term, sizeof(double) * Ln * GS_MAX)); // one term array per source lane of a group
     HIP_TRY_C(hipMalloc((void **)&e->su_ins, Ln));
     HIP_TRY_C(rocprim::radix_sort_pairs(nullptr, e->su_tmp_bytes, e->su_k[0], e->su_k[1], e->su_v[0], e->su_v[1], Ln,
                                         0u, (unsigned)e->bits, e->stream));
@@ -997,6 +1074,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
         HIP_TRY_C(hipMalloc((void **)&ep.deg_after, sizeof(int) * Ln));
         HIP_TRY_C(hipMalloc((void **)&ep.ins, Ln));
         HIP_TRY_C(hipMalloc((void **)&ep.grp_tile, sizeof(int) * ((size_t)V / WAVE + 3)));
+        HIP_TRY_C(hipMalloc((void **)&ep.ggrp_tile, sizeof(int) * ((size_t)V / WAVE + 3)));
         HIP_TRY_C(hipMalloc((void **)&ep.hub_v, sizeof(int) * HUB_CAP));
         HIP_TRY_C(hipMalloc((void **)&ep.hub_degp1, sizeof(int) * HUB_CAP));
     }
@@ -1016,11 +1094,12 @@ void dppr_destroy(dppr_engine *e) {
     }
     for (auto &g : e->groups) {
         (void)hipFree(g.p); (void)hipFree(g.r); (void)hipFree(g.x); (void)hipFree(g.x2);
+        (void)hipFree(g.act[0]); (void)hipFree(g.act[1]);
         (void)hipFree(g.cnt); (void)hipFree(g.dstats);
     }
     for (auto &ep : e->epochs) {
         (void)hipFree(ep.row_ptr); (void)hipFree(ep.adj); (void)hipFree(ep.out_row_ptr); (void)hipFree(ep.out_col); (void)hipFree(ep.b1); (void)hipFree(ep.b2);
-        (void)hipFree(ep.deg_after); (void)hipFree(ep.ins); (void)hipFree(ep.hub_v); (void)hipFree(ep.hub_degp1); (void)hipFree(ep.grp_tile);
+        (void)hipFree(ep.deg_after); (void)hipFree(ep.ins); (void)hipFree(ep.hub_v); (void)hipFree(ep.hub_degp1); (void)hipFree(ep.grp_tile); (void)hipFree(ep.ggrp_tile);
     }
     (void)hipFree(e->w1); (void)hipFree(e->w2); (void)hipFree(e->outdeg);
     (void)hipFree(e->bar);
@@ -1078,6 +1157,12 @@ int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges, int p
     return DPPR_OK;
 }
 
+int dppr_set_group_seeding(dppr_engine *e, int from_tails) {
+    if (!e) return DPPR_ERR_INVALID;
+    e->group_tail_seeding = from_tails != 0;
+    return DPPR_OK;
+}
+
 int dppr_set_incremental_graph(dppr_engine *e, int on) {
     if (!e) return DPPR_ERR_INVALID;
     e->incremental = on != 0;
@@ -1113,15 +1198,16 @@ int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32
                 }
             }
         }
-        // Large windows: the x[u] gathers of a sweep are random 8-byte reads, and what an XCD's 4 MB L2
-        // keeps of them saves 64-byte sectors on the fabric. Gathers follow the in-degree, which is
-        // heavily skewed (LiveJournal stand-in: the top 524 K of 1.18 M vertices take 95 % of them), so
-        // the HOT_SET vertices of highest in-degree get the first ids -- 4 MB of x, densely packed -- and
-        // everybody else follows; inside both sets the order stays hashed, so long rows are still spread
-        // over the tiles (and a window of at most HOT_SET vertices is numbered exactly as before).
-        // Measured on that stand-in: 73 -> 67 us per sweep (262 K: 68 us, 131 K: no gain).
-        constexpr size_t HOT_SET = 524288;
-        if (fresh.size() > HOT_SET) {
+        // Large windows: the x[u] gathers of a sweep are random reads, and what an XCD's 4 MB L2 keeps of
+        // them saves sectors on the fabric. Gathers follow the in-degree, which is heavily skewed
+        // (LiveJournal stand-in: the 8 K / 32 K / 524 K vertices of highest in-degree, of 1.18 M, take 35 % /
+        // 55 % / 95 % of them), so vertices are numbered in BLOCKS of falling in-degree -- the top 8 K first,
+        // then ranks 8 K..16 K, 16 K..32 K, ... up to 512 K, everybody else last: whatever a vertex's state
+        // measures (8 bytes for one source, 64 / 128 for a source group), the ids that fit an L2 are the
+        // hottest ones. Inside a block the order stays hashed, so long rows are still spread over the
+        // tiles. Measured on that stand-in, single source, two blocks (524 K | rest): 73 -> 67 us per sweep.
+        constexpr size_t HOT_MIN = 8192, HOT_SET = 524288;
+        if (fresh.size() > HOT_MIN) {
             std::vector<int32_t> indeg((size_t)e->V, 0);
             for (int i = 0; i < n; ++i) {
                 indeg[(size_t)e2[i]]++;
@@ -1130,9 +1216,21 @@ int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32
             std::vector<int32_t> d;
             d.reserve(fresh.size());
             for (auto &kv : fresh) d.push_back(indeg[(size_t)kv.second]);
-            std::nth_element(d.begin(), d.begin() + (std::ptrdiff_t)HOT_SET, d.end(), std::greater<int32_t>());
-            const int32_t thr = d[HOT_SET]; // vertices with a larger in-degree are hot (at most HOT_SET of them)
-            for (auto &kv : fresh) kv.first = (kv.first >> 1) | (indeg[(size_t)kv.second] > thr ? 0ull : 1ull << 63);
+            std::vector<int32_t> thr; // in-degree of rank 512 K, 256 K, ..., 8 K (non-decreasing)
+            size_t cur = d.size();
+            for (size_t k = HOT_SET; k >= HOT_MIN; k >>= 1) {
+                if (k >= cur) continue;
+                std::nth_element(d.begin(), d.begin() + (std::ptrdiff_t)k, d.begin() + (std::ptrdiff_t)cur,
+                                 std::greater<int32_t>());
+                thr.push_back(d[k]); // vertices with a larger in-degree belong to the first k (at most k of them)
+                cur = k;
+            }
+            for (auto &kv : fresh) {
+                const int32_t dg = indeg[(size_t)kv.second];
+                uint64_t block = 0; // 0 = hottest
+                for (int32_t t : thr) block += dg <= t ? 1u : 0u;
+                kv.first = (kv.first >> 5) | (block << 59);
+            }
         }
         std::sort(fresh.begin(), fresh.end());
         for (auto &kv : fresh) {
@@ -1183,8 +1281,10 @@ int dppr_set_batch(dppr_engine *e, const int32_t *b1, const int32_t *b2, const u
 }
 
 int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, int32_t *out_epoch) {
-    if (!e || !e->loaded || c < 0 || c > e->W || (c > 0 && (!n1 || !n2)))
-        return fail(e, DPPR_ERR_INVALID, "slide: window not loaded or bad c");
+    // c is bounded by max_batch of dppr_create: the batch key buffers (2 * max_batch keys each) and the
+    // merge scratch are sized for it
+    if (!e || !e->loaded || c < 0 || c > e->W || c > e->c || (c > 0 && (!n1 || !n2)))
+        return fail(e, DPPR_ERR_INVALID, "slide: window not loaded, or c exceeds the window / max_batch of dppr_create");
     HIP_TRY(hipSetDevice(e->device));
     const int W = e->W;
     if (!translate(e, n1, c, e->h_tmp1) || !translate(e, n2, c, e->h_tmp2))
@@ -1311,15 +1411,21 @@ int dppr_init_solve(dppr_engine *e, int32_t slot, double eps, float *out_ms) {
     if (out_ms) *out_ms = ms;
     s.converged = true;
     s.conv_eps = eps;
+    s.last_epoch = ep.id;
     return DPPR_OK;
 }
 
 int dppr_incremental_batch_update(dppr_engine *e, int32_t slot, int32_t epoch) {
     GET_SLOT(e, slot);
     GET_EPOCH(e, epoch);
+    if (!epoch_in_sequence(s.last_epoch, ep.id)) return fail(e, DPPR_ERR_INVALID, "epoch out of sequence for this source");
     HIP_TRY(hipSetDevice(e->device));
-    int rc = stream_update(e, s, ep, 0.0, false);
+    // after a converged solve the update also lists the tails that left [-eps, eps] (dppr_seed_lists)
+    const bool seeded = s.converged;
+    int rc = stream_update(e, s, ep, s.conv_eps, seeded);
     if (rc) return rc;
+    s.seed_lists_valid = seeded;
+    s.last_epoch = ep.id;
     s.converged = false;
     s.phase0_done = false;
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1347,7 +1453,11 @@ int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *
     GET_SLOT(e, slot);
     GET_EPOCH(e, epoch);
     if (!(eps > 0)) return fail(e, DPPR_ERR_INVALID, "eps must be positive");
+    if (!epoch_in_sequence(s.last_epoch, ep.id)) return fail(e, DPPR_ERR_INVALID, "epoch out of sequence for this source");
     HIP_TRY(hipSetDevice(e->device));
+    if (!e->persist_ok && e->persist_mode && e->persist_retry > 0 && --e->persist_retry == 0)
+        e->persist_ok = true; // a resident launch gave up a while ago (the CUs were shared): try them again
+    s.seed_lists_valid = false;
     // Seeding from the batch tails is exact only if every |r| <= eps beforehand
     // (the state a completed solve leaves). Otherwise fall back to full Inspect passes.
     const bool seeded = s.converged && s.conv_eps <= eps;
@@ -1393,6 +1503,7 @@ int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *
     s.st.batches++;
     s.converged = true;
     s.conv_eps = eps;
+    s.last_epoch = ep.id;
     return DPPR_OK;
 }
 
@@ -1435,6 +1546,26 @@ int dppr_write(dppr_engine *e, int32_t slot, const double *p, const double *r) {
     }
     s.converged = false;
     s.phase0_done = false;
+    s.last_epoch = -2; // the caller supplied the state: which batches it contains is the caller's business
+    s.seed_lists_valid = false;
+    return DPPR_OK;
+}
+
+int dppr_seed_lists(dppr_engine *e, int32_t slot, int phase, int32_t *out_ids, int32_t *out_count) {
+    GET_SLOT(e, slot);
+    if (!out_ids || !out_count || (phase != 0 && phase != 1)) return DPPR_ERR_INVALID;
+    if (!s.seed_lists_valid)
+        return fail(e, DPPR_ERR_INVALID, "seed_lists: only right after dppr_incremental_batch_update on a converged state");
+    HIP_TRY(hipSetDevice(e->device));
+    int n = 0;
+    int rc = read_count(e, s.cnt + (phase == 0 ? 0 : 3), &n);
+    if (rc) return rc;
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(out_ids, phase == 0 ? s.ft[0] : s.neg, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    for (int i = 0; i < n; ++i) out_ids[i] = e->int2ext[(size_t)out_ids[i]];
+    *out_count = n;
     return DPPR_OK;
 }
 
@@ -1446,8 +1577,10 @@ int dppr_stats(dppr_engine *e, int32_t slot, dppr_stats_t *out) {
     if (rc) return rc;
     // every enqueued vertex is a frontier member of a later iteration, except the seeds
     s.st.sum_N = s.st.sum_F;
-    s.st.algorithmic_bytes = 16ll * e->V * s.st.batches + 45ll * s.st.records + 72ll * s.st.sum_F +
-                             24ll * s.st.sum_E + 4ll * s.st.sum_N;
+    // SURVEY.md 8(d); its Inspect term (8 bytes per vertex and pass) is counted for the passes that RAN:
+    // after a converged solve the frontier is seeded from the batch tails and no vertex is scanned
+    s.st.algorithmic_bytes = 8ll * s.st.inspected + 45ll * s.st.records + 72ll * s.st.sum_F + 24ll * s.st.sum_E +
+                             4ll * s.st.sum_N;
     *out = s.st;
     return DPPR_OK;
 }
@@ -1566,28 +1699,34 @@ int dppr_trace_get(dppr_engine *e, int32_t slot, int64_t *n_iters, int64_t *n_id
     Group &g = (e)->groups[(size_t)(gid)]
 
 int dppr_add_source_group(dppr_engine *e, const int32_t *sources, int32_t n, int32_t *out_group) {
-    if (!e || !sources || n < 1 || n > GS) return fail(e, DPPR_ERR_INVALID, "add_source_group: 1..8 sources");
+    if (!e || !sources || n < 1 || n > GS_MAX) return fail(e, DPPR_ERR_INVALID, "add_source_group: 1..16 sources");
     HIP_TRY(hipSetDevice(e->device));
     Group g;
     g.n = n;
-    for (int s = 0; s < GS; ++s) g.src.s[s] = -1;
+    g.spl = n > OCT ? 2 : 1;
+    g.gw = OCT * g.spl;
+    if (g.spl == 2) e->wide_groups = true; // (recut_stale_groups below adds the second group table to resident epochs)
+    for (int s = 0; s < GS_MAX; ++s) g.src.s[s] = -1;
     for (int s = 0; s < n; ++s) {
         if (sources[s] < 0 || sources[s] >= e->V) return fail(e, DPPR_ERR_INVALID, "add_source_group: vertex out of range");
         g.src_ext[s] = sources[s];
         g.src.s[s] = to_int(e, sources[s]);
     }
-    const size_t V = (size_t)e->V;
-    HIP_TRY(hipMalloc((void **)&g.p, sizeof(D8) * V));
-    HIP_TRY(hipMalloc((void **)&g.r, sizeof(D8) * V));
-    HIP_TRY(hipMalloc((void **)&g.x, sizeof(D8) * V));
-    HIP_TRY(hipMalloc((void **)&g.x2, sizeof(D8) * V));
-    HIP_TRY(hipMalloc((void **)&g.cnt, sizeof(int) * (3 * GS + MAX_CHUNK * GS)));
+    const size_t V = (size_t)e->V, row = sizeof(double) * (size_t)g.gw;
+    g.act_bytes = (V / 32 + 1024 / 32 + 4) * sizeof(uint32_t);
+    HIP_TRY(hipMalloc((void **)&g.p, row * V));
+    HIP_TRY(hipMalloc((void **)&g.r, row * V));
+    HIP_TRY(hipMalloc((void **)&g.x, row * V));
+    HIP_TRY(hipMalloc((void **)&g.x2, row * V));
+    HIP_TRY(hipMalloc((void **)&g.act[0], g.act_bytes));
+    HIP_TRY(hipMalloc((void **)&g.act[1], g.act_bytes));
+    HIP_TRY(hipMalloc((void **)&g.cnt, sizeof(int) * (3 * GS_MAX + MAX_CHUNK * GS_MAX)));
     HIP_TRY(hipMalloc((void **)&g.dstats, sizeof(IterStats)));
-    HIP_TRY(hipMemsetAsync(g.x, 0, sizeof(D8) * V, e->stream));
-    HIP_TRY(hipMemsetAsync(g.x2, 0, sizeof(D8) * V, e->stream));
-    HIP_TRY(hipMemsetAsync(g.cnt, 0, sizeof(int) * (3 * GS + MAX_CHUNK * GS), e->stream));
+    HIP_TRY(hipMemsetAsync(g.act[0], 0, g.act_bytes, e->stream));
+    HIP_TRY(hipMemsetAsync(g.act[1], 0, g.act_bytes, e->stream));
+    HIP_TRY(hipMemsetAsync(g.cnt, 0, sizeof(int) * (3 * GS_MAX + MAX_CHUNK * GS_MAX), e->stream));
     HIP_TRY(hipMemsetAsync(g.dstats, 0, sizeof(IterStats), e->stream));
-    hipLaunchKernelGGL(k_ginit, dim3(grid_for(e->V)), dim3(BLOCK), 0, e->stream, g.p, g.r, e->V, g.src);
+    hipLaunchKernelGGL(k_ginit, dim3(grid_for((int64_t)e->V * g.gw)), dim3(BLOCK), 0, e->stream, g.p, g.r, e->V, g.gw, g.src);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->groups.push_back(g);
@@ -1602,15 +1741,19 @@ int dppr_group_init_solve(dppr_engine *e, int32_t group, double eps, float *out_
     if (!(eps > 0)) return fail(e, DPPR_ERR_INVALID, "eps must be positive");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    hipLaunchKernelGGL(k_ginit, dim3(grid_for(e->V)), dim3(BLOCK), 0, e->stream, g.p, g.r, e->V, g.src);
+    hipLaunchKernelGGL(k_ginit, dim3(grid_for((int64_t)e->V * g.gw)), dim3(BLOCK), 0, e->stream, g.p, g.r, e->V, g.gw, g.src);
     HIP_TRY(hipGetLastError());
-    int rc = group_loop(e, g, ep, 0, eps);
+    g.converged = false;
+    int rc = group_loop(e, g, ep, 0, eps, false);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
     HIP_TRY(hipEventSynchronize(e->ev1));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
     if (out_ms) *out_ms = ms;
+    g.converged = true; // r = e_s >= 0 and phase 0 left every r <= eps: nothing is below -eps
+    g.conv_eps = eps;
+    g.last_epoch = ep.id;
     return DPPR_OK;
 }
 
@@ -1618,13 +1761,17 @@ int dppr_group_update(dppr_engine *e, int32_t group, int32_t epoch, double eps, 
     GET_GROUP(e, group);
     GET_EPOCH(e, epoch);
     if (!(eps > 0)) return fail(e, DPPR_ERR_INVALID, "eps must be positive");
+    if (!epoch_in_sequence(g.last_epoch, ep.id)) return fail(e, DPPR_ERR_INVALID, "epoch out of sequence for this group");
     HIP_TRY(hipSetDevice(e->device));
+    // seeding from the batch tails is exact only if every |r| <= eps beforehand (dppr_update has the same rule)
+    const bool tails = g.converged && g.conv_eps <= eps && e->group_tail_seeding;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
     int rc = group_stream_update(e, g, ep);
     if (rc) return rc;
-    rc = group_loop(e, g, ep, 0, eps);
+    g.converged = false;
+    rc = group_loop(e, g, ep, 0, eps, tails);
     if (rc) return rc;
-    rc = group_loop(e, g, ep, 1, eps);
+    rc = group_loop(e, g, ep, 1, eps, tails);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
     HIP_TRY(hipEventSynchronize(e->ev1));
@@ -1633,6 +1780,9 @@ int dppr_group_update(dppr_engine *e, int32_t group, int32_t epoch, double eps, 
     if (out_ms) *out_ms = ms;
     g.st.gpu_ms += ms;
     g.st.batches++;
+    g.converged = true;
+    g.conv_eps = eps;
+    g.last_epoch = ep.id;
     return DPPR_OK;
 }
 
@@ -1642,15 +1792,24 @@ int dppr_group_read(dppr_engine *e, int32_t group, int32_t index, double *p, dou
     HIP_TRY(hipSetDevice(e->device));
     int rc = sync_map(e);
     if (rc) return rc;
-    const D8 *src[2] = {g.p, g.r};
+    const double *src[2] = {g.p, g.r};
     double *dst[2] = {p, r};
     for (int k = 0; k < 2; ++k) {
         if (!dst[k]) continue;
-        hipLaunchKernelGGL(k_gint_to_ext, dim3(grid_for(e->V)), dim3(BLOCK), 0, e->stream, src[k], index, e->d_ext2int,
+        hipLaunchKernelGGL(k_gint_to_ext, dim3(grid_for(e->V)), dim3(BLOCK), 0, e->stream, src[k], g.gw, index, e->d_ext2int,
                            e->V, e->d_xfer);
         HIP_TRY(hipMemcpyAsync(dst[k], e->d_xfer, sizeof(double) * (size_t)e->V, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
+    return DPPR_OK;
+}
+
+int dppr_group_reset_stats(dppr_engine *e, int32_t group) {
+    GET_GROUP(e, group);
+    HIP_TRY(hipSetDevice(e->device));
+    g.st = dppr_stats_t{};
+    HIP_TRY(hipMemsetAsync(g.dstats, 0, sizeof(IterStats), e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return DPPR_OK;
 }
 
@@ -1665,8 +1824,8 @@ int dppr_group_stats(dppr_engine *e, int32_t group, dppr_stats_t *out) {
     for (int i = 0; i < STAT_SLOTS; ++i) t += h.blk_E[i];
     g.st.sum_E = (int64_t)t;
     g.st.sum_N = g.st.sum_F;
-    g.st.algorithmic_bytes = 16ll * e->V * g.st.batches * g.n + 45ll * g.st.records + 72ll * g.st.sum_F +
-                             24ll * g.st.sum_E + 4ll * g.st.sum_N;
+    g.st.algorithmic_bytes = 8ll * g.st.inspected + 45ll * g.st.records + 72ll * g.st.sum_F + 24ll * g.st.sum_E +
+                             4ll * g.st.sum_N;
     *out = g.st;
     return DPPR_OK;
 }

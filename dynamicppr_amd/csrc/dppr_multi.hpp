@@ -1,311 +1,425 @@
 // dppr_multi.hpp -- f2: multi-source batched sweeps.
 //
 // Several source vertices that share one device graph (BASELINE.json configs 3 and 5 run 10 of
-// them) are solved TOGETHER: their state is interleaved 8-wide, p/r/x[v] = 8 doubles = one
-// 64-byte sector. One sweep then reads every out_col entry once, computes every edge's owner
-// once and gathers ONE sector per edge for all 8 sources -- a single-source sweep pulls the same
-// sector for 8 useful bytes. The per-source arithmetic is exactly that of k_pull_iter
-// (rv += (1.0-ALPHA)*x[u]/(outdeg(v)+1) in CSR order, rv -= x[v], threshold, next snapshot).
-// Group iterations are always dense (the sweep's cost is shared by 8 sources, so sparse push
-// iterations are not worth a second code path): seeding is a dense pass too.
+// them) are solved TOGETHER. Their state is interleaved GW-wide, p/r/x[v] = GW doubles: one
+// 64-byte sector for up to 8 sources (SPL = 1), one 128-byte line for up to 16 (SPL = 2). A sweep
+// reads every out_col entry once and one sector (line) per ACTIVE edge for all sources -- a
+// single-source sweep pulls the same sector for 8 useful bytes.
+//
+// Per source the arithmetic is that of k_pull_iter (dppr_pull.hpp), i.e. what the pushes u -> v of
+// gpu/ExpandRev.cuh:70-73 plus the repair of :708-743 leave in residual[v]:
+//     rn = residual[v] + sum_{u in out(v), x[u] != 0} (1.0-ALPHA) * x[u] / (outdeg(v)+1);  rn -= x[v]
+// then the legal-push test and the next snapshot (x_new[v] = rn, pagerank[v] += ALPHA*rn).
+//
+// How a sweep is laid out on the machine (k_gsweep):
+//  * ACTIVITY BITMAP. bit v of `act` says "some source has x[v] != 0". It is one bit per vertex
+//    (LiveJournal stand-in: 150 KB; friendster: 16 MB), so it lives in L2 where x (75 MB .. 17 GB)
+//    does not. An edge whose head is inactive costs its 4-byte out_col entry and one bit test, no
+//    gather; a vertex that received nothing and is not in the frontier is not touched at all (no
+//    residual read, no snapshot write): x[v] is only meaningful where the bit is set, and nothing
+//    is ever zero-filled. Late iterations of a batch (small frontiers) therefore cost the stream of
+//    out_col, not a full sweep -- the reference's gpu/ExpandRev.cuh:70-77 has no counterpart because
+//    it pushes, at the price of one atomic per edge.
+//  * OCTETS. Eight consecutive lanes serve one edge at a time: lane j holds sources j*SPL.., so
+//    the gather of x[u] is ONE coalesced 64-byte (128-byte) request, not 64 lanes x 64 bytes.
+//  * EDGE-BALANCED SLICES. A workgroup owns a sweep group (<= 1024 consecutive vertices, cut by the
+//    graph builder for equal weight); their out-rows are one contiguous range of out_col, which is
+//    split evenly over the workgroup's 128 octets whatever the degree distribution (a hub's row
+//    is simply shared by many octets). An octet walks its slice in order with a cursor over the
+//    group's non-empty rows (compacted in LDS), keeps the running sum of the current row in
+//    registers and adds it to the row's LDS accumulator once, when the row (or the slice) ends:
+//    one LDS atomic per row piece instead of one per edge and source.
+//  * The vertex side (repair, threshold, next snapshot) is octet-cooperative too: 64/128-byte
+//    coalesced accesses, only for vertices that were touched.
 #pragma once
 
 #include "dppr_kernels.hpp"
 
 namespace dppr {
 
-constexpr int GS = 8; // sources per group = doubles per 64-byte sector
+constexpr int GS_MAX = 16;      // sources per group (SPL = 2); 8 with SPL = 1
+constexpr int OCT = 8;          // lanes that serve one edge / one vertex together
 
-struct alignas(64) D8 {
-    double v[GS];
-};
-struct Src8 {
-    int s[GS]; // internal source vertex per lane of the group, -1 = unused lane
+struct SrcN {
+    int s[GS_MAX]; // internal source vertex per state lane, -1 = unused lane
 };
 
-// r = e_s per source, p = 0
-__global__ __launch_bounds__(BLOCK) void k_ginit(D8 *__restrict__ p, D8 *__restrict__ r, int V, Src8 src) {
-    for (int v = blockIdx.x * BLOCK + threadIdx.x; v < V; v += gridDim.x * BLOCK) {
-        D8 z, e;
-#pragma unroll
-        for (int s = 0; s < GS; ++s) {
-            z.v[s] = 0.0;
-            e.v[s] = (src.s[s] == v) ? 1.0 : 0.0;
-        }
-        p[v] = z;
-        r[v] = e;
+__device__ __forceinline__ unsigned oct_mask(uint64_t ballot) { // the 8 ballot bits of this lane's octet
+    return (unsigned)(ballot >> (lane_id() & ~(OCT - 1))) & 0xffu;
+}
+
+// r = e_s per source, p = 0. One thread per (vertex, state lane).
+__global__ __launch_bounds__(BLOCK) void k_ginit(double *__restrict__ p, double *__restrict__ r, int V, int gw, SrcN src) {
+    const int64_t n = (int64_t)V * gw;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const int v = (int)(i / gw), s = (int)(i % gw);
+        p[i] = 0.0;
+        r[i] = (src.s[s] == v) ? 1.0 : 0.0;
     }
 }
 
 // Dense seeding of a phase: Inspect (gpu/Inspect.cuh:8-48) + the snapshot head of ExpandUnifiedRev
-// (gpu/ExpandRev.cuh:34-42) for every source at once: x[v][s] = legal(r) ? r : 0, p += ALPHA*r.
-__global__ __launch_bounds__(BLOCK) void k_gseed(int V, const D8 *__restrict__ r, D8 *__restrict__ x, D8 *__restrict__ p,
-                                                 int phase, double eps, int *__restrict__ cnt_out) {
-    __shared__ int s_cnt[WAVES_PER_BLOCK][GS];
-    int n_legal[GS];
-#pragma unroll
-    for (int s = 0; s < GS; ++s) n_legal[s] = 0;
-    for (int v = blockIdx.x * BLOCK + threadIdx.x; v < V; v += gridDim.x * BLOCK) {
-        const D8 rv = r[v];
-        D8 xn;
-        bool any = false;
-#pragma unroll
-        for (int s = 0; s < GS; ++s) {
-            const bool lg = legal(rv.v[s], phase, eps);
-            xn.v[s] = lg ? rv.v[s] : 0.0;
-            n_legal[s] += lg ? 1 : 0;
-            any |= lg;
-        }
-        x[v] = xn;
-        if (any) {
-            D8 pv = p[v];
-#pragma unroll
-            for (int s = 0; s < GS; ++s) pv.v[s] += ALPHA * xn.v[s];
-            p[v] = pv;
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < GS; ++s) {
-        const int t = wave_inclusive_scan(n_legal[s]);
-        if (lane_id() == WAVE - 1) s_cnt[wave_id()][s] = t;
-    }
+// (gpu/ExpandRev.cuh:34-42) for every source at once: where some source is legal, x[v][s] =
+// legal(r) ? r : 0 for all s, p += ALPHA*x, and the vertex's activity bit is set. Writes the
+// complete bitmap (every word up to V). Octet per vertex.
+template <int SPL>
+__global__ __launch_bounds__(BLOCK) void k_gseed_dense(int V, const double *__restrict__ r, double *__restrict__ x,
+                                                       double *__restrict__ p, uint32_t *__restrict__ act, int phase,
+                                                       double eps, int *__restrict__ cnt_out) {
+    constexpr int GW = OCT * SPL;
+    __shared__ int s_cnt[GS_MAX];
+    if (threadIdx.x < GS_MAX) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    if (threadIdx.x < GS) {
-        int tot = 0;
-        for (int k = 0; k < WAVES_PER_BLOCK; ++k) tot += s_cnt[k][threadIdx.x];
-        if (tot) atomicAdd(&cnt_out[threadIdx.x], tot);
+    const int j = threadIdx.x & (OCT - 1);
+    int nleg[SPL];
+#pragma unroll
+    for (int q = 0; q < SPL; ++q) nleg[q] = 0;
+    uint8_t *act8 = reinterpret_cast<uint8_t *>(act);
+    const int vper = BLOCK / OCT; // vertices per workgroup pass
+    const int Vpad = (V + 7) & ~7;
+    for (int vb = blockIdx.x * vper; vb < Vpad; vb += gridDim.x * vper) { // workgroup-uniform trip count
+        const int v = vb + (int)threadIdx.x / OCT;
+        bool any = false;
+        double rv[SPL];
+        bool lg[SPL];
+#pragma unroll
+        for (int q = 0; q < SPL; ++q) {
+            rv[q] = v < V ? r[(size_t)v * GW + j * SPL + q] : 0.0;
+            lg[q] = v < V && legal(rv[q], phase, eps);
+            any |= lg[q];
+            nleg[q] += lg[q] ? 1 : 0;
+        }
+        const uint64_t bal = __ballot(any);
+        const unsigned m = oct_mask(bal);
+        if (m) {
+#pragma unroll
+            for (int q = 0; q < SPL; ++q) {
+                const size_t i = (size_t)v * GW + j * SPL + q;
+                x[i] = lg[q] ? rv[q] : 0.0;
+                if (lg[q]) p[i] = p[i] + ALPHA * rv[q];
+            }
+        }
+        // one activity byte per wave pass: bit k = octet k's vertex
+        if (lane_id() == 0) {
+            unsigned byte = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) byte |= ((bal >> (k * OCT)) & 0xffull) ? (1u << k) : 0u;
+            const int v0 = vb + wave_id() * 8;
+            if (v0 < Vpad) act8[v0 >> 3] = (uint8_t)byte;
+        }
     }
+#pragma unroll
+    for (int q = 0; q < SPL; ++q)
+        if (nleg[q]) atomicAdd(&s_cnt[j * SPL + q], nleg[q]);
+    __syncthreads();
+    if (threadIdx.x < GW && s_cnt[threadIdx.x]) atomicAdd(&cnt_out[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
-constexpr int GPB = 512; // workgroup = 512 consecutive vertices (LDS: 32 KiB of per-vertex accumulators)
-constexpr int GPU_SLOTS = 2; // sector gathers in flight per lane
+// Seeding from the batch tails (valid after a converged solve plus a stream update: only tails of
+// batch records can have left [-eps, eps]; cpu/PPRCPUMTCilkRev.h:126-156 seeds from the batch
+// endpoints for the same reason). skeys = the batch's tails, sorted; an octet takes the first
+// record of each tail. `act` must be all zero on entry.
+template <int SPL>
+__global__ __launch_bounds__(BLOCK) void k_gseed_tails(const uint32_t *__restrict__ skeys, int L, const double *__restrict__ r,
+                                                       double *__restrict__ x, double *__restrict__ p,
+                                                       uint32_t *__restrict__ act, int phase, double eps,
+                                                       int *__restrict__ cnt_out) {
+    constexpr int GW = OCT * SPL;
+    __shared__ int s_cnt[GS_MAX];
+    if (threadIdx.x < GS_MAX) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int j = threadIdx.x & (OCT - 1);
+    int nleg[SPL];
+#pragma unroll
+    for (int q = 0; q < SPL; ++q) nleg[q] = 0;
+    const int per = BLOCK / OCT;
+    const int Lpad = (L + per - 1) / per * per;
+    for (int i0 = blockIdx.x * per; i0 < Lpad; i0 += gridDim.x * per) {
+        const int i = i0 + (int)threadIdx.x / OCT;
+        int u = -1;
+        if (i < L) {
+            u = (int)skeys[i];
+            if (i > 0 && (int)skeys[i - 1] == u) u = -1; // not the group leader
+        }
+        bool any = false;
+        double rv[SPL];
+        bool lg[SPL];
+#pragma unroll
+        for (int q = 0; q < SPL; ++q) {
+            rv[q] = u >= 0 ? r[(size_t)u * GW + j * SPL + q] : 0.0;
+            lg[q] = u >= 0 && legal(rv[q], phase, eps);
+            any |= lg[q];
+            nleg[q] += lg[q] ? 1 : 0;
+        }
+        if (oct_mask(__ballot(any))) {
+#pragma unroll
+            for (int q = 0; q < SPL; ++q) {
+                const size_t k = (size_t)u * GW + j * SPL + q;
+                x[k] = lg[q] ? rv[q] : 0.0;
+                if (lg[q]) p[k] = p[k] + ALPHA * rv[q];
+            }
+            if (j == 0) atomicOr(&act[u >> 5], 1u << (u & 31));
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < SPL; ++q)
+        if (nleg[q]) atomicAdd(&s_cnt[j * SPL + q], nleg[q]);
+    __syncthreads();
+    if (threadIdx.x < GW && s_cnt[threadIdx.x]) atomicAdd(&cnt_out[threadIdx.x], s_cnt[threadIdx.x]);
+}
 
-__global__ __launch_bounds__(GPB) void k_pull_multi(int V, const int *__restrict__ cnt_in,
-                                                    const int *__restrict__ out_row_ptr,
-                                                    const int *__restrict__ out_col, const D8 *__restrict__ x,
-                                                    D8 *__restrict__ x_new, D8 *__restrict__ r, D8 *__restrict__ p,
-                                                    int *__restrict__ cnt_out, int *__restrict__ cnt_zero, int phase,
-                                                    double eps, IterStats *__restrict__ stats,
-                                                    int *__restrict__ log_slot, int pull_big_row) {
-    constexpr int NW = GPB / WAVE;
-    constexpr int PUM = GPU_SLOTS;
-    __shared__ int s_own[NW][WAVE * PUM];
-    __shared__ int s_scan[NW][WAVE + 1];
-    __shared__ int s_start[NW][WAVE];
-    __shared__ double s_acc[NW][GS * WAVE]; // [source][lane]: conflict-free for lane-contiguous access
-    __shared__ int s_cnt[NW][GS];
-    __shared__ unsigned long long s_edges[NW];
-    __shared__ int s_bigv[PULL_BIG_CAP], s_bigrs[PULL_BIG_CAP], s_bigd[PULL_BIG_CAP];
-    __shared__ double s_bigacc[PULL_BIG_CAP][GS];
-    __shared__ int s_chunk0[NW][WAVE + 1];
-    __shared__ int s_nbig;
-    const int lane = lane_id(), w = wave_id();
-    // frontier sizes of the 8 sources; the group iterates while ANY of them is non-empty
-    const int my_cnt = lane < GS ? cnt_in[lane] : 0;
-    if (blockIdx.x == 0 && threadIdx.x < GS) {
-        cnt_zero[threadIdx.x] = 0;
-        log_slot[threadIdx.x] = my_cnt;
+// (1.0-ALPHA)*x/den, bit for bit, without the ~11-instruction f64 division sequence per edge and
+// source: with rcp = RN(1/den) (one true division per ROW), q0 = a*rcp is within an ulp of a/den, the
+// remainder r = a - q0*den is exact in an FMA, and q0 + r*rcp rounds to RN(a/den) (Markstein's
+// correction step; den = outdeg+1 is a small integer, never an all-ones significand).
+// tests/test_exact_division.py checks the identity on 2e7 random operands.
+__device__ __forceinline__ double push_term(double x, double den, double rcp) {
+    const double a = ONE_MINUS_ALPHA * x;
+    const double q0 = a * rcp;
+    const double rem = __builtin_fma(-q0, den, a);
+    return __builtin_fma(rem, rcp, q0);
+}
+
+// One frontier iteration (ExpandUnifiedRev + RepairFrontierRev) for all sources of a group.
+// NVX = vertices per sweep group (the LDS accumulators are NVX x GW doubles: 64 KB for both
+// instantiations, two 1024-thread workgroups per CU).
+constexpr int GNT = 1024; // threads per workgroup of k_gsweep
+template <int SPL, int NVX>
+__global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict__ grp_tile, int n_groups,
+                                                   const int *__restrict__ cnt_in, const int *__restrict__ out_row_ptr,
+                                                   const int *__restrict__ out_col, const double *__restrict__ x,
+                                                   double *__restrict__ x_new, const uint32_t *__restrict__ act_in,
+                                                   uint32_t *__restrict__ act_out, double *__restrict__ r,
+                                                   double *__restrict__ p, int *__restrict__ cnt_out,
+                                                   int *__restrict__ cnt_zero, int phase, double eps,
+                                                   IterStats *__restrict__ stats, int *__restrict__ log_slot) {
+    constexpr int GW = OCT * SPL, NW = GNT / WAVE, NOCT = GNT / OCT, WORDS = NVX / 32;
+    constexpr int EB = 8;        // edges an octet tests per step (one per lane)
+    constexpr int GB = EB / SPL; // ... and gathers per sub-step (registers: GB x SPL doubles)
+    constexpr int FU = 4 / SPL;  // vertices an octet finishes per step
+    static_assert(NVX % NOCT == 0 && (NVX / NOCT) % FU == 0, "vertex phase covers the group in whole steps");
+    __shared__ double s_acc[NVX * GW];   // per vertex and source: sum of this sweep's adds (zero between groups)
+    __shared__ int s_cstart[NVX + 1];    // non-empty rows of the group, compacted: first edge (relative)
+    __shared__ unsigned short s_cvid[NVX]; // ... and the row's local vertex index
+    __shared__ int s_ostart[NOCT];       // compacted row in which each octet's slice begins
+    __shared__ uint32_t s_actin[WORDS], s_actout[WORDS], s_touched[WORDS];
+    __shared__ int s_wcnt[NW];
+    __shared__ int s_cnt[GS_MAX];
+    __shared__ unsigned long long s_edges;
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int j = tid & (OCT - 1), oid = tid / OCT;
+
+    // frontier sizes of the sources; the group iterates while ANY of them is non-empty
+    const int my_cnt = lane < GW ? cnt_in[lane] : 0;
+    if (blockIdx.x == 0 && tid < GW) {
+        cnt_zero[tid] = 0;
+        log_slot[tid] = my_cnt;
     }
     if (__ballot(my_cnt != 0) == 0) return;
-    int n_legal[GS];
+    for (int k = tid; k < NVX * GW; k += GNT) s_acc[k] = 0.0;
+    if (tid < WORDS) {
+        s_actout[tid] = 0u;
+        s_touched[tid] = 0u;
+    }
+    if (tid < GS_MAX) s_cnt[tid] = 0;
+    if (tid == 0) s_edges = 0ull;
+    int nleg[SPL];
 #pragma unroll
-    for (int s = 0; s < GS; ++s) n_legal[s] = 0;
-    unsigned long long edges = 0;
+    for (int q = 0; q < SPL; ++q) nleg[q] = 0;
+    unsigned ecount = 0;
 
-    // repair, threshold, next snapshot for one vertex, all sources (acc = residual + gathered adds)
-    auto finish = [&](bool valid, int v, const D8 &acc) {
-        if (!valid) return;
-        const D8 xv = x[v];
-        D8 rn, xn;
-        bool any = false;
-#pragma unroll
-        for (int s = 0; s < GS; ++s) {
-            double t = acc.v[s];
-            if (xv.v[s] != 0.0) t -= xv.v[s];
-            const bool lg = legal(t, phase, eps);
-            rn.v[s] = t;
-            xn.v[s] = lg ? t : 0.0;
-            n_legal[s] += lg ? 1 : 0;
-            any |= lg;
-        }
-        r[v] = rn;
-        x_new[v] = xn;
-        if (any) {
-            D8 pv = p[v];
-#pragma unroll
-            for (int s = 0; s < GS; ++s) pv.v[s] += ALPHA * xn.v[s];
-            p[v] = pv;
-        }
-    };
-
-    const int n_groups = (V + GPB - 1) / GPB;
     for (int g = blockIdx.x; g < n_groups; g += gridDim.x) { // workgroup-uniform loop
-        if (threadIdx.x == 0) s_nbig = 0;
-        __syncthreads();
-        const int v = (g * NW + w) * WAVE + lane;
-        const bool valid = v < V;
+        __syncthreads(); // the previous group's tables are no longer read; the initial fills are in place
+        const int t0 = grp_tile[g], t1 = grp_tile[g + 1];
+        const int v0 = t0 * WAVE;
+        const int nv = min((t1 - t0) * WAVE, V - v0); // <= NVX: the builder cuts these groups for this kernel
+        const int E0 = out_row_ptr[v0];
+        const int Eg = out_row_ptr[v0 + nv] - E0;
         int rs = 0, d = 0;
-        D8 rv;
-#pragma unroll
-        for (int s = 0; s < GS; ++s) rv.v[s] = 0.0;
-        if (valid) {
-            rs = out_row_ptr[v];
-            d = out_row_ptr[v + 1] - rs;
-            rv = r[v];
+        if (tid < nv) {
+            rs = out_row_ptr[v0 + tid] - E0;
+            d = out_row_ptr[v0 + tid + 1] - E0 - rs;
         }
-        bool deferred = false;
-        if (d >= pull_big_row) {
-            const int slot = atomicAdd(&s_nbig, 1);
-            if (slot < PULL_BIG_CAP) {
-                s_bigv[slot] = v;
-                s_bigrs[slot] = rs;
-                s_bigd[slot] = d;
-#pragma unroll
-                for (int s = 0; s < GS; ++s) s_bigacc[slot][s] = 0.0;
-                deferred = true;
-            }
-        }
-        const int dd = deferred ? 0 : d;
-        const int incl = wave_inclusive_scan(dd);
-        const int scan_ex = incl - dd;
-        const int total = __builtin_amdgcn_readlane(incl, WAVE - 1);
-        s_scan[w][lane] = scan_ex;
-        s_start[w][lane] = rs;
-        if (lane == 0) s_scan[w][WAVE] = total;
-#pragma unroll
-        for (int s = 0; s < GS; ++s) s_acc[w][s * WAVE + lane] = rv.v[s];
-
-        // ---- short rows: same owner scheme as k_pull_iter (marks + max-scan), one sector per edge
-        for (int e0 = 0; e0 < total; e0 += WAVE * PUM) {
-#pragma unroll
-            for (int k = 0; k < PUM; ++k) s_own[w][k * WAVE + lane] = -1;
-            __builtin_amdgcn_wave_barrier();
-            const int pos = scan_ex - e0;
-            if (dd > 0 && pos >= 0 && pos < WAVE * PUM) s_own[w][pos] = lane;
-            __builtin_amdgcn_wave_barrier();
-            const uint64_t before = __ballot(dd > 0 && scan_ex <= e0);
-            int carry = before ? 63 - __clzll(before) : -1;
-            int own[PUM], col[PUM];
-#pragma unroll
-            for (int k = 0; k < PUM; ++k) {
-                const int e = e0 + k * WAVE + lane;
-                int o = wave_inclusive_max(s_own[w][k * WAVE + lane]);
-                o = max(o, carry);
-                carry = __builtin_amdgcn_readlane(o, WAVE - 1);
-                own[k] = e < total ? o : -1;
-                col[k] = 0;
-                if (own[k] >= 0) col[k] = out_col[s_start[w][o] + (e - s_scan[w][o])];
-            }
-            D8 xa[PUM];
-#pragma unroll
-            for (int k = 0; k < PUM; ++k) {
-                if (own[k] >= 0) xa[k] = x[col[k]];
-                else {
-#pragma unroll
-                    for (int s = 0; s < GS; ++s) xa[k].v[s] = 0.0;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < PUM; ++k) {
-                const int o = own[k] >= 0 ? own[k] : 0;
-                const double denom = (double)(s_scan[w][o + 1] - s_scan[w][o] + 1);
-#pragma unroll
-                for (int s = 0; s < GS; ++s) {
-                    const bool nz = xa[k].v[s] != 0.0;
-                    if (nz) lds_add(&s_acc[w][s * WAVE + o], ONE_MINUS_ALPHA * xa[k].v[s] / denom);
-                    edges += (unsigned long long)__popcll(__ballot(nz));
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        __builtin_amdgcn_wave_barrier();
-        {
-            D8 acc;
-#pragma unroll
-            for (int s = 0; s < GS; ++s) acc.v[s] = s_acc[w][s * WAVE + lane];
-            finish(valid && !deferred, v, acc);
-        }
-
-        // ---- long rows: 512-edge chunks dealt to the waves, 8 partial sums per lane
+        if (tid < WORDS) s_actin[tid] = tid * 32 < nv ? act_in[(v0 >> 5) + tid] : 0u;
+        // slice of the group's Eg edges per octet (a multiple of EB); its first out_col entry is requested
+        // now, together with the row extents, not after the row tables are built
+        const int per = ((Eg + NOCT - 1) / NOCT + EB - 1) / EB * EB;
+        const int e_begin = oid * per, e_end = min(Eg, e_begin + per);
+        const int *cols = out_col + E0;
+        int mycol = e_begin + j < e_end ? cols[e_begin + j] : -1;
+        // compact the non-empty rows
+        const uint64_t ne = __ballot(d > 0);
+        if (lane == 0) s_wcnt[w] = __popcll(ne);
         __syncthreads();
-        const int nbig = min(s_nbig, PULL_BIG_CAP);
-        if (nbig) { // workgroup-uniform
-            constexpr int CHUNK = WAVE * 8;
-            const int nch = lane < nbig ? (s_bigd[lane] + CHUNK - 1) / CHUNK : 0;
-            const int inc = wave_inclusive_scan(nch);
-            s_chunk0[w][lane] = inc - nch;
-            const int n_chunks = __builtin_amdgcn_readlane(inc, WAVE - 1);
-            if (lane == 0) s_chunk0[w][WAVE] = n_chunks;
-            __builtin_amdgcn_wave_barrier();
-            for (int ch = w; ch < n_chunks; ch += NW) {
-                int lo = 0, hi = WAVE;
+        int woff = 0, ncomp = 0;
 #pragma unroll
-                for (int s2 = 0; s2 < 6; ++s2) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_chunk0[w][mid] <= ch) lo = mid; else hi = mid;
+        for (int k = 0; k < NW; ++k) {
+            const int c = s_wcnt[k];
+            woff += k < w ? c : 0;
+            ncomp += c;
+        }
+        if (d > 0) {
+            const int idx = woff + mbcnt(ne);
+            s_cstart[idx] = rs;
+            s_cvid[idx] = (unsigned short)tid;
+            // octets whose slice begins inside this row
+            const int o_first = (rs + per - 1) / per, o_last = min((rs + d + per - 1) / per - 1, NOCT - 1);
+            for (int o = o_first; o <= o_last; ++o) s_ostart[o] = idx;
+        }
+        if (tid == 0) s_cstart[ncomp] = Eg;
+        __syncthreads();
+
+        // ---- edge phase
+        if (e_begin < e_end) {
+            int crow = s_ostart[oid];
+            int row_beg = s_cstart[crow], row_end = s_cstart[crow + 1];
+            double den = (double)(row_end - row_beg + 1);
+            double rcp = 1.0 / den;
+            double acc[SPL];
+#pragma unroll
+            for (int q = 0; q < SPL; ++q) acc[q] = 0.0;
+            auto flush = [&]() { // the running sums of row `crow` go to its LDS accumulator
+                const int vl = s_cvid[crow];
+                bool nz = false;
+#pragma unroll
+                for (int q = 0; q < SPL; ++q) {
+                    if (acc[q] != 0.0) lds_add(&s_acc[vl * GW + j * SPL + q], acc[q]);
+                    nz |= acc[q] != 0.0;
+                    acc[q] = 0.0;
                 }
-                const int row_rs = s_bigrs[lo], row_d = s_bigd[lo];
-                const int c0 = (ch - s_chunk0[w][lo]) * CHUNK;
-                const int c1 = min(c0 + CHUNK, row_d);
-                const double denom = (double)(row_d + 1);
-                double part[GS];
+                if (nz) atomicOr(&s_touched[vl >> 5], 1u << (vl & 31));
+            };
+            for (int e = e_begin; e < e_end; e += EB) {
+                // which of the step's edges have an active head (one bit test per lane)
+                bool a = false;
+                if (mycol >= 0) a = (act_in[mycol >> 5] >> (mycol & 31)) & 1u;
+                const int ncol = e + EB + j < e_end ? cols[e + EB + j] : -1; // next step's entry, ahead of use
+                const unsigned m = oct_mask(__ballot(a));
 #pragma unroll
-                for (int s = 0; s < GS; ++s) part[s] = 0.0;
-                for (int e0 = c0; e0 < c1; e0 += WAVE) { // wave-uniform trip count (ballots inside)
-                    const int e = e0 + lane;
-                    D8 xb;
-                    if (e < c1) xb = x[out_col[row_rs + e]];
-                    else {
+                for (int h = 0; h < EB; h += GB) {
+                    const unsigned mh = (m >> h) & ((1u << GB) - 1u);
+                    if (mh) {
+                        // the sub-step's gathers are all issued before any is used
+                        double xv[GB][SPL];
 #pragma unroll
-                        for (int s = 0; s < GS; ++s) xb.v[s] = 0.0;
-                    }
+                        for (int k = 0; k < GB; ++k) {
+                            const int ck = __shfl(mycol, (lane & ~(OCT - 1)) + h + k, WAVE);
 #pragma unroll
-                    for (int s = 0; s < GS; ++s) {
-                        const bool nz = xb.v[s] != 0.0;
-                        if (nz) part[s] += ONE_MINUS_ALPHA * xb.v[s] / denom;
-                        edges += (unsigned long long)__popcll(__ballot(nz));
+                            for (int q = 0; q < SPL; ++q) xv[k][q] = 0.0;
+                            if ((mh >> k) & 1u) {
+#pragma unroll
+                                for (int q = 0; q < SPL; ++q) xv[k][q] = x[(size_t)ck * GW + j * SPL + q];
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < GB; ++k) {
+                            if ((mh >> k) & 1u) {
+                                const int ek = e + h + k;
+                                if (ek >= row_end) { // the cursor moves on: non-empty rows are contiguous in edge space
+                                    flush();
+                                    do {
+                                        ++crow;
+                                        row_beg = row_end;
+                                        row_end = s_cstart[crow + 1];
+                                    } while (ek >= row_end);
+                                    den = (double)(row_end - row_beg + 1);
+                                    rcp = 1.0 / den;
+                                }
+#pragma unroll
+                                for (int q = 0; q < SPL; ++q) {
+                                    if (xv[k][q] != 0.0) {
+                                        acc[q] += push_term(xv[k][q], den, rcp);
+                                        ++ecount;
+                                    }
+                                }
+                            }
+                        }
                     }
                 }
+                mycol = ncol;
+            }
+            flush();
+        }
+        __syncthreads();
+
+        // ---- vertex phase: repair, threshold, next snapshot for the vertices that were touched
+        for (int i0 = 0; i0 < NVX / NOCT; i0 += FU) {
+            int vl[FU];
+            bool tch[FU], wasact[FU];
+            double rv[FU][SPL], xo[FU][SPL];
 #pragma unroll
-                for (int s = 0; s < GS; ++s) {
-                    const double t = wave_sum(part[s]);
-                    if (lane == 0 && t != 0.0) lds_add(&s_bigacc[lo][s], t);
+            for (int i = 0; i < FU; ++i) {
+                vl[i] = oid + (i0 + i) * NOCT;
+                const unsigned bit = 1u << (vl[i] & 31);
+                wasact[i] = (s_actin[vl[i] >> 5] & bit) != 0;
+                tch[i] = vl[i] < nv && (wasact[i] || (s_touched[vl[i] >> 5] & bit) != 0);
+#pragma unroll
+                for (int q = 0; q < SPL; ++q) {
+                    rv[i][q] = 0.0;
+                    xo[i][q] = 0.0;
+                }
+                if (tch[i]) {
+                    const size_t base = (size_t)(v0 + vl[i]) * GW + j * SPL;
+#pragma unroll
+                    for (int q = 0; q < SPL; ++q) rv[i][q] = r[base + q];
+                    if (wasact[i]) {
+#pragma unroll
+                        for (int q = 0; q < SPL; ++q) xo[i][q] = x[base + q];
+                    }
                 }
             }
-            __syncthreads();
-            if (w == 0 && lane < nbig) {
-                const int bv = s_bigv[lane];
-                const D8 rb = r[bv];
-                D8 acc;
 #pragma unroll
-                for (int s = 0; s < GS; ++s) acc.v[s] = rb.v[s] + s_bigacc[lane][s];
-                finish(true, bv, acc);
+            for (int i = 0; i < FU; ++i) {
+                if (tch[i]) {
+                    const size_t base = (size_t)(v0 + vl[i]) * GW + j * SPL;
+                    double rn[SPL];
+                    bool lg[SPL], any = false;
+#pragma unroll
+                    for (int q = 0; q < SPL; ++q) {
+                        double *ap = &s_acc[vl[i] * GW + j * SPL + q];
+                        rn[q] = rv[i][q] + *ap;
+                        *ap = 0.0;
+                        if (xo[i][q] != 0.0) rn[q] -= xo[i][q];
+                        lg[q] = legal(rn[q], phase, eps);
+                        any |= lg[q];
+                        nleg[q] += lg[q] ? 1 : 0;
+                        if (rn[q] != rv[i][q]) r[base + q] = rn[q];
+                    }
+                    if (oct_mask(__ballot(any))) {
+#pragma unroll
+                        for (int q = 0; q < SPL; ++q) {
+                            x_new[base + q] = lg[q] ? rn[q] : 0.0;
+                            if (lg[q]) p[base + q] = p[base + q] + ALPHA * rn[q];
+                        }
+                        if (j == 0) atomicOr(&s_actout[vl[i] >> 5], 1u << (vl[i] & 31));
+                    }
+                }
             }
         }
         __syncthreads();
+        if (tid < WORDS) { // the group's words of the next bitmap (complete), tables back to zero
+            if (tid * 32 < nv) act_out[(v0 >> 5) + tid] = s_actout[tid];
+            s_actout[tid] = 0u;
+            s_touched[tid] = 0u;
+        }
     }
     // next frontier sizes: one fire-and-forget atomic per source and workgroup
 #pragma unroll
-    for (int s = 0; s < GS; ++s) {
-        const int t = wave_inclusive_scan(n_legal[s]);
-        if (lane == WAVE - 1) s_cnt[w][s] = t;
-    }
+    for (int q = 0; q < SPL; ++q)
+        if (nleg[q]) atomicAdd(&s_cnt[j * SPL + q], nleg[q]);
+    if (ecount) atomicAdd(&s_edges, (unsigned long long)ecount);
     __syncthreads();
-    if (threadIdx.x < GS) {
-        int tot = 0;
-        for (int k = 0; k < NW; ++k) tot += s_cnt[k][threadIdx.x];
-        if (tot) atomicAdd(&cnt_out[threadIdx.x], tot);
-    }
-    stat_add_edges<NW>(stats, edges, s_edges);
+    if (tid < GW && s_cnt[tid]) atomicAdd(&cnt_out[tid], s_cnt[tid]);
+    if (tid == 0 && s_edges) stats->blk_E[blockIdx.x] += s_edges;
 }
 
-// strided copies between the interleaved group state and an external-id vector of one source
-__global__ __launch_bounds__(BLOCK) void k_gint_to_ext(const D8 *__restrict__ a_int, int lane_s,
+// strided copy from the interleaved group state to an external-id vector of one source
+__global__ __launch_bounds__(BLOCK) void k_gint_to_ext(const double *__restrict__ a_int, int gw, int lane_s,
                                                        const int *__restrict__ ext2int, int V,
                                                        double *__restrict__ a_ext) {
     for (int v = blockIdx.x * BLOCK + threadIdx.x; v < V; v += gridDim.x * BLOCK) {
         const int m = ext2int[v];
-        a_ext[v] = m >= 0 ? a_int[m].v[lane_s] : 0.0;
+        a_ext[v] = m >= 0 ? a_int[(size_t)m * gw + lane_s] : 0.0;
     }
 }
 

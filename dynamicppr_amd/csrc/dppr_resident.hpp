@@ -359,8 +359,9 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
                 const double *src = xin + out_col[s_rs[o] + (e - s_scan[o])];
                 unsigned long long bits = xb_load(src);
                 unsigned polls = 0;
-                while (bits == X_EMPTY && !s_fault) {
-                    if ((polls++ & 1023u) == 1023u) s_fault = 1; // ~ seconds: a device fault, reported below
+                const unsigned long long t_start = wall_clock64();
+                while (bits == X_EMPTY && !s_fault) { // same wall-clock limit as the register-slot gathers above
+                    if ((polls++ & 63u) == 63u && wall_clock64() - t_start > limit_ticks + 100000000ull) s_fault = 1;
                     __builtin_amdgcn_s_sleep(8);
                     bits = xb_load(src);
                 }

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(BLOCK) void k_su_terms(const uint32_t *__restrict__
 }
 
 struct SuSources {
-    int s[8]; // source vertex per lane (blockIdx.y)
+    int s[16]; // source vertex per lane (blockIdx.y)
 };
 __global__ __launch_bounds__(BLOCK) void k_su_apply(const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ svals,
                                                     const double *__restrict__ term_base, const uint8_t *__restrict__ sins,

@@ -54,6 +54,7 @@ EXPORTS = [
     "dppr_reset_stats", "dppr_inspect", "dppr_read_graph", "dppr_graph_edges", "dppr_read_out_graph", "dppr_trace_enable",
     "dppr_trace_get", "dppr_synchronize", "dppr_bench_atomics",
     "dppr_add_source_group", "dppr_group_init_solve", "dppr_group_update", "dppr_group_read", "dppr_group_stats",
+    "dppr_group_reset_stats", "dppr_set_group_seeding", "dppr_seed_lists",
 ]
 
 
@@ -105,6 +106,9 @@ def lib():
     L.dppr_group_update.argtypes = [vp, C.c_int32, C.c_int32, C.c_double, fp]
     L.dppr_group_read.argtypes = [vp, C.c_int32, C.c_int32, dp, dp]
     L.dppr_group_stats.argtypes = [vp, C.c_int32, C.POINTER(Stats)]
+    L.dppr_seed_lists.argtypes = [vp, C.c_int32, C.c_int, ip, ip]
+    L.dppr_group_reset_stats.argtypes = [vp, C.c_int32]
+    L.dppr_set_group_seeding.argtypes = [vp, C.c_int]
     L.dppr_bench_atomics.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, fp]
     for name in EXPORTS:
         if name not in ("dppr_strerror", "dppr_last_error", "dppr_destroy"):
@@ -238,6 +242,13 @@ class Engine:
                                       out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n)), "inspect")
         return out[:n.value].copy()
 
+    def seed_lists(self, slot, phase):
+        out = np.empty(max(4 * self.c, 1), dtype=np.int32)
+        n = C.c_int32(0)
+        self._ck(self._L.dppr_seed_lists(self._h, slot, int(phase), out.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         C.byref(n)), "seed_lists")
+        return out[:n.value].copy()
+
     def read_graph(self, epoch=-1):
         ne = C.c_int32(0)
         self._ck(self._L.dppr_graph_edges(self._h, int(epoch), C.byref(ne)), "graph_edges")
@@ -300,6 +311,12 @@ class Engine:
         st = Stats()
         self._ck(self._L.dppr_group_stats(self._h, group, C.byref(st)), "group_stats")
         return st.as_dict()
+
+    def group_reset_stats(self, group):
+        self._ck(self._L.dppr_group_reset_stats(self._h, group), "group_reset_stats")
+
+    def set_group_seeding(self, from_tails):
+        self._ck(self._L.dppr_set_group_seeding(self._h, int(from_tails)), "set_group_seeding")
 
     def synchronize(self):
         self._ck(self._L.dppr_synchronize(self._h), "synchronize")

@@ -63,7 +63,7 @@ typedef struct dppr_stats_t {
     int64_t inspected;    /* vertices scanned by full Inspect passes */
     int64_t batches;      /* dppr_update calls */
     int64_t pull_iterations; /* iterations evaluated as a dense pull sweep (subset of iterations) */
-    int64_t algorithmic_bytes; /* 16V + 45L + sum(72F + 24E + 4N) per batch */
+    int64_t algorithmic_bytes; /* 8 * inspected + 45 * records + sum(72F + 24E + 4N) */
     double gpu_ms;        /* sum of event-timed regions */
     double push_ms;       /* sum of per-launch event times of the push kernel (profiling on only) */
     int64_t push_launches; /* push-kernel launches timed into push_ms */
@@ -117,7 +117,7 @@ int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges, int p
  * (every iteration its own launch). Such a launch first checks that all its workgroups are
  * running (waiting on one another needs that); timeout_us is how long that roll-call may take before the
  * launch gives up WITHOUT having changed anything and the engine continues with per-iteration
- * launches (0 keeps the default, 50 ms; negative = a roll-call that cannot succeed, which tests
+ * launches, trying resident ones again 64 batches later (0 keeps the default, 50 ms; negative = a roll-call that cannot succeed, which tests
  * use to exercise that path; the results are the same either way).
  * Only valid right after dppr_create. */
 int dppr_set_persistent(dppr_engine *e, int mode, int64_t timeout_us);
@@ -166,6 +166,10 @@ int dppr_init_solve(dppr_engine *e, int32_t slot, double eps, float *out_ms);
  * epoch < 0 means the newest epoch. *out_ms = hipEvent time of exactly that region
  * (batch upload and CSR rebuild excluded, as in the reference). */
 int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *out_ms);
+/* (Epochs must be applied to a source in sequence: after the solve / update on epoch k only epoch
+ * k + 1 is accepted, DPPR_ERR_INVALID otherwise -- with several epochs resident a skipped or replayed
+ * batch would otherwise go unnoticed. dppr_write resets that memory. The same holds for
+ * dppr_incremental_batch_update and dppr_group_update.) */
 
 /* The same region split along the reference's virtual interface, for callers that
  * keep the reference's driver loop and for kernel-level parity tests:
@@ -174,6 +178,11 @@ int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *
  *   PPRRevPushGPU::ExecuteMainLoop(phase) (gpu/PPRRevPushGPU.cuh:97-131): full
  *     Inspect over V, then the Expand/Repair frontier loop. */
 int dppr_incremental_batch_update(dppr_engine *e, int32_t slot, int32_t epoch);
+/* Test hook: the frontier seeds dppr_incremental_batch_update derived from the batch when the state
+ * was converged before it -- phase 0: tails with r > eps, phase 1: tails with r < -eps (eps = that of
+ * the completed solve). This is what cpu/PPRCPUMTCilkRev.h:126-156 (DynPushInit) builds from the batch
+ * endpoints; unordered. Valid only between that call and the next main loop / update. */
+int dppr_seed_lists(dppr_engine *e, int32_t slot, int phase, int32_t *out_ids, int32_t *out_count);
 int dppr_execute_main_loop(dppr_engine *e, int32_t slot, int32_t epoch, int phase, double eps);
 
 /* Replaces: the cudaMemcpy D2H of pagerank/residual in ValidateResult
@@ -186,17 +195,25 @@ int dppr_stats(dppr_engine *e, int32_t slot, dppr_stats_t *out);
 int dppr_reset_stats(dppr_engine *e, int32_t slot);
 
 /* ---- source groups (multi-source batched sweeps) ---------------------------------------
- * Up to 8 sources that share the engine's graph are solved TOGETHER: their p / r / x vectors are
- * interleaved 8-wide (one 64-byte sector per vertex), so one pass over the out-CSR serves all of
- * them (BASELINE.json configs 3 and 5 run 10 sources over the same stream). Per source the
- * arithmetic and the results are those of the single-source calls; group iterations are always
- * dense sweeps. The reference has no counterpart (one source per process, gpu/PPRGPU.cuh:24). */
-int dppr_add_source_group(dppr_engine *e, const int32_t *sources, int32_t n /* 1..8 */, int32_t *out_group);
+ * Up to 16 sources that share the engine's graph are solved TOGETHER: their p / r / x vectors are
+ * interleaved (8 doubles = one 64-byte sector per vertex for up to 8 sources, 16 doubles = one
+ * 128-byte line for 9..16), so one pass over the out-CSR serves all of them (BASELINE.json configs
+ * 3 and 5 run 10 sources over the same stream). Per source the arithmetic and the results are those
+ * of the single-source calls; group iterations are always sweeps, and an activity bitmap keeps a
+ * sweep's cost proportional to what the frontiers touch (dppr_multi.hpp). The reference has no
+ * counterpart (one source per process, gpu/PPRGPU.cuh:24). */
+int dppr_add_source_group(dppr_engine *e, const int32_t *sources, int32_t n /* 1..16 */, int32_t *out_group);
 int dppr_group_init_solve(dppr_engine *e, int32_t group, double eps, float *out_ms);
 /* timed region for all sources of the group at once (same scope as dppr_update) */
 int dppr_group_update(dppr_engine *e, int32_t group, int32_t epoch, double eps, float *out_ms);
 int dppr_group_read(dppr_engine *e, int32_t group, int32_t index, double *p, double *r);
 int dppr_group_stats(dppr_engine *e, int32_t group, dppr_stats_t *out); /* summed over the sources */
+int dppr_group_reset_stats(dppr_engine *e, int32_t group);
+/* How dppr_group_update seeds its two frontier loops. from_tails (default): after a converged solve
+ * only tails of the batch's records can be legal (the argument of cpu/PPRCPUMTCilkRev.h:126-156), so
+ * the frontier is read off the batch; 0: a full Inspect pass over all vertices per phase like
+ * PPRRevPushGPU::ExecuteMainLoop (gpu/PPRRevPushGPU.cuh:97-104). Same frontier either way. */
+int dppr_set_group_seeding(dppr_engine *e, int from_tails);
 
 /* ---- validation / test hooks -------------------------------------------- */
 

@@ -291,7 +291,10 @@ def test_edge_cases():
     p, r = sc.e.read(sc.slot)
     assert p[0] == 0.15 and np.count_nonzero(p) == 1 and np.all(r == 0)
     # slide twice then hit the end of the stream (partial batch is dropped by the host side)
-    assert sc.advance_graphs() and sc.advance_graphs() and not sc.advance_graphs()
+    for _ in range(2):
+        assert sc.advance_graphs()
+        sc.e.update(sc.slot, eps)                 # (epochs are applied in sequence: no skipping)
+    assert not sc.advance_graphs()
     # empty batch: update is a no-op
     sc.e.set_batch(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.uint8))
     sc.e.slide(np.zeros(0, np.int32), np.zeros(0, np.int32))
@@ -312,6 +315,71 @@ def test_edge_cases():
             break
         sc.s.cilk_inc_execute(sc.g)
         sc.e.update(sc.slot, eps)
+
+
+@pytest.mark.parametrize("directed", [1, 0])
+def test_seed_lists_equal_dyn_push_init(directed):
+    """The one iteration where the reference's CPU schedule and this engine coincide exactly: the
+    frontier after the stream update. The lists IncrementalBatchUpdate emits (phase 0: tails with
+    r > eps; phase 1 candidates: tails with r < -eps) must be the sets DynPushInit builds from the
+    batch endpoints (cpu/PPRCPUMTCilkRev.h:126-156), for every batch."""
+    sc = make(directed, c=40)
+    sc.s.cilk_execute(sc.g)
+    sc.e.init_solve(sc.slot, sc.eps)
+    for k in range(6):
+        assert sc.advance_graphs()
+        # oracle: update, then both seed sets read off the updated residuals
+        sc.s.copy_revert_out_degree(sc.g)
+        sc.s.stream_update(sc.g)
+        want = []
+        for phase in (0, 1):
+            sc.s.dyn_push_init(sc.g, phase)
+            want.append(np.sort(sc.s.frontier()))
+        sc.e.incremental_batch_update(sc.slot)
+        for phase in (0, 1):
+            got = np.sort(sc.e.seed_lists(sc.slot, phase))
+            assert np.array_equal(got, want[phase]), (k, phase)
+            assert np.array_equal(got, sc.s.inspect(phase))            # == a full Inspect pass (gpu/Inspect.cuh:8-48)
+        # finish the batch on both sides (the engine through the reference's split driver flow)
+        sc.s.dyn_push_init(sc.g, 0); sc.s.cilk_main_loop(sc.g, 0)
+        sc.s.dyn_push_init(sc.g, 1); sc.s.cilk_main_loop(sc.g, 1)
+        sc.e.execute_main_loop(sc.slot, 0, sc.eps)
+        sc.e.execute_main_loop(sc.slot, 1, sc.eps)
+        with pytest.raises(eng.DpprError):
+            sc.e.seed_lists(sc.slot, 0)                                  # only valid right after the update
+        p, _ = sc.e.read(sc.slot)
+        assert np.max(np.abs(p - sc.s.p)) < NORTH_STAR_TOL
+
+
+def test_epochs_must_be_applied_in_sequence_and_slide_is_bounded():
+    K = 4
+    sc = make(1, c=20, n_epochs=K + 1)
+    gid = sc.e.add_source_group([sc.source, int((sc.source + 1) % sc.V)])
+    sc.e.init_solve(sc.slot, sc.eps)
+    sc.e.group_init_solve(gid, sc.eps)
+    for _ in range(K):
+        assert sc.advance_graphs()
+    with pytest.raises(eng.DpprError):
+        sc.e.update(sc.slot, sc.eps, epoch=2)        # epoch 1 skipped
+    sc.e.update(sc.slot, sc.eps, epoch=1)
+    with pytest.raises(eng.DpprError):
+        sc.e.update(sc.slot, sc.eps, epoch=1)        # replayed
+    with pytest.raises(eng.DpprError):
+        sc.e.update(sc.slot, sc.eps, epoch=3)        # epoch 2 skipped
+    with pytest.raises(eng.DpprError):
+        sc.e.group_update(gid, sc.eps, epoch=2)
+    for k in range(1, K + 1):
+        sc.e.group_update(gid, sc.eps, epoch=k)
+        if k > 1:
+            sc.e.update(sc.slot, sc.eps, epoch=k)
+    p, r = sc.e.read(sc.slot)
+    pg, rg = sc.e.group_read(gid, 0)
+    assert np.max(np.abs(p - pg)) < NORTH_STAR_TOL and np.max(np.abs(r)) < sc.eps
+    # a slide longer than max_batch of dppr_create is refused (its key buffers are sized for max_batch)
+    n = sc.c + 1
+    sc.e.set_batch(np.zeros(2 * n, np.int32), np.ones(2 * n, np.int32), np.zeros(2 * n, np.uint8))
+    with pytest.raises(eng.DpprError):
+        sc.e.slide(np.zeros(n, np.int32), np.ones(n, np.int32))
 
 
 def test_error_paths():
@@ -673,18 +741,11 @@ def test_incremental_graph_equals_full_rebuild(directed):
             assert np.array_equal(oa[0], ob[0]) and np.array_equal(oa[1], ob[1])
 
 
-@pytest.mark.parametrize("big_row", [None, 4])
-@pytest.mark.parametrize("nsrc", [1, 3, 8])
-@pytest.mark.parametrize("directed", [1, 0])
-def test_source_group_matches_oracle_per_source(directed, nsrc, big_row):
-    """f2: up to 8 sources solved together on interleaved state. Every source's p/r must equal the
-    oracle's synchronous schedule for that source (group iterations are dense sweeps), and the
-    summed statistics must equal the sum of the per-source oracle runs."""
-    V, e1, e2 = datagen.rmat_stream(9, 6000, 11)
-    W, c, eps = 600, 20, 1e-9
-    sources = [int(s) for s in datagen.top_sources(V, e1, e2, W, directed, nsrc)]
-    tuning = dict(big_row_edges=big_row) if big_row else {}
-    e = eng.Engine(V, W, directed, c, **tuning)
+def run_source_group(V, e1, e2, W, c, eps, directed, sources, batches, seeding, tuning=None):
+    """Drive a source group and one oracle state per source (synchronous schedule) over the same
+    stream; per-source p/r to rounding, summed statistics equal."""
+    e = eng.Engine(V, W, directed, c, **(tuning or {}))
+    e.set_group_seeding(seeding == "tails")
     g = orc.Graph(V, e1, e2, directed, W, c)
     states = [orc.State(V, s, eps) for s in sources]
     e.load_window(*g.window_edges())
@@ -692,7 +753,8 @@ def test_source_group_matches_oracle_per_source(directed, nsrc, big_row):
     for s in states:
         s.sync_execute(g)
     e.group_init_solve(gid, eps)
-    for k in range(5):
+    inspected0 = e.group_stats(gid)["inspected"]
+    for k in range(batches + 1):
         if k:
             assert not g.stream_updates()
             g.inc_construct(1)
@@ -708,10 +770,62 @@ def test_source_group_matches_oracle_per_source(directed, nsrc, big_row):
     assert st["sum_F"] == sum(s.stats()["F"] for s in states)
     assert st["sum_E"] == sum(s.stats()["E"] for s in states)
     assert st["iterations"] <= sum(s.stats()["iters"] for s in states)
+    # dense seeding scans every vertex twice per batch, tail seeding none after the from-scratch solve
+    assert inspected0 > 0 and ((st["inspected"] > inspected0) if seeding == "dense" else (st["inspected"] == inspected0))
+    return e, gid
+
+
+@pytest.mark.parametrize("seeding", ["tails", "dense"])
+@pytest.mark.parametrize("nsrc", [1, 3, 8, 10, 16])
+@pytest.mark.parametrize("directed", [1, 0])
+def test_source_group_matches_oracle_per_source(directed, nsrc, seeding):
+    """f2: up to 16 sources solved together on interleaved state (8-wide for <= 8 sources, 16-wide
+    above). Every source's p/r must equal the oracle's synchronous schedule for that source (group
+    iterations are sweeps), and the summed statistics must equal the sum of the per-source oracle
+    runs -- with the frontier seeded from the batch tails and with full Inspect passes."""
+    V, e1, e2 = datagen.rmat_stream(9, 6000, 11)
+    W, c, eps = 600, 20, 1e-9
+    sources = [int(s) for s in datagen.top_sources(V, e1, e2, W, directed, nsrc)]
+    e, gid = run_source_group(V, e1, e2, W, c, eps, directed, sources, 5, seeding)
     with pytest.raises(eng.DpprError):
-        e.add_source_group(list(range(9)))
+        e.add_source_group(list(range(17)))
     with pytest.raises(eng.DpprError):
         e.group_read(gid, nsrc)
+
+
+@pytest.mark.parametrize("shape", ["many-groups-hubs", "one-hub-row-spans-all-octets", "tiny-window"])
+@pytest.mark.parametrize("nsrc", [5, 10])
+def test_source_group_sweep_shapes(nsrc, shape):
+    """k_gsweep splits a sweep group's edges evenly over its 128 octets: windows with several
+    sweep groups and hub rows, a window in which one row holds most edges (every octet walks a
+    piece of the same row), and a window smaller than one step per octet."""
+    rng = np.random.default_rng(17)
+    if shape == "many-groups-hubs":
+        V, e1, e2 = datagen.rmat_stream(13, 60000, 21)
+        W, c, directed = 30000, 300, 0
+    elif shape == "one-hub-row-spans-all-octets":
+        V, n = 3000, 40000
+        e1 = np.where(rng.random(n) < 0.8, 7, rng.integers(0, V, n)).astype(np.int32)   # 80 % of the edges leave vertex 7
+        e2 = rng.integers(0, V, n).astype(np.int32)
+        e2 = np.where(e2 == e1, (e2 + 1) % V, e2).astype(np.int32)
+        W, c, directed = 20000, 200, 1
+    else:
+        V, e1, e2 = datagen.rmat_stream(6, 900, 3)
+        W, c, directed = 40, 3, 1
+    ranked = datagen.top_sources(V, e1, e2, W, directed, 40)
+    sources = [int(s) for s in ranked[::4][:nsrc]]
+    run_source_group(V, e1, e2, W, c, 1e-9, directed, sources, 4, "tails")
+
+
+def test_source_group_sources_outside_the_window_and_duplicates():
+    """Sources that have no edge in the window (fresh internal ids: the sweep groups are re-cut) and
+    the same vertex twice in one group."""
+    V, e1, e2 = datagen.rmat_stream(10, 8000, 9)
+    W, c, directed = 500, 10, 1
+    used = set(e1[:W + 60 * c].tolist()) | set(e2[:W + 60 * c].tolist())
+    lonely = [v for v in range(V) if v not in used][:2]
+    top = [int(s) for s in datagen.top_sources(V, e1, e2, W, directed, 2)]
+    run_source_group(V, e1, e2, W, c, 1e-9, directed, lonely + top + [top[0]], 4, "tails")
 
 
 def test_two_engines_on_one_device_from_two_threads():

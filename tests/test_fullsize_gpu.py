@@ -1,0 +1,106 @@
+"""Full-size parity: BASELINE.json configs at their real sizes (seeded stand-ins), the HIP engine in
+PRODUCTION mode (eager schedule, whatever launch form the engine picks) against the oracle's
+restatement of cpu/PPRCPUMTCilkRev at -t 1 on the same stream: |p - p_cpu| < 1e-9 (north-star
+tolerance) after the from-scratch solve and after every batch, plus the reference's Validate()
+residual bound and the loop invariant. The streams are prefixes of the seeded stand-ins (a sliding
+window run reads W + batches*c edges); where they came from is logged."""
+import numpy as np
+import pytest
+
+from dynamicppr_amd import datagen, engine as eng, stream as st
+from oracle import oracle as orc
+from tests.util import invariant_max_err_np
+
+pytestmark = pytest.mark.gpu
+
+NORTH_STAR_TOL = 1e-9
+INVARIANT_TOL = 1e-13
+DATA = "/tmp/dppr_data"
+
+
+def stand_in(key, batches):
+    cfg = datagen.STAND_INS[key]
+    f = cfg.flags.split()
+    opt = {f[i]: f[i + 1] for i in range(0, len(f), 2)}
+    wl = st.workload_config(cfg.edges, 0.1, int(opt.get("-n", 0)), float(opt.get("-r", -1.0)), int(opt.get("-b", 0)),
+                            int(opt.get("-c", 0)), int(opt.get("-l", 0)))
+    limit = wl.window + (batches + 1) * wl.per_batch
+    V, e1, e2, _ = datagen.stand_in_stream(key, DATA, limit=limit)
+    prov = datagen.PROVENANCE[datagen.stand_in_path(key, DATA, limit)]
+    print(f"[stream] {key}: {prov['origin']}, {prov['edges']} edges, {prov['checksum']}")
+    return V, e1, e2, cfg, wl
+
+
+def window_edges(ss, directed):
+    w1, w2 = ss.serialize_edge_stream()
+    return (w1, w2) if directed else (np.concatenate([w1, w2]), np.concatenate([w2, w1]))
+
+
+@pytest.mark.parametrize("key,batches,pick", [("dblp", 3, "top10"), ("youtube", 3, "top10"), ("livejournal", 2, "top1000")])
+def test_production_mode_matches_cilk_oracle_at_full_size(key, batches, pick):
+    V, e1, e2, cfg, wl = stand_in(key, batches)
+    W, c, eps = wl.window, wl.per_batch, 1e-9
+    if pick == "top10":
+        src = int(datagen.top_sources(V, e1, e2, W, cfg.directed, 10)[3])      # scripts/gpu.sh uses index 3 of the top10 file
+    else:
+        src = int(datagen.ranked_sources(V, e1, e2, W, cfg.directed, 10, 1000, 10)[0])
+    e = eng.Engine(V, W, cfg.directed, c)
+    ss = st.SlidingStream(V, e1, e2, cfg.directed, wl)
+    e.load_window(*ss.serialize_edge_stream())
+    slot = e.add_source(src)
+    g = orc.Graph(V, e1, e2, cfg.directed, W, c)
+    s = orc.State(V, src, eps)
+    s.cilk_execute(g)
+    e.init_solve(slot, eps)
+    worst = 0.0
+    for k in range(batches + 1):
+        if k:
+            assert not ss.stream_updates() and not g.stream_updates()
+            g.inc_construct(1)
+            s.cilk_inc_execute(g)
+            e.set_batch(*ss.batch_arrays())
+            e.slide(*ss.new_arrays())
+            e.update(slot, eps)
+        p, r = e.read(slot)
+        assert np.max(np.abs(r)) < eps                                   # gpu/PPRRevPushGPU.cuh:141-143
+        dp = float(np.max(np.abs(p - s.p)))
+        worst = max(worst, dp)
+        assert dp < NORTH_STAR_TOL, (key, k, dp)
+        src_e, dst_e = window_edges(ss, cfg.directed)
+        assert invariant_max_err_np(p, r, src_e, dst_e, V, src) < INVARIANT_TOL
+    print(f"[parity] {key}: max |p_gpu - p_cpu(t=1)| over {batches + 1} solves = {worst:.3e}")
+
+
+def test_livejournal_ten_sources_as_one_group_matches_cilk_oracle():
+    """configs[2] as bench.py runs it: the 10 sources of a top1000 file solved together (16-wide
+    source group). Two of them are compared with the -t 1 oracle after every batch, all of them are
+    held to the residual bound and the invariant."""
+    V, e1, e2, cfg, wl = stand_in("livejournal", 2)
+    W, c, eps = wl.window, wl.per_batch, 1e-9
+    sources = [int(x) for x in datagen.ranked_sources(V, e1, e2, W, cfg.directed, 10, 1000, 10)]
+    e = eng.Engine(V, W, cfg.directed, c)
+    ss = st.SlidingStream(V, e1, e2, cfg.directed, wl)
+    e.load_window(*ss.serialize_edge_stream())
+    gid = e.add_source_group(sources)
+    g = orc.Graph(V, e1, e2, cfg.directed, W, c)
+    checked = [0, 7]
+    states = {i: orc.State(V, sources[i], eps) for i in checked}
+    for s in states.values():
+        s.cilk_execute(g)
+    e.group_init_solve(gid, eps)
+    for k in range(3):
+        if k:
+            assert not ss.stream_updates() and not g.stream_updates()
+            g.inc_construct(1)
+            for s in states.values():
+                s.cilk_inc_execute(g)
+            e.set_batch(*ss.batch_arrays())
+            e.slide(*ss.new_arrays())
+            e.group_update(gid, eps)
+        src_e, dst_e = window_edges(ss, cfg.directed)
+        for i, sv in enumerate(sources):
+            p, r = e.group_read(gid, i)
+            assert np.max(np.abs(r)) < eps
+            assert invariant_max_err_np(p, r, src_e, dst_e, V, sv) < INVARIANT_TOL
+            if i in states:
+                assert np.max(np.abs(p - states[i].p)) < NORTH_STAR_TOL, (k, i)

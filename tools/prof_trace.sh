@@ -31,6 +31,9 @@ c = collections.Counter(); d = collections.Counter()
 for r in seg:
     n = r["Kernel_Name"].split("(")[0][-30:]; c[n] += 1; d[n] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 for n, k in c.most_common(): print(f"{n:32s} x{k:4d} total_us={d[n]/1e3:9.1f}")
+sweeps = [round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, 1) for r in seg
+          if "k_gsweep" in r["Kernel_Name"] or "k_pull_iter" in r["Kernel_Name"]]
+if sweeps: print("sweep durations in launch order (us):", sweeps)
 small = [g for g, _ in gaps if g < 20000]
 print("median gap us", sorted(small)[len(small)//2] / 1e3, "n small", len(small), "sum small", sum(small) / 1e3)
 PY
