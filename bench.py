@@ -72,7 +72,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--group", type=int, default=None, help=argparse.SUPPRESS)  # old spelling of --sources
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
-                    help="engine tuning knob (hub_min_degree, big_row_edges, pull_min_frontier, chunk_iters, pull_block)")
+                    help="engine tuning knob (hub_min_degree, big_row_edges, pull_min_frontier, chunk_iters, pull_block, sweep_bitmap)")
     return ap.parse_args()
 
 
@@ -112,6 +112,9 @@ def main():
     n_steps = a.warmup + a.steps
     S, pick = PLANS.get(a.config, (1, "top10"))
     S = a.sources or a.group or S
+    # a source group's sweeps are event-bracketed on a few FURTHER batches after the timed region (an event
+    # pair per launch widens the dispatch gaps from ~4 to ~10 us: it must not sit in the timed batches)
+    n_prof = min(a.steps, 5) if S > 1 else 0
     pick = a.pick or pick
     if a.bin:
         V, e1, e2 = datagen.read_bin(a.bin)
@@ -129,12 +132,12 @@ def main():
                             int(opt.get("-c", 0)), int(opt.get("-l", 0)))
     W, c = wl.window, wl.per_batch
     max_batches = (stream_len - W) // max(c, 1)
-    if n_steps > max_batches:
-        sys.exit(f"stream too short for {n_steps} batches (max {max_batches})")
+    if n_steps + n_prof > max_batches:
+        sys.exit(f"stream too short for {n_steps + n_prof} batches (max {max_batches})")
     if not a.bin:
         # the run reads W + n_steps * c stream edges: only that prefix of the seeded stream is generated
         # (rank 0 writes the file, the others wait and read it)
-        need = min(stream_len, W + (n_steps + 1) * c)
+        need = min(stream_len, W + (n_steps + n_prof + 1) * c)
         if rank == 0:
             datagen.ensure_stand_in(a.config, a.data_dir, need)
         if D:
@@ -149,18 +152,21 @@ def main():
 
     schedule = eng.SCHEDULE_EAGER if a.schedule == "eager" else eng.SCHEDULE_SYNC
     tune = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.tune}
-    e = eng.Engine(V, W, directed, c, n_epochs=n_steps + 1, device=local_rank, schedule=schedule, **tune)
+    e = eng.Engine(V, W, directed, c, n_epochs=n_steps + n_prof + 1, device=local_rank, schedule=schedule, **tune)
     ss = st.SlidingStream(V, e1, e2, directed, wl)
     e.load_window(*ss.serialize_edge_stream())
     solver = GroupSolver(e, sources) if S > 1 else SingleSolver(e, sources[0])
     init_ms = solver.init_solve(a.eps)
     L = 0
-    for _ in range(n_steps):                      # pre-stage every epoch in HBM
+    w_end = None
+    for k in range(n_steps + n_prof):             # pre-stage every epoch in HBM
         assert not ss.stream_updates()
         b1, b2, ins = ss.batch_arrays()
         L = len(b1)
         e.set_batch(b1, b2, ins)
         e.slide(*ss.new_arrays())
+        if k == n_steps - 1:
+            w_end = [x.copy() for x in ss.serialize_edge_stream()]   # the window at the end of the timed region
 
     def device_sync():
         torch.cuda.synchronize()
@@ -189,7 +195,7 @@ def main():
     units = shard.aggregate_units(S * c * a.steps, D)
 
     # ---------------- parity at the end of the timed region: every source of this rank ----------------
-    w1, w2 = ss.serialize_edge_stream()
+    w1, w2 = w_end
     src_e, dst_e = (w1, w2) if directed else (np.concatenate([w1, w2]), np.concatenate([w2, w1]))
     max_r, max_inv = 0.0, 0.0
     for i, s in enumerate(sources):
@@ -216,6 +222,8 @@ def main():
             "launches": ps["push_launches"], "avg_launch_us": round(1e3 * ps["push_ms"] / max(ps["push_launches"], 1), 3),
             "algorithmic_bytes_per_launch": round(push_bytes / max(ps["push_launches"], 1), 1),
             "whole_batch_algorithmic_GBps": round(stats["algorithmic_bytes"] / (ev_ms * 1e-3) / 1e9, 2),
+            "launches_from": ("a replay of the timed batches from the saved state" if S == 1 else
+                              f"the {n_prof} batches that follow the timed region on the same stream"),
             "note": "achieved = SURVEY.md 8(d) bytes (72 F + 24 E + 4 N, summed over the sources) of the hipEvent-"
                     "bracketed launches / their time; sparse random 8-byte traffic: the kernel is bound by random-"
                     "sector throughput of L2 / Infinity Cache / HBM, not by streaming bandwidth (DESIGN.md section 6)",
@@ -323,14 +331,18 @@ class GroupSolver:
 
     def begin_timed(self):
         self.e.group_reset_stats(self.gid)
-        self.e.set_profiling(True)    # a sweep takes ~100 us: its event pair does not move the batch time
 
     def stats(self):
         return self.e.group_stats(self.gid)
 
     def profile(self, a, n_steps):
+        """The next min(K, 5) batches of the same stream with a hipEvent pair around every sweep."""
+        self.e.group_reset_stats(self.gid)
+        self.e.set_profiling(True)
+        for k in range(n_steps + 1, n_steps + min(a.steps, 5) + 1):
+            self.e.group_update(self.gid, a.eps, epoch=k)
         self.e.set_profiling(False)
-        return self.e.group_stats(self.gid)    # the timed region's own launches were bracketed
+        return self.e.group_stats(self.gid)
 
     def kernel_name(self, ps):
         return "k_gsweep (one frontier iteration of all sources of the group)"

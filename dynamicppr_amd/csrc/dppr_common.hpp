@@ -74,6 +74,18 @@ __device__ __forceinline__ void lds_add(double *p, double v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// (1.0-ALPHA)*x/den, bit for bit, without the ~11-instruction f64 division sequence per edge and
+// source: with rcp = RN(1/den) (one true division per ROW), q0 = a*rcp is within an ulp of a/den, the
+// remainder r = a - q0*den is exact in an FMA, and q0 + r*rcp rounds to RN(a/den) (Markstein's
+// correction step; den = outdeg+1 is a small integer, never an all-ones significand).
+// tests/test_exact_division.py checks the identity on 2e7 random operands.
+__device__ __forceinline__ double push_term(double x, double den, double rcp) {
+    const double a = ONE_MINUS_ALPHA * x;
+    const double q0 = a * rcp;
+    const double rem = __builtin_fma(-q0, den, a);
+    return __builtin_fma(rem, rcp, q0);
+}
+
 // wave-wide sum; every lane gets the total. Same DPP ladder as the integer scans (two 32-bit DPP moves
 // + one v_add_f64 per step; the xor-butterfly over ds_bpermute it replaces cost ~10x the cycles), fixed
 // order -> deterministic.

@@ -9,6 +9,7 @@
 // DPPR_ERR_NO_DEVICE.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -62,6 +63,8 @@ struct Slot {
     double *p = nullptr, *r = nullptr;
     double *x = nullptr, *x2 = nullptr; // dense per-iteration push amounts (x) and pull output (x2)
     double *x3 = nullptr;               // third snapshot vector of the data-flow resident sweep (all zero outside it)
+    uint32_t *act[2] = {nullptr, nullptr}; // activity bitmaps of x / x2 for sweeps on windows that cannot run resident
+    size_t act_bytes = 0;
     int *ft[2] = {nullptr, nullptr};
     int *neg = nullptr;     // phase-1 candidates
     int *cnt = nullptr;     // [0..2] rotating frontier counters, [3] neg candidates, [4] scratch, [5..6] big-row counters
@@ -149,6 +152,9 @@ struct dppr_engine {
     void *inc_tmp = nullptr;
     size_t inc_tmp_bytes = 0;
     bool incremental = true; // dppr_slide merges the batch into the sorted keys (false: full re-sort)
+    bool sweep_bits = false;        // per-iteration single-source sweeps test an activity bitmap before each gather (dppr_set_sweep_bitmap;
+                                    // measured slower on every stand-in, DESIGN.md section 6: off unless asked for)
+    bool hot_blocks = true;         // vertex numbering in blocks of falling in-degree (DPPR_HOT_BLOCKS=0: two blocks, hot | rest)
     bool wide_groups = false;       // a source group of more than 8 sources exists: epochs carry the second group table
     bool group_tail_seeding = true; // source groups seed from the batch tails after a converged solve (false: dense Inspect)
     // stream-update scratch
@@ -515,6 +521,9 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
     const HubTable hubs{ep.hub_v, ep.hub_degp1, ep.n_hubs};
     // the sparse grid must cover the largest frontier a push chunk can meet
     const int push_grid = pull_min == 0x7fffffff ? 2048 : std::min(2048, std::max(64, (pull_min * 4 / WAVE + 3) / 4));
+    // Sweeps on a window that cannot run resident carry the activity bitmap of their snapshot (k_pull_iter<.., true>)
+    const int pcap0 = persist_capacity(e);
+    const bool use_bits = e->sweep_bits && !entry.dense && (pcap0 <= 0 || ep.n_groups > pcap0);
     bool dense_valid = entry.dense; // s.x holds the snapshot of the current frontier (p already updated)
     bool list_valid = !entry.dense; // s.ft[buf] holds the frontier as a list (sweeps only count it)
     bool any_pull = entry.any_pull;
@@ -563,7 +572,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             // ---- a run of dense iterations as ONE resident launch (dppr_resident.hpp)
             if (!dense_valid) {
                 hipLaunchKernelGGL(k_snapshot_dense, dim3(std::min(grid_for(std::max(F, 1 << 14)), 1024)), dim3(BLOCK), 0,
-                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x);
+                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x, (uint32_t *)nullptr);
                 dense_valid = true;
             }
             HIP_TRY(hipMemsetAsync(e->bar, 0, sizeof(GridBar), e->stream));
@@ -624,28 +633,39 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             if ((pull || sync_sched) && !dense_valid) {
                 // grid-stride over a frontier whose size is only known on the device (k > 0): sized for
                 // the last size the host saw, capped
+                const bool bm = use_bits && pull;
+                if (bm) HIP_TRY(hipMemsetAsync(s.act[0], 0, s.act_bytes, e->stream));
                 hipLaunchKernelGGL(k_snapshot_dense, dim3(std::min(grid_for(std::max(F, 1 << 14)), 1024)), dim3(BLOCK), 0,
-                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x);
+                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x, bm ? s.act[0] : (uint32_t *)nullptr);
                 dense_valid = true;
             }
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k], e->stream));
             if (pull) {
                 // workgroup size = max tiles per group x 64 (the groups themselves were cut by the builder)
                 const int pb = sweep_block(e);
-#define DPPR_LAUNCH_PULL(PB)                                                                                          \
-    hipLaunchKernelGGL(k_pull_iter<PB>, dim3(std::min(std::max(ep.n_groups, 1), 1024)), dim3(PB), 0, e->stream,        \
+#define DPPR_LAUNCH_PULL(PB, BITS)                                                                                    \
+    hipLaunchKernelGGL((k_pull_iter<PB, BITS>), dim3(std::min(std::max(ep.n_groups, 1), 1024)), dim3(PB), 0, e->stream, \
                        ep.grp_n_int, ep.grp_tile, ep.n_groups, s.cnt + cur, ep.out_row_ptr, ep.out_col, s.x, s.x2, s.r, \
                        s.p, s.cnt + nxt, s.cnt + zer, phase, eps, s.dstats, log_slot,                                   \
-                       std::min(e->big_row, PULL_BIG_ROW_DEFAULT))
-                switch (pb) {
-                case 256: DPPR_LAUNCH_PULL(256); break;
-                case 384: DPPR_LAUNCH_PULL(384); break;
-                case 512: DPPR_LAUNCH_PULL(512); break;
-                case 576: DPPR_LAUNCH_PULL(576); break;
-                case 640: DPPR_LAUNCH_PULL(640); break;
-                case 768: DPPR_LAUNCH_PULL(768); break;
-                case 896: DPPR_LAUNCH_PULL(896); break;
-                default: DPPR_LAUNCH_PULL(1024); break;
+                       std::min(e->big_row, PULL_BIG_ROW_DEFAULT), s.act[0], s.act[1])
+                if (use_bits) {
+                    switch (pb) {
+                    case 256: DPPR_LAUNCH_PULL(256, true); break;
+                    case 384: DPPR_LAUNCH_PULL(384, true); break;
+                    case 512: DPPR_LAUNCH_PULL(512, true); break;
+                    case 576: DPPR_LAUNCH_PULL(576, true); break;
+                    case 640: DPPR_LAUNCH_PULL(640, true); break;
+                    case 768: DPPR_LAUNCH_PULL(768, true); break;
+                    case 896: DPPR_LAUNCH_PULL(896, true); break;
+                    default: DPPR_LAUNCH_PULL(1024, true); break;
+                    }
+                    std::swap(s.act[0], s.act[1]);
+                } else { // (block sizes that are not 256 / 512 / 1024 never run resident: they always take the form above)
+                    switch (pb) {
+                    case 256: DPPR_LAUNCH_PULL(256, false); break;
+                    case 512: DPPR_LAUNCH_PULL(512, false); break;
+                    default: DPPR_LAUNCH_PULL(1024, false); break;
+                    }
                 }
 #undef DPPR_LAUNCH_PULL
                 std::swap(s.x, s.x2); // the sweep wrote every entry of x2: it is the next snapshot
@@ -1004,6 +1024,8 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
             return bail(_e == hipErrorOutOfMemory ? DPPR_ERR_NOMEM : DPPR_ERR_HIP);     \
         }                                                                               \
     } while (0)
+    if (const char *v = getenv("DPPR_SWEEP_BITS")) e->sweep_bits = atoi(v) != 0; // diagnostic A/B switches
+    if (const char *v = getenv("DPPR_HOT_BLOCKS")) e->hot_blocks = atoi(v) != 0;
     e->device = device;
     e->V = V;
     e->W = W;
@@ -1089,7 +1111,7 @@ void dppr_destroy(dppr_engine *e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto &s : e->slots) {
         (void)hipFree(s.p); (void)hipFree(s.r); (void)hipFree(s.x); (void)hipFree(s.x2); (void)hipFree(s.x3);
-        (void)hipFree(s.ft[0]); (void)hipFree(s.ft[1]); (void)hipFree(s.neg);
+        (void)hipFree(s.ft[0]); (void)hipFree(s.ft[1]); (void)hipFree(s.neg); (void)hipFree(s.act[0]); (void)hipFree(s.act[1]);
         (void)hipFree(s.cnt); (void)hipFree(s.dstats); (void)hipFree(s.big);
     }
     for (auto &g : e->groups) {
@@ -1157,6 +1179,12 @@ int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges, int p
     return DPPR_OK;
 }
 
+int dppr_set_sweep_bitmap(dppr_engine *e, int on) {
+    if (!e) return DPPR_ERR_INVALID;
+    e->sweep_bits = on != 0;
+    return DPPR_OK;
+}
+
 int dppr_set_group_seeding(dppr_engine *e, int from_tails) {
     if (!e) return DPPR_ERR_INVALID;
     e->group_tail_seeding = from_tails != 0;
@@ -1218,7 +1246,7 @@ int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32
             for (auto &kv : fresh) d.push_back(indeg[(size_t)kv.second]);
             std::vector<int32_t> thr; // in-degree of rank 512 K, 256 K, ..., 8 K (non-decreasing)
             size_t cur = d.size();
-            for (size_t k = HOT_SET; k >= HOT_MIN; k >>= 1) {
+            for (size_t k = HOT_SET; k >= (e->hot_blocks ? HOT_MIN : HOT_SET); k >>= 1) {
                 if (k >= cur) continue;
                 std::nth_element(d.begin(), d.begin() + (std::ptrdiff_t)k, d.begin() + (std::ptrdiff_t)cur,
                                  std::greater<int32_t>());
@@ -1366,6 +1394,11 @@ int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
     HIP_TRY(hipMemsetAsync(s.x, 0, sizeof(double) * V, e->stream));
     HIP_TRY(hipMemsetAsync(s.x2, 0, sizeof(double) * V, e->stream));
     HIP_TRY(hipMemsetAsync(s.x3, 0, sizeof(double) * V, e->stream));
+    s.act_bytes = (V / 32 + 64) * sizeof(uint32_t);
+    HIP_TRY(hipMalloc((void **)&s.act[0], s.act_bytes));
+    HIP_TRY(hipMalloc((void **)&s.act[1], s.act_bytes));
+    HIP_TRY(hipMemsetAsync(s.act[0], 0, s.act_bytes, e->stream));
+    HIP_TRY(hipMemsetAsync(s.act[1], 0, s.act_bytes, e->stream));
     HIP_TRY(hipMalloc((void **)&s.ft[0], sizeof(int) * V));
     HIP_TRY(hipMalloc((void **)&s.ft[1], sizeof(int) * V));
     HIP_TRY(hipMalloc((void **)&s.neg, sizeof(int) * (size_t)std::max(4 * e->c, 1)));

@@ -168,18 +168,6 @@ __global__ __launch_bounds__(BLOCK) void k_gseed_tails(const uint32_t *__restric
     if (threadIdx.x < GW && s_cnt[threadIdx.x]) atomicAdd(&cnt_out[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
-// (1.0-ALPHA)*x/den, bit for bit, without the ~11-instruction f64 division sequence per edge and
-// source: with rcp = RN(1/den) (one true division per ROW), q0 = a*rcp is within an ulp of a/den, the
-// remainder r = a - q0*den is exact in an FMA, and q0 + r*rcp rounds to RN(a/den) (Markstein's
-// correction step; den = outdeg+1 is a small integer, never an all-ones significand).
-// tests/test_exact_division.py checks the identity on 2e7 random operands.
-__device__ __forceinline__ double push_term(double x, double den, double rcp) {
-    const double a = ONE_MINUS_ALPHA * x;
-    const double q0 = a * rcp;
-    const double rem = __builtin_fma(-q0, den, a);
-    return __builtin_fma(rem, rcp, q0);
-}
-
 // One frontier iteration (ExpandUnifiedRev + RepairFrontierRev) for all sources of a group.
 // NVX = vertices per sweep group (the LDS accumulators are NVX x GW doubles: 64 KB for both
 // instantiations, two 1024-thread workgroups per CU).

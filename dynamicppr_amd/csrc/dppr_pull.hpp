@@ -58,7 +58,14 @@ __device__ unsigned long long g_stamps[4096 * 8];
 // instead of one. On windows that run this kernel per iteration the sweep is latency-bound per group
 // (DESIGN.md section 6), and the second resident workgroup is worth 12 % (LiveJournal stand-in:
 // 88 -> 77 us per sweep). The block sizes that are not powers of two exist for tests only.
-template <int PULL_BLOCK>
+// BITS: the sweep is given the ACTIVITY BITMAP of the snapshot it reads (bit u = x[u] != 0) and writes the one
+// of the snapshot it produces. A gather is then preceded by a bit test: one bit per vertex stays in L2
+// (LiveJournal stand-in 150 KB, twitter 2.5 MB, friendster 8 MB) where x (9 MB .. 500 MB) does not, and
+// the share of a sweep's edges whose head is NOT in the frontier -- 27 % on the configs[1] stand-in, 45 %
+// on the friendster one, nearly all of them in the tail of a loop -- costs an L2 hit instead of a random
+// sector from Infinity Cache / HBM. x stays a complete snapshot (zeros included) either way, so the other
+// kernels do not care which form ran. Used on windows that cannot run resident (dppr_engine.hip).
+template <int PULL_BLOCK, bool BITS>
 __global__ __launch_bounds__(PULL_BLOCK, (PULL_BLOCK & (PULL_BLOCK - 1)) == 0 ? 8 : 1) void k_pull_iter(int V, const int *__restrict__ grp_tile, int n_groups,
                                                           const int *__restrict__ cnt_in,
                                                           const int *__restrict__ out_row_ptr,
@@ -67,12 +74,16 @@ __global__ __launch_bounds__(PULL_BLOCK, (PULL_BLOCK & (PULL_BLOCK - 1)) == 0 ? 
                                                           double *__restrict__ r, double *__restrict__ p,
                                                           int *__restrict__ cnt_out, int *__restrict__ cnt_zero,
                                                           int phase, double eps, IterStats *__restrict__ stats,
-                                                          int *__restrict__ log_slot, int pull_big_row) {
+                                                          int *__restrict__ log_slot, int pull_big_row,
+                                                          const uint32_t *__restrict__ act_in,
+                                                          uint32_t *__restrict__ act_out) {
     constexpr int PULL_WAVES = PULL_BLOCK / WAVE;
+    __shared__ uint32_t s_bits[BITS ? 2 * PULL_WAVES : 2]; // next snapshot's activity words of the group's tiles
     __shared__ int s_own[PULL_WAVES][WAVE * PU];   // per round: owner marks of the wave's edge window
     __shared__ int s_scan[PULL_WAVES][WAVE + 1];
     __shared__ int s_start[PULL_WAVES][WAVE];
     __shared__ double s_acc[PULL_WAVES][WAVE];
+    __shared__ double s_rcp[PULL_WAVES][WAVE];     // 1 / (outdeg + 1) per row: one division per vertex, none per edge (push_term)
     __shared__ int s_cnt[PULL_WAVES];
     __shared__ unsigned long long s_edges[PULL_WAVES];
     __shared__ PullBig s_big[PULL_BIG_CAP];
@@ -115,7 +126,7 @@ __global__ __launch_bounds__(PULL_BLOCK, (PULL_BLOCK & (PULL_BLOCK - 1)) == 0 ? 
 
     // repair, threshold, next snapshot. pv = pagerank[v], loaded up front with r and x so the
     // "pagerank[v] += ALPHA*rn" of the next snapshot costs no extra round trip
-    auto finish = [&](bool valid, int v, double rv, double xv, double pv, double rn) {
+    auto finish = [&](bool valid, int v, double rv, double xv, double pv, double rn) -> bool {
         if (xv != 0.0) rn -= xv;
         const bool lg = valid && legal(rn, phase, eps);
         if (valid) {
@@ -124,7 +135,10 @@ __global__ __launch_bounds__(PULL_BLOCK, (PULL_BLOCK & (PULL_BLOCK - 1)) == 0 ? 
             if (lg) p[v] = pv + ALPHA * rn;
         }
         n_legal += lg ? 1 : 0;
+        return lg;
     };
+    // x[c] for a head c: behind its activity bit when the sweep has the bitmap
+    auto head_active = [&](int c) -> bool { return ((act_in[c >> 5] >> (c & 31)) & 1u) != 0u; };
 
     for (int g = blockIdx.x; g < n_groups; g += gridDim.x) { // workgroup-uniform loop
         if (threadIdx.x == 0) s_nbig = 0;
@@ -163,6 +177,7 @@ __global__ __launch_bounds__(PULL_BLOCK, (PULL_BLOCK & (PULL_BLOCK - 1)) == 0 ? 
         s_start[w][lane] = rs;
         if (lane == 0) s_scan[w][WAVE] = total;
         s_acc[w][lane] = rv;
+        s_rcp[w][lane] = 1.0 / (double)(dd + 1);
         STAMP(1);
 
         // ---- the wave's own (short) rows: 64*PU consecutive edges of the concatenated list per
@@ -189,14 +204,22 @@ __global__ __launch_bounds__(PULL_BLOCK, (PULL_BLOCK & (PULL_BLOCK - 1)) == 0 ? 
                 if (own[k] >= 0) col[k] = out_col[s_start[w][o] + (e - s_scan[w][o])];
             }
             double xa[PU];
+            if constexpr (BITS) {
+                bool on[PU];
 #pragma unroll
-            for (int k = 0; k < PU; ++k) xa[k] = own[k] >= 0 ? x[col[k]] : 0.0;
+                for (int k = 0; k < PU; ++k) on[k] = own[k] >= 0 && head_active(col[k]);
+#pragma unroll
+                for (int k = 0; k < PU; ++k) xa[k] = on[k] ? x[col[k]] : 0.0;
+            } else {
+#pragma unroll
+                for (int k = 0; k < PU; ++k) xa[k] = own[k] >= 0 ? x[col[k]] : 0.0;
+            }
 #pragma unroll
             for (int k = 0; k < PU; ++k) {
                 const bool nz = xa[k] != 0.0;
                 if (nz) {
                     const int dk = s_scan[w][own[k] + 1] - s_scan[w][own[k]];
-                    lds_add(&s_acc[w][own[k]], ONE_MINUS_ALPHA * xa[k] / (double)(dk + 1));
+                    lds_add(&s_acc[w][own[k]], push_term(xa[k], (double)(dk + 1), s_rcp[w][own[k]]));
                 }
                 edges += (unsigned long long)__popcll(__ballot(nz));
             }
@@ -204,7 +227,14 @@ __global__ __launch_bounds__(PULL_BLOCK, (PULL_BLOCK & (PULL_BLOCK - 1)) == 0 ? 
         }
         __builtin_amdgcn_wave_barrier();
         STAMP(2);
-        finish(valid && !deferred, v, rv, xv, pv, s_acc[w][lane]); // deferred vertices are finished below
+        const bool lgw = finish(valid && !deferred, v, rv, xv, pv, s_acc[w][lane]); // deferred vertices are finished below
+        if constexpr (BITS) {
+            const uint64_t lb = __ballot(lgw);
+            if (lane == 0) {
+                s_bits[2 * w] = (uint32_t)lb;
+                s_bits[2 * w + 1] = (uint32_t)(lb >> 32);
+            }
+        }
         STAMP(3);
 
         // ---- the workgroup's long rows, cut into chunks of PULL_CHUNK edges dealt round-robin to
@@ -229,7 +259,7 @@ __global__ __launch_bounds__(PULL_BLOCK, (PULL_BLOCK & (PULL_BLOCK - 1)) == 0 ? 
                 const int row_rs = s_big[lo].rs, row_d = s_big[lo].d;
                 const int c0 = (ch - s_chunk0[w][lo]) * PULL_CHUNK;
                 const int c1 = min(c0 + PULL_CHUNK, row_d);
-                const double denom = (double)(row_d + 1);
+                const double denom = (double)(row_d + 1), rdenom = 1.0 / denom;
                 double part = 0.0;
                 constexpr int CH_SLOTS = PULL_CHUNK / WAVE; // all of a chunk's loads are issued before any use
                 int colb[CH_SLOTS];
@@ -239,12 +269,20 @@ __global__ __launch_bounds__(PULL_BLOCK, (PULL_BLOCK & (PULL_BLOCK - 1)) == 0 ? 
                     const int e = c0 + k * WAVE + lane;
                     colb[k] = e < c1 ? out_col[row_rs + e] : -1;
                 }
+                if constexpr (BITS) {
+                    bool on[CH_SLOTS];
 #pragma unroll
-                for (int k = 0; k < CH_SLOTS; ++k) xb[k] = colb[k] >= 0 ? x[colb[k]] : 0.0;
+                    for (int k = 0; k < CH_SLOTS; ++k) on[k] = colb[k] >= 0 && head_active(colb[k]);
+#pragma unroll
+                    for (int k = 0; k < CH_SLOTS; ++k) xb[k] = on[k] ? x[colb[k]] : 0.0;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < CH_SLOTS; ++k) xb[k] = colb[k] >= 0 ? x[colb[k]] : 0.0;
+                }
 #pragma unroll
                 for (int k = 0; k < CH_SLOTS; ++k) {
                     const bool nz = xb[k] != 0.0;
-                    if (nz) part += ONE_MINUS_ALPHA * xb[k] / denom;
+                    if (nz) part += push_term(xb[k], denom, rdenom);
                     edges += (unsigned long long)__popcll(__ballot(nz));
                 }
                 part = wave_sum(part);
@@ -259,11 +297,18 @@ __global__ __launch_bounds__(PULL_BLOCK, (PULL_BLOCK & (PULL_BLOCK - 1)) == 0 ? 
                     big = s_big[lane];
                     acc = s_bigacc[lane];
                 }
-                finish(has, big.v, big.rv, big.xv, big.pv, big.rv + acc);
+                const bool lgb = finish(has, big.v, big.rv, big.xv, big.pv, big.rv + acc);
+                if constexpr (BITS) {
+                    if (lgb) atomicOr(&s_bits[(big.v >> 5) - 2 * t0], 1u << (big.v & 31));
+                }
             }
         }
         STAMP(4);
         __syncthreads();
+        if constexpr (BITS) { // the group's tiles are consecutive: 2 words per tile, complete
+            if ((int)threadIdx.x < 2 * (t1 - t0) && t0 * WAVE + (int)threadIdx.x * 32 < V)
+                act_out[2 * t0 + threadIdx.x] = s_bits[threadIdx.x];
+        }
     }
     STAMP(5);
     // count of the next frontier: wave reduce, then ONE fire-and-forget atomic per workgroup

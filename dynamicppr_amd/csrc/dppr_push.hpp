@@ -66,13 +66,14 @@ __global__ __launch_bounds__(BLOCK) void k_inspect(const double *__restrict__ r,
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_snapshot_dense(const int *__restrict__ ft, const int *__restrict__ cnt_in,
                                                           const double *__restrict__ r, double *__restrict__ p,
-                                                          double *__restrict__ x) {
+                                                          double *__restrict__ x, uint32_t *__restrict__ act) {
     const int F = *cnt_in;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < F; i += gridDim.x * BLOCK) {
         const int u = ft[i];
         const double ru = r[u];
         x[u] = ru;
         p[u] += ALPHA * ru;
+        if (act && ru != 0.0) atomicOr(&act[u >> 5], 1u << (u & 31)); // activity bitmap of the snapshot (cleared by the host)
     }
 }
 

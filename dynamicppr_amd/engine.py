@@ -54,7 +54,7 @@ EXPORTS = [
     "dppr_reset_stats", "dppr_inspect", "dppr_read_graph", "dppr_graph_edges", "dppr_read_out_graph", "dppr_trace_enable",
     "dppr_trace_get", "dppr_synchronize", "dppr_bench_atomics",
     "dppr_add_source_group", "dppr_group_init_solve", "dppr_group_update", "dppr_group_read", "dppr_group_stats",
-    "dppr_group_reset_stats", "dppr_set_group_seeding", "dppr_seed_lists",
+    "dppr_group_reset_stats", "dppr_set_group_seeding", "dppr_seed_lists", "dppr_set_sweep_bitmap",
 ]
 
 
@@ -106,6 +106,7 @@ def lib():
     L.dppr_group_update.argtypes = [vp, C.c_int32, C.c_int32, C.c_double, fp]
     L.dppr_group_read.argtypes = [vp, C.c_int32, C.c_int32, dp, dp]
     L.dppr_group_stats.argtypes = [vp, C.c_int32, C.POINTER(Stats)]
+    L.dppr_set_sweep_bitmap.argtypes = [vp, C.c_int]
     L.dppr_seed_lists.argtypes = [vp, C.c_int32, C.c_int, ip, ip]
     L.dppr_group_reset_stats.argtypes = [vp, C.c_int32]
     L.dppr_set_group_seeding.argtypes = [vp, C.c_int]
@@ -134,7 +135,7 @@ class Engine:
 
     def __init__(self, V, W, directed, max_batch, n_epochs=1, device=0, schedule=SCHEDULE_EAGER,
                  hub_min_degree=None, big_row_edges=None, pull_min_frontier=None, chunk_iters=None, pull_block=None,
-                 persistent=None, persist_timeout_us=None):
+                 persistent=None, persist_timeout_us=None, sweep_bitmap=None):
         self._L = lib()
         self._h = C.c_void_p()
         self.V, self.W, self.directed, self.c = int(V), int(W), int(directed), int(max_batch)
@@ -147,6 +148,8 @@ class Engine:
             self._ck(self._L.dppr_set_tuning(self._h, int(hub_min_degree or 256), int(big_row_edges or 512),
                                              int(pull_min_frontier or 0), int(chunk_iters or 0),
                                              int(pull_block or 0)), "set_tuning")
+        if sweep_bitmap is not None:
+            self._ck(self._L.dppr_set_sweep_bitmap(self._h, int(sweep_bitmap)), "set_sweep_bitmap")
         if persistent is not None or persist_timeout_us is not None:
             self._ck(self._L.dppr_set_persistent(self._h, 1 if persistent is None else int(persistent),
                                                  int(persist_timeout_us or 0)), "set_persistent")

@@ -122,6 +122,14 @@ int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges, int p
  * Only valid right after dppr_create. */
 int dppr_set_persistent(dppr_engine *e, int mode, int64_t timeout_us);
 
+/* Single-source per-iteration sweeps (windows too large for a resident launch) can test an activity
+ * bitmap of the snapshot (1 bit per vertex, L2-resident) before each 8-byte gather of x[u], so that
+ * heads outside the frontier cost no random sector (k_pull_iter<.., true>). Off by default: on the
+ * LiveJournal and twitter stand-ins it fetches 30 % / 0 % fewer bytes and is 0 % / 23 % SLOWER (the
+ * extra dependent L2 round trip per edge costs more than the sectors it saves; profiles/r02_pmc_*_bits*).
+ * Source groups always use their bitmap (dppr_multi.hpp). Results are identical either way. */
+int dppr_set_sweep_bitmap(dppr_engine *e, int on);
+
 /* ---- graph side (UNTIMED in the reference's metric) --------------------- */
 
 /* Replaces: SlidingGraphBuilder::InitWindowStream (gpu/SlidingGraphBuilder.cuh:182-192)

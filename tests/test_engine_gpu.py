@@ -38,10 +38,13 @@ TUNINGS = [dict(pull_min_frontier=-1), dict(hub_min_degree=3, big_row_edges=8, p
            dict(pull_min_frontier=1, persistent=0), dict(pull_min_frontier=1, pull_block=256),
            dict(pull_min_frontier=1, pull_block=256, persist_timeout_us=-1),
            # resident launches that may run only 3 sweeps at a time: every one stops mid-phase and is resumed
-           dict(pull_min_frontier=1, chunk_iters=3)]
+           dict(pull_min_frontier=1, chunk_iters=3),
+           # per-iteration sweeps that test the activity bitmap before each gather (several groups / mixed with push / odd block)
+           dict(pull_min_frontier=1, persistent=0, sweep_bitmap=1, pull_block=256, big_row_edges=8),
+           dict(pull_min_frontier=40, persistent=0, sweep_bitmap=1), dict(pull_min_frontier=1, sweep_bitmap=1, pull_block=640)]
 TUNING_IDS = ["push-only", "push-hubs+bigrows", "push-all-hub-all-big", "pull-only", "mixed-pull>=40", "default",
               "mixed-chunk1", "mixed-chunk3", "pull-wg512", "mixed-wg1024", "pull-no-persist", "pull-wg256",
-              "pull-rollcall-fails", "pull-resident-3-sweeps"]
+              "pull-rollcall-fails", "pull-resident-3-sweeps", "pull-bitmap-wg256", "mixed-bitmap", "pull-bitmap-wg640"]
 
 
 def make(directed, schedule=eng.SCHEDULE_EAGER, scale=9, edges=6000, seed=11, W=600, c=6, eps=1e-9, n_epochs=1,
