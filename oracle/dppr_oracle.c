@@ -654,6 +654,108 @@ void orc_sync_inc_execute(orc_state *s, const orc_graph *g) {
     orc_sync_main_loop(s, g, 1);
 }
 
+/* ------------------------------------------------------------------ variants 1-3 (cilk -t 1) */
+/* cpu/PPRCPUMTCilkRevVariants.h at one worker (parallel_for == for, sequence::pack == stable
+ * compaction), the classes main() selects with -o (cpu/PPRCPUMTMain.cpp:26-32):
+ *   1 FAST_FRONTIER PPRCPUMTCilkRevFF      :224-326  snapshot every frontier residual first
+ *       (ft_r = r[u]; p += ALPHA*r[u]; r[u] = 0), push from the snapshot, enqueue on threshold
+ *       crossing, no repair step;
+ *   2 EAGER         PPRCPUMTCilkRevEager   :112-222  eager reads like variant 0, but duplicates are
+ *       kept out by the status array (status[u] = iteration_id for frontier members, a target enters
+ *       when its residual is legal and AtomicUpdateStatus succeeds), repair step as in variant 0;
+ *   3 VANILLA       PPRCPUMTCilkRevVanilla :6-110    snapshot first (like 1) + status array (like 2).
+ * status starts at -1 (cpu/PPRCPUMTCilkRev.h:12-13) and is never reset; AtomicUpdateStatus
+ * (:96-106) compares with the member iteration_id. */
+static int variant_update_status(orc_state *s, int v) { /* cpu/PPRCPUMTCilkRev.h:96-106 */
+    if (s->status[v] < s->iteration_id) {
+        s->status[v] = s->iteration_id;
+        return 1;
+    }
+    return 0;
+}
+
+void orc_variant_main_loop(orc_state *s, const orc_graph *g, int phase, int variant) {
+    double *residual = s->r, *pagerank = s->p;
+    const int *deg = g->deg;
+    if (variant == 0) {
+        orc_cilk_main_loop(s, g, phase);
+        return;
+    }
+    const int pre_extract = variant == 1 || variant == 3; /* FF, VANILLA */
+    const int use_status = variant == 2 || variant == 3;  /* EAGER, VANILLA */
+    for (;;) {
+        int F = s->ft_count;
+        if (F == 0) break;
+        trace_frontier(s, s->ft, F);
+        for (int i = 0; i < F; ++i) { /* first parallel_for of each MainLoop */
+            int u = s->ft[i];
+            if (pre_extract) {        /* Variants.h:24-30 / :242-248 */
+                s->ft_r[i] = residual[u];
+                pagerank[u] += ORC_ALPHA * residual[u];
+                residual[u] = 0.0;
+            } else {                  /* :130-134 */
+                s->status[u] = s->iteration_id;
+            }
+        }
+        int n = 0;
+        int64_t E = 0;
+        for (int i = 0; i < F; ++i) {
+            int u = s->ft[i];
+            double ru;
+            if (pre_extract) {
+                ru = s->ft_r[i];
+            } else {                  /* :139-142 */
+                ru = residual[u];
+                s->ft_r[i] = ru;
+                pagerank[u] += ORC_ALPHA * ru;
+            }
+            const orc_vec *nb = &g->in[u];
+            E += nb->n;
+            for (int j = 0; j < nb->n; ++j) {
+                int v = vec_at(nb, j);
+                double add = (1.0 - ORC_ALPHA) * ru / (deg[v] + 1);
+                double prer = residual[v];
+                residual[v] = prer + add;
+                double curr = prer + add;
+                int is_frontier;
+                if (use_status) is_frontier = LEGAL(curr) && variant_update_status(s, v); /* :52-57 / :154-159 */
+                else is_frontier = LEGAL(prer) == 0 && LEGAL(curr) == 1;                  /* :266-268 */
+                if (is_frontier) s->ft2[n++] = v;
+            }
+        }
+        if (!pre_extract) {           /* EAGER's repair step :195-206 */
+            for (int i = 0; i < F; ++i) {
+                int u = s->ft[i];
+                residual[u] -= s->ft_r[i];
+                if (LEGAL(residual[u])) s->ft2[n++] = u;
+            }
+        }
+        assert(n <= s->V);
+        s->stat_iters++; s->stat_F += F; s->stat_E += E; s->stat_N += n;
+        int *t = s->ft; s->ft = s->ft2; s->ft2 = t;
+        s->ft_count = n;
+        ++s->iteration_id;
+    }
+}
+
+void orc_variant_execute(orc_state *s, const orc_graph *g, int variant) { /* ExecuteImpl, PPRCPUMTCilkRev.h:38-41 */
+    for (int u = 0; u <= s->V; ++u) s->status[u] = -1; /* the constructor's memset, :12-13 */
+    s->iteration_id = 0;
+    orc_cilk_init(s);
+    orc_variant_main_loop(s, g, 0, variant);
+}
+
+void orc_variant_inc_execute(orc_state *s, const orc_graph *g, int variant) { /* IncExecuteImpl :43-73 */
+    orc_copy_revert_out_degree(s, g);
+    orc_stream_update(s, g);
+    ++s->iteration_id;
+    orc_dyn_push_init(s, g, 0);
+    orc_variant_main_loop(s, g, 0, variant);
+    ++s->iteration_id;
+    orc_dyn_push_init(s, g, 1);
+    orc_variant_main_loop(s, g, 1, variant);
+}
+
 /* ------------------------------------------------------------------ ground truth */
 /* cpu/PPRCPUPowVec.h:55-83 CalPPRRev */
 int64_t orc_pow_rev(const orc_graph *g, int source, double alpha, double *out_p) {

@@ -151,6 +151,12 @@ void orc_sync_main_loop(orc_state *s, const orc_graph *g, int phase);
 void orc_sync_execute(orc_state *s, const orc_graph *g);
 void orc_sync_inc_execute(orc_state *s, const orc_graph *g);
 
+/* ---- variants 1-3 of the CPU path at -t 1: cpu/PPRCPUMTCilkRevVariants.h (FF :224-326, Eager
+ * :112-222, Vanilla :6-110), selected by -o (cpu/PPRCPUMTMain.cpp:26-32); variant 0 = schedule A ---- */
+void orc_variant_main_loop(orc_state *s, const orc_graph *g, int phase, int variant);
+void orc_variant_execute(orc_state *s, const orc_graph *g, int variant);
+void orc_variant_inc_execute(orc_state *s, const orc_graph *g, int variant);
+
 /* ---- ground truth: cpu/PPRCPUPowVec.h:55-83 CalPPRRev ---- */
 int64_t orc_pow_rev(const orc_graph *g, int source, double alpha, double *out_p);
 

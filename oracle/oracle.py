@@ -94,6 +94,9 @@ def lib():
                  "orc_stream_update"):
         getattr(L, name).argtypes = [SP, GP]
         getattr(L, name).restype = None
+    for name in ("orc_variant_execute", "orc_variant_inc_execute"):
+        getattr(L, name).argtypes = [SP, GP, C.c_int]
+        getattr(L, name).restype = None
     L.orc_cilk_init.argtypes = [SP]
     L.orc_cilk_inc_execute_mt.argtypes = [SP, GP, C.c_int]
     L.orc_cilk_inc_execute_mt.restype = None
@@ -247,6 +250,8 @@ class State:
     def sync_inc_execute(self, g): lib().orc_sync_inc_execute(self._s, g._g)
     def sync_main_loop(self, g, phase): lib().orc_sync_main_loop(self._s, g._g, phase)
     def cilk_main_loop(self, g, phase): lib().orc_cilk_main_loop(self._s, g._g, phase)
+    def variant_execute(self, g, variant): lib().orc_variant_execute(self._s, g._g, int(variant))
+    def variant_inc_execute(self, g, variant): lib().orc_variant_inc_execute(self._s, g._g, int(variant))
     def copy_revert_out_degree(self, g): lib().orc_copy_revert_out_degree(self._s, g._g)
     def stream_update(self, g): lib().orc_stream_update(self._s, g._g)
     def dyn_push_init(self, g, phase): lib().orc_dyn_push_init(self._s, g._g, phase)

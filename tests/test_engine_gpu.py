@@ -198,6 +198,34 @@ def test_sync_schedule_frontier_sets_bit_exact(directed, tuning):
     assert st["sum_E"] == sc.s.stats()["E"] and st["sum_F"] == sc.s.stats()["F"]
 
 
+@pytest.mark.parametrize("variant", [1, 3])
+@pytest.mark.parametrize("directed", [1, 0])
+def test_sync_schedule_is_the_reference_fast_frontier_variant(directed, variant):
+    """`./pagerank -o 1|3` runs DPPR_SCHEDULE_SYNC: its per-iteration frontier sets, iteration count and
+    traversed edges equal the oracle's restatement of PPRCPUMTCilkRevFF / ...Vanilla
+    (cpu/PPRCPUMTCilkRevVariants.h) at -t 1, batch after batch."""
+    sc = make(directed, schedule=eng.SCHEDULE_SYNC, c=20)
+    sc.s.trace(True)
+    sc.e.trace_enable(sc.slot, True)
+    sc.s.variant_execute(sc.g, variant)
+    sc.e.init_solve(sc.slot, sc.eps)
+    for k in range(5):
+        if k:
+            assert sc.advance_graphs()
+            sc.s.trace(True)
+            sc.e.trace_enable(sc.slot, True)
+            sc.s.variant_inc_execute(sc.g, variant)
+            sc.e.update(sc.slot, sc.eps)
+        want, got = sc.s.traced_frontiers(), sc.e.trace_get(sc.slot)
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert np.array_equal(np.sort(a), np.sort(b))
+        p, r = sc.e.read(sc.slot)
+        assert np.max(np.abs(p - sc.s.p)) < SYNC_TOL and np.max(np.abs(r - sc.s.r)) < SYNC_TOL
+    st, want = sc.e.stats(sc.slot), sc.s.stats()
+    assert (st["iterations"], st["sum_F"], st["sum_E"]) == (want["iters"], want["F"], want["E"])
+
+
 @pytest.mark.parametrize("tuning", TUNINGS, ids=TUNING_IDS)
 @pytest.mark.parametrize("directed", [1, 0])
 def test_sync_schedule_chunked_launches_same_work(directed, tuning):
