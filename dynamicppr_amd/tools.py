@@ -3,8 +3,10 @@
 * :func:`encode_snap` -- ``encoder/GraphEncoder.h:20-98`` ``EncodeSnapToBin``: SNAP edge-list text to the
   ``.bin`` stream (``int32 V`` then ``int32`` pairs). Ids are rebased to ``id - min_id``, ``V`` is the id
   RANGE ``max - min + 1`` (isolated ids included), the edge order is shuffled. The reference shuffles
-  with an unseeded ``rand() % E`` swap per edge (``:72-79``); here it is a seeded uniform permutation,
-  so a conversion is reproducible. ``#`` comment lines of SNAP files are skipped.
+  with an unseeded ``rand() % E`` swap per edge (``:72-79``); the default here is a seeded uniform
+  permutation, ``shuffle="glibc"`` replays the reference's swaps with glibc's ``rand()`` sequence and
+  gives its encoder's output byte for byte. ``#`` comment lines of SNAP files are skipped (the
+  reference's ``file >> vid`` loop never terminates on them).
 * :func:`reverse_bin` -- ``encoder/GraphEncoder.h:100-131``: swap the endpoints of every edge.
 * :func:`workload` -- ``workload/Workload.cpp:30-62`` + ``workload/Graph.h:178-227``: rank vertices by
   (out or in) degree over the whole file or its first 10 % window and write three id files of 10
@@ -24,8 +26,41 @@ import numpy as np
 from . import datagen
 
 
+class GlibcRand:
+    """glibc's ``rand()`` (TYPE_3 additive feedback generator of ``random_r``; ``srand(1)`` is the state
+    a program that never seeds starts in). The reference's tools shuffle and sample with unseeded
+    ``rand()`` (``encoder/GraphEncoder.h:72-79``, ``workload/Graph.h:203``), so on glibc their output is
+    in fact deterministic -- and reproducible here."""
+
+    def __init__(self, seed: int = 1):
+        r = [0] * 34
+        r[0] = seed & 0xFFFFFFFF
+        for i in range(1, 31):
+            hi, lo = divmod(r[i - 1] if r[i - 1] < 2 ** 31 else r[i - 1] - 2 ** 32, 127773)
+            word = 16807 * lo - 2836 * hi
+            if word < 0:
+                word += 2147483647
+            r[i] = word & 0xFFFFFFFF
+        for i in range(31, 34):
+            r[i] = r[i - 31]
+        self.r = r
+        for _ in range(310):
+            self._step()
+
+    def _step(self):
+        r = self.r
+        v = (r[-31] + r[-3]) & 0xFFFFFFFF
+        r.append(v)
+        if len(r) > 64:
+            del r[:len(r) - 34]
+        return v
+
+    def rand(self) -> int:
+        return self._step() >> 1
+
+
 def encode_snap(txt_path: str, out_path: str | None = None, reverse: bool = False, randomize: bool = True,
-                seed: int = 1) -> str:
+                seed: int = 1, shuffle: str = "numpy") -> str:
     rows = []
     with open(txt_path) as f:
         for line in f:
@@ -42,7 +77,17 @@ def encode_snap(txt_path: str, out_path: str | None = None, reverse: bool = Fals
     e2 = (edges[:, 1] - lo).astype(np.int32)
     if reverse:
         e1, e2 = e2, e1
-    if randomize:
+    if randomize and shuffle == "glibc":
+        # the reference's own shuffle, swap for swap (encoder/GraphEncoder.h:72-79): byte-identical output to
+        # its encoder built against glibc (tests/test_tools.py compares with a fixture produced by it)
+        g, n = GlibcRand(seed), len(e1)
+        a, b = e1.tolist(), e2.tolist()
+        for i in range(n):
+            pos = g.rand() % n
+            a[i], a[pos] = a[pos], a[i]
+            b[i], b[pos] = b[pos], b[i]
+        e1, e2 = np.array(a, dtype=np.int32), np.array(b, dtype=np.int32)
+    elif randomize:
         perm = np.random.default_rng(seed).permutation(len(e1))
         e1, e2 = e1[perm], e2[perm]
     if out_path is None:                                     # GraphEncoder.h:81-84 naming
@@ -117,13 +162,14 @@ def main():
     e = sub.add_parser("encode")
     e.add_argument("txt"); e.add_argument("--reverse", action="store_true"); e.add_argument("--seed", type=int, default=1)
     e.add_argument("--out", default=None); e.add_argument("--no-shuffle", action="store_true")
+    e.add_argument("--shuffle", default="numpy", choices=["numpy", "glibc"])
     w = sub.add_parser("workload")
     w.add_argument("bin"); w.add_argument("directed", type=int); w.add_argument("is_window", type=int)
     w.add_argument("is_out_degree", type=int); w.add_argument("--seed", type=int, default=1)
     w.add_argument("--out-dir", default=None)
     a = ap.parse_args()
     if a.cmd == "encode":
-        print("write to file", encode_snap(a.txt, a.out, a.reverse, not a.no_shuffle, a.seed))
+        print("write to file", encode_snap(a.txt, a.out, a.reverse, not a.no_shuffle, a.seed, a.shuffle))
     else:
         for count, (path, ids) in workload(a.bin, a.directed, a.is_window, a.is_out_degree, a.seed, a.out_dir).items():
             print(f"top{count} filename={path}: {list(map(int, ids))}")

@@ -58,3 +58,71 @@ def test_workload_id_files(tmp_path):
     assert out[10][0].endswith("syn.bin_topwindowrev10.txt")
     wdeg, _ = tools.degrees(V, e1[:4000], e2[:4000], 0)
     assert wdeg[np.loadtxt(out[10][0], dtype=np.int64)[0]] == wdeg.max()
+
+
+# ---------------------------------------------------------------------------------------------
+# Pinned against the REAL reference tools: tests/golden/tools_toy.npz holds what encoder/ and
+# workload/ of the reference (compiled from /root/reference, tests/golden/make_tools_golden.py)
+# wrote for a toy SNAP edge list.
+# ---------------------------------------------------------------------------------------------
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tools_toy.npz")
+
+
+def _toy(tmp_path):
+    d = np.load(GOLD)
+    txt = tmp_path / "toy.txt"
+    with open(txt, "w") as f:
+        for a, b in zip(d["snap.src"], d["snap.dst"]):
+            f.write(f"{a}\t{b}\n")
+    return d, str(txt)
+
+
+def test_glibc_rand_sequence():
+    """First outputs of glibc's rand() after srand(1) (the documented sequence every unseeded program sees)."""
+    g = tools.GlibcRand(1)
+    assert [g.rand() for _ in range(5)] == [1804289383, 846930886, 1681692777, 1714636915, 1957747793]
+
+
+def test_encoder_output_is_byte_identical_to_the_reference_encoder(tmp_path):
+    d, txt = _toy(tmp_path)
+    for rev, tag in ((False, "fwd"), (True, "rev")):
+        out = tools.encode_snap(txt, str(tmp_path / f"{tag}.bin"), reverse=rev, shuffle="glibc")
+        V, e1, e2 = datagen.read_bin(out)
+        assert V == int(d[f"bin.{tag}.V"][0]) == int(max(d["snap.src"].max(), d["snap.dst"].max())
+                                                      - min(d["snap.src"].min(), d["snap.dst"].min()) + 1)
+        assert np.array_equal(e1, d[f"bin.{tag}.e1"]) and np.array_equal(e2, d[f"bin.{tag}.e2"])   # order included
+    # the default (numpy) shuffle gives the same rebased multiset
+    out = tools.encode_snap(txt, str(tmp_path / "np.bin"), seed=9)
+    _, e1, e2 = datagen.read_bin(out)
+    assert sorted(zip(e1.tolist(), e2.tolist())) == sorted(zip(d["bin.fwd.e1"].tolist(), d["bin.fwd.e2"].tolist()))
+
+
+def test_workload_files_against_the_reference_workload_tool(tmp_path):
+    d, _ = _toy(tmp_path)
+    V = int(d["bin.fwd.V"][0])
+    binp = str(tmp_path / "toy.bin")
+    datagen.write_bin(binp, V, d["bin.fwd.e1"], d["bin.fwd.e2"])
+    for directed in (1, 0):
+        for window in (0, 1):
+            for outdeg in (1, 0):
+                ours = tools.workload(binp, directed, window, outdeg, seed=3, out_dir=str(tmp_path))
+                n = int(len(d["bin.fwd.e1"]) * 0.1) if window else len(d["bin.fwd.e1"])
+                deg, in_deg = tools.degrees(V, d["bin.fwd.e1"][:n], d["bin.fwd.e2"][:n], directed)
+                cmp_deg = deg if outdeg else in_deg
+                ranked = np.sort(cmp_deg)[::-1]
+                ref10 = d[f"wl.d{directed}.w{window}.o{outdeg}.10"]
+                # top10: the reference's std::sort leaves ties in unspecified order -- the degree sequence is exact,
+                # and so are the ids wherever the degree is unique
+                assert np.array_equal(cmp_deg[ref10], ranked[:10])
+                assert np.array_equal(cmp_deg[ours[10][1]], ranked[:10])
+                for i in range(10):
+                    if np.count_nonzero(cmp_deg == ranked[i]) == 1:
+                        assert ours[10][1][i] == ref10[i]
+                # sampled files: 10 distinct connected ids whose degree lies in the rank range's degree band
+                for count, (lo, hi) in ((1000, (10, 1000)), (1000000, (1000, 1000000))):
+                    hi = min(hi, V)
+                    band = (ranked[hi - 1], ranked[lo])
+                    for ids in (d[f"wl.d{directed}.w{window}.o{outdeg}.{count}"], ours[count][1]):
+                        assert len(ids) == 10 and len(set(ids.tolist())) == 10
+                        assert np.all((cmp_deg[ids] >= band[0]) & (cmp_deg[ids] <= band[1]))
+                        assert np.all(deg[ids] > 0) and np.all(in_deg[ids] > 0)
