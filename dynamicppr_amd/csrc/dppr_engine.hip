@@ -48,10 +48,12 @@ struct Epoch {
     int *grp_tile = nullptr; // V/64 + 2
     int n_groups = 0;
     int grp_n_int = 0;       // internal ids covered by the table
-    // the same for the 16-wide source-group sweep, whose groups hold at most 512 vertices (cut only
-    // once such a group exists)
+    // the same for the source-group sweeps (k_gsweep), cut once a source group exists: many small groups --
+    // two workgroups per CU and an even spread matter there, a bound on the group count does not; at
+    // most 512 vertices each when a 16-wide source group exists
     int *ggrp_tile = nullptr;
     int n_ggroups = 0;
+    int ggrp_max_tiles = 0;
     // hub directory of this epoch (vertices whose pushes are aggregated in LDS)
     int *hub_v = nullptr, *hub_degp1 = nullptr;
     int n_hubs = 0;
@@ -155,7 +157,10 @@ struct dppr_engine {
     bool sweep_bits = false;        // per-iteration single-source sweeps test an activity bitmap before each gather (dppr_set_sweep_bitmap;
                                     // measured slower on every stand-in, DESIGN.md section 6: off unless asked for)
     bool hot_blocks = true;         // vertex numbering in blocks of falling in-degree (DPPR_HOT_BLOCKS=0: two blocks, hot | rest)
-    bool wide_groups = false;       // a source group of more than 8 sources exists: epochs carry the second group table
+    bool any_groups = false;        // a source group exists: epochs carry the second group table
+    int ggroups_min = 256;          // ... of at least this many groups (DPPR_GGROUPS_MIN: tuning runs; 512 / 1008 measured slower on
+                                    // the configs[1] stand-in, equal on the LiveJournal one)
+    bool wide_groups = false;       // ... one of more than 8 sources: its groups hold at most 512 vertices
     bool group_tail_seeding = true; // source groups seed from the batch tails after a converged solve (false: dense Inspect)
     // stream-update scratch
     uint32_t *su_k[2] = {nullptr, nullptr}, *su_v[2] = {nullptr, nullptr};
@@ -237,7 +242,8 @@ int cut_sweep_groups(dppr_engine *e, Epoch &ep);
 // dppr_write to an unseen vertex) is not covered by that epoch's sweep groups: re-cut them.
 int recut_stale_groups(dppr_engine *e) {
     for (auto &ep : e->epochs)
-        if (ep.id >= 0 && (ep.grp_n_int != e->n_int || (e->wide_groups && ep.n_ggroups == 0))) {
+        if (ep.id >= 0 && (ep.grp_n_int != e->n_int || (e->any_groups && ep.n_ggroups == 0) ||
+                           (e->wide_groups && ep.ggrp_max_tiles > 512 / WAVE))) {
             int rc = cut_sweep_groups(e, ep);
             if (rc) return rc;
         }
@@ -411,10 +417,11 @@ int cut_sweep_groups(dppr_engine *e, Epoch &ep) {
     HIP_TRY(hipMemcpyAsync(ep.grp_tile, cut.data(), sizeof(int) * cut.size(), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream)); // `cut` is a local
     ep.n_ggroups = 0;
-    if (e->wide_groups) { // groups of at most 8 tiles for k_gsweep<2, 512>
-        const int gmax = 512 / WAVE;
-        const long long want = std::max<long long>(504, (n_tiles + gmax * 3 / 4 - 1) / std::max(1, gmax * 3 / 4));
+    if (e->any_groups) { // groups of at most 16 (8) tiles for k_gsweep<1, 1024> (<2, 512>)
+        const int gmax = (e->wide_groups ? 512 : 1024) / WAVE;
+        const long long want = std::max<long long>(e->ggroups_min, (n_tiles + gmax * 3 / 4 - 1) / std::max(1, gmax * 3 / 4));
         const long long target = std::max<long long>(1, total_w / want);
+        ep.ggrp_max_tiles = gmax;
         cut.clear();
         cut.push_back(0);
         long long acc = 0;
@@ -849,6 +856,19 @@ int main_loop_inspect(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
     return run_frontier_loop(e, s, ep, phase, eps, 0, 0);
 }
 
+// Stable grouping of the epoch's batch records by tail: su_k[1] = tails ascending, su_v[1] = record indices
+// (ascending inside a tail): key extraction + the device radix sort. `zero` / `zero_ints` are cleared on the
+// way (the counters of what follows).
+int group_records_by_tail(dppr_engine *e, const Epoch &ep, unsigned long long *zero, int nz, int *zero_ints, int nzi) {
+    const int L = ep.L;
+    hipLaunchKernelGGL(k_su_keys, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->su_k[0], e->su_v[0], zero, nz,
+                       zero_ints, nzi);
+    size_t tmp = e->su_tmp_bytes;
+    HIP_TRY(rocprim::radix_sort_pairs(e->su_tmp, tmp, e->su_k[0], e->su_k[1], e->su_v[0], e->su_v[1], (size_t)L, 0u,
+                                      (unsigned)e->bits, e->stream));
+    return DPPR_OK;
+}
+
 // IncrementalBatchUpdate; when seed != 0 also seeds ft[0]/cnt[0] (phase 0) and neg/cnt[3].
 int stream_update(dppr_engine *e, Slot &s, const Epoch &ep, double eps, bool seed, bool zero_bars = false) {
     const int L = ep.L;
@@ -857,12 +877,9 @@ int stream_update(dppr_engine *e, Slot &s, const Epoch &ep, double eps, bool see
         return DPPR_OK;
     }
     // (the batch's first kernel also clears cnt[0..4] and, for a resident launch enqueued ahead, its GridBar)
-    hipLaunchKernelGGL(k_su_keys, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->su_k[0], e->su_v[0],
-                       zero_bars ? reinterpret_cast<unsigned long long *>(e->bar) : nullptr,
-                       zero_bars ? (int)(sizeof(GridBar) / sizeof(unsigned long long)) : 0, s.cnt, 5);
-    size_t tmp = e->su_tmp_bytes;
-    HIP_TRY(rocprim::radix_sort_pairs(e->su_tmp, tmp, e->su_k[0], e->su_k[1], e->su_v[0], e->su_v[1], (size_t)L, 0u,
-                                      (unsigned)e->bits, e->stream));
+    int rc = group_records_by_tail(e, ep, zero_bars ? reinterpret_cast<unsigned long long *>(e->bar) : nullptr,
+                                   zero_bars ? (int)(sizeof(GridBar) / sizeof(unsigned long long)) : 0, s.cnt, 5);
+    if (rc) return rc;
     // without seeding the lists go to scratch space (cnt[4] / neg) and are ignored
     hipLaunchKernelGGL(k_su_apply_fused, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, e->su_k[1], e->su_v[1], ep.b2, ep.ins,
                        ep.deg_after, L, s.p, s.r, s.source, seed ? eps : 1e300, s.ft[0], s.cnt + 0, s.neg, s.cnt + 3);
@@ -919,7 +936,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
     HIP_TRY(hipStreamSynchronize(e->stream));
     bool more = any_left(e->pinned);
     int active_iters = 0;
-    const int sweep_grid = std::min(std::max(g.spl == 1 ? ep.n_groups : ep.n_ggroups, 1), 2048);
+    const int sweep_grid = std::min(std::max(ep.n_ggroups, 1), 2048);
     for (int it = 0; more;) {
         if (it >= e->max_iters) return fail(e, DPPR_ERR_NOT_CONVERGED, "iteration cap hit");
         int n = g.iter_hint[phase] > it ? g.iter_hint[phase] - it + 1 : e->chunk_iters;
@@ -928,8 +945,8 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
             const int nxt = (cur + 1) % 3, zer = (cur + 2) % 3;
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k], e->stream));
             if (g.spl == 1)
-                hipLaunchKernelGGL((k_gsweep<1, 1024>), dim3(sweep_grid), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.grp_tile,
-                                   ep.n_groups, g.cnt + cur * GWM, ep.out_row_ptr, ep.out_col, g.x, g.x2, g.act[0], g.act[1],
+                hipLaunchKernelGGL((k_gsweep<1, 1024>), dim3(sweep_grid), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.ggrp_tile,
+                                   ep.n_ggroups, g.cnt + cur * GWM, ep.out_row_ptr, ep.out_col, g.x, g.x2, g.act[0], g.act[1],
                                    g.r, g.p, g.cnt + nxt * GWM, g.cnt + zer * GWM, phase, eps, g.dstats, log + k * GWM);
             else
                 hipLaunchKernelGGL((k_gsweep<2, 512>), dim3(sweep_grid), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.ggrp_tile,
@@ -968,11 +985,8 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
 int group_stream_update(dppr_engine *e, Group &g, const Epoch &ep) {
     const int L = ep.L;
     if (L == 0) return DPPR_OK;
-    hipLaunchKernelGGL(k_su_keys, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->su_k[0], e->su_v[0],
-                       (unsigned long long *)nullptr, 0, (int *)nullptr, 0);
-    size_t tmp = e->su_tmp_bytes;
-    HIP_TRY(rocprim::radix_sort_pairs(e->su_tmp, tmp, e->su_k[0], e->su_k[1], e->su_v[0], e->su_v[1], (size_t)L, 0u,
-                                      (unsigned)e->bits, e->stream));
+    int rc = group_records_by_tail(e, ep, nullptr, 0, nullptr, 0);
+    if (rc) return rc;
     SuSources srcs{};
     for (int s = 0; s < GS_MAX; ++s) srcs.s[s] = g.src.s[s];
     // blockIdx.y = source lane; state element (v, lane) at base[v * gw + lane]
@@ -1026,6 +1040,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     } while (0)
     if (const char *v = getenv("DPPR_SWEEP_BITS")) e->sweep_bits = atoi(v) != 0; // diagnostic A/B switches
     if (const char *v = getenv("DPPR_HOT_BLOCKS")) e->hot_blocks = atoi(v) != 0;
+    if (const char *v = getenv("DPPR_GGROUPS_MIN")) e->ggroups_min = std::max(1, atoi(v));
     e->device = device;
     e->V = V;
     e->W = W;
@@ -1234,8 +1249,11 @@ int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32
         // measures (8 bytes for one source, 64 / 128 for a source group), the ids that fit an L2 are the
         // hottest ones. Inside a block the order stays hashed, so long rows are still spread over the
         // tiles. Measured on that stand-in, single source, two blocks (524 K | rest): 73 -> 67 us per sweep.
-        constexpr size_t HOT_MIN = 8192, HOT_SET = 524288;
-        if (fresh.size() > HOT_MIN) {
+        // Only for windows beyond a resident launch (> 256 K vertices): below that everything is L2-resident
+        // anyway, and hot tiles next to each other would unbalance the <= 256 groups of a resident launch
+        // (configs[1] stand-in: 0.55 -> 0.91 ms per batch).
+        constexpr size_t HOT_MIN = 8192, HOT_SET = 524288, HOT_WINDOW_MIN = 262144;
+        if (fresh.size() > HOT_WINDOW_MIN) {
             std::vector<int32_t> indeg((size_t)e->V, 0);
             for (int i = 0; i < n; ++i) {
                 indeg[(size_t)e2[i]]++;
@@ -1738,7 +1756,8 @@ int dppr_add_source_group(dppr_engine *e, const int32_t *sources, int32_t n, int
     g.n = n;
     g.spl = n > OCT ? 2 : 1;
     g.gw = OCT * g.spl;
-    if (g.spl == 2) e->wide_groups = true; // (recut_stale_groups below adds the second group table to resident epochs)
+    e->any_groups = true; // (recut_stale_groups below adds the second group table to resident epochs)
+    if (g.spl == 2) e->wide_groups = true;
     for (int s = 0; s < GS_MAX; ++s) g.src.s[s] = -1;
     for (int s = 0; s < n; ++s) {
         if (sources[s] < 0 || sources[s] >= e->V) return fail(e, DPPR_ERR_INVALID, "add_source_group: vertex out of range");

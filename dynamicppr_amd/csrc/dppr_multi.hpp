@@ -216,13 +216,31 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
     for (int q = 0; q < SPL; ++q) nleg[q] = 0;
     unsigned ecount = 0;
 
+    // A group's work is a chain of dependent memory round trips (group table -> row extents -> out_col ->
+    // activity bits -> x -> residuals), which is what a sweep of a SMALL window costs. The chain is kept
+    // short by asking early: the next group's extents while this one is processed, the next step's bits
+    // and the step after's out_col entries while this step's gathers are in flight, pagerank together
+    // with the residual.
+    int nt0 = 0, nt1 = 0, nE0 = 0, nE1 = 0;
+    if ((int)blockIdx.x < n_groups) {
+        nt0 = grp_tile[blockIdx.x];
+        nt1 = grp_tile[blockIdx.x + 1];
+        nE0 = out_row_ptr[nt0 * WAVE];
+        nE1 = out_row_ptr[nt0 * WAVE + min((nt1 - nt0) * WAVE, V - nt0 * WAVE)];
+    }
     for (int g = blockIdx.x; g < n_groups; g += gridDim.x) { // workgroup-uniform loop
         __syncthreads(); // the previous group's tables are no longer read; the initial fills are in place
-        const int t0 = grp_tile[g], t1 = grp_tile[g + 1];
+        const int t0 = nt0, t1 = nt1;
         const int v0 = t0 * WAVE;
         const int nv = min((t1 - t0) * WAVE, V - v0); // <= NVX: the builder cuts these groups for this kernel
-        const int E0 = out_row_ptr[v0];
-        const int Eg = out_row_ptr[v0 + nv] - E0;
+        const int E0 = nE0;
+        const int Eg = nE1 - E0;
+        if (g + (int)gridDim.x < n_groups) { // the next group's extents: two dependent scalar loads, hidden behind this group
+            nt0 = grp_tile[g + gridDim.x];
+            nt1 = grp_tile[g + gridDim.x + 1];
+            nE0 = out_row_ptr[nt0 * WAVE];
+            nE1 = out_row_ptr[nt0 * WAVE + min((nt1 - nt0) * WAVE, V - nt0 * WAVE)];
+        }
         int rs = 0, d = 0;
         if (tid < nv) {
             rs = out_row_ptr[v0 + tid] - E0;
@@ -235,6 +253,7 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
         const int e_begin = oid * per, e_end = min(Eg, e_begin + per);
         const int *cols = out_col + E0;
         int mycol = e_begin + j < e_end ? cols[e_begin + j] : -1;
+        int ncol = e_begin + EB + j < e_end ? cols[e_begin + EB + j] : -1;
         // compact the non-empty rows
         const uint64_t ne = __ballot(d > 0);
         if (lane == 0) s_wcnt[w] = __popcll(ne);
@@ -277,11 +296,13 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
                 }
                 if (nz) atomicOr(&s_touched[vl >> 5], 1u << (vl & 31));
             };
+            uint32_t aw = mycol >= 0 ? act_in[mycol >> 5] : 0u; // activity word of the first step's head
             for (int e = e_begin; e < e_end; e += EB) {
-                // which of the step's edges have an active head (one bit test per lane)
-                bool a = false;
-                if (mycol >= 0) a = (act_in[mycol >> 5] >> (mycol & 31)) & 1u;
-                const int ncol = e + EB + j < e_end ? cols[e + EB + j] : -1; // next step's entry, ahead of use
+                // which of the step's edges have an active head (one bit per lane); the NEXT step's word and
+                // the out_col entry of the step after are requested before this step's gathers
+                const bool a = mycol >= 0 && ((aw >> (mycol & 31)) & 1u);
+                const uint32_t naw = ncol >= 0 ? act_in[ncol >> 5] : 0u;
+                const int nncol = e + 2 * EB + j < e_end ? cols[e + 2 * EB + j] : -1;
                 const unsigned m = oct_mask(__ballot(a));
 #pragma unroll
                 for (int h = 0; h < EB; h += GB) {
@@ -325,6 +346,8 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
                     }
                 }
                 mycol = ncol;
+                aw = naw;
+                ncol = nncol;
             }
             flush();
         }
@@ -334,7 +357,7 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
         for (int i0 = 0; i0 < NVX / NOCT; i0 += FU) {
             int vl[FU];
             bool tch[FU], wasact[FU];
-            double rv[FU][SPL], xo[FU][SPL];
+            double rv[FU][SPL], xo[FU][SPL], pv[FU][SPL];
 #pragma unroll
             for (int i = 0; i < FU; ++i) {
                 vl[i] = oid + (i0 + i) * NOCT;
@@ -345,11 +368,15 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
                 for (int q = 0; q < SPL; ++q) {
                     rv[i][q] = 0.0;
                     xo[i][q] = 0.0;
+                    pv[i][q] = 0.0;
                 }
                 if (tch[i]) {
                     const size_t base = (size_t)(v0 + vl[i]) * GW + j * SPL;
 #pragma unroll
-                    for (int q = 0; q < SPL; ++q) rv[i][q] = r[base + q];
+                    for (int q = 0; q < SPL; ++q) {
+                        rv[i][q] = r[base + q];
+                        pv[i][q] = p[base + q]; // needed only if the vertex ends up legal: asked for now, not after the test
+                    }
                     if (wasact[i]) {
 #pragma unroll
                         for (int q = 0; q < SPL; ++q) xo[i][q] = x[base + q];
@@ -377,7 +404,7 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
 #pragma unroll
                         for (int q = 0; q < SPL; ++q) {
                             x_new[base + q] = lg[q] ? rn[q] : 0.0;
-                            if (lg[q]) p[base + q] = p[base + q] + ALPHA * rn[q];
+                            if (lg[q]) p[base + q] = pv[i][q] + ALPHA * rn[q];
                         }
                         if (j == 0) atomicOr(&s_actout[vl[i] >> 5], 1u << (vl[i] & 31));
                     }

@@ -31,8 +31,11 @@ namespace dppr {
 //              (cpu/PPRCPUMTCilkRev.h:126-156 seeds from batch endpoints for the same reason).
 // ---------------------------------------------------------------------------
 // (also zeroes `nz` 8-byte words at `zero` and `nzi` ints at `zero_ints` when given: the first kernel of a
-// batch clears the counters of what follows instead of separate fills; one workgroup's bitonic sort in
-// LDS was tried for the grouping of small batches and is 3x slower than the device radix sort)
+// batch clears the counters of what follows instead of separate fills. Tried for the grouping of small
+// batches and NOT faster than the device radix sort's five launches (26 us of kernels + ~20 us of gaps for
+// the 12 K records of the configs[1] stand-in): one workgroup's bitonic sort in LDS (3x slower), rocPRIM's
+// single-workgroup path (39 us), and a hand-written single-workgroup stable LSD radix sort, two 10-bit
+// passes with ballot-ladder ranks (45 us: 160 ballot steps per wave and pass on ONE CU's four SIMDs))
 __global__ __launch_bounds__(BLOCK) void k_su_keys(const int *__restrict__ e1, int L, uint32_t *__restrict__ keys,
                                                    uint32_t *__restrict__ vals, unsigned long long *__restrict__ zero,
                                                    int nz, int *__restrict__ zero_ints, int nzi) {

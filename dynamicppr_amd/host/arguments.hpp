@@ -60,7 +60,7 @@ inline void PrintUsage() {
               << "--validate: residual bound + power-iteration check after every solve\n"
               << "--split: drive each batch through IncrementalBatchUpdate/ExecuteMainLoop(0)/(1)\n"
               << "--sync: synchronous (deterministic) push schedule\n"
-              << "--no-groups: with several sources per GPU, solve them one at a time (default: 8 together)\n"
+              << "--no-groups: with several sources per GPU, solve them one at a time (default: up to 16 together)\n"
               << "EXAMPLE: ./pagerank -d ../data/com-dblp.ungraph.bin -a 0 -i 0 -y 1 -w 0.1 -n 0 -r 0.01 -b 1000 -s 1\n"
               << "EXAMPLE: ./pagerank -d ../data/com-dblp.ungraph.bin -a 0 -i 0 -y 1 -w 0.1 -n 1 -c 100 -l 10000 -s 1"
               << std::endl;

@@ -56,13 +56,13 @@ public:
             graph->SerializeEdgeStream(&init_stream);
             DPPR_CHECK(engine, dppr_load_window(engine, init_stream.edge1, init_stream.edge2, init_stream.length));
         }
-        // several sources on one device are solved together, 8 per group (multi-source batched
+        // several sources on one device are solved together, up to 16 per group (multi-source batched
         // sweeps); --split keeps the reference's one-source-at-a-time driver flow
         use_groups = source_vertex_ids.size() > 1 && !gSplitInterface && !gNoGroups;
         if (!quiet_) std::cout << "start..." << std::endl;
         if (use_groups) {
-            for (size_t i = 0; i < source_vertex_ids.size(); i += 8) {
-                const int32_t n = (int32_t)std::min<size_t>(8, source_vertex_ids.size() - i);
+            for (size_t i = 0; i < source_vertex_ids.size(); i += kGroupMax) {
+                const int32_t n = (int32_t)std::min<size_t>(kGroupMax, source_vertex_ids.size() - i);
                 int32_t gid = -1;
                 DPPR_CHECK(engine, dppr_add_source_group(engine, source_vertex_ids.data() + i, n, &gid));
                 groups.push_back(gid);
@@ -144,7 +144,7 @@ public:
     // gpu/PPRRevPushGPU.cuh:134-164: residual bound, then |p - p_pow| < 100 eps with the
     // power iteration of cpu/PPRCPUPowVec.h:55-83 on the current window graph.
     void ReadSource(size_t i, double *p, double *r) {
-        if (use_groups) DPPR_CHECK(engine, dppr_group_read(engine, groups[i / 8], (int32_t)(i % 8), p, r));
+        if (use_groups) DPPR_CHECK(engine, dppr_group_read(engine, groups[i / kGroupMax], (int32_t)(i % kGroupMax), p, r));
         else DPPR_CHECK(engine, dppr_read(engine, slots[i], p, r));
     }
 
@@ -215,7 +215,8 @@ public:
     int device_id;
     std::vector<IndexType> source_vertex_ids;
     std::vector<int32_t> slots;  // one per source (single-source mode)
-    std::vector<int32_t> groups; // one per 8 sources (group mode: several sources per device)
+    static constexpr size_t kGroupMax = 16; // sources per group (dppr_add_source_group)
+    std::vector<int32_t> groups; // one per 16 sources (group mode: several sources per device)
     bool use_groups = false;
     std::vector<float> ppr_time; // ms per source (single mode) or per group, timed region only
     size_t batches_done = 0;

@@ -97,18 +97,20 @@ def test_cli_end_to_end_matches_oracle(pagerank, small_bin, tmp_path, directed, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nsrc", [3, 10, 18])
 @pytest.mark.parametrize("extra", [[], ["--no-groups"], ["--validate"]])
-def test_cli_multiple_sources_one_gpu(pagerank, small_bin, tmp_path, extra):
-    """Several sources on one device: solved 8 together as a source group by default."""
+def test_cli_multiple_sources_one_gpu(pagerank, small_bin, tmp_path, extra, nsrc):
+    """Several sources on one device: solved up to 16 together as a source group by default (3: one
+    8-wide group, 10: one 16-wide group, 18: a 16-wide and an 8-wide one)."""
     path, V, e1, e2 = small_bin
-    srcs = [int(x) for x in datagen.top_sources(V, e1, e2, 600, 1, 3)]
+    srcs = [int(x) for x in datagen.top_sources(V, e1, e2, 600, 1, nsrc)]
     sf = tmp_path / "sources.txt"
     sf.write_text("\n".join(map(str, srcs)) + "\n")
     dump = str(tmp_path / "out.dump")
     r = run([pagerank, "-d", path, "-a", "0", "-i", "1", "-y", "1", "-n", "1", "-c", "7", "-l", "21",
              "--sources", str(sf), "--dump", dump, "-g", "1"] + extra)
     assert r.returncode == 0, r.stdout
-    assert "aggregate_edge_num %d" % (7 * 3 * 3) in r.stdout
+    assert "aggregate_edge_num %d" % (7 * 3 * nsrc) in r.stdout
     got = read_dump(dump)
     assert sorted(got) == sorted(srcs)
     for sv in srcs:
