@@ -32,10 +32,17 @@ WORKER = textwrap.dedent("""
     from oracle import oracle as orc
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    V, e1, e2 = datagen.rmat_stream(9, 6000, 11)
+    # the stream: rank 0 writes the stand-in prefix, everybody waits at the barrier and reads the same file
+    # (what bench.py does for --gpus N); sources: every rank draws ITS ids from ranks [10, 1000) (a top1000 file)
+    if rank == 0:
+        datagen.ensure_stand_in("dblp", {out!r}, 6000)
+    dist.barrier()
+    path = datagen.ensure_stand_in("dblp", {out!r}, 6000)
+    assert rank == 0 or datagen.PROVENANCE[path]["origin"] == "cached"
+    V, e1, e2 = datagen.read_bin(path)
     wl = st.workload_config(len(e1), 0.1, 0, 0.01, 5)
-    sources = datagen.top_sources(V, e1, e2, wl.window, 1, 10)
-    mine = shard.assign_sources(sources, rank, world, per_rank=1)
+    mine = [int(x) for x in datagen.ranked_sources(V, e1, e2, wl.window, 1, 10, 200, 10, seed=1 + rank)[:1]]
+    checksum = datagen.PROVENANCE[path]["checksum"]
     g = orc.Graph(V, e1, e2, 1, wl.window, wl.per_batch)
     s = orc.State(V, mine[0], 1e-9)
     s.cilk_execute(g)
@@ -48,7 +55,7 @@ WORKER = textwrap.dedent("""
         time.sleep(0.05 * (rank + 1))          # rank 1 is the slow one
     dt, w = shard.timed_region(run, lambda: None, dist)
     units = shard.aggregate_units(wl.per_batch * steps * len(mine), dist)
-    json.dump(dict(rank=rank, world=w, source=mine[0], dt=dt, units=units, psum=float(s.p.sum())),
+    json.dump(dict(rank=rank, world=w, source=mine[0], dt=dt, units=units, psum=float(s.p.sum()), checksum=checksum),
               open(os.path.join({out!r}, "rank%d.json" % rank), "w"))
     dist.barrier()
     dist.destroy_process_group()
@@ -74,3 +81,4 @@ def test_two_rank_gloo_run(tmp_path):
     assert a["dt"] == b["dt"] and a["dt"] >= 0.1            # MAX over ranks: the slow rank's time
     assert a["units"] == b["units"] == 2 * 6 * 3            # SUM over ranks of c * steps
     assert a["psum"] != b["psum"]
+    assert a["checksum"] == b["checksum"]                   # one stream file, written once
