@@ -59,6 +59,20 @@ __device__ __forceinline__ int wave_inclusive_max(int x) { // for values >= -1
     return x;
 }
 
+// Streamed-once data (out_col). Measured with a non-temporal load (-DDPPR_NT_STREAM=1), on the theory that the
+// stream would then not push gathered x lines out of L2: LiveJournal single source 69.5 -> 79.6 us per sweep,
+// 10-source batch 20.2 -> 20.8 ms, twitter unchanged -- plain loads stay.
+#ifndef DPPR_NT_STREAM
+#define DPPR_NT_STREAM 0
+#endif
+__device__ __forceinline__ int ld_stream(const int *p) {
+#if DPPR_NT_STREAM
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 // device-scope returning f64 atomics (global_atomic_add_f64 / global_atomic_swap_x2)
 __device__ __forceinline__ double atomic_add_ret(double *p, double v) {
     return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -252,8 +252,8 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
         const int per = ((Eg + NOCT - 1) / NOCT + EB - 1) / EB * EB;
         const int e_begin = oid * per, e_end = min(Eg, e_begin + per);
         const int *cols = out_col + E0;
-        int mycol = e_begin + j < e_end ? cols[e_begin + j] : -1;
-        int ncol = e_begin + EB + j < e_end ? cols[e_begin + EB + j] : -1;
+        int mycol = e_begin + j < e_end ? ld_stream(&cols[e_begin + j]) : -1;
+        int ncol = e_begin + EB + j < e_end ? ld_stream(&cols[e_begin + EB + j]) : -1;
         // compact the non-empty rows
         const uint64_t ne = __ballot(d > 0);
         if (lane == 0) s_wcnt[w] = __popcll(ne);
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
                 // the out_col entry of the step after are requested before this step's gathers
                 const bool a = mycol >= 0 && ((aw >> (mycol & 31)) & 1u);
                 const uint32_t naw = ncol >= 0 ? act_in[ncol >> 5] : 0u;
-                const int nncol = e + 2 * EB + j < e_end ? cols[e + 2 * EB + j] : -1;
+                const int nncol = e + 2 * EB + j < e_end ? ld_stream(&cols[e + 2 * EB + j]) : -1;
                 const unsigned m = oct_mask(__ballot(a));
 #pragma unroll
                 for (int h = 0; h < EB; h += GB) {

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(PULL_BLOCK, (PULL_BLOCK & (PULL_BLOCK - 1)) == 0 ? 
                 carry = __builtin_amdgcn_readlane(o, WAVE - 1);
                 own[k] = e < total ? o : -1;
                 col[k] = 0;
-                if (own[k] >= 0) col[k] = out_col[s_start[w][o] + (e - s_scan[w][o])];
+                if (own[k] >= 0) col[k] = ld_stream(&out_col[s_start[w][o] + (e - s_scan[w][o])]);
             }
             double xa[PU];
             if constexpr (BITS) {
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(PULL_BLOCK, (PULL_BLOCK & (PULL_BLOCK - 1)) == 0 ? 
 #pragma unroll
                 for (int k = 0; k < CH_SLOTS; ++k) {
                     const int e = c0 + k * WAVE + lane;
-                    colb[k] = e < c1 ? out_col[row_rs + e] : -1;
+                    colb[k] = e < c1 ? ld_stream(&out_col[row_rs + e]) : -1;
                 }
                 if constexpr (BITS) {
                     bool on[CH_SLOTS];
