@@ -31,6 +31,14 @@
 //    one LDS atomic per row piece instead of one per edge and source.
 //  * The vertex side (repair, threshold, next snapshot) is octet-cooperative too: 64/128-byte
 //    coalesced accesses, only for vertices that were touched.
+//  * ONE COPY OF THE RESIDUAL. While a vertex is active its snapshot row IS its residual row:
+//    x[v][s] holds the current residual of EVERY source s (a source is in the frontier iff that value
+//    is legal -- the gather applies the legal-push test instead of "non-zero"), and residual[v] is
+//    not read or written until the vertex leaves the frontier, when the row is written back. A
+//    frontier vertex costs x read + x_new write + pagerank read/write per sweep, not those plus a
+//    residual read and write. For a legal source the new residual is exactly the sum of the sweep's
+//    adds (what PPRRevPushGPUFF's `residual[u] = 0` at the snapshot gives, gpu/Inspect.cuh:51-65);
+//    between loops every bit is clear and residual[] is complete.
 #pragma once
 
 #include "dppr_kernels.hpp"
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(BLOCK) void k_gseed_dense(int V, const double *__re
 #pragma unroll
             for (int q = 0; q < SPL; ++q) {
                 const size_t i = (size_t)v * GW + j * SPL + q;
-                x[i] = lg[q] ? rv[q] : 0.0;
+                x[i] = rv[q]; // the whole residual row moves to the snapshot (dppr_multi.hpp header)
                 if (lg[q]) p[i] = p[i] + ALPHA * rv[q];
             }
         }
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(BLOCK) void k_gseed_tails(const uint32_t *__restric
 #pragma unroll
             for (int q = 0; q < SPL; ++q) {
                 const size_t k = (size_t)u * GW + j * SPL + q;
-                x[k] = lg[q] ? rv[q] : 0.0;
+                x[k] = rv[q];
                 if (lg[q]) p[k] = p[k] + ALPHA * rv[q];
             }
             if (j == 0) atomicOr(&act[u >> 5], 1u << (u & 31));
@@ -336,7 +344,7 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
                                 }
 #pragma unroll
                                 for (int q = 0; q < SPL; ++q) {
-                                    if (xv[k][q] != 0.0) {
+                                    if (legal(xv[k][q], phase, eps)) { // the head's residual for this source is being pushed
                                         acc[q] += push_term(xv[k][q], den, rcp);
                                         ++ecount;
                                     }
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
         for (int i0 = 0; i0 < NVX / NOCT; i0 += FU) {
             int vl[FU];
             bool tch[FU], wasact[FU];
-            double rv[FU][SPL], xo[FU][SPL], pv[FU][SPL];
+            double cur[FU][SPL], pv[FU][SPL]; // cur: the residual row -- from x if the vertex was active, else from r
 #pragma unroll
             for (int i = 0; i < FU; ++i) {
                 vl[i] = oid + (i0 + i) * NOCT;
@@ -366,20 +374,16 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
                 tch[i] = vl[i] < nv && (wasact[i] || (s_touched[vl[i] >> 5] & bit) != 0);
 #pragma unroll
                 for (int q = 0; q < SPL; ++q) {
-                    rv[i][q] = 0.0;
-                    xo[i][q] = 0.0;
+                    cur[i][q] = 0.0;
                     pv[i][q] = 0.0;
                 }
                 if (tch[i]) {
                     const size_t base = (size_t)(v0 + vl[i]) * GW + j * SPL;
+                    const double *row = wasact[i] ? x : r;
 #pragma unroll
                     for (int q = 0; q < SPL; ++q) {
-                        rv[i][q] = r[base + q];
+                        cur[i][q] = row[base + q];
                         pv[i][q] = p[base + q]; // needed only if the vertex ends up legal: asked for now, not after the test
-                    }
-                    if (wasact[i]) {
-#pragma unroll
-                        for (int q = 0; q < SPL; ++q) xo[i][q] = x[base + q];
                     }
                 }
             }
@@ -388,25 +392,30 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
                 if (tch[i]) {
                     const size_t base = (size_t)(v0 + vl[i]) * GW + j * SPL;
                     double rn[SPL];
-                    bool lg[SPL], any = false;
+                    bool lg[SPL], any = false, changed = false;
 #pragma unroll
                     for (int q = 0; q < SPL; ++q) {
                         double *ap = &s_acc[vl[i] * GW + j * SPL + q];
-                        rn[q] = rv[i][q] + *ap;
+                        const double a = *ap;
                         *ap = 0.0;
-                        if (xo[i][q] != 0.0) rn[q] -= xo[i][q];
+                        // RepairFrontierRev: a source that was pushed keeps only what arrived during the sweep
+                        const bool pushed = wasact[i] && legal(cur[i][q], phase, eps);
+                        rn[q] = pushed ? a : cur[i][q] + a;
                         lg[q] = legal(rn[q], phase, eps);
                         any |= lg[q];
+                        changed |= rn[q] != cur[i][q];
                         nleg[q] += lg[q] ? 1 : 0;
-                        if (rn[q] != rv[i][q]) r[base + q] = rn[q];
                     }
-                    if (oct_mask(__ballot(any))) {
+                    if (oct_mask(__ballot(any))) { // stays / becomes active: the row lives in the next snapshot
 #pragma unroll
                         for (int q = 0; q < SPL; ++q) {
-                            x_new[base + q] = lg[q] ? rn[q] : 0.0;
+                            x_new[base + q] = rn[q];
                             if (lg[q]) p[base + q] = pv[i][q] + ALPHA * rn[q];
                         }
                         if (j == 0) atomicOr(&s_actout[vl[i] >> 5], 1u << (vl[i] & 31));
+                    } else if (wasact[i] || changed) { // inactive now: the row goes (back) to residual[]
+#pragma unroll
+                        for (int q = 0; q < SPL; ++q) r[base + q] = rn[q];
                     }
                 }
             }
