@@ -94,6 +94,10 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback)")
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:   # more ranks than devices (a smoke run of the N > 1 path on a small node): share them
+        print(f"[rank {rank}] only {ndev} device(s): sharing device {local_rank % ndev}", file=sys.stderr, flush=True)
+        local_rank %= ndev
     torch.cuda.set_device(local_rank)
     if world > 1:
         # RCCL (backend "nccl") carries only the barrier and two scalar reductions; if it cannot come up

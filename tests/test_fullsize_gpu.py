@@ -104,3 +104,35 @@ def test_livejournal_ten_sources_as_one_group_matches_cilk_oracle():
             assert invariant_max_err_np(p, r, src_e, dst_e, V, sv) < INVARIANT_TOL
             if i in states:
                 assert np.max(np.abs(p - states[i].p)) < NORTH_STAR_TOL, (k, i)
+
+
+def test_youtube_eight_sources_as_one_group_matches_cilk_oracle():
+    """configs[1] window with 8 top-degree sources on 8-wide state (k_gsweep<1, 1024>): every source
+    against the -t 1 oracle after the from-scratch solve and two batches."""
+    V, e1, e2, cfg, wl = stand_in("youtube", 2)
+    W, c, eps = wl.window, wl.per_batch, 1e-9
+    sources = [int(x) for x in datagen.top_sources(V, e1, e2, W, cfg.directed, 8)]
+    e = eng.Engine(V, W, cfg.directed, c)
+    ss = st.SlidingStream(V, e1, e2, cfg.directed, wl)
+    e.load_window(*ss.serialize_edge_stream())
+    gid = e.add_source_group(sources)
+    g = orc.Graph(V, e1, e2, cfg.directed, W, c)
+    states = [orc.State(V, sv, eps) for sv in sources]
+    for s in states:
+        s.cilk_execute(g)
+    e.group_init_solve(gid, eps)
+    for k in range(3):
+        if k:
+            assert not ss.stream_updates() and not g.stream_updates()
+            g.inc_construct(1)
+            for s in states:
+                s.cilk_inc_execute(g)
+            e.set_batch(*ss.batch_arrays())
+            e.slide(*ss.new_arrays())
+            e.group_update(gid, eps)
+        src_e, dst_e = window_edges(ss, cfg.directed)
+        for i, sv in enumerate(sources):
+            p, r = e.group_read(gid, i)
+            assert np.max(np.abs(r)) < eps
+            assert np.max(np.abs(p - states[i].p)) < NORTH_STAR_TOL, (k, i)
+            assert invariant_max_err_np(p, r, src_e, dst_e, V, sv) < INVARIANT_TOL
