@@ -29,6 +29,7 @@ static constexpr int MAX_CHUNK = 64;
 // 2 x MAX_CHUNK entries: a whole batch) follows the header
 static constexpr int CNT_HDR = 16;
 static constexpr int PERSIST_RETRY_BATCHES = 64; // after a failed roll-call: batches on per-iteration launches before the next try
+static constexpr int GMULTI_MAX = 2 * MAX_CHUNK; // sweeps a multi-sweep launch of a source group may run
 static constexpr int RESIDENT_MARGIN = 8; // sweeps a resident launch is given beyond what the last batch needed
 
 namespace {
@@ -100,6 +101,7 @@ struct Group {
     uint32_t *act[2] = {nullptr, nullptr}; // activity bitmaps that go with x / x2
     size_t act_bytes = 0;
     int *cnt = nullptr;        // [3][GS_MAX] rotating frontier sizes, then the per-chunk log [MAX][GS_MAX]
+    int *mlog = nullptr;       // multi-sweep launches: [GS_MAX] status word + padding, then one row of frontier sizes per sweep
     IterStats *dstats = nullptr;
     dppr_stats_t st{};
     int iter_hint[2] = {0, 0};
@@ -157,6 +159,8 @@ struct dppr_engine {
     bool sweep_bits = false;        // per-iteration single-source sweeps test an activity bitmap before each gather (dppr_set_sweep_bitmap;
                                     // measured slower on every stand-in, DESIGN.md section 6: off unless asked for)
     bool hot_blocks = true;         // vertex numbering in blocks of falling in-degree (DPPR_HOT_BLOCKS=0: two blocks, hot | rest)
+    bool group_resident = true;     // source groups on windows whose sweep groups are all resident run a loop as multi-sweep launches
+    int gmulti_cap[2] = {-1, -1};   // co-resident workgroups of k_gsweep<.., true> per state width (-1: not queried yet)
     bool any_groups = false;        // a source group exists: epochs carry the second group table
     int ggroups_min = 256;          // ... of at least this many groups (DPPR_GGROUPS_MIN: tuning runs; 512 / 1008 measured slower on
                                     // the configs[1] stand-in, equal on the LiveJournal one)
@@ -899,6 +903,20 @@ int pull_device_stats(dppr_engine *e, Slot &s) {
 }
 
 // ---------------------------------------------------------------------------- f2: groups
+// workgroups of the multi-sweep form of k_gsweep that the device holds at once
+int group_multi_capacity(dppr_engine *e, int spl) {
+    int &cap = e->gmulti_cap[spl - 1];
+    if (cap < 0) {
+        int per_cu = 0, cus = 0;
+        hipError_t rc = spl == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gsweep<1, 1024, true>, GNT, 0)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gsweep<2, 512, true>, GNT, 0);
+        if (rc != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess)
+            per_cu = 0;
+        cap = std::min(per_cu * cus, STAT_SLOTS);
+    }
+    return cap;
+}
+
 // One frontier loop of a source group. `tails`: the state was converged before the batch's stream
 // update, so only the batch tails (sorted in su_k[1]) can be legal -- no pass over all vertices.
 int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps, bool tails) {
@@ -926,7 +944,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
         g.st.inspected += (int64_t)e->n_int * g.n;
     }
     HIP_TRY(hipGetLastError());
-    int *log = g.cnt + 3 * GWM;
+    int *log = g.cnt + 5 * GWM;
     auto any_left = [&](const int *c) {
         for (int s = 0; s < GWM; ++s)
             if (c[s] > 0) return true;
@@ -939,30 +957,92 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
     const int sweep_grid = std::min(std::max(ep.n_ggroups, 1), 2048);
     for (int it = 0; more;) {
         if (it >= e->max_iters) return fail(e, DPPR_ERR_NOT_CONVERGED, "iteration cap hit");
+        // ---- a window whose sweep groups are all resident at once: a run of sweeps as ONE launch (k_gsweep<.., true>)
+        const int mcap = e->group_resident && e->persist_mode && e->persist_ok && e->chunk_iters > 1 ? group_multi_capacity(e, g.spl) : 0;
+        if (mcap > 0 && ep.n_ggroups > 0 && ep.n_ggroups <= mcap) {
+            int n = g.iter_hint[phase] > it ? g.iter_hint[phase] - it + RESIDENT_MARGIN : 2 * e->chunk_iters;
+            n = std::max(2, std::min(n, GMULTI_MAX));
+            if (e->chunk_explicit) n = std::min(n, std::max(e->chunk_iters, 2)); // (tests: launches that stop mid-loop and are resumed)
+            HIP_TRY(hipMemsetAsync(g.mlog, 0, sizeof(int) * (size_t)(n + 2) * GWM, e->stream));
+            HIP_TRY(hipMemsetAsync(e->bar, 0, sizeof(GridBar), e->stream));
+            if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
+            int *status = g.mlog, *rows = g.mlog + GWM;
+            if (g.spl == 1)
+                hipLaunchKernelGGL((k_gsweep<1, 1024, true>), dim3(ep.n_ggroups), dim3(GNT), 0, e->stream, ep.grp_n_int,
+                                   ep.ggrp_tile, ep.n_ggroups, g.cnt + cur * GWM, ep.out_row_ptr, ep.out_col, g.x, g.x2, g.act[0],
+                                   g.act[1], g.r, g.p, g.cnt + 3 * GWM, g.cnt + 4 * GWM, phase, eps, g.dstats, rows, n, e->bar,
+                                   status, e->persist_ticks, e->persist_rollcall_extra);
+            else
+                hipLaunchKernelGGL((k_gsweep<2, 512, true>), dim3(ep.n_ggroups), dim3(GNT), 0, e->stream, ep.grp_n_int,
+                                   ep.ggrp_tile, ep.n_ggroups, g.cnt + cur * GWM, ep.out_row_ptr, ep.out_col, g.x, g.x2, g.act[0],
+                                   g.act[1], g.r, g.p, g.cnt + 3 * GWM, g.cnt + 4 * GWM, phase, eps, g.dstats, rows, n, e->bar,
+                                   status, e->persist_ticks, e->persist_rollcall_extra);
+            if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[1], e->stream));
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(e->pinned, g.mlog, sizeof(int) * (size_t)(n + 2) * GWM, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            const int st = e->pinned[0];
+            g.st.persist_launches++;
+            if (st & GSM_FAULT) return fail(e, DPPR_ERR_HIP, "a grid barrier of the multi-sweep group launch timed out");
+            if (st & GSM_ABORTED) { // not co-resident: nothing was changed; one-sweep launches from here on (re-armed later)
+                g.st.persist_aborts++;
+                e->persist_ok = false;
+                e->persist_retry = PERSIST_RETRY_BATCHES;
+                continue;
+            }
+            const int sweeps = st & GSM_SWEEPS;
+            for (int k = 0; k < sweeps; ++k) {
+                const int *f = e->pinned + GWM + k * GWM;
+                g.st.iterations++;
+                g.st.pull_iterations++;
+                for (int s = 0; s < GWM; ++s) g.st.sum_F += f[s];
+                active_iters = it + k + 1;
+            }
+            if (e->profiling) {
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, e->evpool[0], e->evpool[1]));
+                g.st.push_ms += ms;
+                g.st.push_launches++;
+            }
+            if (sweeps & 1) {
+                std::swap(g.x, g.x2);
+                std::swap(g.act[0], g.act[1]);
+            }
+            it += sweeps;
+            if (st & GSM_CONVERGED) break;
+            // out of sweeps: the live frontier sizes are in row `sweeps`; the launch left them in cnt[3] -- make them cnt[0]
+            HIP_TRY(hipMemcpyAsync(g.cnt, g.cnt + 3 * GWM, sizeof(int) * GWM, hipMemcpyDeviceToDevice, e->stream));
+            HIP_TRY(hipMemsetAsync(g.cnt + GWM, 0, sizeof(int) * 2 * GWM, e->stream));
+            cur = 0;
+            more = any_left(e->pinned + GWM + sweeps * GWM);
+            continue;
+        }
         int n = g.iter_hint[phase] > it ? g.iter_hint[phase] - it + 1 : e->chunk_iters;
         n = std::max(1, std::min(n, MAX_CHUNK));
         for (int k = 0; k < n; ++k) {
             const int nxt = (cur + 1) % 3, zer = (cur + 2) % 3;
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k], e->stream));
             if (g.spl == 1)
-                hipLaunchKernelGGL((k_gsweep<1, 1024>), dim3(sweep_grid), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.ggrp_tile,
+                hipLaunchKernelGGL((k_gsweep<1, 1024, false>), dim3(sweep_grid), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.ggrp_tile,
                                    ep.n_ggroups, g.cnt + cur * GWM, ep.out_row_ptr, ep.out_col, g.x, g.x2, g.act[0], g.act[1],
-                                   g.r, g.p, g.cnt + nxt * GWM, g.cnt + zer * GWM, phase, eps, g.dstats, log + k * GWM);
+                                   g.r, g.p, g.cnt + nxt * GWM, g.cnt + zer * GWM, phase, eps, g.dstats, log + k * GWM, 1,
+                                   (GridBar *)nullptr, (int *)nullptr, 0ull, 0);
             else
-                hipLaunchKernelGGL((k_gsweep<2, 512>), dim3(sweep_grid), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.ggrp_tile,
+                hipLaunchKernelGGL((k_gsweep<2, 512, false>), dim3(sweep_grid), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.ggrp_tile,
                                    ep.n_ggroups, g.cnt + cur * GWM, ep.out_row_ptr, ep.out_col, g.x, g.x2, g.act[0], g.act[1],
-                                   g.r, g.p, g.cnt + nxt * GWM, g.cnt + zer * GWM, phase, eps, g.dstats, log + k * GWM);
+                                   g.r, g.p, g.cnt + nxt * GWM, g.cnt + zer * GWM, phase, eps, g.dstats, log + k * GWM, 1,
+                                   (GridBar *)nullptr, (int *)nullptr, 0ull, 0);
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k + 1], e->stream));
             std::swap(g.x, g.x2);
             std::swap(g.act[0], g.act[1]);
             cur = nxt;
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(e->pinned, g.cnt, sizeof(int) * (size_t)(3 * GWM + n * GWM), hipMemcpyDeviceToHost,
+        HIP_TRY(hipMemcpyAsync(e->pinned, g.cnt, sizeof(int) * (size_t)(5 * GWM + n * GWM), hipMemcpyDeviceToHost,
                                e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
         for (int k = 0; k < n; ++k) {
-            const int *f = e->pinned + 3 * GWM + k * GWM;
+            const int *f = e->pinned + 5 * GWM + k * GWM;
             if (!any_left(f)) continue;
             g.st.iterations++;
             g.st.pull_iterations++;
@@ -1055,7 +1135,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     HIP_TRY_C(hipEventCreate(&e->ev0));
     HIP_TRY_C(hipEventCreate(&e->ev1));
     for (auto &ev : e->evpool) HIP_TRY_C(hipEventCreate(&ev));
-    HIP_TRY_C(hipHostMalloc((void **)&e->pinned, sizeof(int) * (3 * GS_MAX + MAX_CHUNK * GS_MAX + 16), hipHostMallocDefault));
+    HIP_TRY_C(hipHostMalloc((void **)&e->pinned, sizeof(int) * ((GMULTI_MAX + 2) * GS_MAX + 3 * GS_MAX + MAX_CHUNK * GS_MAX + 16), hipHostMallocDefault));
     const size_t Wn = (size_t)std::max(W, 1), Edn = (size_t)std::max(e->Ed, 1), Ln = (size_t)std::max(4 * c, 1);
     HIP_TRY_C(hipMalloc((void **)&e->w1, sizeof(int) * Wn));
     HIP_TRY_C(hipMalloc((void **)&e->w2, sizeof(int) * Wn));
@@ -1132,7 +1212,7 @@ void dppr_destroy(dppr_engine *e) {
     for (auto &g : e->groups) {
         (void)hipFree(g.p); (void)hipFree(g.r); (void)hipFree(g.x); (void)hipFree(g.x2);
         (void)hipFree(g.act[0]); (void)hipFree(g.act[1]);
-        (void)hipFree(g.cnt); (void)hipFree(g.dstats);
+        (void)hipFree(g.cnt); (void)hipFree(g.mlog); (void)hipFree(g.dstats);
     }
     for (auto &ep : e->epochs) {
         (void)hipFree(ep.row_ptr); (void)hipFree(ep.adj); (void)hipFree(ep.out_row_ptr); (void)hipFree(ep.out_col); (void)hipFree(ep.b1); (void)hipFree(ep.b2);
@@ -1197,6 +1277,12 @@ int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges, int p
 int dppr_set_sweep_bitmap(dppr_engine *e, int on) {
     if (!e) return DPPR_ERR_INVALID;
     e->sweep_bits = on != 0;
+    return DPPR_OK;
+}
+
+int dppr_set_group_resident(dppr_engine *e, int on) {
+    if (!e) return DPPR_ERR_INVALID;
+    e->group_resident = on != 0;
     return DPPR_OK;
 }
 
@@ -1772,11 +1858,12 @@ int dppr_add_source_group(dppr_engine *e, const int32_t *sources, int32_t n, int
     HIP_TRY(hipMalloc((void **)&g.x2, row * V));
     HIP_TRY(hipMalloc((void **)&g.act[0], g.act_bytes));
     HIP_TRY(hipMalloc((void **)&g.act[1], g.act_bytes));
-    HIP_TRY(hipMalloc((void **)&g.cnt, sizeof(int) * (3 * GS_MAX + MAX_CHUNK * GS_MAX)));
+    HIP_TRY(hipMalloc((void **)&g.cnt, sizeof(int) * (5 * GS_MAX + MAX_CHUNK * GS_MAX))); // rows 3, 4: scratch of multi-sweep launches
+    HIP_TRY(hipMalloc((void **)&g.mlog, sizeof(int) * (size_t)(GMULTI_MAX + 2) * GS_MAX));
     HIP_TRY(hipMalloc((void **)&g.dstats, sizeof(IterStats)));
     HIP_TRY(hipMemsetAsync(g.act[0], 0, g.act_bytes, e->stream));
     HIP_TRY(hipMemsetAsync(g.act[1], 0, g.act_bytes, e->stream));
-    HIP_TRY(hipMemsetAsync(g.cnt, 0, sizeof(int) * (3 * GS_MAX + MAX_CHUNK * GS_MAX), e->stream));
+    HIP_TRY(hipMemsetAsync(g.cnt, 0, sizeof(int) * (5 * GS_MAX + MAX_CHUNK * GS_MAX), e->stream));
     HIP_TRY(hipMemsetAsync(g.dstats, 0, sizeof(IterStats), e->stream));
     hipLaunchKernelGGL(k_ginit, dim3(grid_for((int64_t)e->V * g.gw)), dim3(BLOCK), 0, e->stream, g.p, g.r, e->V, g.gw, g.src);
     HIP_TRY(hipGetLastError());

@@ -176,19 +176,63 @@ __global__ __launch_bounds__(BLOCK) void k_gseed_tails(const uint32_t *__restric
     if (threadIdx.x < GW && s_cnt[threadIdx.x]) atomicAdd(&cnt_out[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
+// Memory accesses of the sweep: plain in a one-sweep launch; in a multi-sweep launch everything another
+// workgroup wrote during the launch is read past the L1 (agent scope, `sc1`) and every store another
+// workgroup will read is agent-scope too (see k_pull_resident for the measured visibility rules).
+template <bool COH>
+__device__ __forceinline__ double gs_ld(const double *p) {
+    if constexpr (COH)
+        return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
+                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    else
+        return *p;
+}
+template <bool COH>
+__device__ __forceinline__ uint32_t gs_ldu(const uint32_t *p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void gs_st(double *p, double v) {
+    if constexpr (COH)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+}
+template <bool COH>
+__device__ __forceinline__ void gs_stu(uint32_t *p, uint32_t v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+// status word of a multi-sweep launch
+constexpr int GSM_ABORTED = 1 << 30;   // the roll-call failed: nothing was changed
+constexpr int GSM_FAULT = 1 << 29;     // a wait timed out after a successful roll-call
+constexpr int GSM_CONVERGED = 1 << 28; // every frontier emptied
+constexpr int GSM_SWEEPS = (1 << 16) - 1;
+
 // One frontier iteration (ExpandUnifiedRev + RepairFrontierRev) for all sources of a group.
 // NVX = vertices per sweep group (the LDS accumulators are NVX x GW doubles: 64 KB for both
 // instantiations, two 1024-thread workgroups per CU).
+//
+// MULTI = a RUN of iterations as one launch, for windows whose groups are all resident at once (one
+// workgroup per group): the group's row tables are built once and stay in LDS, iterations are
+// separated by a grid barrier (arrival counters of dppr_resident.hpp, replicated, polled by one wave;
+// ~5 us, which is what a dependent kernel boundary costs too -- what disappears is the launch ramp,
+// the per-launch table set-up chain and the no-op launches at the end of a chunk). Per iteration g the
+// frontier sizes of all sources are row g of `mlog` (row 0 = cnt_in): the loop ends when a row is
+// all zero. Co-residency is verified by the same roll-call as k_pull_resident's before anything is
+// changed; a failed roll-call leaves everything untouched and the host goes on with one-sweep launches.
 constexpr int GNT = 1024; // threads per workgroup of k_gsweep
-template <int SPL, int NVX>
+template <int SPL, int NVX, bool MULTI>
 __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict__ grp_tile, int n_groups,
-                                                   const int *__restrict__ cnt_in, const int *__restrict__ out_row_ptr,
-                                                   const int *__restrict__ out_col, const double *__restrict__ x,
-                                                   double *__restrict__ x_new, const uint32_t *__restrict__ act_in,
-                                                   uint32_t *__restrict__ act_out, double *__restrict__ r,
-                                                   double *__restrict__ p, int *__restrict__ cnt_out,
-                                                   int *__restrict__ cnt_zero, int phase, double eps,
-                                                   IterStats *__restrict__ stats, int *__restrict__ log_slot) {
+                                                   const int *cnt_in, const int *__restrict__ out_row_ptr,
+                                                   const int *__restrict__ out_col, double *x_a, double *x_b,
+                                                   uint32_t *act_a, uint32_t *act_b, double *r, double *p, int *cnt_out,
+                                                   int *cnt_zero, int phase, double eps, IterStats *__restrict__ stats,
+                                                   int *log_slot, int n_iter, GridBar *bar, int *status,
+                                                   unsigned long long limit_ticks, int rollcall_extra) {
     constexpr int GW = OCT * SPL, NW = GNT / WAVE, NOCT = GNT / OCT, WORDS = NVX / 32;
     constexpr int EB = 8;        // edges an octet tests per step (one per lane)
     constexpr int GB = EB / SPL; // ... and gathers per sub-step (registers: GB x SPL doubles)
@@ -202,27 +246,76 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
     __shared__ int s_wcnt[NW];
     __shared__ int s_cnt[GS_MAX];
     __shared__ unsigned long long s_edges;
+    __shared__ int s_flag[2]; // MULTI: {go on (roll-call ok / frontier not empty), fault}
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const int j = tid & (OCT - 1), oid = tid / OCT;
 
     // frontier sizes of the sources; the group iterates while ANY of them is non-empty
-    const int my_cnt = lane < GW ? cnt_in[lane] : 0;
-    if (blockIdx.x == 0 && tid < GW) {
-        cnt_zero[tid] = 0;
-        log_slot[tid] = my_cnt;
+    if constexpr (!MULTI) {
+        const int my_cnt = lane < GW ? cnt_in[lane] : 0;
+        if (blockIdx.x == 0 && tid < GW) {
+            cnt_zero[tid] = 0;
+            log_slot[tid] = my_cnt;
+        }
+        if (__ballot(my_cnt != 0) == 0) return;
     }
-    if (__ballot(my_cnt != 0) == 0) return;
     for (int k = tid; k < NVX * GW; k += GNT) s_acc[k] = 0.0;
     if (tid < WORDS) {
         s_actout[tid] = 0u;
         s_touched[tid] = 0u;
     }
     if (tid < GS_MAX) s_cnt[tid] = 0;
-    if (tid == 0) s_edges = 0ull;
+    if (tid == 0) {
+        s_edges = 0ull;
+        s_flag[0] = 1;
+        s_flag[1] = 0;
+    }
     int nleg[SPL];
 #pragma unroll
     for (int q = 0; q < SPL; ++q) nleg[q] = 0;
     unsigned ecount = 0;
+
+    // ---- MULTI: roll-call (every workgroup of the launch is running) before anything is changed
+    const unsigned G = gridDim.x;
+    const unsigned subs_used = G < (unsigned)BAR_SUBS ? G : (unsigned)BAR_SUBS;
+    const unsigned long long n_sub = lane < (int)subs_used ? (G - lane + BAR_SUBS - 1) / BAR_SUBS : 0;
+    const int my_rep = (blockIdx.x / BAR_SUBS) % BAR_REPS;
+    if constexpr (MULTI) {
+        const unsigned long long t_entry = wall_clock64();
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_fetch_add(&bar->roll[blockIdx.x % BAR_SUBS].w, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w == 0) {
+            if (blockIdx.x == 0) {
+                unsigned polls = 0;
+                bool all_here = false;
+                for (;;) {
+                    const unsigned long long word = lane < (int)subs_used ? bar_load(&bar->roll[lane].w) : 0;
+                    if (__ballot((word >> 32) >= n_sub + (lane == 0 ? (unsigned long long)rollcall_extra : 0ull)) == ~0ull) {
+                        all_here = true;
+                        break;
+                    }
+                    if ((polls++ & 31u) == 0 && (bar_load(&bar->gen.w) != 0 || wall_clock64() - t_entry > limit_ticks)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (lane == 0) (void)bar_cas(&bar->gen.w, 0ull, all_here ? BAR_READY : BAR_ABORT);
+            }
+            if (lane == 0) {
+                unsigned long long word;
+                unsigned polls = 0;
+                while ((word = bar_load(&bar->gen.w)) == 0) {
+                    if ((polls++ & 31u) == 0 && wall_clock64() - t_entry > limit_ticks) (void)bar_cas(&bar->gen.w, 0ull, BAR_ABORT);
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                s_flag[0] = word != BAR_ABORT;
+            }
+        }
+        __syncthreads();
+        if (!s_flag[0]) {
+            if (blockIdx.x == 0 && tid == 0) *status = GSM_ABORTED;
+            return;
+        }
+    }
 
     // A group's work is a chain of dependent memory round trips (group table -> row extents -> out_col ->
     // activity bits -> x -> residuals), which is what a sweep of a SMALL window costs. The chain is kept
@@ -236,7 +329,9 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
         nE0 = out_row_ptr[nt0 * WAVE];
         nE1 = out_row_ptr[nt0 * WAVE + min((nt1 - nt0) * WAVE, V - nt0 * WAVE)];
     }
-    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) { // workgroup-uniform loop
+    int sweeps_done = 0;
+    bool converged = false, fault = false;
+    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) { // workgroup-uniform loop (MULTI: one group per workgroup)
         __syncthreads(); // the previous group's tables are no longer read; the initial fills are in place
         const int t0 = nt0, t1 = nt1;
         const int v0 = t0 * WAVE;
@@ -254,12 +349,13 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
             rs = out_row_ptr[v0 + tid] - E0;
             d = out_row_ptr[v0 + tid + 1] - E0 - rs;
         }
-        if (tid < WORDS) s_actin[tid] = tid * 32 < nv ? act_in[(v0 >> 5) + tid] : 0u;
         // slice of the group's Eg edges per octet (a multiple of EB); its first out_col entry is requested
         // now, together with the row extents, not after the row tables are built
         const int per = ((Eg + NOCT - 1) / NOCT + EB - 1) / EB * EB;
         const int e_begin = oid * per, e_end = min(Eg, e_begin + per);
         const int *cols = out_col + E0;
+        // (the first sweep's activity words and out_col entries are requested together with the row extents)
+        if (tid < WORDS) s_actin[tid] = tid * 32 < nv ? gs_ldu<MULTI>(act_a + (v0 >> 5) + tid) : 0u;
         int mycol = e_begin + j < e_end ? ld_stream(&cols[e_begin + j]) : -1;
         int ncol = e_begin + EB + j < e_end ? ld_stream(&cols[e_begin + EB + j]) : -1;
         // compact the non-empty rows
@@ -282,150 +378,231 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
             for (int o = o_first; o <= o_last; ++o) s_ostart[o] = idx;
         }
         if (tid == 0) s_cstart[ncomp] = Eg;
-        __syncthreads();
 
-        // ---- edge phase
-        if (e_begin < e_end) {
-            int crow = s_ostart[oid];
-            int row_beg = s_cstart[crow], row_end = s_cstart[crow + 1];
-            double den = (double)(row_end - row_beg + 1);
-            double rcp = 1.0 / den;
-            double acc[SPL];
-#pragma unroll
-            for (int q = 0; q < SPL; ++q) acc[q] = 0.0;
-            auto flush = [&]() { // the running sums of row `crow` go to its LDS accumulator
-                const int vl = s_cvid[crow];
-                bool nz = false;
-#pragma unroll
-                for (int q = 0; q < SPL; ++q) {
-                    if (acc[q] != 0.0) lds_add(&s_acc[vl * GW + j * SPL + q], acc[q]);
-                    nz |= acc[q] != 0.0;
-                    acc[q] = 0.0;
+        // ---- the sweeps over this group's tables: one (a one-sweep launch) or a run of them (MULTI)
+        for (int it = 0; it < (MULTI ? n_iter : 1); ++it) {
+            const double *x = (it & 1) ? x_b : x_a;
+            double *x_new = (it & 1) ? x_a : x_b;
+            const uint32_t *act_in = (it & 1) ? act_b : act_a;
+            uint32_t *act_out = (it & 1) ? act_a : act_b;
+            if constexpr (MULTI) {
+                // frontier sizes of iteration `it`: row `it` of the log (row 0 = what the seeding left in cnt_in)
+                const int *row = it == 0 ? cnt_in : log_slot + (size_t)it * GS_MAX;
+                const int f = lane < GW ? (int)gs_ldu<true>(reinterpret_cast<const uint32_t *>(row + lane)) : 0;
+                if (it == 0 && blockIdx.x == 0 && tid < GW) log_slot[tid] = f;
+                if (__ballot(f != 0) == 0) { // every workgroup reads the same row: all of them stop here
+                    converged = true;
+                    break;
                 }
-                if (nz) atomicOr(&s_touched[vl >> 5], 1u << (vl & 31));
-            };
-            uint32_t aw = mycol >= 0 ? act_in[mycol >> 5] : 0u; // activity word of the first step's head
-            for (int e = e_begin; e < e_end; e += EB) {
-                // which of the step's edges have an active head (one bit per lane); the NEXT step's word and
-                // the out_col entry of the step after are requested before this step's gathers
-                const bool a = mycol >= 0 && ((aw >> (mycol & 31)) & 1u);
-                const uint32_t naw = ncol >= 0 ? act_in[ncol >> 5] : 0u;
-                const int nncol = e + 2 * EB + j < e_end ? ld_stream(&cols[e + 2 * EB + j]) : -1;
-                const unsigned m = oct_mask(__ballot(a));
+            }
+            if (it > 0) { // (MULTI only)
+                if (tid < WORDS) s_actin[tid] = tid * 32 < nv ? gs_ldu<MULTI>(act_in + (v0 >> 5) + tid) : 0u;
+                mycol = e_begin + j < e_end ? ld_stream(&cols[e_begin + j]) : -1;
+                ncol = e_begin + EB + j < e_end ? ld_stream(&cols[e_begin + EB + j]) : -1;
+            }
+            __syncthreads();
+
+            // ---- edge phase
+            if (e_begin < e_end) {
+                int crow = s_ostart[oid];
+                int row_beg = s_cstart[crow], row_end = s_cstart[crow + 1];
+                double den = (double)(row_end - row_beg + 1);
+                double rcp = 1.0 / den;
+                double acc[SPL];
 #pragma unroll
-                for (int h = 0; h < EB; h += GB) {
-                    const unsigned mh = (m >> h) & ((1u << GB) - 1u);
-                    if (mh) {
-                        // the sub-step's gathers are all issued before any is used
-                        double xv[GB][SPL];
+                for (int q = 0; q < SPL; ++q) acc[q] = 0.0;
+                auto flush = [&]() { // the running sums of row `crow` go to its LDS accumulator
+                    const int vl = s_cvid[crow];
+                    bool nz = false;
 #pragma unroll
-                        for (int k = 0; k < GB; ++k) {
-                            const int ck = __shfl(mycol, (lane & ~(OCT - 1)) + h + k, WAVE);
+                    for (int q = 0; q < SPL; ++q) {
+                        if (acc[q] != 0.0) lds_add(&s_acc[vl * GW + j * SPL + q], acc[q]);
+                        nz |= acc[q] != 0.0;
+                        acc[q] = 0.0;
+                    }
+                    if (nz) atomicOr(&s_touched[vl >> 5], 1u << (vl & 31));
+                };
+                uint32_t aw = mycol >= 0 ? gs_ldu<MULTI>(act_in + (mycol >> 5)) : 0u; // activity word of the first step's head
+                for (int e = e_begin; e < e_end; e += EB) {
+                    // which of the step's edges have an active head (one bit per lane); the NEXT step's word and
+                    // the out_col entry of the step after are requested before this step's gathers
+                    const bool a = mycol >= 0 && ((aw >> (mycol & 31)) & 1u);
+                    const uint32_t naw = ncol >= 0 ? gs_ldu<MULTI>(act_in + (ncol >> 5)) : 0u;
+                    const int nncol = e + 2 * EB + j < e_end ? ld_stream(&cols[e + 2 * EB + j]) : -1;
+                    const unsigned m = oct_mask(__ballot(a));
 #pragma unroll
-                            for (int q = 0; q < SPL; ++q) xv[k][q] = 0.0;
-                            if ((mh >> k) & 1u) {
+                    for (int h = 0; h < EB; h += GB) {
+                        const unsigned mh = (m >> h) & ((1u << GB) - 1u);
+                        if (mh) {
+                            // the sub-step's gathers are all issued before any is used
+                            double xv[GB][SPL];
 #pragma unroll
-                                for (int q = 0; q < SPL; ++q) xv[k][q] = x[(size_t)ck * GW + j * SPL + q];
-                            }
-                        }
+                            for (int k = 0; k < GB; ++k) {
+                                const int ck = __shfl(mycol, (lane & ~(OCT - 1)) + h + k, WAVE);
 #pragma unroll
-                        for (int k = 0; k < GB; ++k) {
-                            if ((mh >> k) & 1u) {
-                                const int ek = e + h + k;
-                                if (ek >= row_end) { // the cursor moves on: non-empty rows are contiguous in edge space
-                                    flush();
-                                    do {
-                                        ++crow;
-                                        row_beg = row_end;
-                                        row_end = s_cstart[crow + 1];
-                                    } while (ek >= row_end);
-                                    den = (double)(row_end - row_beg + 1);
-                                    rcp = 1.0 / den;
+                                for (int q = 0; q < SPL; ++q) xv[k][q] = 0.0;
+                                if ((mh >> k) & 1u) {
+#pragma unroll
+                                    for (int q = 0; q < SPL; ++q) xv[k][q] = gs_ld<MULTI>(x + (size_t)ck * GW + j * SPL + q);
                                 }
+                            }
 #pragma unroll
-                                for (int q = 0; q < SPL; ++q) {
-                                    if (legal(xv[k][q], phase, eps)) { // the head's residual for this source is being pushed
-                                        acc[q] += push_term(xv[k][q], den, rcp);
-                                        ++ecount;
+                            for (int k = 0; k < GB; ++k) {
+                                if ((mh >> k) & 1u) {
+                                    const int ek = e + h + k;
+                                    if (ek >= row_end) { // the cursor moves on: non-empty rows are contiguous in edge space
+                                        flush();
+                                        do {
+                                            ++crow;
+                                            row_beg = row_end;
+                                            row_end = s_cstart[crow + 1];
+                                        } while (ek >= row_end);
+                                        den = (double)(row_end - row_beg + 1);
+                                        rcp = 1.0 / den;
+                                    }
+#pragma unroll
+                                    for (int q = 0; q < SPL; ++q) {
+                                        if (legal(xv[k][q], phase, eps)) { // the head's residual for this source is being pushed
+                                            acc[q] += push_term(xv[k][q], den, rcp);
+                                            ++ecount;
+                                        }
                                     }
                                 }
                             }
                         }
                     }
+                    mycol = ncol;
+                    aw = naw;
+                    ncol = nncol;
                 }
-                mycol = ncol;
-                aw = naw;
-                ncol = nncol;
+                flush();
             }
-            flush();
-        }
-        __syncthreads();
+            __syncthreads();
 
-        // ---- vertex phase: repair, threshold, next snapshot for the vertices that were touched
-        for (int i0 = 0; i0 < NVX / NOCT; i0 += FU) {
-            int vl[FU];
-            bool tch[FU], wasact[FU];
-            double cur[FU][SPL], pv[FU][SPL]; // cur: the residual row -- from x if the vertex was active, else from r
+            // ---- vertex phase: repair, threshold, next snapshot for the vertices that were touched
+            for (int i0 = 0; i0 < NVX / NOCT; i0 += FU) {
+                int vl[FU];
+                bool tch[FU], wasact[FU];
+                double cur[FU][SPL], pv[FU][SPL]; // cur: the residual row -- from x if the vertex was active, else from r
 #pragma unroll
-            for (int i = 0; i < FU; ++i) {
-                vl[i] = oid + (i0 + i) * NOCT;
-                const unsigned bit = 1u << (vl[i] & 31);
-                wasact[i] = (s_actin[vl[i] >> 5] & bit) != 0;
-                tch[i] = vl[i] < nv && (wasact[i] || (s_touched[vl[i] >> 5] & bit) != 0);
-#pragma unroll
-                for (int q = 0; q < SPL; ++q) {
-                    cur[i][q] = 0.0;
-                    pv[i][q] = 0.0;
-                }
-                if (tch[i]) {
-                    const size_t base = (size_t)(v0 + vl[i]) * GW + j * SPL;
-                    const double *row = wasact[i] ? x : r;
+                for (int i = 0; i < FU; ++i) {
+                    vl[i] = oid + (i0 + i) * NOCT;
+                    const unsigned bit = 1u << (vl[i] & 31);
+                    wasact[i] = (s_actin[vl[i] >> 5] & bit) != 0;
+                    tch[i] = vl[i] < nv && (wasact[i] || (s_touched[vl[i] >> 5] & bit) != 0);
 #pragma unroll
                     for (int q = 0; q < SPL; ++q) {
-                        cur[i][q] = row[base + q];
-                        pv[i][q] = p[base + q]; // needed only if the vertex ends up legal: asked for now, not after the test
+                        cur[i][q] = 0.0;
+                        pv[i][q] = 0.0;
                     }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < FU; ++i) {
-                if (tch[i]) {
-                    const size_t base = (size_t)(v0 + vl[i]) * GW + j * SPL;
-                    double rn[SPL];
-                    bool lg[SPL], any = false, changed = false;
-#pragma unroll
-                    for (int q = 0; q < SPL; ++q) {
-                        double *ap = &s_acc[vl[i] * GW + j * SPL + q];
-                        const double a = *ap;
-                        *ap = 0.0;
-                        // RepairFrontierRev: a source that was pushed keeps only what arrived during the sweep
-                        const bool pushed = wasact[i] && legal(cur[i][q], phase, eps);
-                        rn[q] = pushed ? a : cur[i][q] + a;
-                        lg[q] = legal(rn[q], phase, eps);
-                        any |= lg[q];
-                        changed |= rn[q] != cur[i][q];
-                        nleg[q] += lg[q] ? 1 : 0;
-                    }
-                    if (oct_mask(__ballot(any))) { // stays / becomes active: the row lives in the next snapshot
+                    if (tch[i]) {
+                        const size_t base = (size_t)(v0 + vl[i]) * GW + j * SPL;
+                        const double *row = wasact[i] ? x : r;
 #pragma unroll
                         for (int q = 0; q < SPL; ++q) {
-                            x_new[base + q] = rn[q];
-                            if (lg[q]) p[base + q] = pv[i][q] + ALPHA * rn[q];
+                            cur[i][q] = gs_ld<MULTI>(row + base + q);
+                            pv[i][q] = gs_ld<MULTI>(p + base + q); // needed only if the vertex ends up legal: asked for now, not after the test
                         }
-                        if (j == 0) atomicOr(&s_actout[vl[i] >> 5], 1u << (vl[i] & 31));
-                    } else if (wasact[i] || changed) { // inactive now: the row goes (back) to residual[]
+                    }
+                }
 #pragma unroll
-                        for (int q = 0; q < SPL; ++q) r[base + q] = rn[q];
+                for (int i = 0; i < FU; ++i) {
+                    if (tch[i]) {
+                        const size_t base = (size_t)(v0 + vl[i]) * GW + j * SPL;
+                        double rn[SPL];
+                        bool lg[SPL], any = false, changed = false;
+#pragma unroll
+                        for (int q = 0; q < SPL; ++q) {
+                            double *ap = &s_acc[vl[i] * GW + j * SPL + q];
+                            const double a = *ap;
+                            *ap = 0.0;
+                            // RepairFrontierRev: a source that was pushed keeps only what arrived during the sweep
+                            const bool pushed = wasact[i] && legal(cur[i][q], phase, eps);
+                            rn[q] = pushed ? a : cur[i][q] + a;
+                            lg[q] = legal(rn[q], phase, eps);
+                            any |= lg[q];
+                            changed |= rn[q] != cur[i][q];
+                            nleg[q] += lg[q] ? 1 : 0;
+                        }
+                        if (oct_mask(__ballot(any))) { // stays / becomes active: the row lives in the next snapshot
+#pragma unroll
+                            for (int q = 0; q < SPL; ++q) {
+                                gs_st<MULTI>(x_new + base + q, rn[q]);
+                                if (lg[q]) p[base + q] = pv[i][q] + ALPHA * rn[q];
+                            }
+                            if (j == 0) atomicOr(&s_actout[vl[i] >> 5], 1u << (vl[i] & 31));
+                        } else if (wasact[i] || changed) { // inactive now: the row goes (back) to residual[]
+#pragma unroll
+                            for (int q = 0; q < SPL; ++q) r[base + q] = rn[q];
+                        }
                     }
                 }
             }
+            __syncthreads();
+            if (tid < WORDS) { // the group's words of the next bitmap (complete), tables back to zero
+                if (tid * 32 < nv) gs_stu<MULTI>(act_out + (v0 >> 5) + tid, s_actout[tid]);
+                s_actout[tid] = 0u;
+                s_touched[tid] = 0u;
+            }
+            if constexpr (MULTI) {
+                // ---- end of iteration `it`: this workgroup's frontier counts go to row it + 1 of the log, its stores are
+                // drained, it arrives, and it waits until everybody has
+#pragma unroll
+                for (int q = 0; q < SPL; ++q) {
+                    if (nleg[q]) atomicAdd(&s_cnt[j * SPL + q], nleg[q]);
+                    nleg[q] = 0;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid < GW) {
+                    if (s_cnt[tid])
+                        __hip_atomic_fetch_add(log_slot + (size_t)(it + 1) * GS_MAX + tid, s_cnt[tid], __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                    s_cnt[tid] = 0;
+                }
+                if (w == 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the count adds of this wave's lanes)
+                    if (lane < BAR_REPS)
+                        __hip_atomic_fetch_add(&bar->sub[it & 1][lane][blockIdx.x % BAR_SUBS].w, 1ull << 32, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long rounds = (unsigned long long)((it >> 1) + 1);
+                    unsigned polls = 0;
+                    const unsigned long long t_start = wall_clock64();
+                    bool ok = true;
+                    for (;;) {
+                        const unsigned long long word = lane < (int)subs_used ? bar_load(&bar->sub[it & 1][my_rep][lane].w) : 0;
+                        if (__ballot((word >> 32) >= n_sub * rounds) == ~0ull) break;
+                        if ((polls++ & 63u) == 63u && wall_clock64() - t_start > limit_ticks + 100000000ull) {
+                            ok = false;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(BAR_POLL_SLEEP);
+                    }
+                    if (lane == 0 && !ok) s_flag[1] = 1;
+                }
+                __syncthreads();
+                sweeps_done = it + 1;
+                if (s_flag[1]) {
+                    fault = true;
+                    break;
+                }
+            }
         }
+        if constexpr (MULTI) break; // one group per workgroup
+    }
+    if constexpr (MULTI) {
+        if (blockIdx.x == 0 && tid < GS_MAX) { // the live frontier sizes for whoever continues, counters as a one-sweep launch leaves them
+            const int f = (tid < GW && !converged && !fault)
+                              ? (int)gs_ldu<true>(reinterpret_cast<const uint32_t *>(log_slot + (size_t)sweeps_done * GS_MAX + tid)) : 0;
+            cnt_out[tid] = f;
+            cnt_zero[tid] = 0;
+        }
+        if (blockIdx.x == 0 && tid == 0)
+            *status = sweeps_done | (fault ? GSM_FAULT : 0) | (converged ? GSM_CONVERGED : 0);
+        if (ecount) atomicAdd(&s_edges, (unsigned long long)ecount);
         __syncthreads();
-        if (tid < WORDS) { // the group's words of the next bitmap (complete), tables back to zero
-            if (tid * 32 < nv) act_out[(v0 >> 5) + tid] = s_actout[tid];
-            s_actout[tid] = 0u;
-            s_touched[tid] = 0u;
-        }
+        if (tid == 0 && s_edges) stats->blk_E[blockIdx.x] += s_edges;
+        return;
     }
     // next frontier sizes: one fire-and-forget atomic per source and workgroup
 #pragma unroll

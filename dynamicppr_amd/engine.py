@@ -54,7 +54,7 @@ EXPORTS = [
     "dppr_reset_stats", "dppr_inspect", "dppr_read_graph", "dppr_graph_edges", "dppr_read_out_graph", "dppr_trace_enable",
     "dppr_trace_get", "dppr_synchronize", "dppr_bench_atomics",
     "dppr_add_source_group", "dppr_group_init_solve", "dppr_group_update", "dppr_group_read", "dppr_group_stats",
-    "dppr_group_reset_stats", "dppr_set_group_seeding", "dppr_seed_lists", "dppr_set_sweep_bitmap",
+    "dppr_group_reset_stats", "dppr_set_group_seeding", "dppr_seed_lists", "dppr_set_sweep_bitmap", "dppr_set_group_resident",
 ]
 
 
@@ -107,6 +107,7 @@ def lib():
     L.dppr_group_read.argtypes = [vp, C.c_int32, C.c_int32, dp, dp]
     L.dppr_group_stats.argtypes = [vp, C.c_int32, C.POINTER(Stats)]
     L.dppr_set_sweep_bitmap.argtypes = [vp, C.c_int]
+    L.dppr_set_group_resident.argtypes = [vp, C.c_int]
     L.dppr_seed_lists.argtypes = [vp, C.c_int32, C.c_int, ip, ip]
     L.dppr_group_reset_stats.argtypes = [vp, C.c_int32]
     L.dppr_set_group_seeding.argtypes = [vp, C.c_int]
@@ -317,6 +318,9 @@ class Engine:
 
     def group_reset_stats(self, group):
         self._ck(self._L.dppr_group_reset_stats(self._h, group), "group_reset_stats")
+
+    def set_group_resident(self, on):
+        self._ck(self._L.dppr_set_group_resident(self._h, int(on)), "set_group_resident")
 
     def set_group_seeding(self, from_tails):
         self._ck(self._L.dppr_set_group_seeding(self._h, int(from_tails)), "set_group_seeding")

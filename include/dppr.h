@@ -217,6 +217,11 @@ int dppr_group_update(dppr_engine *e, int32_t group, int32_t epoch, double eps, 
 int dppr_group_read(dppr_engine *e, int32_t group, int32_t index, double *p, double *r);
 int dppr_group_stats(dppr_engine *e, int32_t group, dppr_stats_t *out); /* summed over the sources */
 int dppr_group_reset_stats(dppr_engine *e, int32_t group);
+/* Windows whose sweep groups are all resident at once run a frontier loop of a source group as
+ * multi-sweep launches (grid barrier between sweeps, row tables kept in LDS; dppr_multi.hpp). on by
+ * default; 0 = one launch per sweep everywhere. The roll-call / time-out rules are those of
+ * dppr_set_persistent. Same results. */
+int dppr_set_group_resident(dppr_engine *e, int on);
 /* How dppr_group_update seeds its two frontier loops. from_tails (default): after a converged solve
  * only tails of the batch's records can be legal (the argument of cpu/PPRCPUMTCilkRev.h:126-156), so
  * the frontier is read off the batch; 0: a full Inspect pass over all vertices per phase like

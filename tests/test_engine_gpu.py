@@ -772,11 +772,12 @@ def test_incremental_graph_equals_full_rebuild(directed):
             assert np.array_equal(oa[0], ob[0]) and np.array_equal(oa[1], ob[1])
 
 
-def run_source_group(V, e1, e2, W, c, eps, directed, sources, batches, seeding, tuning=None):
+def run_source_group(V, e1, e2, W, c, eps, directed, sources, batches, seeding, tuning=None, resident=True):
     """Drive a source group and one oracle state per source (synchronous schedule) over the same
     stream; per-source p/r to rounding, summed statistics equal."""
     e = eng.Engine(V, W, directed, c, **(tuning or {}))
     e.set_group_seeding(seeding == "tails")
+    e.set_group_resident(resident)
     g = orc.Graph(V, e1, e2, directed, W, c)
     states = [orc.State(V, s, eps) for s in sources]
     e.load_window(*g.window_edges())
@@ -846,6 +847,30 @@ def test_source_group_sweep_shapes(nsrc, shape):
     ranked = datagen.top_sources(V, e1, e2, W, directed, 40)
     sources = [int(s) for s in ranked[::4][:nsrc]]
     run_source_group(V, e1, e2, W, c, 1e-9, directed, sources, 4, "tails")
+
+
+@pytest.mark.parametrize("mode", ["one-launch-per-sweep", "multi-sweep", "multi-sweep-3-at-a-time", "rollcall-fails"])
+@pytest.mark.parametrize("nsrc", [4, 12])
+def test_source_group_launch_forms(nsrc, mode):
+    """The frontier loop of a source group as one launch per sweep, as multi-sweep launches (grid barrier
+    between sweeps; the default on windows whose groups are all resident), as multi-sweep launches that
+    may only run 3 sweeps and are resumed, and with a roll-call that cannot succeed (the launch gives up
+    untouched, one-sweep launches go on): same per-source results and statistics."""
+    V, e1, e2 = datagen.rmat_stream(12, 40000, 7)
+    W, c, directed = 12000, 120, 0
+    sources = [int(x) for x in datagen.top_sources(V, e1, e2, W, directed, nsrc)]
+    tuning = {"multi-sweep-3-at-a-time": dict(chunk_iters=3), "rollcall-fails": dict(persist_timeout_us=-1)}.get(mode)
+    e, gid = run_source_group(V, e1, e2, W, c, 1e-9, directed, sources, 3, "tails", tuning=tuning,
+                              resident=mode != "one-launch-per-sweep")
+    st = e.group_stats(gid)
+    if mode == "one-launch-per-sweep":
+        assert st["persist_launches"] == 0
+    elif mode == "rollcall-fails":
+        assert st["persist_launches"] == 1 and st["persist_aborts"] == 1
+    else:
+        assert st["persist_launches"] >= 7 and st["persist_aborts"] == 0
+        if mode == "multi-sweep-3-at-a-time":
+            assert st["persist_launches"] > st["iterations"] / 4
 
 
 def test_source_group_sources_outside_the_window_and_duplicates():
