@@ -159,6 +159,7 @@ struct dppr_engine {
     bool sweep_bits = false;        // per-iteration single-source sweeps test an activity bitmap before each gather (dppr_set_sweep_bitmap;
                                     // measured slower on every stand-in, DESIGN.md section 6: off unless asked for)
     bool hot_blocks = true;         // vertex numbering in blocks of falling in-degree (DPPR_HOT_BLOCKS=0: two blocks, hot | rest)
+    int gsweep_grid_cap = 2048;     // workgroups of a one-sweep launch of k_gsweep (DPPR_GSWEEP_GRID: tuning runs)
     bool group_resident = true;     // source groups on windows whose sweep groups are all resident run a loop as multi-sweep launches
     int gmulti_cap[2] = {-1, -1};   // co-resident workgroups of k_gsweep<.., true> per state width (-1: not queried yet)
     bool any_groups = false;        // a source group exists: epochs carry the second group table
@@ -954,7 +955,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
     HIP_TRY(hipStreamSynchronize(e->stream));
     bool more = any_left(e->pinned);
     int active_iters = 0;
-    const int sweep_grid = std::min(std::max(ep.n_ggroups, 1), 2048);
+    const int sweep_grid = std::min(std::max(ep.n_ggroups, 1), e->gsweep_grid_cap);
     for (int it = 0; more;) {
         if (it >= e->max_iters) return fail(e, DPPR_ERR_NOT_CONVERGED, "iteration cap hit");
         // ---- a window whose sweep groups are all resident at once: a run of sweeps as ONE launch (k_gsweep<.., true>)
@@ -1120,6 +1121,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     } while (0)
     if (const char *v = getenv("DPPR_SWEEP_BITS")) e->sweep_bits = atoi(v) != 0; // diagnostic A/B switches
     if (const char *v = getenv("DPPR_HOT_BLOCKS")) e->hot_blocks = atoi(v) != 0;
+    if (const char *v = getenv("DPPR_GSWEEP_GRID")) e->gsweep_grid_cap = std::max(1, std::min(atoi(v), STAT_SLOTS));
     if (const char *v = getenv("DPPR_GGROUPS_MIN")) e->ggroups_min = std::max(1, atoi(v));
     e->device = device;
     e->V = V;
