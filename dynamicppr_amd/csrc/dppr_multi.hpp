@@ -226,7 +226,7 @@ constexpr int GSM_SWEEPS = (1 << 16) - 1;
 // changed; a failed roll-call leaves everything untouched and the host goes on with one-sweep launches.
 constexpr int GNT = 1024; // threads per workgroup of k_gsweep
 template <int SPL, int NVX, bool MULTI>
-__global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict__ grp_tile, int n_groups,
+__global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int *__restrict__ grp_tile, int n_groups,
                                                    const int *cnt_in, const int *__restrict__ out_row_ptr,
                                                    const int *__restrict__ out_col, double *x_a, double *x_b,
                                                    uint32_t *act_a, uint32_t *act_b, double *r, double *p, int *cnt_out,
@@ -236,7 +236,10 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
     constexpr int GW = OCT * SPL, NW = GNT / WAVE, NOCT = GNT / OCT, WORDS = NVX / 32;
     constexpr int EB = 8;        // edges an octet tests per step (one per lane)
     constexpr int GB = EB / SPL; // ... and gathers per sub-step (registers: GB x SPL doubles)
-    constexpr int FU = 4 / SPL;  // vertices an octet finishes per step
+    // vertices an octet finishes per step. A wait for loaded values also waits for every older store, so a second
+    // step costs the store latency again: the multi-sweep form (one workgroup per CU is enough there: 128 VGPRs)
+    // requests ALL its rows before any is stored; the one-sweep form has 64 VGPRs and takes steps of 4 / 2.
+    constexpr int FU = MULTI ? NVX / NOCT : 4 / SPL;
     static_assert(NVX % NOCT == 0 && (NVX / NOCT) % FU == 0, "vertex phase covers the group in whole steps");
     __shared__ double s_acc[NVX * GW];   // per vertex and source: sum of this sweep's adds (zero between groups)
     __shared__ int s_cstart[NVX + 1];    // non-empty rows of the group, compacted: first edge (relative)
@@ -395,6 +398,8 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
                     break;
                 }
             }
+#define GSTAMP(i) do { if (MULTI && it == 12) STAMP(i); } while (0)
+            GSTAMP(0);
             if (it > 0) { // (MULTI only)
                 if (tid < WORDS) s_actin[tid] = tid * 32 < nv ? gs_ldu<MULTI>(act_in + (v0 >> 5) + tid) : 0u;
                 mycol = e_begin + j < e_end ? ld_stream(&cols[e_begin + j]) : -1;
@@ -477,7 +482,9 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
                 }
                 flush();
             }
+            GSTAMP(1);
             __syncthreads();
+            GSTAMP(2);
 
             // ---- vertex phase: repair, threshold, next snapshot for the vertices that were touched
             for (int i0 = 0; i0 < NVX / NOCT; i0 += FU) {
@@ -538,7 +545,9 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
                     }
                 }
             }
+            GSTAMP(3);
             __syncthreads();
+            GSTAMP(4);
             if (tid < WORDS) { // the group's words of the next bitmap (complete), tables back to zero
                 if (tid * 32 < nv) gs_stu<MULTI>(act_out + (v0 >> 5) + tid, s_actout[tid]);
                 s_actout[tid] = 0u;
@@ -554,6 +563,7 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
+                GSTAMP(5);
                 if (tid < GW) {
                     if (s_cnt[tid])
                         __hip_atomic_fetch_add(log_slot + (size_t)(it + 1) * GS_MAX + tid, s_cnt[tid], __ATOMIC_RELAXED,
@@ -581,6 +591,7 @@ __global__ __launch_bounds__(GNT, 8) void k_gsweep(int V, const int *__restrict_
                     if (lane == 0 && !ok) s_flag[1] = 1;
                 }
                 __syncthreads();
+                GSTAMP(6);
                 sweeps_done = it + 1;
                 if (s_flag[1]) {
                     fault = true;

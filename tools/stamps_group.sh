@@ -1,0 +1,40 @@
+#!/bin/bash
+# Diagnostic: stage times of ONE sweep (the 13th of a multi-sweep launch) of k_gsweep<.., true>, per workgroup.
+# Builds a SEPARATE library with -DDPPR_STAMPS (never the product build).
+# usage: tools/stamps_group.sh [config] [sources]
+set -e
+cd $GRAFT_REPO_ROOT
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -ffp-contract=off -munsafe-fp-atomics \
+   -DDPPR_STAMPS -o /tmp/libdppr_hip_stamps.so dynamicppr_amd/csrc/dppr_engine.hip
+DPPR_LIB=/tmp/libdppr_hip_stamps.so CFG=${1:-youtube} NSRC=${2:-8} python3 - <<'PY'
+import ctypes as C, numpy as np, os, sys
+sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+from dynamicppr_amd import datagen, engine as eng, stream as st
+key, nsrc = os.environ["CFG"], int(os.environ["NSRC"])
+cfg = datagen.STAND_INS[key]
+wl = st.workload_config(cfg.edges, 0.1, 0, 0.01, 100)
+V, e1, e2, _ = datagen.stand_in_stream(key, "/tmp/dppr_data", limit=wl.window + 8 * wl.per_batch)
+srcs = [int(x) for x in datagen.top_sources(V, e1, e2, wl.window, cfg.directed, nsrc)]
+e = eng.Engine(V, wl.window, cfg.directed, wl.per_batch)
+ss = st.SlidingStream(V, e1, e2, cfg.directed, wl)
+e.load_window(*ss.serialize_edge_stream()); gid = e.add_source_group(srcs); e.group_init_solve(gid, 1e-9)
+L = eng.lib()
+L.dppr_debug_stamps.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+rows = 512
+for b in range(3):
+    ss.stream_updates(); e.set_batch(*ss.batch_arrays()); e.slide(*ss.new_arrays()); e.group_update(gid, 1e-9)
+buf = np.zeros(rows * 8, dtype=np.uint64)
+assert L.dppr_debug_stamps(buf.ctypes.data_as(C.POINTER(C.c_uint64)), rows) == 0
+s = buf.reshape(rows, 8).astype(np.int64)
+s = s[s[:, 0] > 0]
+print("workgroups with stamps:", len(s))
+names = ["bits/cols reload + edge phase", "barrier (all flushes in)", "vertex phase", "barrier", "act_out + count + drain stores", "arrive + wait for everybody"]
+t0 = s[:, 0].min()
+print("sweep start spread (cycles): median", int(np.median(s[:, 0] - t0)), "max", int((s[:, 0] - t0).max()))
+for i, n in enumerate(names):
+    d = s[:, i + 1] - s[:, i]
+    print(f"{n:34s} median {int(np.median(d)):7d} cyc   p90 {int(np.percentile(d, 90)):7d}   max {int(d.max()):7d}")
+tot = s[:, 6] - s[:, 0]
+print("sweep median", int(np.median(tot)), "max", int(tot.max()), "| span first start -> last end", int(s[:, 6].max() - t0))
+print(e.group_stats(gid))
+PY
