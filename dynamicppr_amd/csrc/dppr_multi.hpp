@@ -239,6 +239,8 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
     // vertices an octet finishes per step. A wait for loaded values also waits for every older store, so a second
     // step costs the store latency again: the multi-sweep form (one workgroup per CU is enough there: 128 VGPRs)
     // requests ALL its rows before any is stored; the one-sweep form has 64 VGPRs and takes steps of 4 / 2.
+    // (the one-sweep 16-wide form with 128 VGPRs and all rows at once, one workgroup per CU: 19.05 vs 18.65 ms per
+    // LiveJournal batch -- the halved occupancy costs more than the vertex phase gains)
     constexpr int FU = MULTI ? NVX / NOCT : 4 / SPL;
     static_assert(NVX % NOCT == 0 && (NVX / NOCT) % FU == 0, "vertex phase covers the group in whole steps");
     __shared__ double s_acc[NVX * GW];   // per vertex and source: sum of this sweep's adds (zero between groups)
@@ -254,6 +256,7 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
     const int j = tid & (OCT - 1), oid = tid / OCT;
 
     // frontier sizes of the sources; the group iterates while ANY of them is non-empty
+    bool stamp_dense = false; // (diagnostic builds: a one-sweep launch is stamped when its frontier is dense)
     if constexpr (!MULTI) {
         const int my_cnt = lane < GW ? cnt_in[lane] : 0;
         if (blockIdx.x == 0 && tid < GW) {
@@ -261,7 +264,11 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
             log_slot[tid] = my_cnt;
         }
         if (__ballot(my_cnt != 0) == 0) return;
+#ifdef DPPR_STAMPS
+        stamp_dense = (long long)__builtin_amdgcn_readlane(wave_inclusive_scan(my_cnt), WAVE - 1) > 4ll * V;
+#endif
     }
+    (void)stamp_dense;
     for (int k = tid; k < NVX * GW; k += GNT) s_acc[k] = 0.0;
     if (tid < WORDS) {
         s_actout[tid] = 0u;
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
                     break;
                 }
             }
-#define GSTAMP(i) do { if (MULTI && it == 12) STAMP(i); } while (0)
+#define GSTAMP(i) do { if (MULTI ? it == 12 : stamp_dense) STAMP(i); } while (0)
             GSTAMP(0);
             if (it > 0) { // (MULTI only)
                 if (tid < WORDS) s_actin[tid] = tid * 32 < nv ? gs_ldu<MULTI>(act_in + (v0 >> 5) + tid) : 0u;

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Diagnostic: stage times of ONE sweep (the 13th of a multi-sweep launch) of k_gsweep<.., true>, per workgroup.
+# Diagnostic: stage times of ONE sweep of k_gsweep per workgroup: the 13th of a multi-sweep launch on resident-size
+# windows, the last dense one-sweep launch otherwise (there the last two stages are not stamped).
 # Builds a SEPARATE library with -DDPPR_STAMPS (never the product build).
 # usage: tools/stamps_group.sh [config] [sources]
 set -e
@@ -12,15 +13,16 @@ sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
 from dynamicppr_amd import datagen, engine as eng, stream as st
 key, nsrc = os.environ["CFG"], int(os.environ["NSRC"])
 cfg = datagen.STAND_INS[key]
-wl = st.workload_config(cfg.edges, 0.1, 0, 0.01, 100)
+f = cfg.flags.split(); opt = {f[i]: f[i + 1] for i in range(0, len(f), 2)}
+wl = st.workload_config(cfg.edges, 0.1, int(opt.get("-n", 0)), float(opt.get("-r", -1.0)), int(opt.get("-b", 0)), int(opt.get("-c", 0)), int(opt.get("-l", 0)))
 V, e1, e2, _ = datagen.stand_in_stream(key, "/tmp/dppr_data", limit=wl.window + 8 * wl.per_batch)
-srcs = [int(x) for x in datagen.top_sources(V, e1, e2, wl.window, cfg.directed, nsrc)]
+srcs = [int(x) for x in (datagen.ranked_sources(V, e1, e2, wl.window, cfg.directed, 10, 1000, max(nsrc, 10))[:nsrc] if nsrc > 8 else datagen.top_sources(V, e1, e2, wl.window, cfg.directed, nsrc))]
 e = eng.Engine(V, wl.window, cfg.directed, wl.per_batch)
 ss = st.SlidingStream(V, e1, e2, cfg.directed, wl)
 e.load_window(*ss.serialize_edge_stream()); gid = e.add_source_group(srcs); e.group_init_solve(gid, 1e-9)
 L = eng.lib()
 L.dppr_debug_stamps.argtypes = [C.POINTER(C.c_uint64), C.c_int]
-rows = 512
+rows = 2048
 for b in range(3):
     ss.stream_updates(); e.set_batch(*ss.batch_arrays()); e.slide(*ss.new_arrays()); e.group_update(gid, 1e-9)
 buf = np.zeros(rows * 8, dtype=np.uint64)
@@ -32,9 +34,11 @@ names = ["bits/cols reload + edge phase", "barrier (all flushes in)", "vertex ph
 t0 = s[:, 0].min()
 print("sweep start spread (cycles): median", int(np.median(s[:, 0] - t0)), "max", int((s[:, 0] - t0).max()))
 for i, n in enumerate(names):
+    if (s[:, i + 1] <= 0).any(): break
     d = s[:, i + 1] - s[:, i]
     print(f"{n:34s} median {int(np.median(d)):7d} cyc   p90 {int(np.percentile(d, 90)):7d}   max {int(d.max()):7d}")
-tot = s[:, 6] - s[:, 0]
-print("sweep median", int(np.median(tot)), "max", int(tot.max()), "| span first start -> last end", int(s[:, 6].max() - t0))
+last = 6 if (s[:, 6] > 0).all() else 4
+tot = s[:, last] - s[:, 0]
+print("sweep (group) median", int(np.median(tot)), "max", int(tot.max()))
 print(e.group_stats(gid))
 PY
