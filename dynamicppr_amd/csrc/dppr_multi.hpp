@@ -265,10 +265,17 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
         }
         if (__ballot(my_cnt != 0) == 0) return;
 #ifdef DPPR_STAMPS
+#ifdef DPPR_STAMP_SPARSE
+        stamp_dense = (long long)__builtin_amdgcn_readlane(wave_inclusive_scan(my_cnt), WAVE - 1) * 64 < (long long)V;
+#else
         stamp_dense = (long long)__builtin_amdgcn_readlane(wave_inclusive_scan(my_cnt), WAVE - 1) > 4ll * V;
+#endif
 #endif
     }
     (void)stamp_dense;
+#ifdef DPPR_STAMPS
+    if (stamp_dense) STAMP(7);
+#endif
     for (int k = tid; k < NVX * GW; k += GNT) s_acc[k] = 0.0;
     if (tid < WORDS) {
         s_actout[tid] = 0u;

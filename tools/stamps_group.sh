@@ -6,7 +6,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -ffp-contract=off -munsafe-fp-atomics \
-   -DDPPR_STAMPS -o /tmp/libdppr_hip_stamps.so dynamicppr_amd/csrc/dppr_engine.hip
+   -DDPPR_STAMPS $DPPR_STAMP_FLAGS -o /tmp/libdppr_hip_stamps.so dynamicppr_amd/csrc/dppr_engine.hip
 DPPR_LIB=/tmp/libdppr_hip_stamps.so CFG=${1:-youtube} NSRC=${2:-8} python3 - <<'PY'
 import ctypes as C, numpy as np, os, sys
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
@@ -37,6 +37,9 @@ for i, n in enumerate(names):
     if (s[:, i + 1] <= 0).any(): break
     d = s[:, i + 1] - s[:, i]
     print(f"{n:34s} median {int(np.median(d)):7d} cyc   p90 {int(np.percentile(d, 90)):7d}   max {int(d.max()):7d}")
+if (s[:, 7] > 0).all():
+    d = s[:, 0] - s[:, 7]
+    print(f"{'kernel entry -> first sweep start':34s} median {int(np.median(d)):7d} cyc   p90 {int(np.percentile(d, 90)):7d}   max {int(d.max()):7d}  (last group of the workgroup)")
 last = 6 if (s[:, 6] > 0).all() else 4
 tot = s[:, last] - s[:, 0]
 print("sweep (group) median", int(np.median(tot)), "max", int(tot.max()))
