@@ -37,6 +37,9 @@ for i, n in enumerate(names):
     if (s[:, i + 1] <= 0).any(): break
     d = s[:, i + 1] - s[:, i]
     print(f"{n:34s} median {int(np.median(d)):7d} cyc   p90 {int(np.percentile(d, 90)):7d}   max {int(d.max()):7d}")
+if (s[:, 7] > 0).all() and len(s) > 1100:
+    d1 = (s[:, 0] - s[:, 7])[1100:]
+    print(f"{'  ... workgroups with ONE group':34s} median {int(np.median(d1)):7d} cyc   p90 {int(np.percentile(d1, 90)):7d}")
 if (s[:, 7] > 0).all():
     d = s[:, 0] - s[:, 7]
     print(f"{'kernel entry -> first sweep start':34s} median {int(np.median(d)):7d} cyc   p90 {int(np.percentile(d, 90)):7d}   max {int(d.max()):7d}  (last group of the workgroup)")
