@@ -51,6 +51,7 @@ PLANS = {
 PMC_FILES = {
     ("youtube", 1): ("profiles/r01_final_pmc_traffic_youtube.json", ("k_pull_resident",)),
     ("livejournal", 10): ("profiles/r02_pmc_traffic_livejournal_group10.json", ("k_gsweep",)),
+    ("twitter", 8): ("profiles/r02_pmc_traffic_twitter_group8.json", ("k_gsweep",)),
 }
 
 
