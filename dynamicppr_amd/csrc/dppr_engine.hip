@@ -55,6 +55,8 @@ struct Epoch {
     int *ggrp_tile = nullptr;
     int n_ggroups = 0;
     int ggrp_max_tiles = 0;
+    int *gtab = nullptr;     // row tables of those groups (k_gtables): GT_STRIDE(512 | 1024) ints per group
+    size_t gtab_cap = 0;     // ints allocated
     // hub directory of this epoch (vertices whose pushes are aggregated in LDS)
     int *hub_v = nullptr, *hub_degp1 = nullptr;
     int n_hubs = 0;
@@ -442,6 +444,24 @@ int cut_sweep_groups(dppr_engine *e, Epoch &ep) {
         if (cut.back() != n_tiles) cut.push_back(n_tiles);
         ep.n_ggroups = (int)cut.size() - 1;
         HIP_TRY(hipMemcpyAsync(ep.ggrp_tile, cut.data(), sizeof(int) * cut.size(), hipMemcpyHostToDevice, e->stream));
+        // the groups' row tables, once per epoch (every sweep of every source group of this epoch loads them)
+        const int nvx = gmax * WAVE;
+        const size_t need = (size_t)ep.n_ggroups * (size_t)GT_STRIDE(nvx);
+        if (need > ep.gtab_cap) {
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            (void)hipFree(ep.gtab);
+            ep.gtab = nullptr;
+            ep.gtab_cap = 0;
+            HIP_TRY(hipMalloc((void **)&ep.gtab, sizeof(int) * (need + need / 8 + 1024)));
+            ep.gtab_cap = need + need / 8 + 1024;
+        }
+        if (nvx == 512)
+            hipLaunchKernelGGL(k_gtables<512>, dim3(std::min(ep.n_ggroups, 1024)), dim3(GNT), 0, e->stream, NV, ep.ggrp_tile,
+                               ep.n_ggroups, ep.out_row_ptr, ep.gtab);
+        else
+            hipLaunchKernelGGL(k_gtables<1024>, dim3(std::min(ep.n_ggroups, 1024)), dim3(GNT), 0, e->stream, NV, ep.ggrp_tile,
+                               ep.n_ggroups, ep.out_row_ptr, ep.gtab);
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
     return DPPR_OK;
@@ -908,7 +928,7 @@ int pull_device_stats(dppr_engine *e, Slot &s) {
 int group_multi_capacity(dppr_engine *e, int spl) {
     int &cap = e->gmulti_cap[spl - 1];
     if (cap < 0) {
-        int per_cu = 0, cus = 0;
+        int per_cu = 0, cus = 0; // (the 8-wide form on 512-vertex groups needs no more than the 1024-vertex one)
         hipError_t rc = spl == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gsweep<1, 1024, true>, GNT, 0)
                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gsweep<2, 512, true>, GNT, 0);
         if (rc != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess)
@@ -956,6 +976,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
     bool more = any_left(e->pinned);
     int active_iters = 0;
     const int sweep_grid = std::min(std::max(ep.n_ggroups, 1), e->gsweep_grid_cap);
+    const int nvx = ep.ggrp_max_tiles * WAVE; // vertices per sweep group of this epoch's tables: 1024, or 512 once a 16-wide group exists
     for (int it = 0; more;) {
         if (it >= e->max_iters) return fail(e, DPPR_ERR_NOT_CONVERGED, "iteration cap hit");
         // ---- a window whose sweep groups are all resident at once: a run of sweeps as ONE launch (k_gsweep<.., true>)
@@ -968,16 +989,15 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
             HIP_TRY(hipMemsetAsync(e->bar, 0, sizeof(GridBar), e->stream));
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
             int *status = g.mlog, *rows = g.mlog + GWM;
-            if (g.spl == 1)
-                hipLaunchKernelGGL((k_gsweep<1, 1024, true>), dim3(ep.n_ggroups), dim3(GNT), 0, e->stream, ep.grp_n_int,
-                                   ep.ggrp_tile, ep.n_ggroups, g.cnt + cur * GWM, ep.out_row_ptr, ep.out_col, g.x, g.x2, g.act[0],
-                                   g.act[1], g.r, g.p, g.cnt + 3 * GWM, g.cnt + 4 * GWM, phase, eps, g.dstats, rows, n, e->bar,
-                                   status, e->persist_ticks, e->persist_rollcall_extra);
-            else
-                hipLaunchKernelGGL((k_gsweep<2, 512, true>), dim3(ep.n_ggroups), dim3(GNT), 0, e->stream, ep.grp_n_int,
-                                   ep.ggrp_tile, ep.n_ggroups, g.cnt + cur * GWM, ep.out_row_ptr, ep.out_col, g.x, g.x2, g.act[0],
-                                   g.act[1], g.r, g.p, g.cnt + 3 * GWM, g.cnt + 4 * GWM, phase, eps, g.dstats, rows, n, e->bar,
-                                   status, e->persist_ticks, e->persist_rollcall_extra);
+#define DPPR_LAUNCH_GMULTI(SPL, NVX)                                                                                     \
+    hipLaunchKernelGGL((k_gsweep<SPL, NVX, true>), dim3(ep.n_ggroups), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.gtab,       \
+                       ep.n_ggroups, g.cnt + cur * GWM, ep.out_row_ptr, ep.out_col, g.x, g.x2, g.act[0], g.act[1], g.r, g.p, \
+                       g.cnt + 3 * GWM, g.cnt + 4 * GWM, phase, eps, g.dstats, rows, n, e->bar, status, e->persist_ticks,    \
+                       e->persist_rollcall_extra)
+            if (g.spl == 2) DPPR_LAUNCH_GMULTI(2, 512);
+            else if (nvx == 512) DPPR_LAUNCH_GMULTI(1, 512); // (an 8-wide group on an engine that also has a 16-wide one)
+            else DPPR_LAUNCH_GMULTI(1, 1024);
+#undef DPPR_LAUNCH_GMULTI
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[1], e->stream));
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(e->pinned, g.mlog, sizeof(int) * (size_t)(n + 2) * GWM, hipMemcpyDeviceToHost, e->stream));
@@ -1023,16 +1043,15 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
         for (int k = 0; k < n; ++k) {
             const int nxt = (cur + 1) % 3, zer = (cur + 2) % 3;
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k], e->stream));
-            if (g.spl == 1)
-                hipLaunchKernelGGL((k_gsweep<1, 1024, false>), dim3(sweep_grid), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.ggrp_tile,
-                                   ep.n_ggroups, g.cnt + cur * GWM, ep.out_row_ptr, ep.out_col, g.x, g.x2, g.act[0], g.act[1],
-                                   g.r, g.p, g.cnt + nxt * GWM, g.cnt + zer * GWM, phase, eps, g.dstats, log + k * GWM, 1,
-                                   (GridBar *)nullptr, (int *)nullptr, 0ull, 0);
-            else
-                hipLaunchKernelGGL((k_gsweep<2, 512, false>), dim3(sweep_grid), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.ggrp_tile,
-                                   ep.n_ggroups, g.cnt + cur * GWM, ep.out_row_ptr, ep.out_col, g.x, g.x2, g.act[0], g.act[1],
-                                   g.r, g.p, g.cnt + nxt * GWM, g.cnt + zer * GWM, phase, eps, g.dstats, log + k * GWM, 1,
-                                   (GridBar *)nullptr, (int *)nullptr, 0ull, 0);
+#define DPPR_LAUNCH_GSWEEP(SPL, NVX)                                                                                      \
+    hipLaunchKernelGGL((k_gsweep<SPL, NVX, false>), dim3(sweep_grid), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.gtab,          \
+                       ep.n_ggroups, g.cnt + cur * GWM, ep.out_row_ptr, ep.out_col, g.x, g.x2, g.act[0], g.act[1], g.r, g.p,  \
+                       g.cnt + nxt * GWM, g.cnt + zer * GWM, phase, eps, g.dstats, log + k * GWM, 1, (GridBar *)nullptr,      \
+                       (int *)nullptr, 0ull, 0)
+            if (g.spl == 2) DPPR_LAUNCH_GSWEEP(2, 512);
+            else if (nvx == 512) DPPR_LAUNCH_GSWEEP(1, 512);
+            else DPPR_LAUNCH_GSWEEP(1, 1024);
+#undef DPPR_LAUNCH_GSWEEP
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k + 1], e->stream));
             std::swap(g.x, g.x2);
             std::swap(g.act[0], g.act[1]);
@@ -1218,7 +1237,7 @@ void dppr_destroy(dppr_engine *e) {
     }
     for (auto &ep : e->epochs) {
         (void)hipFree(ep.row_ptr); (void)hipFree(ep.adj); (void)hipFree(ep.out_row_ptr); (void)hipFree(ep.out_col); (void)hipFree(ep.b1); (void)hipFree(ep.b2);
-        (void)hipFree(ep.deg_after); (void)hipFree(ep.ins); (void)hipFree(ep.hub_v); (void)hipFree(ep.hub_degp1); (void)hipFree(ep.grp_tile); (void)hipFree(ep.ggrp_tile);
+        (void)hipFree(ep.deg_after); (void)hipFree(ep.ins); (void)hipFree(ep.hub_v); (void)hipFree(ep.hub_degp1); (void)hipFree(ep.grp_tile); (void)hipFree(ep.ggrp_tile); (void)hipFree(ep.gtab);
     }
     (void)hipFree(e->w1); (void)hipFree(e->w2); (void)hipFree(e->outdeg);
     (void)hipFree(e->bar);

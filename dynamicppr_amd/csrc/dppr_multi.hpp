@@ -176,6 +176,73 @@ __global__ __launch_bounds__(BLOCK) void k_gseed_tails(const uint32_t *__restric
     if (threadIdx.x < GW && s_cnt[threadIdx.x]) atomicAdd(&cnt_out[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
+// ---------------------------------------------------------------------------
+// Row tables of the sweep groups, built ONCE per epoch (untimed graph build) and loaded by every sweep.
+// What a workgroup of k_gsweep needs before it can walk its group's edges -- the group's extents, its
+// non-empty rows compacted (first edge + local vertex index) and, per octet, the row its slice begins in --
+// is a pure function of the epoch's graph and of the group cut. Per group, GT_STRIDE(NVX) ints:
+//   [0..7]  v0, nv, E0, Eg, per (edges per octet slice), ncomp (non-empty rows), -, -
+//   [8 ..]  cstart[NVX + 1]  (entries beyond ncomp hold Eg),  ostart[GNT / 8],  cvid[NVX] as 16-bit values
+// (k_gsweep used to rebuild this per group and per sweep: two dependent scalar loads, the row extents, a
+// ballot compaction across the workgroup, two integer divisions per row and three barriers; on the
+// LiveJournal stand-in that set-up was half of the 55-60 us a near-empty sweep costs.)
+// ---------------------------------------------------------------------------
+constexpr int GNT = 1024; // threads per workgroup of k_gsweep
+constexpr int GT_HDR = 8;
+__host__ __device__ constexpr int GT_STRIDE(int nvx) { return (GT_HDR + nvx + 1 + GNT / OCT + nvx / 2 + 3) / 4 * 4; }
+
+template <int NVX>
+__global__ __launch_bounds__(GNT) void k_gtables(int V, const int *__restrict__ grp_tile, int n_groups,
+                                                 const int *__restrict__ out_row_ptr, int *__restrict__ tables) {
+    constexpr int NW = GNT / WAVE, NOCT = GNT / OCT, EB = 8;
+    __shared__ int s_wcnt[NW];
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        __syncthreads();
+        int *T = tables + (size_t)g * GT_STRIDE(NVX);
+        const int t0 = grp_tile[g], t1 = grp_tile[g + 1];
+        const int v0 = t0 * WAVE;
+        const int nv = min((t1 - t0) * WAVE, V - v0);
+        const int E0 = out_row_ptr[v0];
+        const int Eg = out_row_ptr[v0 + nv] - E0;
+        int rs = 0, d = 0;
+        if (tid < nv) {
+            rs = out_row_ptr[v0 + tid] - E0;
+            d = out_row_ptr[v0 + tid + 1] - E0 - rs;
+        }
+        const int per = ((Eg + NOCT - 1) / NOCT + EB - 1) / EB * EB;
+        const uint64_t ne = __ballot(d > 0);
+        if (lane == 0) s_wcnt[w] = __popcll(ne);
+        __syncthreads();
+        int woff = 0, ncomp = 0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int c = s_wcnt[k];
+            woff += k < w ? c : 0;
+            ncomp += c;
+        }
+        int *cstart = T + GT_HDR, *ostart = T + GT_HDR + NVX + 1;
+        unsigned short *cvid = reinterpret_cast<unsigned short *>(T + GT_HDR + NVX + 1 + NOCT);
+        // defaults first (entries beyond ncomp, octets without a slice), the real entries after the barrier
+        if (tid <= NVX && tid >= ncomp) cstart[tid] = Eg;
+        if (tid == 0 && NVX >= GNT) cstart[NVX] = Eg; // (NVX == GNT: entry NVX has no thread of its own)
+        if (tid < NOCT) ostart[tid] = 0;
+        if (tid < NVX && tid >= ncomp) cvid[tid] = 0;
+        if (tid == 0) {
+            T[0] = v0; T[1] = nv; T[2] = E0; T[3] = Eg; T[4] = per; T[5] = ncomp; T[6] = 0; T[7] = 0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the defaults have landed before another thread overwrites one
+        __syncthreads();
+        if (d > 0) {
+            const int idx = woff + mbcnt(ne);
+            cstart[idx] = rs;
+            cvid[idx] = (unsigned short)tid;
+            const int o_first = (rs + per - 1) / per, o_last = min((rs + d + per - 1) / per - 1, NOCT - 1);
+            for (int o = o_first; o <= o_last; ++o) ostart[o] = idx; // octets whose slice begins inside this row
+        }
+    }
+}
+
 // Memory accesses of the sweep: plain in a one-sweep launch; in a multi-sweep launch everything another
 // workgroup wrote during the launch is read past the L1 (agent scope, `sc1`) and every store another
 // workgroup will read is agent-scope too (see k_pull_resident for the measured visibility rules).
@@ -224,16 +291,15 @@ constexpr int GSM_SWEEPS = (1 << 16) - 1;
 // frontier sizes of all sources are row g of `mlog` (row 0 = cnt_in): the loop ends when a row is
 // all zero. Co-residency is verified by the same roll-call as k_pull_resident's before anything is
 // changed; a failed roll-call leaves everything untouched and the host goes on with one-sweep launches.
-constexpr int GNT = 1024; // threads per workgroup of k_gsweep
 template <int SPL, int NVX, bool MULTI>
-__global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int *__restrict__ grp_tile, int n_groups,
+__global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int *__restrict__ gtab, int n_groups,
                                                    const int *cnt_in, const int *__restrict__ out_row_ptr,
                                                    const int *__restrict__ out_col, double *x_a, double *x_b,
                                                    uint32_t *act_a, uint32_t *act_b, double *r, double *p, int *cnt_out,
                                                    int *cnt_zero, int phase, double eps, IterStats *__restrict__ stats,
                                                    int *log_slot, int n_iter, GridBar *bar, int *status,
                                                    unsigned long long limit_ticks, int rollcall_extra) {
-    constexpr int GW = OCT * SPL, NW = GNT / WAVE, NOCT = GNT / OCT, WORDS = NVX / 32;
+    constexpr int GW = OCT * SPL, NOCT = GNT / OCT, WORDS = NVX / 32;
     constexpr int EB = 8;        // edges an octet tests per step (one per lane)
     constexpr int GB = EB / SPL; // ... and gathers per sub-step (registers: GB x SPL doubles)
     // vertices an octet finishes per step. A wait for loaded values also waits for every older store, so a second
@@ -248,7 +314,6 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
     __shared__ unsigned short s_cvid[NVX]; // ... and the row's local vertex index
     __shared__ int s_ostart[NOCT];       // compacted row in which each octet's slice begins
     __shared__ uint32_t s_actin[WORDS], s_actout[WORDS], s_touched[WORDS];
-    __shared__ int s_wcnt[NW];
     __shared__ int s_cnt[GS_MAX];
     __shared__ unsigned long long s_edges;
     __shared__ int s_flag[2]; // MULTI: {go on (roll-call ok / frontier not empty), fault}
@@ -339,62 +404,42 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
     // short by asking early: the next group's extents while this one is processed, the next step's bits
     // and the step after's out_col entries while this step's gathers are in flight, pagerank together
     // with the residual.
-    int nt0 = 0, nt1 = 0, nE0 = 0, nE1 = 0;
+    (void)out_row_ptr;
+    constexpr int STRIDE = GT_STRIDE(NVX);
+    // the next group's header (extents, slice length) is requested while this group is processed
+    int hv0 = 0, hnv = 0, hE0 = 0, hEg = 0, hper = 0;
     if ((int)blockIdx.x < n_groups) {
-        nt0 = grp_tile[blockIdx.x];
-        nt1 = grp_tile[blockIdx.x + 1];
-        nE0 = out_row_ptr[nt0 * WAVE];
-        nE1 = out_row_ptr[nt0 * WAVE + min((nt1 - nt0) * WAVE, V - nt0 * WAVE)];
+        const int *H = gtab + (size_t)blockIdx.x * STRIDE;
+        hv0 = H[0]; hnv = H[1]; hE0 = H[2]; hEg = H[3]; hper = H[4];
     }
     int sweeps_done = 0;
     bool converged = false, fault = false;
     for (int g = blockIdx.x; g < n_groups; g += gridDim.x) { // workgroup-uniform loop (MULTI: one group per workgroup)
         __syncthreads(); // the previous group's tables are no longer read; the initial fills are in place
-        const int t0 = nt0, t1 = nt1;
-        const int v0 = t0 * WAVE;
-        const int nv = min((t1 - t0) * WAVE, V - v0); // <= NVX: the builder cuts these groups for this kernel
-        const int E0 = nE0;
-        const int Eg = nE1 - E0;
-        if (g + (int)gridDim.x < n_groups) { // the next group's extents: two dependent scalar loads, hidden behind this group
-            nt0 = grp_tile[g + gridDim.x];
-            nt1 = grp_tile[g + gridDim.x + 1];
-            nE0 = out_row_ptr[nt0 * WAVE];
-            nE1 = out_row_ptr[nt0 * WAVE + min((nt1 - nt0) * WAVE, V - nt0 * WAVE)];
+        const int *T = gtab + (size_t)g * STRIDE;
+        const int v0 = hv0, nv = hnv, E0 = hE0, Eg = hEg, per = hper; // nv <= NVX: the builder cuts these groups for this kernel
+        if (g + (int)gridDim.x < n_groups) {
+            const int *H = gtab + (size_t)(g + gridDim.x) * STRIDE;
+            hv0 = H[0]; hnv = H[1]; hE0 = H[2]; hEg = H[3]; hper = H[4];
         }
-        int rs = 0, d = 0;
-        if (tid < nv) {
-            rs = out_row_ptr[v0 + tid] - E0;
-            d = out_row_ptr[v0 + tid + 1] - E0 - rs;
-        }
-        // slice of the group's Eg edges per octet (a multiple of EB); its first out_col entry is requested
-        // now, together with the row extents, not after the row tables are built
-        const int per = ((Eg + NOCT - 1) / NOCT + EB - 1) / EB * EB;
+        // the group's row tables (built once per epoch, k_gtables) -> LDS; the first sweep's activity words and
+        // out_col entries are requested in the same round trip
         const int e_begin = oid * per, e_end = min(Eg, e_begin + per);
         const int *cols = out_col + E0;
-        // (the first sweep's activity words and out_col entries are requested together with the row extents)
-        if (tid < WORDS) s_actin[tid] = tid * 32 < nv ? gs_ldu<MULTI>(act_a + (v0 >> 5) + tid) : 0u;
+        {
+            const int c0 = tid < NVX ? T[GT_HDR + tid] : 0;
+            const int os = tid < NOCT ? T[GT_HDR + NVX + 1 + tid] : 0;
+            const unsigned short cv = tid < NVX ? reinterpret_cast<const unsigned short *>(T + GT_HDR + NVX + 1 + NOCT)[tid] : 0;
+            if (tid < WORDS) s_actin[tid] = tid * 32 < nv ? gs_ldu<MULTI>(act_a + (v0 >> 5) + tid) : 0u;
+            if (tid < NVX) {
+                s_cstart[tid] = c0;
+                s_cvid[tid] = cv;
+            }
+            if (tid < NOCT) s_ostart[tid] = os;
+            if (tid == 0) s_cstart[NVX] = Eg; // (entry NVX is Eg whatever ncomp is: rows are never more than NVX)
+        }
         int mycol = e_begin + j < e_end ? ld_stream(&cols[e_begin + j]) : -1;
         int ncol = e_begin + EB + j < e_end ? ld_stream(&cols[e_begin + EB + j]) : -1;
-        // compact the non-empty rows
-        const uint64_t ne = __ballot(d > 0);
-        if (lane == 0) s_wcnt[w] = __popcll(ne);
-        __syncthreads();
-        int woff = 0, ncomp = 0;
-#pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            const int c = s_wcnt[k];
-            woff += k < w ? c : 0;
-            ncomp += c;
-        }
-        if (d > 0) {
-            const int idx = woff + mbcnt(ne);
-            s_cstart[idx] = rs;
-            s_cvid[idx] = (unsigned short)tid;
-            // octets whose slice begins inside this row
-            const int o_first = (rs + per - 1) / per, o_last = min((rs + d + per - 1) / per - 1, NOCT - 1);
-            for (int o = o_first; o <= o_last; ++o) s_ostart[o] = idx;
-        }
-        if (tid == 0) s_cstart[ncomp] = Eg;
 
         // ---- the sweeps over this group's tables: one (a one-sweep launch) or a run of them (MULTI)
         for (int it = 0; it < (MULTI ? n_iter : 1); ++it) {

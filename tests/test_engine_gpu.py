@@ -917,3 +917,34 @@ def test_two_engines_on_one_device_from_two_threads():
     assert not any(t.is_alive() for t in threads), "a driver thread hangs"
     assert not errors, errors
     assert sum(sc.e.stats(sc.slot)["persist_launches"] for sc in scs) > 0
+
+
+def test_narrow_and_wide_source_groups_share_an_engine():
+    """An 8-wide and a 16-wide group on ONE engine: the epochs' group tables are then cut for 512-vertex
+    groups and the 8-wide sweep runs on them too (k_gsweep<1, 512>); results per source as always."""
+    V, e1, e2 = datagen.rmat_stream(11, 30000, 13)
+    W, c, directed, eps = 6000, 60, 1, 1e-9
+    top = [int(x) for x in datagen.top_sources(V, e1, e2, W, directed, 14)]
+    narrow, wide = top[:4], top[4:]
+    e = eng.Engine(V, W, directed, c, n_epochs=4)
+    g = orc.Graph(V, e1, e2, directed, W, c)
+    states = [orc.State(V, s, eps) for s in narrow + wide]
+    e.load_window(*g.window_edges())
+    ga = e.add_source_group(narrow)
+    e.group_init_solve(ga, eps)                   # solved on 1024-vertex tables ...
+    gb = e.add_source_group(wide)                  # ... which are re-cut for 512 here
+    e.group_init_solve(gb, eps)
+    for s in states:
+        s.sync_execute(g)
+    for k in range(1, 4):
+        assert not g.stream_updates()
+        g.inc_construct(1)
+        e.set_batch(*g.batch())
+        e.slide(*g.new_stream())
+        for s in states:
+            s.sync_inc_execute(g)
+        e.group_update(ga, eps, epoch=k)
+        e.group_update(gb, eps, epoch=k)
+        for i, s in enumerate(states):
+            p, r = e.group_read(ga, i) if i < 4 else e.group_read(gb, i - 4)
+            assert np.max(np.abs(p - s.p)) < SYNC_TOL and np.max(np.abs(r - s.r)) < SYNC_TOL, (k, i)
