@@ -455,7 +455,9 @@ int cut_sweep_groups(dppr_engine *e, Epoch &ep) {
             HIP_TRY(hipMalloc((void **)&ep.gtab, sizeof(int) * (need + need / 8 + 1024)));
             ep.gtab_cap = need + need / 8 + 1024;
         }
-        if (nvx == 512)
+        if (ep.n_ggroups <= 0) {
+            // (no vertex has an id yet: nothing to sweep)
+        } else if (nvx == 512)
             hipLaunchKernelGGL(k_gtables<512>, dim3(std::min(ep.n_ggroups, 1024)), dim3(GNT), 0, e->stream, NV, ep.ggrp_tile,
                                ep.n_ggroups, ep.out_row_ptr, ep.gtab);
         else

@@ -8,8 +8,12 @@
 //
 // Per source the arithmetic is that of k_pull_iter (dppr_pull.hpp), i.e. what the pushes u -> v of
 // gpu/ExpandRev.cuh:70-73 plus the repair of :708-743 leave in residual[v]:
-//     rn = residual[v] + sum_{u in out(v), x[u] != 0} (1.0-ALPHA) * x[u] / (outdeg(v)+1);  rn -= x[v]
+//     rn = residual[v] + sum_{u in out(v), u pushed} (1.0-ALPHA) * residual[u] / (outdeg(v)+1);  rn -= (v's own push)
 // then the legal-push test and the next snapshot (x_new[v] = rn, pagerank[v] += ALPHA*rn).
+//
+// Kernels: k_ginit, k_gseed_dense / k_gseed_tails (the frontier of a loop), k_gtables (a sweep group's
+// row tables, once per epoch), k_gsweep (one sweep per launch, or -- on windows whose groups are all
+// resident -- a run of sweeps with a grid barrier in between).
 //
 // How a sweep is laid out on the machine (k_gsweep):
 //  * ACTIVITY BITMAP. bit v of `act` says "some source has x[v] != 0". It is one bit per vertex
