@@ -136,3 +136,42 @@ def test_youtube_eight_sources_as_one_group_matches_cilk_oracle():
             assert np.max(np.abs(r)) < eps
             assert np.max(np.abs(p - states[i].p)) < NORTH_STAR_TOL, (k, i)
             assert invariant_max_err_np(p, r, src_e, dst_e, V, sv) < INVARIANT_TOL
+
+
+@pytest.mark.parametrize("key,nsrc", [("twitter", 1), ("friendster", 2)])
+def test_eight_gpu_configs_at_full_size_on_one_gpu_properties(key, nsrc):
+    """BASELINE.json configs[3] / configs[4] at their real window sizes (146.8 M / 180.6 M stream edges;
+    one rank's share of the sources: one twitter source on the single-source path, two friendster
+    sources as a group). The -t 1 oracle would need minutes per batch here, so the checks are the
+    size-independent ones: the reference's residual bound (gpu/PPRRevPushGPU.cuh:141-143), the loop
+    invariant of SURVEY.md section 0 evaluated from the raw window edges, and the statistics."""
+    V, e1, e2, cfg, wl = stand_in(key, 1)
+    W, c, eps = wl.window, wl.per_batch, 1e-9
+    if nsrc == 1:
+        sources = [int(datagen.top_sources(V, e1, e2, W, cfg.directed, 10)[0])]
+    else:
+        sources = [int(x) for x in datagen.ranked_sources(V, e1, e2, W, cfg.directed, 10, 1000, 10)[:nsrc]]
+    e = eng.Engine(V, W, cfg.directed, c)
+    ss = st.SlidingStream(V, e1, e2, cfg.directed, wl)
+    e.load_window(*ss.serialize_edge_stream())
+    if nsrc == 1:
+        h = e.add_source(sources[0])
+        e.init_solve(h, eps)
+    else:
+        h = e.add_source_group(sources)
+        e.group_init_solve(h, eps)
+    for k in range(2):
+        if k:
+            assert not ss.stream_updates()
+            e.set_batch(*ss.batch_arrays())
+            e.slide(*ss.new_arrays())
+            e.update(h, eps) if nsrc == 1 else e.group_update(h, eps)
+        src_e, dst_e = window_edges(ss, cfg.directed)
+        for i, sv in enumerate(sources):
+            p, r = e.read(h) if nsrc == 1 else e.group_read(h, i)
+            assert np.max(np.abs(r)) < eps
+            assert invariant_max_err_np(p, r, src_e, dst_e, V, sv) < INVARIANT_TOL
+            assert p[sv] >= 0.15
+    stats = e.stats(h) if nsrc == 1 else e.group_stats(h)
+    assert stats["batches"] == 1 and stats["sum_E"] > len(src_e) and stats["pull_iterations"] > 0
+    e.close()
