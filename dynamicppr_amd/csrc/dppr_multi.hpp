@@ -344,6 +344,7 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
     (void)stamp_dense;
 #ifdef DPPR_STAMPS
     if (stamp_dense) STAMP(7);
+    if (!MULTI && stamp_dense && tid == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + 5] = wall_clock64(); // (100 MHz, same on every CU)
 #endif
     for (int k = tid; k < NVX * GW; k += GNT) s_acc[k] = 0.0;
     if (tid < WORDS) {
@@ -678,6 +679,9 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
         if (tid == 0 && s_edges) stats->blk_E[blockIdx.x] += s_edges;
         return;
     }
+#ifdef DPPR_STAMPS
+    if (!MULTI && stamp_dense && tid == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + 6] = wall_clock64();
+#endif
     // next frontier sizes: one fire-and-forget atomic per source and workgroup
 #pragma unroll
     for (int q = 0; q < SPL; ++q)

@@ -31,10 +31,11 @@ s = buf.reshape(rows, 8).astype(np.int64)
 s = s[s[:, 0] > 0]
 print("workgroups with stamps:", len(s))
 names = ["bits/cols reload + edge phase", "barrier (all flushes in)", "vertex phase", "barrier", "act_out + count + drain stores", "arrive + wait for everybody"]
+onesweep = e.group_stats(gid)["persist_launches"] == 0  # (then columns 5, 6 hold wall-clock entry / exit, not stages)
 t0 = s[:, 0].min()
 print("sweep start spread (cycles): median", int(np.median(s[:, 0] - t0)), "max", int((s[:, 0] - t0).max()))
 for i, n in enumerate(names):
-    if (s[:, i + 1] <= 0).any(): break
+    if (s[:, i + 1] <= 0).any() or (onesweep and i >= 4): break
     d = s[:, i + 1] - s[:, i]
     print(f"{n:34s} median {int(np.median(d)):7d} cyc   p90 {int(np.percentile(d, 90)):7d}   max {int(d.max()):7d}")
 if (s[:, 7] > 0).all() and len(s) > 1100:
@@ -43,8 +44,18 @@ if (s[:, 7] > 0).all() and len(s) > 1100:
 if (s[:, 7] > 0).all():
     d = s[:, 0] - s[:, 7]
     print(f"{'kernel entry -> first sweep start':34s} median {int(np.median(d)):7d} cyc   p90 {int(np.percentile(d, 90)):7d}   max {int(d.max()):7d}  (last group of the workgroup)")
-last = 6 if (s[:, 6] > 0).all() else 4
+last = 4 if onesweep else 6
 tot = s[:, last] - s[:, 0]
 print("sweep (group) median", int(np.median(tot)), "max", int(tot.max()))
+if onesweep and (s[:, 5] > 0).all() and (s[:, 6] > 0).all():
+    # one-sweep launch: entry / exit of every workgroup on the 100 MHz wall clock -> occupancy over the launch
+    a, b = s[:, 5], s[:, 6]
+    span = b.max() - a.min()
+    life = b - a
+    print("launch span", span / 100.0, "us; workgroup lifetime median", float(np.median(life)) / 100.0, "us; alive on average", round(float(life.sum()) / float(span), 1))
+    ts = a.min() + (np.arange(25) + 0.5) * span / 25
+    print("alive at 25 instants:", [int(((a <= t) & (b > t)).sum()) for t in ts])
+    order = np.argsort(a)
+    print("entry of workgroup #0/#511/#512/#1024/#1536/#2047 (us after first):", [float(a[order[k]] - a.min()) / 100.0 for k in (0, 511, 512, 1024, 1536, len(a) - 1)])
 print(e.group_stats(gid))
 PY
