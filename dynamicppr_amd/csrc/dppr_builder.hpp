@@ -210,4 +210,79 @@ __global__ __launch_bounds__(BLOCK) void k_bench_atomics(double *__restrict__ ta
     if (acc == 123.456) *sink = acc; // keep the returned values live
 }
 
+// ---------------------------------------------------------------------------
+// Renumbering of the internal ids (dppr_engine.hip: compact_ids / flush_moves). Internal ids are handed out on
+// first sight and a vertex keeps its id when its last edge leaves the window -- its p / r must stay readable --
+// so over a long stream the id space [0, n_int) outgrows the vertices that still have edges (stand-ins:
+// + 29 % / + 42 % after the reference's default 100 batches). When every solver state has caught up with the
+// newest epoch, a slide may renumber: vertices with an edge in the window (and the sources) keep their relative
+// order at the front, the others are PARKED at the top of the id capacity [V - n_parked, V), outside of every
+// sweep and scan, state rows included. A parked vertex that shows up in a later batch is given a fresh id and its
+// rows are moved there (the parked zone stays dense: its lowest entry fills the hole).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_mark_live(const int *__restrict__ w1, const int *__restrict__ w2, int W,
+                                                     uint8_t *__restrict__ live) {
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < W; i += gridDim.x * BLOCK) {
+        live[w1[i]] = 1;
+        live[w2[i]] = 1;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_remap_ids(int *__restrict__ a, int n, const int *__restrict__ perm) {
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) a[i] = perm[a[i]];
+}
+
+// dst[perm[v]] = src[v] for every old position v that holds a vertex (perm >= 0); rows of w elements; dst is zero
+// wherever no vertex lands (fresh ids find zero rows)
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_permute_rows(T *__restrict__ dst, const T *__restrict__ src,
+                                                        const int *__restrict__ perm, int V, int w) {
+    const int64_t n = (int64_t)V * w;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const int v = (int)(i / w), k = (int)(i % w);
+        const int m = perm[v];
+        if (m >= 0) dst[(int64_t)m * w + k] = src[i];
+    }
+}
+
+// row moves of a revival, in two steps so that a position may be source and destination at once:
+// tmp[i] = a[src[i]];  then  a[dst[i]] = tmp[i]  (dst < 0: the row is only vacated);  then the vacated rows are zeroed
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_rows_gather(T *__restrict__ tmp, const T *__restrict__ a,
+                                                       const int *__restrict__ src, int n, int w) {
+    const int64_t tot = (int64_t)n * w;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < tot; i += (int64_t)gridDim.x * BLOCK)
+        tmp[i] = a[(int64_t)src[i / w] * w + i % w];
+}
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_rows_scatter(T *__restrict__ a, const T *__restrict__ tmp,
+                                                        const int *__restrict__ dst, int n, int w) {
+    const int64_t tot = (int64_t)n * w;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < tot; i += (int64_t)gridDim.x * BLOCK)
+        a[(int64_t)dst[i / w] * w + i % w] = tmp[i];
+}
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_rows_zero(T *__restrict__ a, const int *__restrict__ pos, int n, int w) {
+    const int64_t tot = (int64_t)n * w;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < tot; i += (int64_t)gridDim.x * BLOCK)
+        a[(int64_t)pos[i / w] * w + i % w] = T(0);
+}
+
+// A parked vertex has no edge: a push from it (gpu/ExpandRev.cuh:34-77 with an empty neighbour list, then
+// RepairFrontierRev) is pagerank += ALPHA * residual, residual = 0. Parked rows satisfy |residual| <= the eps they
+// were parked under; a solve with a SMALLER eps settles them here first. n = rows x lanes; counts what it pushed.
+__global__ __launch_bounds__(BLOCK) void k_settle_parked(double *__restrict__ p, double *__restrict__ r, int64_t n,
+                                                         double eps, int *__restrict__ cnt) {
+    int hits = 0;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const double rv = r[i];
+        if (rv > eps || rv < -eps) {
+            p[i] = p[i] + ALPHA * rv;
+            r[i] = 0.0;
+            ++hits;
+        }
+    }
+    if (hits) atomicAdd(cnt, hits);
+}
+
 } // namespace dppr

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -82,6 +83,7 @@ struct Slot {
     IterStats *dstats = nullptr;
     bool converged = false; // |r| <= eps everywhere (state after a completed solve)
     double conv_eps = 0.0;
+    double park_eps = 0.0;  // parked rows satisfy |r| <= park_eps (0: they are exactly zero)
     int last_epoch = -2;    // epoch whose batch was applied last (-2: unknown, e.g. after dppr_write: anything goes)
     bool seed_lists_valid = false; // ft[0]/cnt[0] and neg/cnt[3] hold the lists of the last dppr_incremental_batch_update
     bool phase0_done = false; // ExecuteMainLoop(0) completed since the last modification
@@ -109,6 +111,7 @@ struct Group {
     int iter_hint[2] = {0, 0};
     bool converged = false;    // |r| <= conv_eps for every source (state after a completed solve)
     double conv_eps = 0.0;
+    double park_eps = 0.0;     // parked rows satisfy |r| <= park_eps
     int last_epoch = -2;       // epoch whose batch was applied last (-2: unknown)
 };
 
@@ -186,8 +189,23 @@ struct dppr_engine {
     std::vector<Group> groups;
     int *pinned = nullptr; // host-pinned readback words
     // vertex compaction: external id <-> internal id (assigned on first appearance)
-    std::vector<int32_t> ext2int, int2ext;
+    std::vector<int32_t> ext2int, int2ext; // both V long; int2ext[i] = -1: position i holds no vertex
     int n_int = 0;
+    // renumbering (dppr_builder.hpp): ids [0, n_int) are swept and scanned, [V - n_parked, V) hold the state rows of
+    // vertices without an edge in the window
+    int n_parked = 0;
+    bool renumber = true;          // dppr_set_renumbering
+    int renumber_growth_pct = 25;  // a slide considers it once n_int has grown by this much since the last numbering ...
+    int renumber_min_parked = 1024; // ... and does it if at least this many ids (and 1/8 of the live ones) would be parked
+    int renumber_next = 0;         // n_int at which the next slide looks at the live count
+    int renumberings = 0;
+    long long revivals = 0;
+    std::vector<int32_t> mv_src, mv_dst, mv_zero; // pending row moves of revived vertices (flush_moves)
+    std::unordered_map<int32_t, int32_t> mv_origin; // position -> position whose rows it will receive (-1: zero rows)
+    int *mv_idx = nullptr;         // device: src | dst | zero lists
+    size_t mv_idx_cap = 0;
+    double *mv_tmp = nullptr;      // device: the rows in flight
+    size_t mv_tmp_cap = 0;
     int *d_ext2int = nullptr;  // device copy of ext2int, refreshed on demand
     bool map_dirty = true;
     double *d_xfer = nullptr;  // V doubles: staging of p / r in external order
@@ -222,14 +240,44 @@ int fail(dppr_engine *e, int code, const char *msg) {
     return code;
 }
 
+// A parked vertex is needed again: fresh id at the end of the live zone, its rows follow (flush_moves), the lowest
+// parked entry fills the hole so that the parked zone stays [V - n_parked, V) without gaps. Only the host maps
+// change here; mv_origin composes the moves (a position may receive rows and give its own away in one slide).
+void revive(dppr_engine *e, int ext) {
+    const int q = e->ext2int[(size_t)ext];
+    const int lo = e->V - e->n_parked;
+    auto origin = [&](int pos) {
+        auto it = e->mv_origin.find(pos);
+        return it == e->mv_origin.end() ? pos : it->second;
+    };
+    const int fresh = e->n_int++; // < lo: n_int + n_parked never exceeds the vertices that have an id
+    const int oq = origin(q), olo = origin(lo);
+    e->mv_origin[fresh] = oq;
+    e->ext2int[(size_t)ext] = fresh;
+    e->int2ext[(size_t)fresh] = ext;
+    if (q != lo) {
+        const int y = e->int2ext[(size_t)lo];
+        e->mv_origin[q] = olo;
+        e->ext2int[(size_t)y] = q;
+        e->int2ext[(size_t)q] = y;
+    }
+    e->mv_origin[lo] = -1; // vacated: zero rows (the live zone grows into it)
+    e->int2ext[(size_t)lo] = -1;
+    e->n_parked--;
+    e->revivals++;
+    e->map_dirty = true;
+}
+
 inline int to_int(dppr_engine *e, int ext) { // external -> internal id, assigning a new one on first sight
     int32_t &m = e->ext2int[(size_t)ext];
     if (m < 0) {
         m = e->n_int++;
-        e->int2ext.push_back(ext);
+        e->int2ext[(size_t)m] = ext;
         e->map_dirty = true;
+    } else if (m >= e->V - e->n_parked) {
+        revive(e, ext);
     }
-    return m;
+    return e->ext2int[(size_t)ext];
 }
 
 // translate an id array; returns false if any id is outside [0, V)
@@ -262,6 +310,219 @@ int sync_map(dppr_engine *e) {
     HIP_TRY(hipMemcpyAsync(e->d_ext2int, e->ext2int.data(), sizeof(int) * (size_t)e->V, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->map_dirty = false;
+    return DPPR_OK;
+}
+
+// Apply the row moves that revivals queued (to_int): every solver state's p / r rows, in one gather + scatter + zero
+// per array. States that lag behind the newest epoch may be moved too: a parked row is not touched by any epoch,
+// and the fresh id lies beyond the ids every older epoch sweeps.
+int flush_moves(dppr_engine *e) {
+    if (e->mv_origin.empty()) return DPPR_OK;
+    e->mv_src.clear();
+    e->mv_dst.clear();
+    e->mv_zero.clear();
+    for (const auto &kv : e->mv_origin) {
+        if (kv.second < 0) e->mv_zero.push_back(kv.first);
+        else if (kv.second != kv.first) {
+            e->mv_src.push_back(kv.second);
+            e->mv_dst.push_back(kv.first);
+        }
+    }
+    e->mv_origin.clear();
+    const int n = (int)e->mv_src.size(), nz = (int)e->mv_zero.size();
+    if (e->slots.empty() && e->groups.empty()) return DPPR_OK;
+    const size_t need_idx = (size_t)2 * n + nz + 1;
+    if (need_idx > e->mv_idx_cap) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        (void)hipFree(e->mv_idx);
+        e->mv_idx = nullptr;
+        e->mv_idx_cap = 0;
+        HIP_TRY(hipMalloc((void **)&e->mv_idx, sizeof(int) * (need_idx * 2 + 1024)));
+        e->mv_idx_cap = need_idx * 2 + 1024;
+    }
+    const size_t need_tmp = (size_t)std::max(n, 1) * GS_MAX;
+    if (need_tmp > e->mv_tmp_cap) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        (void)hipFree(e->mv_tmp);
+        e->mv_tmp = nullptr;
+        e->mv_tmp_cap = 0;
+        HIP_TRY(hipMalloc((void **)&e->mv_tmp, sizeof(double) * (need_tmp * 2 + 4096)));
+        e->mv_tmp_cap = need_tmp * 2 + 4096;
+    }
+    int *d_src = e->mv_idx, *d_dst = e->mv_idx + n, *d_zero = e->mv_idx + 2 * n;
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(d_src, e->mv_src.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(d_dst, e->mv_dst.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+    }
+    if (nz > 0) HIP_TRY(hipMemcpyAsync(d_zero, e->mv_zero.data(), sizeof(int) * (size_t)nz, hipMemcpyHostToDevice, e->stream));
+    auto move = [&](double *a, int w) -> int {
+        if (n > 0) {
+            hipLaunchKernelGGL(k_rows_gather<double>, dim3(grid_for((int64_t)n * w)), dim3(BLOCK), 0, e->stream, e->mv_tmp, a, d_src, n, w);
+            hipLaunchKernelGGL(k_rows_scatter<double>, dim3(grid_for((int64_t)n * w)), dim3(BLOCK), 0, e->stream, a, e->mv_tmp, d_dst, n, w);
+        }
+        if (nz > 0)
+            hipLaunchKernelGGL(k_rows_zero<double>, dim3(grid_for((int64_t)nz * w)), dim3(BLOCK), 0, e->stream, a, d_zero, nz, w);
+        HIP_TRY(hipGetLastError());
+        return DPPR_OK;
+    };
+    for (auto &s : e->slots) {
+        if (int rc = move(s.p, 1)) return rc;
+        if (int rc = move(s.r, 1)) return rc;
+    }
+    for (auto &g : e->groups) {
+        if (int rc = move(g.p, g.gw)) return rc;
+        if (int rc = move(g.r, g.gw)) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream)); // the host index vectors are reused
+    return DPPR_OK;
+}
+
+// Parked rows were inert under the eps they were parked with; a solve with a smaller one pushes them first.
+int settle_parked(dppr_engine *e, double *p, double *r, int w, double eps, double *park_eps, dppr_stats_t *st) {
+    if (e->n_parked == 0 || !(eps < *park_eps)) return DPPR_OK;
+    const size_t base = (size_t)(e->V - e->n_parked) * (size_t)w;
+    const int64_t n = (int64_t)e->n_parked * w;
+    int *cnt = e->hub_hist + 41; // scratch word
+    HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int), e->stream));
+    hipLaunchKernelGGL(k_settle_parked, dim3(grid_for(n)), dim3(BLOCK), 0, e->stream, p + base, r + base, n, eps, cnt);
+    HIP_TRY(hipGetLastError());
+    int pushed = 0;
+    HIP_TRY(hipMemcpyAsync(&pushed, cnt, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (st) st->sum_F += pushed;
+    *park_eps = eps;
+    return DPPR_OK;
+}
+
+// Renumber the internal ids (dppr_builder.hpp has the why). Called by dppr_slide before anything of the new batch is
+// looked at; does nothing unless every solver state is converged on the newest epoch (older epochs and their CSRs
+// are in the old numbering: nothing may still need them) and enough ids would be parked. On success every epoch is
+// invalidated, the ring, the out-degrees, the id maps, the staged batch and every state row are in the new
+// numbering, and *did tells the caller to sort the whole window for the epoch it is about to build.
+int compact_ids(dppr_engine *e, bool *did) {
+    *did = false;
+    if (!e->renumber || e->W == 0 || e->n_int < e->renumber_next) return DPPR_OK;
+    if (e->slots.empty() && e->groups.empty()) return DPPR_OK;
+    for (const auto &s : e->slots)
+        if (!s.converged || s.last_epoch != e->newest) return DPPR_OK;
+    for (const auto &g : e->groups)
+        if (!g.converged || g.last_epoch != e->newest) return DPPR_OK;
+    if (int rc = flush_moves(e)) return rc;
+    const int V = e->V, n_old = e->n_int, R_old = e->n_parked;
+    // which ids have an edge in the window
+    uint8_t *d_live = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_live, (size_t)std::max(n_old, 1)));
+    HIP_TRY(hipMemsetAsync(d_live, 0, (size_t)std::max(n_old, 1), e->stream));
+    hipLaunchKernelGGL(k_mark_live, dim3(grid_for(e->W)), dim3(BLOCK), 0, e->stream, e->w1, e->w2, e->W, d_live);
+    std::vector<uint8_t> live((size_t)std::max(n_old, 1));
+    hipError_t herr = hipMemcpyAsync(live.data(), d_live, (size_t)n_old, hipMemcpyDeviceToHost, e->stream);
+    if (herr == hipSuccess) herr = hipStreamSynchronize(e->stream);
+    (void)hipFree(d_live);
+    HIP_TRY(herr);
+    if (e->batch_staged) { // the staged records are in internal ids already: their vertices stay where they are
+        for (int v : e->st_b1) live[(size_t)v] = 1;
+        for (int v : e->st_b2) live[(size_t)v] = 1;
+    }
+    for (const auto &s : e->slots) live[(size_t)s.source] = 1;
+    for (const auto &g : e->groups)
+        for (int k = 0; k < g.n; ++k) live[(size_t)g.src.s[k]] = 1;
+    int n_live = 0;
+    for (int v = 0; v < n_old; ++v) n_live += live[(size_t)v];
+    const int to_park = n_old - n_live;
+    if (to_park < e->renumber_min_parked || to_park < n_live / 8) {
+        e->renumber_next = n_old + std::max(n_old / 8, 1); // look again after some more growth
+        return DPPR_OK;
+    }
+    // old position -> new position
+    std::vector<int32_t> perm((size_t)V, -1), new_i2e((size_t)V, -1);
+    const int R_new = R_old + to_park, base = V - R_new;
+    int nl = 0, np = 0;
+    for (int v = 0; v < n_old; ++v) perm[(size_t)v] = live[(size_t)v] ? nl++ : base + np++;
+    for (int v = V - R_old; v < V; ++v) perm[(size_t)v] = base + np++;
+    for (int v = 0; v < V; ++v) {
+        const int m = perm[(size_t)v];
+        if (m < 0) continue;
+        const int ext = e->int2ext[(size_t)v];
+        new_i2e[(size_t)m] = ext;
+        e->ext2int[(size_t)ext] = m;
+    }
+    e->int2ext.swap(new_i2e);
+    e->n_int = n_live;
+    e->n_parked = R_new;
+    e->map_dirty = true;
+    // device side
+    int *d_perm = nullptr;
+    double *tmp = nullptr;
+    int maxw = 1;
+    for (const auto &g : e->groups) maxw = std::max(maxw, g.gw);
+    HIP_TRY(hipMalloc((void **)&d_perm, sizeof(int) * (size_t)V));
+    if (hipMalloc((void **)&tmp, sizeof(double) * (size_t)V * (size_t)maxw) != hipSuccess) {
+        (void)hipFree(d_perm);
+        return fail(e, DPPR_ERR_NOMEM, "renumbering: no memory for the row scratch");
+    }
+    auto cleanup = [&]() {
+        (void)hipFree(d_perm);
+        (void)hipFree(tmp);
+    };
+#define RN_TRY(call)                                                     \
+    do {                                                                 \
+        hipError_t _e = (call);                                          \
+        if (_e != hipSuccess) {                                          \
+            cleanup();                                                   \
+            e->err = std::string("renumbering: ") + hipGetErrorString(_e); \
+            return DPPR_ERR_HIP;                                         \
+        }                                                                \
+    } while (0)
+    RN_TRY(hipMemcpyAsync(d_perm, perm.data(), sizeof(int) * (size_t)V, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_remap_ids, dim3(grid_for(e->W)), dim3(BLOCK), 0, e->stream, e->w1, e->W, d_perm);
+    hipLaunchKernelGGL(k_remap_ids, dim3(grid_for(e->W)), dim3(BLOCK), 0, e->stream, e->w2, e->W, d_perm);
+    { // out-degrees (ints) through the row scratch
+        int *itmp = reinterpret_cast<int *>(tmp);
+        RN_TRY(hipMemsetAsync(itmp, 0, sizeof(int) * (size_t)V, e->stream));
+        hipLaunchKernelGGL(k_permute_rows<int>, dim3(grid_for(V)), dim3(BLOCK), 0, e->stream, itmp, e->outdeg, d_perm, V, 1);
+        RN_TRY(hipMemcpyAsync(e->outdeg, itmp, sizeof(int) * (size_t)V, hipMemcpyDeviceToDevice, e->stream));
+    }
+    auto permute = [&](double *&a, int w) -> hipError_t { // a's rows in the new order; the old array becomes the scratch
+        hipError_t r = hipMemsetAsync(tmp, 0, sizeof(double) * (size_t)V * (size_t)w, e->stream);
+        if (r != hipSuccess) return r;
+        hipLaunchKernelGGL(k_permute_rows<double>, dim3(grid_for((int64_t)V * w)), dim3(BLOCK), 0, e->stream, tmp, a, d_perm, V, w);
+        r = hipMemcpyAsync(a, tmp, sizeof(double) * (size_t)V * (size_t)w, hipMemcpyDeviceToDevice, e->stream);
+        return r != hipSuccess ? r : hipGetLastError();
+    };
+    for (auto &s : e->slots) {
+        RN_TRY(permute(s.p, 1));
+        RN_TRY(permute(s.r, 1));
+        // between two loops the snapshot vectors are all zero and the lists empty: nothing to carry over
+        RN_TRY(hipMemsetAsync(s.x, 0, sizeof(double) * (size_t)V, e->stream));
+        RN_TRY(hipMemsetAsync(s.x2, 0, sizeof(double) * (size_t)V, e->stream));
+        RN_TRY(hipMemsetAsync(s.x3, 0, sizeof(double) * (size_t)V, e->stream));
+        RN_TRY(hipMemsetAsync(s.act[0], 0, s.act_bytes, e->stream));
+        RN_TRY(hipMemsetAsync(s.act[1], 0, s.act_bytes, e->stream));
+        s.source = perm[(size_t)s.source];
+        s.seed_lists_valid = false;
+        s.phase0_done = false;
+        s.park_eps = std::max(s.park_eps, s.conv_eps);
+    }
+    for (auto &g : e->groups) {
+        RN_TRY(permute(g.p, g.gw));
+        RN_TRY(permute(g.r, g.gw));
+        // (snapshot rows mean something only where an activity bit is set, and between loops none is)
+        RN_TRY(hipMemsetAsync(g.act[0], 0, g.act_bytes, e->stream));
+        RN_TRY(hipMemsetAsync(g.act[1], 0, g.act_bytes, e->stream));
+        for (int k = 0; k < g.n; ++k) g.src.s[k] = perm[(size_t)g.src.s[k]];
+        g.park_eps = std::max(g.park_eps, g.conv_eps);
+    }
+    RN_TRY(hipStreamSynchronize(e->stream));
+#undef RN_TRY
+    cleanup();
+    if (e->batch_staged) {
+        for (auto &v : e->st_b1) v = perm[(size_t)v];
+        for (auto &v : e->st_b2) v = perm[(size_t)v];
+    }
+    for (auto &ep : e->epochs) ep.id = -1; // CSRs, group tables and batch records of the old numbering
+    e->renumber_next = n_live + std::max(n_live * e->renumber_growth_pct / 100, 1);
+    e->renumberings++;
+    *did = true;
     return DPPR_OK;
 }
 
@@ -1143,6 +1404,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     if (const char *v = getenv("DPPR_SWEEP_BITS")) e->sweep_bits = atoi(v) != 0; // diagnostic A/B switches
     if (const char *v = getenv("DPPR_HOT_BLOCKS")) e->hot_blocks = atoi(v) != 0;
     if (const char *v = getenv("DPPR_GSWEEP_GRID")) e->gsweep_grid_cap = std::max(1, std::min(atoi(v), STAT_SLOTS));
+    if (const char *v = getenv("DPPR_RENUMBER")) e->renumber = atoi(v) != 0;
     if (const char *v = getenv("DPPR_GGROUPS_MIN")) e->ggroups_min = std::max(1, atoi(v));
     e->device = device;
     e->V = V;
@@ -1170,7 +1432,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     HIP_TRY_C(hipMalloc((void **)&e->d_ext2int, sizeof(int) * (size_t)V));
     HIP_TRY_C(hipMalloc((void **)&e->d_xfer, sizeof(double) * (size_t)V));
     e->ext2int.assign((size_t)V, -1);
-    e->int2ext.reserve(1024);
+    e->int2ext.assign((size_t)V, -1);
     HIP_TRY_C(hipMalloc((void **)&e->hub_hist, sizeof(int) * 64));
     HIP_TRY_C(hipMalloc((void **)&e->bar, sizeof(GridBar)));
     HIP_TRY_C(hipMalloc((void **)&e->keys_a, sizeof(uint64_t) * Edn));
@@ -1244,6 +1506,7 @@ void dppr_destroy(dppr_engine *e) {
     (void)hipFree(e->w1); (void)hipFree(e->w2); (void)hipFree(e->outdeg);
     (void)hipFree(e->bar);
     (void)hipFree(e->hub_slot_of); (void)hipFree(e->hub_hist); (void)hipFree(e->d_ext2int); (void)hipFree(e->d_xfer);
+    (void)hipFree(e->mv_idx); (void)hipFree(e->mv_tmp);
     (void)hipFree(e->keys_a); (void)hipFree(e->keys_b); (void)hipFree(e->sort_tmp);
     (void)hipFree(e->in_sorted); (void)hipFree(e->out_sorted); (void)hipFree(e->keep); (void)hipFree(e->inc_tmp);
     for (int k = 0; k < 4; ++k) { (void)hipFree(e->bk[k]); (void)hipFree(e->bks[k]); }
@@ -1312,6 +1575,24 @@ int dppr_set_group_resident(dppr_engine *e, int on) {
 int dppr_set_group_seeding(dppr_engine *e, int from_tails) {
     if (!e) return DPPR_ERR_INVALID;
     e->group_tail_seeding = from_tails != 0;
+    return DPPR_OK;
+}
+
+int dppr_set_renumbering(dppr_engine *e, int on, int growth_pct, int min_parked) {
+    if (!e || growth_pct < 0 || min_parked < 0) return fail(e, DPPR_ERR_INVALID, "set_renumbering: bad argument");
+    e->renumber = on != 0;
+    if (growth_pct > 0) e->renumber_growth_pct = growth_pct;
+    if (min_parked > 0) e->renumber_min_parked = min_parked;
+    e->renumber_next = std::min(e->renumber_next, e->n_int + std::max(e->n_int * e->renumber_growth_pct / 100, 1));
+    return DPPR_OK;
+}
+
+int dppr_id_space(dppr_engine *e, int32_t *n_ids, int32_t *n_parked, int32_t *renumberings, int64_t *revivals) {
+    if (!e) return DPPR_ERR_INVALID;
+    if (n_ids) *n_ids = e->n_int;
+    if (n_parked) *n_parked = e->n_parked;
+    if (renumberings) *renumberings = e->renumberings;
+    if (revivals) *revivals = e->revivals;
     return DPPR_OK;
 }
 
@@ -1417,6 +1698,7 @@ int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32
     if (rc) return rc;
     ep.id = 0;
     e->newest = 0;
+    e->renumber_next = e->n_int + std::max(e->n_int * e->renumber_growth_pct / 100, 1);
     e->loaded = true;
     e->batch_staged = false;
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1432,7 +1714,8 @@ int dppr_set_batch(dppr_engine *e, const int32_t *b1, const int32_t *b2, const u
     e->st_b2.resize((size_t)L);
     e->st_ins.assign(ins, ins + L);
     e->batch_staged = true;
-    return DPPR_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    return flush_moves(e); // (a record may have named a parked vertex)
 }
 
 int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, int32_t *out_epoch) {
@@ -1442,13 +1725,16 @@ int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, 
         return fail(e, DPPR_ERR_INVALID, "slide: window not loaded, or c exceeds the window / max_batch of dppr_create");
     HIP_TRY(hipSetDevice(e->device));
     const int W = e->W;
+    bool renumbered = false;
+    if (int rc = compact_ids(e, &renumbered)) return rc;
     if (!translate(e, n1, c, e->h_tmp1) || !translate(e, n2, c, e->h_tmp2))
         return fail(e, DPPR_ERR_INVALID, "slide: vertex id out of range");
+    if (int rc = flush_moves(e)) return rc;
     n1 = e->h_tmp1.data();
     n2 = e->h_tmp2.data();
     // the c oldest edges sit at ring positions head .. head+c (mod W): retire their degrees (and
     // note their keys), overwrite them with the new edges, add the new degrees (and note those keys)
-    const bool inc = e->incremental && c > 0 && 2 * c <= e->Ed;
+    const bool inc = e->incremental && c > 0 && 2 * c <= e->Ed && !renumbered; // (renumbered: the sorted keys are stale)
     const int per = e->directed ? 1 : 2; // keys per stream edge in the in-orientation array
     int done = 0;
     while (done < c) {
@@ -1512,6 +1798,7 @@ int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
     s.source_ext = source;
     s.source = to_int(e, source);
     source = s.source;
+    if (int rc = flush_moves(e)) return rc;
     const size_t V = (size_t)e->V;
     HIP_TRY(hipMalloc((void **)&s.p, sizeof(double) * V));
     HIP_TRY(hipMalloc((void **)&s.r, sizeof(double) * V));
@@ -1562,6 +1849,7 @@ int dppr_init_solve(dppr_engine *e, int32_t slot, double eps, float *out_ms) {
     hipLaunchKernelGGL(k_init, dim3(grid_for(e->V)), dim3(BLOCK), 0, e->stream, s.p, s.r, e->V, s.source);
     HIP_TRY(hipGetLastError());
     s.converged = false;
+    s.park_eps = 0.0; // (parked rows are zero again)
     int rc = main_loop_inspect(e, s, ep, 0, eps);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
@@ -1597,7 +1885,9 @@ int dppr_execute_main_loop(dppr_engine *e, int32_t slot, int32_t epoch, int phas
     GET_EPOCH(e, epoch);
     if ((phase != 0 && phase != 1) || !(eps > 0)) return fail(e, DPPR_ERR_INVALID, "phase must be 0/1, eps > 0");
     HIP_TRY(hipSetDevice(e->device));
-    int rc = main_loop_inspect(e, s, ep, phase, eps);
+    int rc = settle_parked(e, s.p, s.r, 1, eps, &s.park_eps, &s.st);
+    if (rc) return rc;
+    rc = main_loop_inspect(e, s, ep, phase, eps);
     if (rc) return rc;
     if (phase == 0) {
         s.phase0_done = true;
@@ -1622,8 +1912,10 @@ int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *
     // (the state a completed solve leaves). Otherwise fall back to full Inspect passes.
     const bool seeded = s.converged && s.conv_eps <= eps;
     const bool ahead = seeded && can_batch_ahead(e, s, ep);
+    int rc = settle_parked(e, s.p, s.r, 1, eps, &s.park_eps, &s.st);
+    if (rc) return rc;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    int rc = stream_update(e, s, ep, eps, seeded, ahead);
+    rc = stream_update(e, s, ep, eps, seeded, ahead);
     if (rc) return rc;
     s.converged = false;
     if (seeded) {
@@ -1690,7 +1982,9 @@ int dppr_write(dppr_engine *e, int32_t slot, const double *p, const double *r) {
     // vertices that carry a value get an internal id first
     for (int v = 0; v < e->V; ++v)
         if ((p && p[v] != 0.0) || (r && r[v] != 0.0)) (void)to_int(e, v);
-    int rc = sync_map(e);
+    int rc = flush_moves(e);
+    if (rc) return rc;
+    rc = sync_map(e);
     if (rc) return rc;
     rc = recut_stale_groups(e);
     if (rc) return rc;
@@ -1706,6 +2000,7 @@ int dppr_write(dppr_engine *e, int32_t slot, const double *p, const double *r) {
     }
     s.converged = false;
     s.phase0_done = false;
+    if (r) s.park_eps = 0.0; // (every vertex that carries a value has a live id now; parked rows were written as zeros)
     s.last_epoch = -2; // the caller supplied the state: which batches it contains is the caller's business
     s.seed_lists_valid = false;
     return DPPR_OK;
@@ -1768,6 +2063,22 @@ int dppr_inspect(dppr_engine *e, int32_t slot, int phase, double eps, int32_t *o
     if (n > 0) {
         HIP_TRY(hipMemcpyAsync(out_ids, s.ft[1], sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    if (e->n_parked > 0 && eps < s.park_eps) { // parked rows are inert down to park_eps only
+        const int base = e->V - e->n_parked;
+        int m = 0;
+        HIP_TRY(hipMemsetAsync(s.cnt + 4, 0, sizeof(int), e->stream));
+        hipLaunchKernelGGL(k_inspect, dim3(grid_for(e->n_parked, BLOCK * INSPECT_ITEMS)), dim3(BLOCK), 0, e->stream, s.r + base,
+                           e->n_parked, phase, eps, s.ft[1], s.cnt + 4);
+        HIP_TRY(hipGetLastError());
+        rc = read_count(e, s.cnt + 4, &m);
+        if (rc) return rc;
+        if (m > 0) {
+            HIP_TRY(hipMemcpyAsync(out_ids + n, s.ft[1], sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            for (int i = n; i < n + m; ++i) out_ids[i] += base;
+        }
+        n += m;
     }
     for (int i = 0; i < n; ++i) out_ids[i] = e->int2ext[(size_t)out_ids[i]];
     *out_count = n;
@@ -1871,8 +2182,10 @@ int dppr_add_source_group(dppr_engine *e, const int32_t *sources, int32_t n, int
     for (int s = 0; s < n; ++s) {
         if (sources[s] < 0 || sources[s] >= e->V) return fail(e, DPPR_ERR_INVALID, "add_source_group: vertex out of range");
         g.src_ext[s] = sources[s];
-        g.src.s[s] = to_int(e, sources[s]);
     }
+    for (int s = 0; s < n; ++s) (void)to_int(e, sources[s]);
+    for (int s = 0; s < n; ++s) g.src.s[s] = e->ext2int[(size_t)sources[s]]; // (after ALL revivals: one may move another)
+    if (int rc = flush_moves(e)) return rc;
     const size_t V = (size_t)e->V, row = sizeof(double) * (size_t)g.gw;
     g.act_bytes = (V / 32 + 1024 / 32 + 4) * sizeof(uint32_t);
     HIP_TRY(hipMalloc((void **)&g.p, row * V));
@@ -1906,6 +2219,7 @@ int dppr_group_init_solve(dppr_engine *e, int32_t group, double eps, float *out_
     hipLaunchKernelGGL(k_ginit, dim3(grid_for((int64_t)e->V * g.gw)), dim3(BLOCK), 0, e->stream, g.p, g.r, e->V, g.gw, g.src);
     HIP_TRY(hipGetLastError());
     g.converged = false;
+    g.park_eps = 0.0;
     int rc = group_loop(e, g, ep, 0, eps, false);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
@@ -1927,8 +2241,10 @@ int dppr_group_update(dppr_engine *e, int32_t group, int32_t epoch, double eps, 
     HIP_TRY(hipSetDevice(e->device));
     // seeding from the batch tails is exact only if every |r| <= eps beforehand (dppr_update has the same rule)
     const bool tails = g.converged && g.conv_eps <= eps && e->group_tail_seeding;
+    int rc = settle_parked(e, g.p, g.r, g.gw, eps, &g.park_eps, &g.st);
+    if (rc) return rc;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    int rc = group_stream_update(e, g, ep);
+    rc = group_stream_update(e, g, ep);
     if (rc) return rc;
     g.converged = false;
     rc = group_loop(e, g, ep, 0, eps, tails);

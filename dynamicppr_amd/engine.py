@@ -55,6 +55,7 @@ EXPORTS = [
     "dppr_trace_get", "dppr_synchronize", "dppr_bench_atomics",
     "dppr_add_source_group", "dppr_group_init_solve", "dppr_group_update", "dppr_group_read", "dppr_group_stats",
     "dppr_group_reset_stats", "dppr_set_group_seeding", "dppr_seed_lists", "dppr_set_sweep_bitmap", "dppr_set_group_resident",
+    "dppr_set_renumbering", "dppr_id_space",
 ]
 
 
@@ -80,6 +81,8 @@ def lib():
     L.dppr_set_schedule.argtypes = [vp, C.c_int]
     L.dppr_set_profiling.argtypes = [vp, C.c_int]
     L.dppr_set_incremental_graph.argtypes = [vp, C.c_int]
+    L.dppr_set_renumbering.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.dppr_id_space.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     L.dppr_set_tuning.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.dppr_set_persistent.argtypes = [vp, C.c_int, C.c_int64]
     L.dppr_load_window.argtypes = [vp, ip, ip, C.c_int32]
@@ -175,6 +178,16 @@ class Engine:
 
     def set_incremental_graph(self, on):
         self._ck(self._L.dppr_set_incremental_graph(self._h, int(on)), "set_incremental_graph")
+
+    def set_renumbering(self, on, growth_pct=0, min_parked=0):
+        """Renumbering of the internal ids at slide time (include/dppr.h); 0 keeps a threshold as it is."""
+        self._ck(self._L.dppr_set_renumbering(self._h, int(on), int(growth_pct), int(min_parked)), "set_renumbering")
+
+    def id_space(self):
+        """dict(ids=swept ids, parked=ids parked with their state, renumberings=, revivals=)"""
+        a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+        self._ck(self._L.dppr_id_space(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "id_space")
+        return {"ids": a.value, "parked": b.value, "renumberings": c.value, "revivals": d.value}
 
     def set_profiling(self, on):
         self._ck(self._L.dppr_set_profiling(self._h, int(on)), "set_profiling")

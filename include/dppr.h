@@ -159,6 +159,20 @@ int dppr_slide(dppr_engine *e, const int32_t *new_e1, const int32_t *new_e2, int
  * (thrust::sort in BuildCSRGraph, gpu/SlidingGraphBuilder.cuh:203-221). Same CSR either way. */
 int dppr_set_incremental_graph(dppr_engine *e, int on);
 
+/* Renumbering of the internal vertex ids (no counterpart in the reference, whose kernels scan all V ids every
+ * iteration: gpu/Inspect.cuh:8-48). The engine numbers vertices by first appearance and sweeps only those ids; a
+ * vertex whose last edge left the window keeps p / r, so on a long stream the id space outgrows the vertices that
+ * still have edges. on (default): a dppr_slide that finds EVERY source slot / group converged on the newest epoch,
+ * the id space grown by growth_pct % (default 25) since the last numbering and at least min_parked (default 1024,
+ * and 1/8 of the live vertices) ids without an edge, renumbers: live vertices first, the others parked at the top
+ * of the id capacity with their state rows, outside of every sweep; a parked vertex that shows up in a later batch
+ * gets a fresh id and its rows back. Results are those of a run without renumbering; older epochs become
+ * unavailable at that slide (they are in the old numbering), which is why slots that lag behind block it.
+ * growth_pct / min_parked = 0 keep their current values. */
+int dppr_set_renumbering(dppr_engine *e, int on, int growth_pct, int min_parked);
+/* ids in use by sweeps and scans, parked ids, renumberings so far, parked vertices that came back (any may be NULL) */
+int dppr_id_space(dppr_engine *e, int32_t *n_ids, int32_t *n_parked, int32_t *renumberings, int64_t *revivals);
+
 /* ---- per-source state ---------------------------------------------------- */
 
 /* Allocates pagerank/residual/frontier state for one source vertex
