@@ -195,7 +195,7 @@ struct dppr_engine {
     // vertices without an edge in the window
     int n_parked = 0;
     bool renumber = true;          // dppr_set_renumbering
-    int renumber_growth_pct = 25;  // a slide considers it once n_int has grown by this much since the last numbering ...
+    int renumber_growth_pct = 15;  // a slide considers it once n_int has grown by this much since the last numbering ...
     int renumber_min_parked = 1024; // ... and does it if at least this many ids (and 1/8 of the live ones) would be parked
     int renumber_next = 0;         // n_int at which the next slide looks at the live count
     int renumberings = 0;
@@ -1405,6 +1405,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     if (const char *v = getenv("DPPR_HOT_BLOCKS")) e->hot_blocks = atoi(v) != 0;
     if (const char *v = getenv("DPPR_GSWEEP_GRID")) e->gsweep_grid_cap = std::max(1, std::min(atoi(v), STAT_SLOTS));
     if (const char *v = getenv("DPPR_RENUMBER")) e->renumber = atoi(v) != 0;
+    if (const char *v = getenv("DPPR_RENUMBER_PCT")) e->renumber_growth_pct = std::max(1, atoi(v));
     if (const char *v = getenv("DPPR_GGROUPS_MIN")) e->ggroups_min = std::max(1, atoi(v));
     e->device = device;
     e->V = V;

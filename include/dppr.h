@@ -163,7 +163,7 @@ int dppr_set_incremental_graph(dppr_engine *e, int on);
  * iteration: gpu/Inspect.cuh:8-48). The engine numbers vertices by first appearance and sweeps only those ids; a
  * vertex whose last edge left the window keeps p / r, so on a long stream the id space outgrows the vertices that
  * still have edges. on (default): a dppr_slide that finds EVERY source slot / group converged on the newest epoch,
- * the id space grown by growth_pct % (default 25) since the last numbering and at least min_parked (default 1024,
+ * the id space grown by growth_pct % (default 15) since the last numbering and at least min_parked (default 1024,
  * and 1/8 of the live vertices) ids without an edge, renumbers: live vertices first, the others parked at the top
  * of the id capacity with their state rows, outside of every sweep; a parked vertex that shows up in a later batch
  * gets a fresh id and its rows back. Results are those of a run without renumbering; older epochs become

@@ -18,7 +18,7 @@ open("/tmp/long_run_sources.txt", "w").write("\n".join(str(int(s)) for s in src[
 print(f"BIN={path} DIRECTED={cfg.directed}")
 PY
 )
-for rn in 1 0; do
+for rn in ${RN:-1 0}; do
   DPPR_RENUMBER=$rn dynamicppr_amd/host/pagerank -d $BIN -a 0 -i $DIRECTED -y 1 -w 0.1 -n 0 -r 0.01 -b $B --sources /tmp/long_run_sources.txt 2>&1 \
     | grep -E "ppr_latency|ppr_throughput|stream_batch_count" | tail -3 | tr '\n' ' ' | sed "s/^/renumber=$rn $CFG b=$B nsrc=$NS: /"; echo
 done
