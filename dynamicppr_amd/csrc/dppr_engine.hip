@@ -1406,6 +1406,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     if (const char *v = getenv("DPPR_GSWEEP_GRID")) e->gsweep_grid_cap = std::max(1, std::min(atoi(v), STAT_SLOTS));
     if (const char *v = getenv("DPPR_RENUMBER")) e->renumber = atoi(v) != 0;
     if (const char *v = getenv("DPPR_RENUMBER_PCT")) e->renumber_growth_pct = std::max(1, atoi(v));
+    if (const char *v = getenv("DPPR_RENUMBER_MIN")) e->renumber_min_parked = std::max(1, atoi(v));
     if (const char *v = getenv("DPPR_GGROUPS_MIN")) e->ggroups_min = std::max(1, atoi(v));
     e->device = device;
     e->V = V;

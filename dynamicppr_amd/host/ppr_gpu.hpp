@@ -129,6 +129,13 @@ public:
         }
         batches_done = stream_batch_count - 1;
         if (!quiet_) Report(stream_batch_count);
+        if (!quiet_) { // (not a line of the reference: how far the engine's internal id space is from the window's vertices)
+            int32_t ids = 0, parked = 0, renumberings = 0;
+            int64_t revivals = 0;
+            DPPR_CHECK(engine, dppr_id_space(engine, &ids, &parked, &renumberings, &revivals));
+            std::cout << "id_space ids=" << ids << " parked=" << parked << " renumberings=" << renumberings
+                      << " revivals=" << revivals << std::endl;
+        }
     }
 
     // the reference's four virtuals (gpu/PPRGPU.cuh:179-182), per source slot

@@ -138,3 +138,42 @@ def test_sweep_tool_scrapes_the_stdout_contract(pagerank, small_bin, tmp_path):
     assert [x["variant"] for x in rows] == [0, 1, 2, 3]
     assert all(x["ppr_latency_ms"] and x["ppr_throughput"] and x["ppr_throughput"] > 0 for x in rows)
     assert len(os.listdir(tmp_path / "log")) == 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nsrc", [1, 3])
+def test_cli_long_churning_stream_renumbers_and_matches_oracle(pagerank, tmp_path, nsrc):
+    """The reference driver's flow (slide, update, slide, ...) over a stream that churns through the id range: the
+    engine renumbers its internal ids several times on the way (thresholds lowered through the tuning variables);
+    results and --validate are those of the oracle."""
+    from tests.test_renumbering_gpu import churn_stream
+    V, n, batches = 4096, 6000, 45
+    e1, e2 = churn_stream(V, n, 400, 9)
+    path = str(tmp_path / "churn.bin")
+    datagen.write_bin(path, V, e1, e2)
+    W, c = 600, 100
+    srcs = [0, 1, 2][:nsrc]
+    sf = tmp_path / "sources.txt"
+    sf.write_text("\n".join(map(str, srcs)) + "\n")
+    dump = str(tmp_path / "out.dump")
+    outs = {}
+    for renumber in ("1", "0"):
+        env = dict(os.environ, DPPR_RENUMBER=renumber, DPPR_RENUMBER_PCT="10", DPPR_RENUMBER_MIN="8")
+        r = subprocess.run([pagerank, "-d", path, "-a", "0", "-i", "1", "-y", "1", "-w", "0.1", "-n", "1", "-c", str(c),
+                            "-l", str(c * batches), "--sources", str(sf), "--validate", "--dump", dump],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+        assert r.returncode == 0, r.stdout
+        assert "validate failed" not in r.stdout
+        m = re.search(r"id_space ids=(\d+) parked=(\d+) renumberings=(\d+) revivals=(\d+)", r.stdout)
+        assert m and ((int(m.group(3)) >= 3 and int(m.group(2)) > 0) if renumber == "1" else m.group(3) == "0"), r.stdout[-400:]
+        outs[renumber] = read_dump(dump)
+    for sv in srcs:
+        g = orc.Graph(V, e1, e2, 1, W, c)
+        s = orc.State(V, sv, 1e-9)
+        s.cilk_execute(g)
+        for _ in range(batches):
+            assert not g.stream_updates()
+            g.inc_construct(1)
+            s.cilk_inc_execute(g)
+        for k in outs:
+            assert np.max(np.abs(outs[k][sv][0] - s.p)) < 1e-9 and np.max(np.abs(outs[k][sv][1])) < 1e-9, (k, sv)
