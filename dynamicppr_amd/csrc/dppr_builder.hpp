@@ -228,6 +228,14 @@ __global__ __launch_bounds__(BLOCK) void k_mark_live(const int *__restrict__ w1,
     }
 }
 
+__global__ __launch_bounds__(BLOCK) void k_in_degree(const int *__restrict__ w1, const int *__restrict__ w2, int W, int directed,
+                                                     int *__restrict__ indeg) {
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < W; i += gridDim.x * BLOCK) {
+        atomicAdd(&indeg[w2[i]], 1);
+        if (!directed) atomicAdd(&indeg[w1[i]], 1);
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_remap_ids(int *__restrict__ a, int n, const int *__restrict__ perm) {
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) a[i] = perm[a[i]];
 }

@@ -313,6 +313,51 @@ int sync_map(dppr_engine *e) {
     return DPPR_OK;
 }
 
+// The order in which a set of vertices is numbered: `fresh` holds (hash of the external id, tag) pairs and comes back
+// sorted. The hash alone gives a pseudo-random order (high-degree vertices show up early in a stream, and packing
+// them into the first tiles would serialise the sweeps on a few workgroups).
+// Large windows: the x[u] gathers of a sweep are random reads, and what an XCD's 4 MB L2 keeps of
+// them saves sectors on the fabric. Gathers follow the in-degree, which is heavily skewed
+// (LiveJournal stand-in: the 8 K / 32 K / 524 K vertices of highest in-degree, of 1.18 M, take 35 % /
+// 55 % / 95 % of them), so vertices are numbered in BLOCKS of falling in-degree -- the top 8 K first,
+// then ranks 8 K..16 K, 16 K..32 K, ... up to 512 K, everybody else last: whatever a vertex's state
+// measures (8 bytes for one source, 64 / 128 for a source group), the ids that fit an L2 are the
+// hottest ones. Inside a block the order stays hashed, so long rows are still spread over the
+// tiles. Measured on that stand-in, single source, two blocks (524 K | rest): 73 -> 67 us per sweep.
+// Only for windows beyond a resident launch (> 256 K vertices): below that everything is L2-resident
+// anyway, and hot tiles next to each other would unbalance the <= 256 groups of a resident launch
+// (configs[1] stand-in: 0.55 -> 0.91 ms per batch). indeg[tag] = in-degree in the window (nullptr: hash only).
+constexpr size_t HOT_MIN = 8192, HOT_SET = 524288, HOT_WINDOW_MIN = 262144;
+inline uint64_t id_hash(int v) {
+    uint64_t z = (uint64_t)v + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+void numbering_order(const dppr_engine *e, std::vector<std::pair<uint64_t, int32_t>> &fresh, const int32_t *indeg) {
+    if (indeg && fresh.size() > HOT_WINDOW_MIN) {
+        std::vector<int32_t> d;
+        d.reserve(fresh.size());
+        for (auto &kv : fresh) d.push_back(indeg[(size_t)kv.second]);
+        std::vector<int32_t> thr; // in-degree of rank 512 K, 256 K, ..., 8 K (non-decreasing)
+        size_t cur = d.size();
+        for (size_t k = HOT_SET; k >= (e->hot_blocks ? HOT_MIN : HOT_SET); k >>= 1) {
+            if (k >= cur) continue;
+            std::nth_element(d.begin(), d.begin() + (std::ptrdiff_t)k, d.begin() + (std::ptrdiff_t)cur,
+                             std::greater<int32_t>());
+            thr.push_back(d[k]); // vertices with a larger in-degree belong to the first k (at most k of them)
+            cur = k;
+        }
+        for (auto &kv : fresh) {
+            const int32_t dg = indeg[(size_t)kv.second];
+            uint64_t block = 0; // 0 = hottest
+            for (int32_t t : thr) block += dg <= t ? 1u : 0u;
+            kv.first = (kv.first >> 5) | (block << 59);
+        }
+    }
+    std::sort(fresh.begin(), fresh.end());
+}
+
 // Apply the row moves that revivals queued (to_int): every solver state's p / r rows, in one gather + scatter + zero
 // per array. States that lag behind the newest epoch may be moved too: a parked row is not touched by any epoch,
 // and the fresh id lies beyond the ids every older epoch sweeps.
@@ -433,11 +478,37 @@ int compact_ids(dppr_engine *e, bool *did) {
         e->renumber_next = n_old + std::max(n_old / 8, 1); // look again after some more growth
         return DPPR_OK;
     }
-    // old position -> new position
+    // old position -> new position. Live vertices are numbered afresh the way dppr_load_window numbers a window
+    // (hashed, hot blocks on large windows): arrivals are appended in arrival order between two renumberings, and a
+    // tail of low-degree late-comers next to each other unbalances the sweep groups (configs[1] stand-in in step,
+    // survivors kept in their old order instead: 0.52 ms per batch at the start, 0.61 after 400 batches of the
+    // same work). Beyond REHASH_MAX live vertices the old relative order is kept (a host sort of that many pairs
+    // would stall the stream; the blocks of the initial numbering survive).
+    constexpr int REHASH_MAX = 8 << 20;
     std::vector<int32_t> perm((size_t)V, -1), new_i2e((size_t)V, -1);
     const int R_new = R_old + to_park, base = V - R_new;
     int nl = 0, np = 0;
-    for (int v = 0; v < n_old; ++v) perm[(size_t)v] = live[(size_t)v] ? nl++ : base + np++;
+    if (n_live <= REHASH_MAX) {
+        std::vector<int32_t> indeg;
+        if ((size_t)n_live > HOT_WINDOW_MIN) {
+            int *d_deg = e->hub_slot_of; // (scratch of the CSR build, V ints)
+            HIP_TRY(hipMemsetAsync(d_deg, 0, sizeof(int) * (size_t)n_old, e->stream));
+            hipLaunchKernelGGL(k_in_degree, dim3(grid_for(e->W)), dim3(BLOCK), 0, e->stream, e->w1, e->w2, e->W, e->directed, d_deg);
+            indeg.resize((size_t)n_old);
+            HIP_TRY(hipMemcpyAsync(indeg.data(), d_deg, sizeof(int) * (size_t)n_old, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+        }
+        std::vector<std::pair<uint64_t, int32_t>> order;
+        order.reserve((size_t)n_live);
+        for (int v = 0; v < n_old; ++v)
+            if (live[(size_t)v]) order.emplace_back(id_hash(e->int2ext[(size_t)v]), v);
+        numbering_order(e, order, indeg.empty() ? nullptr : indeg.data());
+        for (auto &kv : order) perm[(size_t)kv.second] = nl++;
+        for (int v = 0; v < n_old; ++v)
+            if (!live[(size_t)v]) perm[(size_t)v] = base + np++;
+    } else {
+        for (int v = 0; v < n_old; ++v) perm[(size_t)v] = live[(size_t)v] ? nl++ : base + np++;
+    }
     for (int v = V - R_old; v < V; ++v) perm[(size_t)v] = base + np++;
     for (int v = 0; v < V; ++v) {
         const int m = perm[(size_t)v];
@@ -1626,51 +1697,19 @@ int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32
                 if (v < 0 || v >= e->V) return fail(e, DPPR_ERR_INVALID, "load_window: vertex id out of range");
                 if (e->ext2int[(size_t)v] == -1) {
                     e->ext2int[(size_t)v] = -2; // seen, not numbered yet
-                    uint64_t z = (uint64_t)v + 0x9E3779B97F4A7C15ull;
-                    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-                    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-                    fresh.emplace_back(z ^ (z >> 31), v);
+                    fresh.emplace_back(id_hash(v), v);
                 }
             }
         }
-        // Large windows: the x[u] gathers of a sweep are random reads, and what an XCD's 4 MB L2 keeps of
-        // them saves sectors on the fabric. Gathers follow the in-degree, which is heavily skewed
-        // (LiveJournal stand-in: the 8 K / 32 K / 524 K vertices of highest in-degree, of 1.18 M, take 35 % /
-        // 55 % / 95 % of them), so vertices are numbered in BLOCKS of falling in-degree -- the top 8 K first,
-        // then ranks 8 K..16 K, 16 K..32 K, ... up to 512 K, everybody else last: whatever a vertex's state
-        // measures (8 bytes for one source, 64 / 128 for a source group), the ids that fit an L2 are the
-        // hottest ones. Inside a block the order stays hashed, so long rows are still spread over the
-        // tiles. Measured on that stand-in, single source, two blocks (524 K | rest): 73 -> 67 us per sweep.
-        // Only for windows beyond a resident launch (> 256 K vertices): below that everything is L2-resident
-        // anyway, and hot tiles next to each other would unbalance the <= 256 groups of a resident launch
-        // (configs[1] stand-in: 0.55 -> 0.91 ms per batch).
-        constexpr size_t HOT_MIN = 8192, HOT_SET = 524288, HOT_WINDOW_MIN = 262144;
+        std::vector<int32_t> indeg;
         if (fresh.size() > HOT_WINDOW_MIN) {
-            std::vector<int32_t> indeg((size_t)e->V, 0);
+            indeg.assign((size_t)e->V, 0);
             for (int i = 0; i < n; ++i) {
                 indeg[(size_t)e2[i]]++;
                 if (!e->directed) indeg[(size_t)e1[i]]++;
             }
-            std::vector<int32_t> d;
-            d.reserve(fresh.size());
-            for (auto &kv : fresh) d.push_back(indeg[(size_t)kv.second]);
-            std::vector<int32_t> thr; // in-degree of rank 512 K, 256 K, ..., 8 K (non-decreasing)
-            size_t cur = d.size();
-            for (size_t k = HOT_SET; k >= (e->hot_blocks ? HOT_MIN : HOT_SET); k >>= 1) {
-                if (k >= cur) continue;
-                std::nth_element(d.begin(), d.begin() + (std::ptrdiff_t)k, d.begin() + (std::ptrdiff_t)cur,
-                                 std::greater<int32_t>());
-                thr.push_back(d[k]); // vertices with a larger in-degree belong to the first k (at most k of them)
-                cur = k;
-            }
-            for (auto &kv : fresh) {
-                const int32_t dg = indeg[(size_t)kv.second];
-                uint64_t block = 0; // 0 = hottest
-                for (int32_t t : thr) block += dg <= t ? 1u : 0u;
-                kv.first = (kv.first >> 5) | (block << 59);
-            }
         }
-        std::sort(fresh.begin(), fresh.end());
+        numbering_order(e, fresh, indeg.empty() ? nullptr : indeg.data());
         for (auto &kv : fresh) {
             e->ext2int[(size_t)kv.second] = -1;
             (void)to_int(e, kv.second);
