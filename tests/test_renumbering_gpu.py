@@ -37,12 +37,21 @@ def live_count(g, V):
     return len(np.unique(np.concatenate([w1, w2])))
 
 
+# the launch forms whose idle state a renumbering has to leave intact: resident sweeps (default), per-iteration pull
+# sweeps with and without the activity bitmap, push only (hub table + big rows), mixed with one-iteration chunks
+FORMS = [dict(), dict(pull_min_frontier=1, persistent=0), dict(pull_min_frontier=1, persistent=0, sweep_bitmap=1, pull_block=256),
+         dict(hub_min_degree=3, big_row_edges=8, pull_min_frontier=-1), dict(pull_min_frontier=40, chunk_iters=1),
+         dict(pull_min_frontier=1, chunk_iters=3)]
+FORM_IDS = ["default", "pull-per-iteration", "pull-bitmap-wg256", "push-hubs-bigrows", "mixed-chunk1", "resident-3-sweeps"]
+
+
+@pytest.mark.parametrize("tuning", FORMS, ids=FORM_IDS)
 @pytest.mark.parametrize("directed", [1, 0])
-def test_long_stream_sync_schedule_slot_and_group_renumbered(directed):
+def test_long_stream_sync_schedule_slot_and_group_renumbered(directed, tuning):
     V, W, c, eps, batches = 4096, 1500, 100, 1e-9, 60
     e1, e2 = churn_stream(V, W + batches * c, 400, 5 + directed)
     g = orc.Graph(V, e1, e2, directed, W, c)
-    e = eng.Engine(V, W, directed, c, schedule=eng.SCHEDULE_SYNC)
+    e = eng.Engine(V, W, directed, c, schedule=eng.SCHEDULE_SYNC, **tuning)
     e.set_renumbering(1, growth_pct=10, min_parked=16)
     e.load_window(*g.window_edges())
     sources = [0, 1, int(e1[0]), 2, 3]  # e1[0]: a band vertex that retires early (a SOURCE is never parked)
