@@ -109,6 +109,7 @@ struct Group {
     IterStats *dstats = nullptr;
     dppr_stats_t st{};
     int iter_hint[2] = {0, 0};
+    int iter_hist[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; // sweeps the last four loops of each phase took
     bool converged = false;    // |r| <= conv_eps for every source (state after a completed solve)
     double conv_eps = 0.0;
     double park_eps = 0.0;     // parked rows satisfy |r| <= park_eps
@@ -1310,6 +1311,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
     bool more = any_left(e->pinned);
     int active_iters = 0;
     const int sweep_grid = std::min(std::max(ep.n_ggroups, 1), e->gsweep_grid_cap);
+    int follow = 4; // size of the next follow-up chunk of one-sweep launches
     const int nvx = ep.ggrp_max_tiles * WAVE; // vertices per sweep group of this epoch's tables: 1024, or 512 once a 16-wide group exists
     for (int it = 0; more;) {
         if (it >= e->max_iters) return fail(e, DPPR_ERR_NOT_CONVERGED, "iteration cap hit");
@@ -1372,7 +1374,21 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
             more = any_left(e->pinned + GWM + sweeps * GWM);
             continue;
         }
-        int n = g.iter_hint[phase] > it ? g.iter_hint[phase] - it + 1 : e->chunk_iters;
+        // One-sweep launches are enqueued in chunks; a launch that finds every frontier empty returns at once, but it
+        // still costs a dispatch (~4 us + gap). Consecutive batches take about the same number of sweeps, so the first
+        // chunk is the SHORTEST of the last four loops of this phase (almost surely needed in full), and what follows
+        // doubles from 4: a boundary (read-back + relaunch) costs about three empty dispatches.
+        int n;
+        if (it == 0) {
+            int lo = 0;
+            for (int h : g.iter_hist[phase]) lo = h > 0 && (lo == 0 || h < lo) ? h : lo;
+            n = lo > 0 ? lo : e->chunk_iters;
+            follow = 4;
+        } else {
+            n = std::min(follow, e->chunk_iters);
+            follow *= 2;
+        }
+        if (e->chunk_explicit) n = std::min(n, std::max(e->chunk_iters, 1));
         n = std::max(1, std::min(n, MAX_CHUNK));
         for (int k = 0; k < n; ++k) {
             const int nxt = (cur + 1) % 3, zer = (cur + 2) % 3;
@@ -1413,6 +1429,8 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
         it += n;
     }
     g.iter_hint[phase] = active_iters;
+    for (int k = 3; k > 0; --k) g.iter_hist[phase][k] = g.iter_hist[phase][k - 1];
+    g.iter_hist[phase][0] = active_iters;
     return DPPR_OK;
 }
 
