@@ -221,3 +221,55 @@ def test_smaller_eps_after_parking_settles_the_parked_rows():
     for i, s in enumerate([0, 1, 2]):
         p, r = e.group_read(gid, i)
         assert np.max(np.abs(r)) < 1e-9 and invariant_max_err_np(p, r, src, dst, V, s) < 1e-13
+
+
+@pytest.mark.parametrize("seed", list(range(1, 9)))
+def test_randomised_churn_with_random_staging(seed):
+    """Random stream shape, thresholds, source mix and staging pattern (in step / a few epochs ahead), synchronous
+    schedule: every state equals the oracle's whenever it has caught up."""
+    rng = np.random.default_rng(1000 + seed)
+    V = int(rng.choice([1024, 4096, 8192]))
+    W = int(rng.integers(300, 1500))
+    c = int(rng.integers(20, max(21, W // 8)))
+    directed = int(rng.integers(0, 2))
+    band = int(rng.integers(60, 400))
+    ahead_max = int(rng.integers(1, 6))
+    batches = 50
+    e1, e2 = churn_stream(V, W + batches * c, band, 7000 + seed, back=float(rng.uniform(0.0, 0.15)), hubs=int(rng.integers(2, 8)))
+    eps = float(rng.choice([1e-9, 1e-7]))
+    nsrc = int(rng.integers(2, 12))
+    sources = [int(x) for x in rng.choice(np.unique(np.concatenate([e1[:W], e2[:W]])), nsrc, replace=False)]
+    g = orc.Graph(V, e1, e2, directed, W, c)
+    states = [orc.State(V, s, eps) for s in sources]
+    e = eng.Engine(V, W, directed, c, n_epochs=ahead_max + 2, schedule=eng.SCHEDULE_SYNC)
+    e.set_renumbering(1, growth_pct=int(rng.integers(3, 20)), min_parked=int(rng.integers(1, 32)))
+    e.load_window(*g.window_edges())
+    slot = e.add_source(sources[0])
+    gid = e.add_source_group(sources)
+    for s in states:
+        s.sync_execute(g)
+    e.init_solve(slot, eps)
+    e.group_init_solve(gid, eps)
+    done = 0
+    while done < batches:
+        n = int(min(batches - done, rng.integers(1, ahead_max + 1)))
+        staged = []
+        for _ in range(n):
+            assert not g.stream_updates()
+            g.inc_construct(1)
+            e.set_batch(*g.batch())
+            staged.append(e.slide(*g.new_stream()))
+            for s in states:
+                s.sync_inc_execute(g)
+        for ep in staged:
+            e.update(slot, eps, epoch=ep)
+            e.group_update(gid, eps, epoch=ep)
+        done += n
+        p, r = e.read(slot)
+        assert np.max(np.abs(p - states[0].p)) < SYNC_TOL and np.max(np.abs(r - states[0].r)) < SYNC_TOL, (seed, done)
+        for i, s in enumerate(states):
+            p, r = e.group_read(gid, i)
+            assert np.max(np.abs(p - s.p)) < SYNC_TOL and np.max(np.abs(r - s.r)) < SYNC_TOL, (seed, done, i)
+    sp = e.id_space()
+    print("id space", seed, sp)
+    assert sp["ids"] + sp["parked"] <= V
