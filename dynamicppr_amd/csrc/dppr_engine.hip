@@ -356,7 +356,25 @@ void numbering_order(const dppr_engine *e, std::vector<std::pair<uint64_t, int32
             kv.first = (kv.first >> 5) | (block << 59);
         }
     }
-    std::sort(fresh.begin(), fresh.end());
+    // sorted by (key, tag): one counting pass on the top 16 key bits (block + hash bits: near-uniform), then the
+    // buckets, a few dozen entries each, one by one -- a plain std::sort of a million pairs is most of what a
+    // renumbering slide costs
+    if (fresh.size() < (1u << 16)) {
+        std::sort(fresh.begin(), fresh.end());
+        return;
+    }
+    constexpr int RB = 16;
+    std::vector<uint32_t> start((size_t)(1 << RB) + 1, 0);
+    for (auto &kv : fresh) start[(size_t)(kv.first >> (64 - RB)) + 1]++;
+    for (size_t b = 0; b < ((size_t)1 << RB); ++b) start[b + 1] += start[b];
+    std::vector<std::pair<uint64_t, int32_t>> out(fresh.size());
+    {
+        std::vector<uint32_t> pos(start.begin(), start.end() - 1);
+        for (auto &kv : fresh) out[pos[(size_t)(kv.first >> (64 - RB))]++] = kv;
+    }
+    for (size_t b = 0; b < ((size_t)1 << RB); ++b)
+        if (start[b + 1] - start[b] > 1) std::sort(out.begin() + start[b], out.begin() + start[b + 1]);
+    fresh.swap(out);
 }
 
 // Apply the row moves that revivals queued (to_int): every solver state's p / r rows, in one gather + scatter + zero
