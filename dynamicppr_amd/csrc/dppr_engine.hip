@@ -197,7 +197,7 @@ struct dppr_engine {
     int n_parked = 0;
     bool renumber = true;          // dppr_set_renumbering
     int renumber_growth_pct = 15;  // a slide considers it once n_int has grown by this much since the last numbering ...
-    int renumber_min_parked = 1024; // ... and does it if at least this many ids (and 1/8 of the live ones) would be parked
+    int renumber_min_parked = 1024; // ... and does it if at least this many ids (and growth_pct / 2 % of the live ones) would be parked
     int renumber_next = 0;         // n_int at which the next slide looks at the live count
     int renumberings = 0;
     long long revivals = 0;
@@ -493,7 +493,7 @@ int compact_ids(dppr_engine *e, bool *did) {
     int n_live = 0;
     for (int v = 0; v < n_old; ++v) n_live += live[(size_t)v];
     const int to_park = n_old - n_live;
-    if (to_park < e->renumber_min_parked || to_park < n_live / 8) {
+    if (to_park < e->renumber_min_parked || (long long)to_park * 200 < (long long)n_live * e->renumber_growth_pct) {
         e->renumber_next = n_old + std::max(n_old / 8, 1); // look again after some more growth
         return DPPR_OK;
     }

@@ -164,7 +164,7 @@ int dppr_set_incremental_graph(dppr_engine *e, int on);
  * vertex whose last edge left the window keeps p / r, so on a long stream the id space outgrows the vertices that
  * still have edges. on (default): a dppr_slide that finds EVERY source slot / group converged on the newest epoch,
  * the id space grown by growth_pct % (default 15) since the last numbering and at least min_parked (default 1024,
- * and 1/8 of the live vertices) ids without an edge, renumbers: live vertices first, the others parked at the top
+ * and growth_pct / 2 % of the live vertices) ids without an edge, renumbers: live vertices first, the others parked at the top
  * of the id capacity with their state rows, outside of every sweep; a parked vertex that shows up in a later batch
  * gets a fresh id and its rows back. Results are those of a run without renumbering; older epochs become
  * unavailable at that slide (they are in the old numbering), which is why slots that lag behind block it.

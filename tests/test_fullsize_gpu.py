@@ -175,3 +175,50 @@ def test_eight_gpu_configs_at_full_size_on_one_gpu_properties(key, nsrc):
     stats = e.stats(h) if nsrc == 1 else e.group_stats(h)
     assert stats["batches"] == 1 and stats["sum_E"] > len(src_e) and stats["pull_iterations"] > 0
     e.close()
+
+
+@pytest.mark.parametrize("key,nsrc,batches", [("youtube", 1, 90), ("livejournal", 10, 36)])
+def test_long_in_step_run_at_full_size_renumbers_and_agrees_with_an_unrenumbered_engine(key, nsrc, batches):
+    """The reference driver's flow at full size with the id renumbering at work (threshold lowered so that it
+    happens several times within the test): p of every source agrees with an engine that never renumbers, the
+    residual bound and the loop invariant hold on both, and the renumbered engine sweeps fewer ids."""
+    V, e1, e2, cfg, wl = stand_in(key, batches)
+    W, c, eps = wl.window, wl.per_batch, 1e-9
+    if nsrc == 1:
+        sources = [int(datagen.top_sources(V, e1, e2, W, cfg.directed, 10)[3])]
+    else:
+        sources = [int(x) for x in datagen.ranked_sources(V, e1, e2, W, cfg.directed, 10, 1000, nsrc)]
+    engines = []
+    for on in (1, 0):
+        e = eng.Engine(V, W, cfg.directed, c)
+        e.set_renumbering(on, growth_pct=4, min_parked=256)
+        ss = st.SlidingStream(V, e1, e2, cfg.directed, wl)
+        e.load_window(*ss.serialize_edge_stream())
+        if nsrc == 1:
+            h = e.add_source(sources[0])
+            e.init_solve(h, eps)
+        else:
+            h = e.add_source_group(sources)
+            e.group_init_solve(h, eps)
+        engines.append((e, ss, h))
+    for k in range(batches):
+        for e, ss, h in engines:
+            assert not ss.stream_updates()
+            e.set_batch(*ss.batch_arrays())
+            e.slide(*ss.new_arrays())
+            if nsrc == 1:
+                e.update(h, eps)
+            else:
+                e.group_update(h, eps)
+    (ea, ssa, ha), (eb, _, hb) = engines
+    src, dst = window_edges(ssa, cfg.directed)
+    for i, sv in enumerate(sources):
+        pa, ra = ea.read(ha) if nsrc == 1 else ea.group_read(ha, i)
+        pb, rb = eb.read(hb) if nsrc == 1 else eb.group_read(hb, i)
+        assert max(np.max(np.abs(ra)), np.max(np.abs(rb))) < eps
+        assert np.max(np.abs(pa - pb)) < NORTH_STAR_TOL, (key, i)
+        assert invariant_max_err_np(pa, ra, src, dst, V, sv) < INVARIANT_TOL
+        assert invariant_max_err_np(pb, rb, src, dst, V, sv) < INVARIANT_TOL
+    a, b = ea.id_space(), eb.id_space()
+    print("[id space]", key, a, b)
+    assert a["renumberings"] >= 2 and a["parked"] > 0 and b["renumberings"] == 0 and a["ids"] < b["ids"]
