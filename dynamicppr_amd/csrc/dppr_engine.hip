@@ -78,6 +78,7 @@ struct Slot {
     int *log = nullptr;     // per-chunk log: frontier size seen by each enqueued iteration
     long long iter_seq = 0; // running iteration number (selects the big-row counter)
     int iter_hint[2] = {0, 0}; // iterations the last loop of each phase took (sizes the next chunks)
+    int iter_hist[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; // ... and the last four
     bool start_dense[2] = {false, false}; // the last loop of each phase began with a frontier worth a sweep
     int last_F0[2] = {0, 0};   // ... and its size
     IterStats *dstats = nullptr;
@@ -922,6 +923,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
         return DPPR_OK;
     };
     int F = entry.F, prevF = 0, active_iters = entry.it;
+    int follow = 4; // size of the next follow-up chunk of per-iteration sweeps
     int rc = DPPR_OK;
     if (F < 0 && (rc = read_count(e, s.cnt + cur, &F))) return rc;
     if (entry.it == 0) {
@@ -950,6 +952,18 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
         const int pcap = persist_capacity(e);
         const bool resident = pull && n >= 2 && !s.trace && pcap > 0 && ep.n_groups > 0 && ep.n_groups <= pcap;
         if (resident && s.iter_hint[phase] > it) n += RESIDENT_MARGIN - 1;
+        if (!resident && pull && n > 1) {
+            // per-iteration sweeps: a launch that finds the frontier empty is still a dispatch, a chunk boundary (read-back
+            // + relaunch) costs about three of them -- go as far as the SHORTEST of the last four loops of this phase went
+            // (almost surely needed in full), then in chunks that double from 4 (group_loop sizes its chunks the same way)
+            int lo = 0;
+            for (int h : s.iter_hist[phase]) lo = h > 0 && (lo == 0 || h < lo) ? h : lo;
+            if (lo > it) n = lo - it;
+            else if (lo > 0) {
+                n = std::min(follow, e->chunk_iters);
+                follow *= 2;
+            }
+        }
         n = std::min(n, MAX_CHUNK);
         if (e->chunk_explicit) n = std::min(n, std::max(e->chunk_iters, 1));
         if (!pull && !list_valid && (rc = make_list())) return rc;
@@ -1100,6 +1114,8 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
         it += n;
     }
     s.iter_hint[phase] = active_iters;
+    for (int k = 3; k > 0; --k) s.iter_hist[phase][k] = s.iter_hist[phase][k - 1];
+    s.iter_hist[phase][0] = active_iters;
     if (any_pull && !x_clean) { // leave both dense vectors all-zero for the next loop
         // only internal ids below n_int are ever written
         HIP_TRY(hipMemsetAsync(s.x, 0, sizeof(double) * (size_t)e->n_int, e->stream));
