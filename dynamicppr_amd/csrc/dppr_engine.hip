@@ -357,14 +357,14 @@ void numbering_order(const dppr_engine *e, std::vector<std::pair<uint64_t, int32
             kv.first = (kv.first >> 5) | (block << 59);
         }
     }
-    // sorted by (key, tag): one counting pass on the top 16 key bits (block + hash bits: near-uniform), then the
+    // sorted by (key, tag): one counting pass on the top 16 / 21 key bits (block + hash bits: near-uniform), then the
     // buckets, a few dozen entries each, one by one -- a plain std::sort of a million pairs is most of what a
     // renumbering slide costs
     if (fresh.size() < (1u << 16)) {
         std::sort(fresh.begin(), fresh.end());
         return;
     }
-    constexpr int RB = 16;
+    const int RB = fresh.size() > (1u << 19) ? 21 : 16; // (hot blocks take the top 5 bits: the cold block needs the rest)
     std::vector<uint32_t> start((size_t)(1 << RB) + 1, 0);
     for (auto &kv : fresh) start[(size_t)(kv.first >> (64 - RB)) + 1]++;
     for (size_t b = 0; b < ((size_t)1 << RB); ++b) start[b + 1] += start[b];
@@ -474,6 +474,16 @@ int compact_ids(dppr_engine *e, bool *did) {
         if (!g.converged || g.last_epoch != e->newest) return DPPR_OK;
     if (int rc = flush_moves(e)) return rc;
     const int V = e->V, n_old = e->n_int, R_old = e->n_parked;
+    static const bool trace = getenv("DPPR_RENUMBER_TRACE") != nullptr; // (diagnostic: where a renumbering's time goes)
+    timespec t_mark;
+    clock_gettime(CLOCK_MONOTONIC, &t_mark);
+    auto mark = [&](const char *what) {
+        if (!trace) return;
+        timespec now;
+        clock_gettime(CLOCK_MONOTONIC, &now);
+        fprintf(stderr, "[renumber] %-28s %8.2f ms\n", what, (now.tv_sec - t_mark.tv_sec) * 1e3 + (now.tv_nsec - t_mark.tv_nsec) * 1e-6);
+        t_mark = now;
+    };
     // which ids have an edge in the window
     uint8_t *d_live = nullptr;
     HIP_TRY(hipMalloc((void **)&d_live, (size_t)std::max(n_old, 1)));
@@ -493,6 +503,7 @@ int compact_ids(dppr_engine *e, bool *did) {
         for (int k = 0; k < g.n; ++k) live[(size_t)g.src.s[k]] = 1;
     int n_live = 0;
     for (int v = 0; v < n_old; ++v) n_live += live[(size_t)v];
+    mark("live flags");
     const int to_park = n_old - n_live;
     if (to_park < e->renumber_min_parked || (long long)to_park * 200 < (long long)n_live * e->renumber_growth_pct) {
         e->renumber_next = n_old + std::max(n_old / 8, 1); // look again after some more growth
@@ -518,11 +529,14 @@ int compact_ids(dppr_engine *e, bool *did) {
             HIP_TRY(hipMemcpyAsync(indeg.data(), d_deg, sizeof(int) * (size_t)n_old, hipMemcpyDeviceToHost, e->stream));
             HIP_TRY(hipStreamSynchronize(e->stream));
         }
+        mark("  in-degrees");
         std::vector<std::pair<uint64_t, int32_t>> order;
         order.reserve((size_t)n_live);
         for (int v = 0; v < n_old; ++v)
             if (live[(size_t)v]) order.emplace_back(id_hash(e->int2ext[(size_t)v]), v);
+        mark("  (hash, id) pairs");
         numbering_order(e, order, indeg.empty() ? nullptr : indeg.data());
+        mark("  blocks + sort");
         for (auto &kv : order) perm[(size_t)kv.second] = nl++;
         for (int v = 0; v < n_old; ++v)
             if (!live[(size_t)v]) perm[(size_t)v] = base + np++;
@@ -530,6 +544,7 @@ int compact_ids(dppr_engine *e, bool *did) {
         for (int v = 0; v < n_old; ++v) perm[(size_t)v] = live[(size_t)v] ? nl++ : base + np++;
     }
     for (int v = V - R_old; v < V; ++v) perm[(size_t)v] = base + np++;
+    mark("numbering order");
     for (int v = 0; v < V; ++v) {
         const int m = perm[(size_t)v];
         if (m < 0) continue;
@@ -541,6 +556,7 @@ int compact_ids(dppr_engine *e, bool *did) {
     e->n_int = n_live;
     e->n_parked = R_new;
     e->map_dirty = true;
+    mark("host maps");
     // device side
     int *d_perm = nullptr;
     double *tmp = nullptr;
@@ -564,6 +580,7 @@ int compact_ids(dppr_engine *e, bool *did) {
             return DPPR_ERR_HIP;                                         \
         }                                                                \
     } while (0)
+    mark("scratch allocation");
     RN_TRY(hipMemcpyAsync(d_perm, perm.data(), sizeof(int) * (size_t)V, hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(k_remap_ids, dim3(grid_for(e->W)), dim3(BLOCK), 0, e->stream, e->w1, e->W, d_perm);
     hipLaunchKernelGGL(k_remap_ids, dim3(grid_for(e->W)), dim3(BLOCK), 0, e->stream, e->w2, e->W, d_perm);
@@ -605,7 +622,9 @@ int compact_ids(dppr_engine *e, bool *did) {
     }
     RN_TRY(hipStreamSynchronize(e->stream));
 #undef RN_TRY
+    mark("ring, degrees, state rows");
     cleanup();
+    mark("scratch release");
     if (e->batch_staged) {
         for (auto &v : e->st_b1) v = perm[(size_t)v];
         for (auto &v : e->st_b2) v = perm[(size_t)v];
