@@ -61,6 +61,7 @@ inline void PrintUsage() {
               << "--split: drive each batch through IncrementalBatchUpdate/ExecuteMainLoop(0)/(1)\n"
               << "--sync: synchronous (deterministic) push schedule\n"
               << "--no-groups: with several sources per GPU, solve them one at a time (default: up to 16 together)\n"
+              << "--profile: per-iteration frontier lines and the phase-time report of the reference's -DPROFILE build (implies --split)\n"
               << "EXAMPLE: ./pagerank -d ../data/com-dblp.ungraph.bin -a 0 -i 0 -y 1 -w 0.1 -n 0 -r 0.01 -b 1000 -s 1\n"
               << "EXAMPLE: ./pagerank -d ../data/com-dblp.ungraph.bin -a 0 -i 0 -y 1 -w 0.1 -n 1 -c 100 -l 10000 -s 1"
               << std::endl;
@@ -121,6 +122,8 @@ inline void ArgumentsParser(int argc, char **argv) {
     gSplitInterface = has(argc, argv, "--split");
     gSchedule = has(argc, argv, "--sync") ? 1 : 0;
     gNoGroups = has(argc, argv, "--no-groups");
+    gProfile = has(argc, argv, "--profile");
+    if (gProfile) gSplitInterface = true; // the phases are timed and traced around the three virtual calls
     // -o: the reference's four variants are implementation ablations (eager vs pre-extracted residuals,
     // threshold-crossing vs status-array dedup, gpu/PPRRevPushGPUVariants.cuh); all of them enqueue a
     // vertex exactly when its residual ends the iteration legal. This engine has two schedules: the

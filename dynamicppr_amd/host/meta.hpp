@@ -42,4 +42,5 @@ inline std::string gDumpPath;         // --dump : write p/r of every source afte
 inline bool gValidate = false;        // --validate : the reference's -DVALIDATE checks at run time
 inline bool gSplitInterface = false;  // --split : drive the timed region through the 3 virtual calls
 inline int gSchedule = 0;             // --sync : deterministic synchronous schedule
+inline bool gProfile = false;         // --profile : the reference's -DPROFILE output (per-iteration frontier lines, phase times)
 inline bool gNoGroups = false;        // --no-groups : solve several sources one at a time instead of up to 16 together

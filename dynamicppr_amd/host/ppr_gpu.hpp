@@ -32,6 +32,31 @@
         }                                                                                           \
     } while (0)
 
+// --profile: what the reference prints when it is compiled with -DPROFILE (ProfileCommon.h:6-31 phase and counter
+// names, GPUProfiler::ReportProfile gpu/GPUProfiler.cuh:42-55, the per-iteration line of gpu/PPRRevPushGPU.cuh:109-111).
+// Phases are timed on the host clock around calls that synchronise the stream, scoped as gpu/PPRGPU.cuh:47-163 scopes
+// them. Inspect, Expand and RepairFrontier are ONE kernel per iteration here: their event-timed total is reported as
+// expand_time, inspect_time / repair_frontier_time stay 0 (as do the phases the reference's GPU path never starts).
+struct HostProfile {
+    enum Phase { INSPECT, EXPAND, INIT_GRAPH_CALC, DYNA_GRAPH_CALC, EXCLUDE_GRAPH_UPDATE, SORT, REDUCE, REPAIR_FRONTIER,
+                 INC_UPDATE, PUSH, TOTAL, PPR, PPR_UPDATE, PPR_QUERY, N_PHASES };
+    double ms[N_PHASES] = {0};
+    timespec t0[N_PHASES];
+    void Start(Phase p) { clock_gettime(CLOCK_MONOTONIC, &t0[p]); }
+    void End(Phase p) {
+        timespec b;
+        clock_gettime(CLOCK_MONOTONIC, &b);
+        ms[p] += (b.tv_sec - t0[p].tv_sec) * 1e3 + (b.tv_nsec - t0[p].tv_nsec) * 1e-6;
+    }
+    static const char *Name(int p) {
+        static const char *names[N_PHASES] = {"inspect_time", "expand_time", "init_graph_calculation_time",
+                                              "dynamic_graph_calculation_time", "exclude_graph_update_time", "sort_time",
+                                              "reduce_time", "repair_frontier_time", "inc_update_time", "push_time",
+                                              "total_time", "ppr_time", "ppr_update_time", "ppr_query_time"};
+        return names[p];
+    }
+};
+
 class PPRGPU {
 public:
     PPRGPU(SlidingGraphVec *g, int device, const std::vector<IndexType> &sources, bool quiet)
@@ -51,6 +76,8 @@ public:
 
     // gpu/PPRGPU.cuh:64-108
     virtual void DynamicExecute() {
+        prof.Start(HostProfile::TOTAL);
+        prof.Start(HostProfile::INIT_GRAPH_CALC);
         {
             EdgeBatch init_stream(graph->sliding_window_size);
             graph->SerializeEdgeStream(&init_stream);
@@ -59,6 +86,7 @@ public:
         // several sources on one device are solved together, up to 16 per group (multi-source batched
         // sweeps); --split keeps the reference's one-source-at-a-time driver flow
         use_groups = source_vertex_ids.size() > 1 && !gSplitInterface && !gNoGroups;
+        if (gProfile) DPPR_CHECK(engine, dppr_set_profiling(engine, 1));
         if (!quiet_) std::cout << "start..." << std::endl;
         if (use_groups) {
             for (size_t i = 0; i < source_vertex_ids.size(); i += kGroupMax) {
@@ -81,13 +109,52 @@ public:
                 DPPR_CHECK(engine, dppr_add_source(engine, source_vertex_ids[i], &slots[i]));
             for (size_t i = 0; i < slots.size(); ++i) { // Init + ExecuteMainLoop(0)
                 float ms = 0;
+                if (gProfile) DPPR_CHECK(engine, dppr_trace_enable(engine, slots[i], 1));
                 DPPR_CHECK(engine, dppr_init_solve(engine, slots[i], gTolerance, &ms));
+                if (gProfile) PrintIterations(i, 0);
                 if (!quiet_) std::cout << "elapsed time=" << ms << "ms" << std::endl;
                 if (gValidate) ValidateResult(i);
             }
         }
+        prof.End(HostProfile::INIT_GRAPH_CALC);
+        prof.Start(HostProfile::DYNA_GRAPH_CALC);
         SlidingWindowExecuteMainLoop();
+        prof.End(HostProfile::DYNA_GRAPH_CALC);
+        prof.End(HostProfile::TOTAL);
         if (!quiet_) std::cout << "finish!" << std::endl;
+        if (gProfile && !quiet_) ReportProfile();
+    }
+
+    // gpu/PPRRevPushGPU.cuh:109-111: one line per frontier iteration of the loop that just ran (the engine's iteration
+    // trace holds the frontier of every iteration; it is cleared for the next loop)
+    void PrintIterations(size_t i, size_t phase_id) {
+        int64_t n_iters = 0, n_ids = 0;
+        DPPR_CHECK(engine, dppr_trace_get(engine, slots[i], &n_iters, &n_ids, nullptr, nullptr));
+        std::vector<int64_t> off((size_t)n_iters + 1, 0);
+        if (n_iters > 0) DPPR_CHECK(engine, dppr_trace_get(engine, slots[i], nullptr, nullptr, off.data(), nullptr));
+        if (!quiet_)
+            for (int64_t it = 0; it < n_iters; ++it)
+                std::cout << "phase_id=" << phase_id << ",iteration_id=" << it << ",frontier_count=" << off[(size_t)it + 1] - off[(size_t)it]
+                          << std::endl;
+        DPPR_CHECK(engine, dppr_trace_enable(engine, slots[i], 1)); // (clears it)
+    }
+
+    // GPUProfiler::ReportProfile (gpu/GPUProfiler.cuh:42-55)
+    void ReportProfile() {
+        long long traverse = 0, expand = 0;
+        for (size_t i = 0; i < slots.size(); ++i) {
+            dppr_stats_t st;
+            DPPR_CHECK(engine, dppr_stats(engine, slots[i], &st));
+            prof.ms[HostProfile::EXPAND] += st.push_ms;
+            traverse += st.sum_E;
+            expand += st.sum_F;
+        }
+        std::cout << "****************** profile time **********************" << std::endl;
+        for (int j = 0; j < HostProfile::N_PHASES; ++j) std::cout << "[" << HostProfile::Name(j) << "]=" << prof.ms[j] << "ms ";
+        std::cout << std::endl;
+        std::cout << "[traverse_count]=" << traverse << " [expand_count]=" << expand
+                  << " [update_pos_residual_count]=0 [update_neg_residual_count]=0 [update_random_walk_count]=0 " << std::endl;
+        std::cout << "****************** end profile  **********************" << std::endl;
     }
 
     // gpu/PPRGPU.cuh:109-177
@@ -96,11 +163,14 @@ public:
         while (stream_batch_count++ < gStreamBatchCount) {
             if (!quiet_ && (gStreamUpdateCountPerBatch > 100 || stream_batch_count % 100 == 0))
                 Report(stream_batch_count);
+            prof.Start(HostProfile::EXCLUDE_GRAPH_UPDATE);
             if (graph->StreamUpdates(gStreamUpdateCountPerBatch)) break; // partial batch: dropped
             // ---- untimed: batch upload + device graph rebuild ----
             DPPR_CHECK(engine, dppr_set_batch(engine, graph->edge_batch->edge1, graph->edge_batch->edge2,
                                               graph->edge_batch->is_insert, graph->edge_batch->length));
             GPUBuildSlidingGraph();
+            prof.End(HostProfile::EXCLUDE_GRAPH_UPDATE);
+            prof.Start(HostProfile::PPR);
             // ---- timed: IncrementalBatchUpdate + ExecuteMainLoop(0) + (1), per source or per group ----
             for (size_t k = 0; k < groups.size(); ++k) {
                 float ms = 0;
@@ -115,9 +185,15 @@ public:
                     // timed on the host: the three calls each synchronise the stream
                     struct timespec a, b;
                     clock_gettime(CLOCK_MONOTONIC, &a);
+                    prof.Start(HostProfile::INC_UPDATE);
                     IncrementalBatchUpdate(i);
+                    prof.End(HostProfile::INC_UPDATE);
+                    prof.Start(HostProfile::PUSH);
                     ExecuteMainLoop(i, 0);
+                    if (gProfile) PrintIterations(i, 0);
                     ExecuteMainLoop(i, 1);
+                    if (gProfile) PrintIterations(i, 1);
+                    prof.End(HostProfile::PUSH);
                     clock_gettime(CLOCK_MONOTONIC, &b);
                     ms = (float)((b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6);
                 } else {
@@ -126,6 +202,7 @@ public:
                 ppr_time[i] += ms;
                 if (gValidate) ValidateResult(i);
             }
+            prof.End(HostProfile::PPR);
         }
         batches_done = stream_batch_count - 1;
         if (!quiet_) Report(stream_batch_count);
@@ -226,6 +303,7 @@ public:
     std::vector<int32_t> groups; // one per 16 sources (group mode: several sources per device)
     bool use_groups = false;
     std::vector<float> ppr_time; // ms per source (single mode) or per group, timed region only
+    HostProfile prof;
     size_t batches_done = 0;
 
 protected:

@@ -177,3 +177,49 @@ def test_cli_long_churning_stream_renumbers_and_matches_oracle(pagerank, tmp_pat
             s.cilk_inc_execute(g)
         for k in outs:
             assert np.max(np.abs(outs[k][sv][0] - s.p)) < 1e-9 and np.max(np.abs(outs[k][sv][1])) < 1e-9, (k, sv)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("directed", [1, 0])
+def test_cli_profile_output_matches_the_reference_profile_build(pagerank, small_bin, directed):
+    """--profile = the reference compiled with -DPROFILE: one `phase_id=..,iteration_id=..,frontier_count=..` line per
+    frontier iteration (gpu/PPRRevPushGPU.cuh:109-111) and the phase report of GPUProfiler::ReportProfile. With --sync
+    the frontier sizes are those of the oracle's synchronous schedule, iteration for iteration."""
+    path, V, e1, e2 = small_bin
+    W, c, batches = 600, 6, 4
+    src = int(datagen.top_sources(V, e1, e2, W, directed, 1)[0])
+    r = run([pagerank, "-d", path, "-a", "0", "-i", str(directed), "-y", "1", "-w", "0.1", "-n", "0", "-r", "0.01",
+             "-b", str(batches), "-s", str(src), "--sync", "--profile"])
+    assert r.returncode == 0, r.stdout
+    got = [(int(a), int(b), int(f)) for a, b, f in re.findall(r"^phase_id=(\d+),iteration_id=(\d+),frontier_count=(\d+)$", r.stdout, flags=re.M)]
+    g = orc.Graph(V, e1, e2, directed, W, c)
+    s = orc.State(V, src, 1e-9)
+    s.trace(True)
+    want = []
+
+    def loop(phase):
+        before = len(s.traced_frontiers())
+        s.sync_main_loop(g, phase)
+        for it, f in enumerate(s.traced_frontiers()[before:]):
+            want.append((phase, it, len(f)))
+
+    s.sync_execute(g)  # the from-scratch solve: Init + ExecuteMainLoop(0)
+    want += [(0, it, len(f)) for it, f in enumerate(s.traced_frontiers())]
+    for _ in range(batches):
+        assert not g.stream_updates()
+        g.inc_construct(1)
+        s.copy_revert_out_degree(g)
+        s.stream_update(g)
+        loop(0)
+        loop(1)
+    assert got == want
+    m = re.search(r"\*+ profile time \*+\n(.*)\n(.*)\n\*+ end profile", r.stdout)
+    assert m, r.stdout[-600:]
+    t = {k: float(v) for k, v in re.findall(r"\[(\w+)\]=([-+.e\d]+)ms", m.group(1))}
+    assert list(t) == ["inspect_time", "expand_time", "init_graph_calculation_time", "dynamic_graph_calculation_time",
+                       "exclude_graph_update_time", "sort_time", "reduce_time", "repair_frontier_time", "inc_update_time",
+                       "push_time", "total_time", "ppr_time", "ppr_update_time", "ppr_query_time"]
+    assert t["total_time"] >= t["init_graph_calculation_time"] + t["dynamic_graph_calculation_time"] - 1e-3
+    assert t["ppr_time"] >= t["inc_update_time"] + t["push_time"] - 1e-3 and t["push_time"] > 0 and t["expand_time"] > 0
+    cnt = {k: int(v) for k, v in re.findall(r"\[(\w+)\]=(\d+) ", m.group(2))}
+    assert cnt["expand_count"] == sum(f for _, _, f in want) and cnt["traverse_count"] == s.stats()["E"]
