@@ -252,19 +252,21 @@ void revive(dppr_engine *e, int ext) {
         auto it = e->mv_origin.find(pos);
         return it == e->mv_origin.end() ? pos : it->second;
     };
-    const int fresh = e->n_int++; // < lo: n_int + n_parked never exceeds the vertices that have an id
+    // fresh <= lo: n_int + n_parked never exceeds the vertices that have an id (== lo when every vertex has one and the
+    // two zones touch: then the revived vertex takes the slot the parked zone gives up)
+    const int fresh = e->n_int++;
     const int oq = origin(q), olo = origin(lo);
-    e->mv_origin[fresh] = oq;
-    e->ext2int[(size_t)ext] = fresh;
-    e->int2ext[(size_t)fresh] = ext;
-    if (q != lo) {
+    if (q != lo) { // the lowest parked entry fills the hole
         const int y = e->int2ext[(size_t)lo];
         e->mv_origin[q] = olo;
         e->ext2int[(size_t)y] = q;
         e->int2ext[(size_t)q] = y;
     }
-    e->mv_origin[lo] = -1; // vacated: zero rows (the live zone grows into it)
+    e->mv_origin[lo] = -1; // vacated: zero rows (the live zone grows into it) -- unless it is `fresh` itself, below
     e->int2ext[(size_t)lo] = -1;
+    e->mv_origin[fresh] = oq;
+    e->ext2int[(size_t)ext] = fresh;
+    e->int2ext[(size_t)fresh] = ext;
     e->n_parked--;
     e->revivals++;
     e->map_dirty = true;

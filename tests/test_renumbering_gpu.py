@@ -273,3 +273,48 @@ def test_randomised_churn_with_random_staging(seed):
     sp = e.id_space()
     print("id space", seed, sp)
     assert sp["ids"] + sp["parked"] <= V
+
+
+@pytest.mark.parametrize("directed", [1, 0])
+def test_every_vertex_has_an_id_and_the_two_zones_touch(directed):
+    """A small id range that the stream exhausts: live zone and parked zone fill the whole capacity, a revived vertex
+    takes exactly the slot the parked zone gives up."""
+    V, W, c, eps, batches = 96, 60, 6, 1e-9, 120
+    rng = np.random.default_rng(77 + directed)
+    n = W + batches * c
+    centre = (np.arange(n) // 3) % V  # the active band wanders around the whole range, several times
+    e1 = ((centre + rng.integers(0, 24, n)) % V).astype(np.int32)
+    e2 = ((centre + rng.integers(0, 24, n)) % V).astype(np.int32)
+    e2[e1 == e2] = (e2[e1 == e2] + 1) % V
+    g = orc.Graph(V, e1, e2, directed, W, c)
+    sources = [int(e1[0]), int(e2[0]), 5]
+    states = [orc.State(V, s, eps) for s in sources]
+    e = eng.Engine(V, W, directed, c, schedule=eng.SCHEDULE_SYNC)
+    e.set_renumbering(1, growth_pct=2, min_parked=1)
+    e.load_window(*g.window_edges())
+    slot = e.add_source(sources[0])
+    gid = e.add_source_group(sources)
+    for s in states:
+        s.sync_execute(g)
+    e.init_solve(slot, eps)
+    e.group_init_solve(gid, eps)
+    touched = False
+    for k in range(batches):
+        assert not g.stream_updates()
+        g.inc_construct(1)
+        e.set_batch(*g.batch())
+        e.slide(*g.new_stream())
+        for s in states:
+            s.sync_inc_execute(g)
+        e.update(slot, eps)
+        e.group_update(gid, eps)
+        sp = e.id_space()
+        assert sp["ids"] + sp["parked"] <= V
+        touched |= sp["ids"] + sp["parked"] == V
+        p, r = e.read(slot)
+        assert np.max(np.abs(p - states[0].p)) < SYNC_TOL and np.max(np.abs(r - states[0].r)) < SYNC_TOL, k
+        for i, s in enumerate(states):
+            p, r = e.group_read(gid, i)
+            assert np.max(np.abs(p - s.p)) < SYNC_TOL and np.max(np.abs(r - s.r)) < SYNC_TOL, (k, i)
+    sp = e.id_space()
+    assert touched and sp["renumberings"] >= 3 and sp["revivals"] > 10, sp
