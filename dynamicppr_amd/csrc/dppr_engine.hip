@@ -1478,6 +1478,12 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
                 HIP_TRY(hipEventElapsedTime(&ms, e->evpool[2 * k], e->evpool[2 * k + 1]));
                 g.st.push_ms += ms;
                 g.st.push_launches++;
+                static const bool trace = getenv("DPPR_GROUP_TRACE") != nullptr; // (diagnostic: one line per sweep)
+                if (trace) {
+                    long long F = 0;
+                    for (int s = 0; s < GWM; ++s) F += f[s];
+                    fprintf(stderr, "[gsweep] phase %d sweep %3d  frontier pairs %9lld  %7.1f us\n", phase, it + k, F, ms * 1e3);
+                }
             }
         }
         more = any_left(e->pinned + cur * GWM);
