@@ -1,0 +1,39 @@
+"""bench.py end to end on the smallest stand-in: ONE JSON line with the keys the driver and the judge read
+(metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype /
+data / config.workload, plus roofline, cpu_baseline and the in-run parity block), consistent with each other."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("extra,sources", [([], 1), (["--sources", "3"], 3), (["--sources", "10"], 10)])
+def test_bench_line_contract(extra, sources):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "dblp", "--steps", "4", "--warmup", "2",
+                        "--cpu-batches", "1"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"] and len(d["config"]["sources"]) == sources
+    # value = edge updates of all sources per second of the timed region
+    c = d["config"]["batch_c"]
+    assert abs(d["value"] - sources * c / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and 0 < rf["frac"] < 1
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    pr = d["parity"]
+    assert pr["ok"] is True and pr["max_abs_residual"] < pr["eps"] and pr["invariant_max_err"] < 1e-12
+    assert pr["max_abs_dp_vs_cpu_t1"] is not None and pr["max_abs_dp_vs_cpu_t1"] < pr["tolerance"]
