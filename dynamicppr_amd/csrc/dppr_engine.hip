@@ -19,6 +19,7 @@
 #include <rocprim/rocprim.hpp> // device radix sort only (CSR rebuild, batch grouping); no CUB/Thrust in kernels
 
 #include "../../include/dppr.h"
+#include "dppr_idspace.hpp"
 #include "dppr_kernels.hpp"
 #include "dppr_multi.hpp"
 
@@ -119,7 +120,7 @@ struct Group {
 
 } // namespace
 
-struct dppr_engine {
+struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pending row moves: dppr_idspace.hpp)
     int device = 0;
     int V = 0, W = 0, c = 0, directed = 1, n_epochs = 1;
     int Ed = 0;   // directed edges in the window
@@ -190,26 +191,19 @@ struct dppr_engine {
     std::vector<Slot> slots;
     std::vector<Group> groups;
     int *pinned = nullptr; // host-pinned readback words
-    // vertex compaction: external id <-> internal id (assigned on first appearance)
-    std::vector<int32_t> ext2int, int2ext; // both V long; int2ext[i] = -1: position i holds no vertex
-    int n_int = 0;
-    // renumbering (dppr_builder.hpp): ids [0, n_int) are swept and scanned, [V - n_parked, V) hold the state rows of
-    // vertices without an edge in the window
-    int n_parked = 0;
-    bool renumber = true;          // dppr_set_renumbering
+    // vertex compaction: external id <-> internal id (assigned on first appearance), live zone [0, n_int) and parked
+    // zone [V - n_parked, V): IdSpace. Renumbering (dppr_builder.hpp) is decided here:
+    bool renumber_on = true;       // dppr_set_renumbering
     int renumber_growth_pct = 15;  // a slide considers it once n_int has grown by this much since the last numbering ...
     int renumber_min_parked = 1024; // ... and does it if at least this many ids (and growth_pct / 2 % of the live ones) would be parked
     int renumber_next = 0;         // n_int at which the next slide looks at the live count
     int renumberings = 0;
-    long long revivals = 0;
-    std::vector<int32_t> mv_src, mv_dst, mv_zero; // pending row moves of revived vertices (flush_moves)
-    std::unordered_map<int32_t, int32_t> mv_origin; // position -> position whose rows it will receive (-1: zero rows)
+    std::vector<int32_t> mv_src, mv_dst, mv_zero; // row moves of revived vertices being applied (flush_moves)
     int *mv_idx = nullptr;         // device: src | dst | zero lists
     size_t mv_idx_cap = 0;
     double *mv_tmp = nullptr;      // device: the rows in flight
     size_t mv_tmp_cap = 0;
     int *d_ext2int = nullptr;  // device copy of ext2int, refreshed on demand
-    bool map_dirty = true;
     double *d_xfer = nullptr;  // V doubles: staging of p / r in external order
     std::vector<int32_t> h_tmp1, h_tmp2;
     std::vector<int32_t> h_tiles; // host copy of the tile edge prefix / group table
@@ -242,47 +236,7 @@ int fail(dppr_engine *e, int code, const char *msg) {
     return code;
 }
 
-// A parked vertex is needed again: fresh id at the end of the live zone, its rows follow (flush_moves), the lowest
-// parked entry fills the hole so that the parked zone stays [V - n_parked, V) without gaps. Only the host maps
-// change here; mv_origin composes the moves (a position may receive rows and give its own away in one slide).
-void revive(dppr_engine *e, int ext) {
-    const int q = e->ext2int[(size_t)ext];
-    const int lo = e->V - e->n_parked;
-    auto origin = [&](int pos) {
-        auto it = e->mv_origin.find(pos);
-        return it == e->mv_origin.end() ? pos : it->second;
-    };
-    // fresh <= lo: n_int + n_parked never exceeds the vertices that have an id (== lo when every vertex has one and the
-    // two zones touch: then the revived vertex takes the slot the parked zone gives up)
-    const int fresh = e->n_int++;
-    const int oq = origin(q), olo = origin(lo);
-    if (q != lo) { // the lowest parked entry fills the hole
-        const int y = e->int2ext[(size_t)lo];
-        e->mv_origin[q] = olo;
-        e->ext2int[(size_t)y] = q;
-        e->int2ext[(size_t)q] = y;
-    }
-    e->mv_origin[lo] = -1; // vacated: zero rows (the live zone grows into it) -- unless it is `fresh` itself, below
-    e->int2ext[(size_t)lo] = -1;
-    e->mv_origin[fresh] = oq;
-    e->ext2int[(size_t)ext] = fresh;
-    e->int2ext[(size_t)fresh] = ext;
-    e->n_parked--;
-    e->revivals++;
-    e->map_dirty = true;
-}
-
-inline int to_int(dppr_engine *e, int ext) { // external -> internal id, assigning a new one on first sight
-    int32_t &m = e->ext2int[(size_t)ext];
-    if (m < 0) {
-        m = e->n_int++;
-        e->int2ext[(size_t)m] = ext;
-        e->map_dirty = true;
-    } else if (m >= e->V - e->n_parked) {
-        revive(e, ext);
-    }
-    return e->ext2int[(size_t)ext];
-}
+inline int to_int(dppr_engine *e, int ext) { return e->to_int(ext); } // (IdSpace: assigns, or revives a parked vertex)
 
 // translate an id array; returns false if any id is outside [0, V)
 bool translate(dppr_engine *e, const int32_t *src, int n, std::vector<int32_t> &dst) {
@@ -385,17 +339,7 @@ void numbering_order(const dppr_engine *e, std::vector<std::pair<uint64_t, int32
 // and the fresh id lies beyond the ids every older epoch sweeps.
 int flush_moves(dppr_engine *e) {
     if (e->mv_origin.empty()) return DPPR_OK;
-    e->mv_src.clear();
-    e->mv_dst.clear();
-    e->mv_zero.clear();
-    for (const auto &kv : e->mv_origin) {
-        if (kv.second < 0) e->mv_zero.push_back(kv.first);
-        else if (kv.second != kv.first) {
-            e->mv_src.push_back(kv.second);
-            e->mv_dst.push_back(kv.first);
-        }
-    }
-    e->mv_origin.clear();
+    e->take_moves(e->mv_src, e->mv_dst, e->mv_zero);
     const int n = (int)e->mv_src.size(), nz = (int)e->mv_zero.size();
     if (e->slots.empty() && e->groups.empty()) return DPPR_OK;
     const size_t need_idx = (size_t)2 * n + nz + 1;
@@ -468,14 +412,14 @@ int settle_parked(dppr_engine *e, double *p, double *r, int w, double eps, doubl
 // numbering, and *did tells the caller to sort the whole window for the epoch it is about to build.
 int compact_ids(dppr_engine *e, bool *did) {
     *did = false;
-    if (!e->renumber || e->W == 0 || e->n_int < e->renumber_next) return DPPR_OK;
+    if (!e->renumber_on || e->W == 0 || e->n_int < e->renumber_next) return DPPR_OK;
     if (e->slots.empty() && e->groups.empty()) return DPPR_OK;
     for (const auto &s : e->slots)
         if (!s.converged || s.last_epoch != e->newest) return DPPR_OK;
     for (const auto &g : e->groups)
         if (!g.converged || g.last_epoch != e->newest) return DPPR_OK;
     if (int rc = flush_moves(e)) return rc;
-    const int V = e->V, n_old = e->n_int, R_old = e->n_parked;
+    const int V = e->V, n_old = e->n_int;
     static const bool trace = getenv("DPPR_RENUMBER_TRACE") != nullptr; // (diagnostic: where a renumbering's time goes)
     timespec t_mark;
     clock_gettime(CLOCK_MONOTONIC, &t_mark);
@@ -518,9 +462,7 @@ int compact_ids(dppr_engine *e, bool *did) {
     // same work). Beyond REHASH_MAX live vertices the old relative order is kept (a host sort of that many pairs
     // would stall the stream; the blocks of the initial numbering survive).
     constexpr int REHASH_MAX = 8 << 20;
-    std::vector<int32_t> perm((size_t)V, -1), new_i2e((size_t)V, -1);
-    const int R_new = R_old + to_park, base = V - R_new;
-    int nl = 0, np = 0;
+    std::vector<int32_t> perm, order;
     if (n_live <= REHASH_MAX) {
         std::vector<int32_t> indeg;
         if ((size_t)n_live > HOT_WINDOW_MIN) {
@@ -532,32 +474,17 @@ int compact_ids(dppr_engine *e, bool *did) {
             HIP_TRY(hipStreamSynchronize(e->stream));
         }
         mark("  in-degrees");
-        std::vector<std::pair<uint64_t, int32_t>> order;
-        order.reserve((size_t)n_live);
+        std::vector<std::pair<uint64_t, int32_t>> keyed;
+        keyed.reserve((size_t)n_live);
         for (int v = 0; v < n_old; ++v)
-            if (live[(size_t)v]) order.emplace_back(id_hash(e->int2ext[(size_t)v]), v);
+            if (live[(size_t)v]) keyed.emplace_back(id_hash(e->int2ext[(size_t)v]), v);
         mark("  (hash, id) pairs");
-        numbering_order(e, order, indeg.empty() ? nullptr : indeg.data());
+        numbering_order(e, keyed, indeg.empty() ? nullptr : indeg.data());
         mark("  blocks + sort");
-        for (auto &kv : order) perm[(size_t)kv.second] = nl++;
-        for (int v = 0; v < n_old; ++v)
-            if (!live[(size_t)v]) perm[(size_t)v] = base + np++;
-    } else {
-        for (int v = 0; v < n_old; ++v) perm[(size_t)v] = live[(size_t)v] ? nl++ : base + np++;
+        order.reserve(keyed.size());
+        for (auto &kv : keyed) order.push_back(kv.second);
     }
-    for (int v = V - R_old; v < V; ++v) perm[(size_t)v] = base + np++;
-    mark("numbering order");
-    for (int v = 0; v < V; ++v) {
-        const int m = perm[(size_t)v];
-        if (m < 0) continue;
-        const int ext = e->int2ext[(size_t)v];
-        new_i2e[(size_t)m] = ext;
-        e->ext2int[(size_t)ext] = m;
-    }
-    e->int2ext.swap(new_i2e);
-    e->n_int = n_live;
-    e->n_parked = R_new;
-    e->map_dirty = true;
+    e->renumber(live, order, perm); // (IdSpace: perm, the maps, n_int, n_parked)
     mark("host maps");
     // device side
     int *d_perm = nullptr;
@@ -1554,7 +1481,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     if (const char *v = getenv("DPPR_SWEEP_BITS")) e->sweep_bits = atoi(v) != 0; // diagnostic A/B switches
     if (const char *v = getenv("DPPR_HOT_BLOCKS")) e->hot_blocks = atoi(v) != 0;
     if (const char *v = getenv("DPPR_GSWEEP_GRID")) e->gsweep_grid_cap = std::max(1, std::min(atoi(v), STAT_SLOTS));
-    if (const char *v = getenv("DPPR_RENUMBER")) e->renumber = atoi(v) != 0;
+    if (const char *v = getenv("DPPR_RENUMBER")) e->renumber_on = atoi(v) != 0;
     if (const char *v = getenv("DPPR_RENUMBER_PCT")) e->renumber_growth_pct = std::max(1, atoi(v));
     if (const char *v = getenv("DPPR_RENUMBER_MIN")) e->renumber_min_parked = std::max(1, atoi(v));
     if (const char *v = getenv("DPPR_GGROUPS_MIN")) e->ggroups_min = std::max(1, atoi(v));
@@ -1583,8 +1510,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     HIP_TRY_C(hipMalloc((void **)&e->hub_slot_of, sizeof(int) * (size_t)V));
     HIP_TRY_C(hipMalloc((void **)&e->d_ext2int, sizeof(int) * (size_t)V));
     HIP_TRY_C(hipMalloc((void **)&e->d_xfer, sizeof(double) * (size_t)V));
-    e->ext2int.assign((size_t)V, -1);
-    e->int2ext.assign((size_t)V, -1);
+    e->init_ids(V);
     HIP_TRY_C(hipMalloc((void **)&e->hub_hist, sizeof(int) * 64));
     HIP_TRY_C(hipMalloc((void **)&e->bar, sizeof(GridBar)));
     HIP_TRY_C(hipMalloc((void **)&e->keys_a, sizeof(uint64_t) * Edn));
@@ -1732,7 +1658,7 @@ int dppr_set_group_seeding(dppr_engine *e, int from_tails) {
 
 int dppr_set_renumbering(dppr_engine *e, int on, int growth_pct, int min_parked) {
     if (!e || growth_pct < 0 || min_parked < 0) return fail(e, DPPR_ERR_INVALID, "set_renumbering: bad argument");
-    e->renumber = on != 0;
+    e->renumber_on = on != 0;
     if (growth_pct > 0) e->renumber_growth_pct = growth_pct;
     if (min_parked > 0) e->renumber_min_parked = min_parked;
     e->renumber_next = std::min(e->renumber_next, e->n_int + std::max(e->n_int * e->renumber_growth_pct / 100, 1));

@@ -1,0 +1,26 @@
+"""Host side of the engine's vertex numbering (dynamicppr_amd/csrc/dppr_idspace.hpp: id maps, parked zone, composed
+row moves of revived vertices, renumbering permutations) driven on the CPU by tests/native/idspace_test.cpp against
+plain host arrays, built with the address and undefined-behaviour sanitizers. CPU only."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("native") / "idspace_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-Wall",
+                           "-Werror", "-o", exe, os.path.join(ROOT, "tests", "native", "idspace_test.cpp")])
+    return exe
+
+
+# (capacity, operations): tiny ranges keep the live and the parked zone touching nearly all the time
+@pytest.mark.parametrize("seed,cap,ops", [(1, 40, 20000), (2, 40, 20000), (3, 7, 20000), (4, 3, 5000), (5, 500, 30000), (6, 97, 30000),
+                                          (7, 2, 2000), (8, 1, 500)])
+def test_random_sightings_revivals_flushes_and_renumberings(driver, seed, cap, ops):
+    r = subprocess.run([driver, str(seed), str(cap), str(ops)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " 0 failures" in r.stdout
