@@ -24,3 +24,19 @@ def test_random_sightings_revivals_flushes_and_renumberings(driver, seed, cap, o
     r = subprocess.run([driver, str(seed), str(cap), str(ops)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
     assert " 0 failures" in r.stdout
+
+
+@pytest.fixture(scope="module")
+def numbering_driver(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("native") / "numbering_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-Wall",
+                           "-Werror", "-o", exe, os.path.join(ROOT, "tests", "native", "numbering_test.cpp")])
+    return exe
+
+
+# n: hash only (small windows), one counting pass on 16 / 21 key bits, with hot blocks of falling in-degree or two blocks
+@pytest.mark.parametrize("seed,n,hot", [(1, 300000, 1), (2, 700000, 1), (3, 700000, 0), (4, 5000, 1), (5, 100000, 1), (6, 262145, 1),
+                                        (7, 1, 1), (8, 65536, 1), (9, 524289, 0)])
+def test_numbering_order_equals_its_plain_restatement(numbering_driver, seed, n, hot):
+    r = subprocess.run([numbering_driver, str(seed), str(n), str(hot)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and ": 0 mismatches" in r.stdout, r.stdout[-2000:]
