@@ -19,6 +19,7 @@
 #include <rocprim/rocprim.hpp> // device radix sort only (CSR rebuild, batch grouping); no CUB/Thrust in kernels
 
 #include "../../include/dppr.h"
+#include "dppr_cut.hpp"
 #include "dppr_idspace.hpp"
 #include "dppr_kernels.hpp"
 #include "dppr_multi.hpp"
@@ -604,58 +605,19 @@ int cut_sweep_groups(dppr_engine *e, Epoch &ep) {
                                e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
-    const long long total_w = (n_tiles ? (long long)e->h_tiles[(size_t)n_tiles] : 0) + 2ll * WAVE * n_tiles;
     std::vector<int32_t> cut;
-    auto greedy = [&](long long want_groups) {
-        const long long target = std::max<long long>(1, total_w / std::max<long long>(1, want_groups));
-        cut.clear();
-        cut.push_back(0);
-        long long acc = 0;
-        int first = 0;
-        for (int t = 0; t < n_tiles; ++t) {
-            acc += (long long)(e->h_tiles[(size_t)t + 1] - e->h_tiles[(size_t)t]) + 2 * WAVE;
-            if (acc >= target || t + 1 - first == max_tiles) {
-                cut.push_back(t + 1);
-                first = t + 1;
-                acc = 0;
-            }
-        }
-        if (cut.back() != n_tiles) cut.push_back(n_tiles);
-    };
+    const int32_t *prefix = e->h_tiles.data();
     // A window small enough for one workgroup per group to be resident at once gets at most that
     // many groups (then runs of dense iterations are single launches, dppr_resident.hpp). A resident
     // workgroup's time is its edge count (every iteration all workgroups wait for the slowest one's
-    // values), so this cut MINIMISES THE LARGEST group: bisection on the bound, first-fit inside.
+    // values), so this cut MINIMISES THE LARGEST group (dppr_cut.hpp); per tile the per-vertex work of a
+    // resident workgroup is small and fixed (weight 8). Otherwise: many groups of about equal weight.
     const int cap = persist_capacity(e);
     bool fitted = false;
-    if (cap > 0 && (long long)n_tiles <= (long long)cap * max_tiles * 7 / 8) {
-        const long long vterm = 8; // per tile: the per-vertex work of a resident workgroup is small and fixed
-        auto pack = [&](long long bound) { // first-fit with groups of weight <= bound; false if a tile alone exceeds it
-            cut.clear();
-            cut.push_back(0);
-            long long acc = 0;
-            int first = 0;
-            for (int t = 0; t < n_tiles; ++t) {
-                const long long wt = (long long)(e->h_tiles[(size_t)t + 1] - e->h_tiles[(size_t)t]) + vterm;
-                if (t > first && (acc + wt > bound || t - first == max_tiles)) {
-                    cut.push_back(t);
-                    first = t;
-                    acc = 0;
-                }
-                acc += wt;
-            }
-            cut.push_back(n_tiles);
-            return (int)cut.size() - 1;
-        };
-        long long lo = 1, hi = (long long)e->h_tiles[(size_t)n_tiles] + vterm * n_tiles + 1;
-        while (lo < hi) { // smallest bound that needs at most cap groups
-            const long long mid = (lo + hi) / 2;
-            if (pack(mid) <= cap) hi = mid; else lo = mid + 1;
-        }
-        fitted = pack(lo) <= cap;
-    }
+    if (cap > 0 && (long long)n_tiles <= (long long)cap * max_tiles * 7 / 8) fitted = cut_minmax(prefix, n_tiles, max_tiles, cap, 8, cut);
     if (!fitted)
-        greedy(std::max<long long>(252, (n_tiles + max_tiles * 3 / 4 - 1) / std::max(1, max_tiles * 3 / 4)));
+        cut_greedy(prefix, n_tiles, max_tiles,
+                   std::max<long long>(252, (n_tiles + max_tiles * 3 / 4 - 1) / std::max(1, max_tiles * 3 / 4)), 2 * WAVE, cut);
     ep.n_groups = (int)cut.size() - 1;
     ep.grp_n_int = NV;
     HIP_TRY(hipMemcpyAsync(ep.grp_tile, cut.data(), sizeof(int) * cut.size(), hipMemcpyHostToDevice, e->stream));
@@ -664,21 +626,8 @@ int cut_sweep_groups(dppr_engine *e, Epoch &ep) {
     if (e->any_groups) { // groups of at most 16 (8) tiles for k_gsweep<1, 1024> (<2, 512>)
         const int gmax = (e->wide_groups ? 512 : 1024) / WAVE;
         const long long want = std::max<long long>(e->ggroups_min, (n_tiles + gmax * 3 / 4 - 1) / std::max(1, gmax * 3 / 4));
-        const long long target = std::max<long long>(1, total_w / want);
         ep.ggrp_max_tiles = gmax;
-        cut.clear();
-        cut.push_back(0);
-        long long acc = 0;
-        int first = 0;
-        for (int t = 0; t < n_tiles; ++t) {
-            acc += (long long)(e->h_tiles[(size_t)t + 1] - e->h_tiles[(size_t)t]) + 2 * WAVE;
-            if (acc >= target || t + 1 - first == gmax) {
-                cut.push_back(t + 1);
-                first = t + 1;
-                acc = 0;
-            }
-        }
-        if (cut.back() != n_tiles) cut.push_back(n_tiles);
+        cut_greedy(prefix, n_tiles, gmax, want, 2 * WAVE, cut);
         ep.n_ggroups = (int)cut.size() - 1;
         HIP_TRY(hipMemcpyAsync(ep.ggrp_tile, cut.data(), sizeof(int) * cut.size(), hipMemcpyHostToDevice, e->stream));
         // the groups' row tables, once per epoch (every sweep of every source group of this epoch loads them)

@@ -1,4 +1,4 @@
-"""Host side of the engine's vertex numbering (dynamicppr_amd/csrc/dppr_idspace.hpp: id maps, parked zone, composed
+"""Host logic of the engine kept in HIP-free headers. Vertex numbering (dynamicppr_amd/csrc/dppr_idspace.hpp: id maps, parked zone, composed
 row moves of revived vertices, renumbering permutations) driven on the CPU by tests/native/idspace_test.cpp against
 plain host arrays, built with the address and undefined-behaviour sanitizers. CPU only."""
 import os
@@ -40,3 +40,14 @@ def numbering_driver(tmp_path_factory):
 def test_numbering_order_equals_its_plain_restatement(numbering_driver, seed, n, hot):
     r = subprocess.run([numbering_driver, str(seed), str(n), str(hot)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0 and ": 0 mismatches" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_sweep_group_cuts(tmp_path, seed):
+    """dppr_cut.hpp: cuts are well formed on random tile weights, a greedy group is closed by the tile that takes it to the
+    target, and the min-max cut of a resident launch equals an exhaustive optimum on small inputs."""
+    exe = str(tmp_path / "cut_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-Wall",
+                           "-Werror", "-o", exe, os.path.join(ROOT, "tests", "native", "cut_test.cpp")])
+    r = subprocess.run([exe, str(seed), "3000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and " 0 failures" in r.stdout, r.stdout[-2000:]
