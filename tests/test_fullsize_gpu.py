@@ -177,7 +177,8 @@ def test_eight_gpu_configs_at_full_size_on_one_gpu_properties(key, nsrc):
     e.close()
 
 
-@pytest.mark.parametrize("key,nsrc,batches", [("youtube", 1, 90), ("livejournal", 10, 36)])
+# (twitter: beyond 8 M live vertices a renumbering keeps the survivors' relative order instead of numbering afresh)
+@pytest.mark.parametrize("key,nsrc,batches", [("youtube", 1, 90), ("livejournal", 10, 36), ("twitter", 1, 9)])
 def test_long_in_step_run_at_full_size_renumbers_and_agrees_with_an_unrenumbered_engine(key, nsrc, batches):
     """The reference driver's flow at full size with the id renumbering at work (threshold lowered so that it
     happens several times within the test): p of every source agrees with an engine that never renumbers, the
@@ -191,7 +192,7 @@ def test_long_in_step_run_at_full_size_renumbers_and_agrees_with_an_unrenumbered
     engines = []
     for on in (1, 0):
         e = eng.Engine(V, W, cfg.directed, c)
-        e.set_renumbering(on, growth_pct=4, min_parked=256)
+        e.set_renumbering(on, growth_pct=2 if key == "twitter" else 4, min_parked=256)
         ss = st.SlidingStream(V, e1, e2, cfg.directed, wl)
         e.load_window(*ss.serialize_edge_stream())
         if nsrc == 1:
@@ -221,4 +222,4 @@ def test_long_in_step_run_at_full_size_renumbers_and_agrees_with_an_unrenumbered
         assert invariant_max_err_np(pb, rb, src, dst, V, sv) < INVARIANT_TOL
     a, b = ea.id_space(), eb.id_space()
     print("[id space]", key, a, b)
-    assert a["renumberings"] >= 2 and a["parked"] > 0 and b["renumberings"] == 0 and a["ids"] < b["ids"]
+    assert a["renumberings"] >= (1 if key == "twitter" else 2) and a["parked"] > 0 and b["renumberings"] == 0 and a["ids"] < b["ids"]
