@@ -236,6 +236,44 @@ __global__ __launch_bounds__(BLOCK) void k_in_degree(const int *__restrict__ w1,
     }
 }
 
+// Numbering order of a renumbering, on the device (the host version is dppr::numbering_order, dppr_idspace.hpp: same
+// hash, same blocks of falling in-degree). key = block << 58 | hash >> 6 for a live vertex, top bit set for the others
+// (they sort behind every live one, in id order); a radix sort of (key, id) pairs gives the order.
+struct HotThresholds {
+    int n;      // thresholds in use (0: hashed order only)
+    int thr[8]; // in-degree of rank 512 K, 256 K, ..., 8 K among the live vertices (non-decreasing)
+};
+__device__ __forceinline__ uint64_t id_hash_dev(int v) { // = dppr::id_hash
+    uint64_t z = (uint64_t)v + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(BLOCK) void k_live_degree(const uint8_t *__restrict__ live, const int *__restrict__ indeg, int n,
+                                                       int *__restrict__ out) {
+    for (int v = blockIdx.x * BLOCK + threadIdx.x; v < n; v += gridDim.x * BLOCK) out[v] = live[v] ? indeg[v] : -1;
+}
+__global__ __launch_bounds__(BLOCK) void k_number_keys(const uint8_t *__restrict__ live, const int *__restrict__ int2ext,
+                                                       const int *__restrict__ indeg, HotThresholds ht, int n,
+                                                       uint64_t *__restrict__ keys, int *__restrict__ vals) {
+    for (int v = blockIdx.x * BLOCK + threadIdx.x; v < n; v += gridDim.x * BLOCK) {
+        uint64_t key = (1ull << 63) | (uint64_t)(uint32_t)v;
+        if (live[v]) {
+            const uint64_t h = id_hash_dev(int2ext[v]);
+            if (ht.n > 0) {
+                const int dg = indeg[v];
+                uint64_t block = 0; // 0 = hottest
+                for (int k = 0; k < ht.n; ++k) block += dg <= ht.thr[k] ? 1u : 0u;
+                key = (h >> 6) | (block << 58);
+            } else {
+                key = h >> 1;
+            }
+        }
+        keys[v] = key;
+        vals[v] = v;
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_remap_ids(int *__restrict__ a, int n, const int *__restrict__ perm) {
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) a[i] = perm[a[i]];
 }

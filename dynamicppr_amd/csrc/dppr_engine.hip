@@ -343,6 +343,76 @@ int settle_parked(dppr_engine *e, double *p, double *r, int w, double eps, doubl
     return DPPR_OK;
 }
 
+// The live vertices of a renumbering in the order they are to be numbered: hashed, in blocks of falling in-degree on
+// large windows -- what dppr::numbering_order does for dppr_load_window on the host, here as device keys and one
+// radix sort (a host sort of a million pairs was most of a renumbering slide; of thirty million it would stall the
+// stream). live[v] for the old ids v < n_old; order receives the n_live ids.
+int device_numbering_order(dppr_engine *e, const std::vector<uint8_t> &live, int n_old, int n_live, std::vector<int32_t> &order) {
+    order.clear();
+    if (n_live <= 0) return DPPR_OK;
+    const size_t n = (size_t)n_old;
+    uint8_t *d_live = nullptr;
+    int *d_i2e = nullptr, *d_vals = nullptr, *d_vals2 = nullptr, *d_deg2 = nullptr;
+    uint64_t *d_keys = nullptr, *d_keys2 = nullptr;
+    void *d_tmp = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_live); (void)hipFree(d_i2e); (void)hipFree(d_vals); (void)hipFree(d_vals2); (void)hipFree(d_deg2);
+        (void)hipFree(d_keys); (void)hipFree(d_keys2); (void)hipFree(d_tmp);
+    };
+#define NO_TRY(call)                                                          \
+    do {                                                                      \
+        hipError_t _e = (call);                                               \
+        if (_e != hipSuccess) {                                               \
+            cleanup();                                                        \
+            e->err = std::string("renumbering order: ") + hipGetErrorString(_e); \
+            return _e == hipErrorOutOfMemory ? DPPR_ERR_NOMEM : DPPR_ERR_HIP; \
+        }                                                                     \
+    } while (0)
+    NO_TRY(hipMalloc((void **)&d_live, n));
+    NO_TRY(hipMalloc((void **)&d_i2e, sizeof(int) * n));
+    NO_TRY(hipMalloc((void **)&d_vals, sizeof(int) * n));
+    NO_TRY(hipMalloc((void **)&d_vals2, sizeof(int) * n));
+    NO_TRY(hipMalloc((void **)&d_keys, sizeof(uint64_t) * n));
+    NO_TRY(hipMalloc((void **)&d_keys2, sizeof(uint64_t) * n));
+    NO_TRY(hipMemcpyAsync(d_live, live.data(), n, hipMemcpyHostToDevice, e->stream));
+    NO_TRY(hipMemcpyAsync(d_i2e, e->int2ext.data(), sizeof(int) * n, hipMemcpyHostToDevice, e->stream));
+    HotThresholds ht{};
+    int *d_deg = e->hub_slot_of; // (scratch of the CSR build, V ints)
+    if ((size_t)n_live > HOT_WINDOW_MIN) {
+        NO_TRY(hipMalloc((void **)&d_deg2, sizeof(int) * n));
+        NO_TRY(hipMemsetAsync(d_deg, 0, sizeof(int) * n, e->stream));
+        hipLaunchKernelGGL(k_in_degree, dim3(grid_for(e->W)), dim3(BLOCK), 0, e->stream, e->w1, e->w2, e->W, e->directed, d_deg);
+        hipLaunchKernelGGL(k_live_degree, dim3(grid_for(n_old)), dim3(BLOCK), 0, e->stream, d_live, d_deg, n_old, d_vals);
+        size_t tb = 0;
+        NO_TRY(rocprim::radix_sort_keys_desc(nullptr, tb, d_vals, d_deg2, n, 0u, 32u, e->stream));
+        NO_TRY(hipMalloc(&d_tmp, tb));
+        NO_TRY(rocprim::radix_sort_keys_desc(d_tmp, tb, d_vals, d_deg2, n, 0u, 32u, e->stream));
+        // in-degree of rank k among the live vertices (the non-live ones sorted last as -1)
+        for (size_t k = HOT_SET; k >= (e->hot_blocks ? HOT_MIN : HOT_SET); k >>= 1) {
+            if (k >= (size_t)n_live) continue;
+            NO_TRY(hipMemcpyAsync(&ht.thr[ht.n], d_deg2 + k, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+            ht.n++;
+        }
+        NO_TRY(hipStreamSynchronize(e->stream));
+        (void)hipFree(d_tmp);
+        d_tmp = nullptr;
+    }
+    hipLaunchKernelGGL(k_number_keys, dim3(grid_for(n_old)), dim3(BLOCK), 0, e->stream, d_live, d_i2e, d_deg, ht, n_old, d_keys, d_vals);
+    {
+        size_t tb = 0;
+        NO_TRY(rocprim::radix_sort_pairs(nullptr, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0u, 64u, e->stream));
+        NO_TRY(hipMalloc(&d_tmp, tb));
+        NO_TRY(rocprim::radix_sort_pairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0u, 64u, e->stream));
+    }
+    order.resize((size_t)n_live);
+    NO_TRY(hipMemcpyAsync(order.data(), d_vals2, sizeof(int) * (size_t)n_live, hipMemcpyDeviceToHost, e->stream));
+    NO_TRY(hipStreamSynchronize(e->stream));
+    NO_TRY(hipGetLastError());
+#undef NO_TRY
+    cleanup();
+    return DPPR_OK;
+}
+
 // Renumber the internal ids (dppr_builder.hpp has the why). Called by dppr_slide before anything of the new batch is
 // looked at; does nothing unless every solver state is converged on the newest epoch (older epochs and their CSRs
 // are in the old numbering: nothing may still need them) and enough ids would be parked. On success every epoch is
@@ -397,31 +467,10 @@ int compact_ids(dppr_engine *e, bool *did) {
     // (hashed, hot blocks on large windows): arrivals are appended in arrival order between two renumberings, and a
     // tail of low-degree late-comers next to each other unbalances the sweep groups (configs[1] stand-in in step,
     // survivors kept in their old order instead: 0.52 ms per batch at the start, 0.61 after 400 batches of the
-    // same work). Beyond REHASH_MAX live vertices the old relative order is kept (a host sort of that many pairs
-    // would stall the stream; the blocks of the initial numbering survive).
-    constexpr int REHASH_MAX = 8 << 20;
+    // same work). The order is computed on the device (hash + in-degree blocks as keys, one radix sort).
     std::vector<int32_t> perm, order;
-    if (n_live <= REHASH_MAX) {
-        std::vector<int32_t> indeg;
-        if ((size_t)n_live > HOT_WINDOW_MIN) {
-            int *d_deg = e->hub_slot_of; // (scratch of the CSR build, V ints)
-            HIP_TRY(hipMemsetAsync(d_deg, 0, sizeof(int) * (size_t)n_old, e->stream));
-            hipLaunchKernelGGL(k_in_degree, dim3(grid_for(e->W)), dim3(BLOCK), 0, e->stream, e->w1, e->w2, e->W, e->directed, d_deg);
-            indeg.resize((size_t)n_old);
-            HIP_TRY(hipMemcpyAsync(indeg.data(), d_deg, sizeof(int) * (size_t)n_old, hipMemcpyDeviceToHost, e->stream));
-            HIP_TRY(hipStreamSynchronize(e->stream));
-        }
-        mark("  in-degrees");
-        std::vector<std::pair<uint64_t, int32_t>> keyed;
-        keyed.reserve((size_t)n_live);
-        for (int v = 0; v < n_old; ++v)
-            if (live[(size_t)v]) keyed.emplace_back(id_hash(e->int2ext[(size_t)v]), v);
-        mark("  (hash, id) pairs");
-        numbering_order(keyed, indeg.empty() ? nullptr : indeg.data(), e->hot_blocks);
-        mark("  blocks + sort");
-        order.reserve(keyed.size());
-        for (auto &kv : keyed) order.push_back(kv.second);
-    }
+    if (int rc = device_numbering_order(e, live, n_old, n_live, order)) return rc;
+    mark("numbering order (device)");
     e->renumber(live, order, perm); // (IdSpace: perm, the maps, n_int, n_parked)
     mark("host maps");
     // device side
