@@ -177,7 +177,7 @@ def test_eight_gpu_configs_at_full_size_on_one_gpu_properties(key, nsrc):
     e.close()
 
 
-# (twitter: beyond 8 M live vertices a renumbering keeps the survivors' relative order instead of numbering afresh)
+# (twitter: 11.7 M live vertices -- numbering keys, thresholds and sort of that size on the device)
 @pytest.mark.parametrize("key,nsrc,batches", [("youtube", 1, 90), ("livejournal", 10, 36), ("twitter", 1, 9)])
 def test_long_in_step_run_at_full_size_renumbers_and_agrees_with_an_unrenumbered_engine(key, nsrc, batches):
     """The reference driver's flow at full size with the id renumbering at work (threshold lowered so that it
