@@ -120,15 +120,19 @@ struct IdSpace {
             for (int v = 0; v < n_old; ++v) perm[(size_t)v] = live[(size_t)v] ? nl++ : base + np++;
         }
         for (int v = cap - R_old; v < cap; ++v) perm[(size_t)v] = base + np++;
-        std::vector<int32_t> new_i2e((size_t)cap, -1);
-        for (int v = 0; v < cap; ++v) {
+        // the maps: only the two old zones hold vertices (the rest of int2ext is -1 already and stays so, except where
+        // the parked zone grows into it)
+        std::vector<int32_t> old_live(int2ext.begin(), int2ext.begin() + n_old);
+        std::vector<int32_t> old_parked(int2ext.begin() + (cap - R_old), int2ext.end());
+        std::fill(int2ext.begin(), int2ext.begin() + n_old, -1);
+        std::fill(int2ext.begin() + (cap - R_old), int2ext.end(), -1);
+        auto place = [&](int v, int ext) {
             const int m = perm[(size_t)v];
-            if (m < 0) continue;
-            const int ext = int2ext[(size_t)v];
-            new_i2e[(size_t)m] = ext;
+            int2ext[(size_t)m] = ext;
             ext2int[(size_t)ext] = m;
-        }
-        int2ext.swap(new_i2e);
+        };
+        for (int v = 0; v < n_old; ++v) place(v, old_live[(size_t)v]);
+        for (int i = 0; i < R_old; ++i) place(cap - R_old + i, old_parked[(size_t)i]);
         n_int = n_live;
         n_parked = R_new;
         map_dirty = true;
