@@ -343,6 +343,12 @@ int settle_parked(dppr_engine *e, double *p, double *r, int w, double eps, doubl
     return DPPR_OK;
 }
 
+// n_int at which a slide looks at the live count again: grown by growth_pct % (64-bit: n * pct overflows an int at friendster scale)
+inline int renumber_threshold(int n, int growth_pct) {
+    const long long t = (long long)n + std::max<long long>((long long)n * growth_pct / 100, 1);
+    return (int)std::min<long long>(t, 0x7fffffff);
+}
+
 // The live vertices of a renumbering in the order they are to be numbered: hashed, in blocks of falling in-degree on
 // large windows -- what dppr::numbering_order does for dppr_load_window on the host, here as device keys and one
 // radix sort (a host sort of a million pairs was most of a renumbering slide; of thirty million it would stall the
@@ -460,7 +466,7 @@ int compact_ids(dppr_engine *e, bool *did) {
     mark("live flags");
     const int to_park = n_old - n_live;
     if (to_park < e->renumber_min_parked || (long long)to_park * 200 < (long long)n_live * e->renumber_growth_pct) {
-        e->renumber_next = n_old + std::max(n_old / 8, 1); // look again after some more growth
+        e->renumber_next = renumber_threshold(n_old, 12); // look again after some more growth
         return DPPR_OK;
     }
     // old position -> new position. Live vertices are numbered afresh the way dppr_load_window numbers a window
@@ -546,7 +552,7 @@ int compact_ids(dppr_engine *e, bool *did) {
         for (auto &v : e->st_b2) v = perm[(size_t)v];
     }
     for (auto &ep : e->epochs) ep.id = -1; // CSRs, group tables and batch records of the old numbering
-    e->renumber_next = n_live + std::max(n_live * e->renumber_growth_pct / 100, 1);
+    e->renumber_next = renumber_threshold(n_live, e->renumber_growth_pct);
     e->renumberings++;
     *did = true;
     return DPPR_OK;
@@ -1596,7 +1602,7 @@ int dppr_set_renumbering(dppr_engine *e, int on, int growth_pct, int min_parked)
     e->renumber_on = on != 0;
     if (growth_pct > 0) e->renumber_growth_pct = growth_pct;
     if (min_parked > 0) e->renumber_min_parked = min_parked;
-    e->renumber_next = std::min(e->renumber_next, e->n_int + std::max(e->n_int * e->renumber_growth_pct / 100, 1));
+    e->renumber_next = std::min(e->renumber_next, renumber_threshold(e->n_int, e->renumber_growth_pct));
     return DPPR_OK;
 }
 
@@ -1679,7 +1685,7 @@ int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32
     if (rc) return rc;
     ep.id = 0;
     e->newest = 0;
-    e->renumber_next = e->n_int + std::max(e->n_int * e->renumber_growth_pct / 100, 1);
+    e->renumber_next = renumber_threshold(e->n_int, e->renumber_growth_pct);
     e->loaded = true;
     e->batch_staged = false;
     HIP_TRY(hipStreamSynchronize(e->stream));
