@@ -71,6 +71,8 @@ def parse_args():
     ap.add_argument("--directed", type=int, default=None)
     ap.add_argument("--cpu-batches", type=int, default=None, help="batches timed on the CPU oracle (bounded sample)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="default workload at N = 1 only: do not append the configs[1] (single source, resident path) line")
     ap.add_argument("--group", type=int, default=None, help=argparse.SUPPRESS)  # old spelling of --sources
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
                     help="engine tuning knob (hub_min_degree, big_row_edges, pull_min_frontier, chunk_iters, pull_block, sweep_bitmap)")
@@ -265,6 +267,11 @@ def main():
             "edges_pushed_per_step": round(stats["sum_E"] / a.steps, 1),
             "parity": parity, "roofline": roof, "cpu_baseline": cpu,
         }
+        # the default run also reports configs[1] (com-youtube stand-in, one top-10 source: the single-source resident
+        # path) under its own key: a second, short run of this script as a child process once this one's numbers are in
+        if world == 1 and a.config == "livejournal" and not a.bin and not a.no_extra and not a.no_cpu_baseline:
+            line["configs1_single_source"] = extra_line(["--config", "youtube", "--steps", "40", "--warmup", "5", "--no-cpu-baseline",
+                                                         "--data-dir", a.data_dir])
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -272,6 +279,20 @@ def main():
     if rank == 0 and not parity["ok"]:
         print(f"PARITY FAILED: {parity}", file=sys.stderr, flush=True)
         sys.exit(3)
+
+
+def extra_line(args):
+    """Run this script on another workload (child process, its own engine) and keep the figures that matter."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=900)
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        return {"workload": d["config"]["workload"], "ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"],
+                "steps": d["steps"], "warmup": d["warmup"], "roofline_kernel": d["roofline"]["kernel"],
+                "roofline_frac": d["roofline"]["frac"], "avg_launch_us": d["roofline"]["avg_launch_us"], "parity_ok": d["parity"]["ok"]}
+    except Exception as ex:  # the extra line never takes the headline down with it
+        return {"error": f"{type(ex).__name__}: {ex}"}
 
 
 class SingleSolver:
