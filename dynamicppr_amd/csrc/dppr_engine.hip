@@ -1712,11 +1712,24 @@ int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, 
         return fail(e, DPPR_ERR_INVALID, "slide: window not loaded, or c exceeds the window / max_batch of dppr_create");
     HIP_TRY(hipSetDevice(e->device));
     const int W = e->W;
+    static const bool slide_trace = getenv("DPPR_SLIDE_TRACE") != nullptr; // (diagnostic: phases of a slide; each mark synchronises)
+    timespec t_mark;
+    clock_gettime(CLOCK_MONOTONIC, &t_mark);
+    auto mark = [&](const char *what) {
+        if (!slide_trace) return;
+        (void)hipStreamSynchronize(e->stream);
+        timespec now;
+        clock_gettime(CLOCK_MONOTONIC, &now);
+        fprintf(stderr, "[slide] %-34s %8.1f us\n", what, (now.tv_sec - t_mark.tv_sec) * 1e6 + (now.tv_nsec - t_mark.tv_nsec) * 1e-3);
+        t_mark = now;
+    };
     bool renumbered = false;
     if (int rc = compact_ids(e, &renumbered)) return rc;
+    mark("renumbering check");
     if (!translate(e, n1, c, e->h_tmp1) || !translate(e, n2, c, e->h_tmp2))
         return fail(e, DPPR_ERR_INVALID, "slide: vertex id out of range");
     if (int rc = flush_moves(e)) return rc;
+    mark("translate new edges");
     n1 = e->h_tmp1.data();
     n2 = e->h_tmp2.data();
     // the c oldest edges sit at ring positions head .. head+c (mod W): retire their degrees (and
@@ -1743,6 +1756,7 @@ int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, 
         done += len;
     }
     if (W > 0) e->head = (e->head + c) % W;
+    mark("ring, degrees, batch keys");
     const int id = e->newest + 1;
     Epoch &ep = e->epochs[id % e->n_epochs];
     ep.id = -1;
@@ -1754,8 +1768,10 @@ int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, 
         rc = sort_window_full(e);
     }
     if (rc) return rc;
+    mark("sorted keys (merge / full sort)");
     rc = build_epoch(e, ep);
     if (rc) return rc;
+    mark("hubs, CSRs, group cut + tables");
     ep.L = 0;
     if (e->batch_staged) {
         const int L = (int)e->st_b1.size();
@@ -1771,6 +1787,7 @@ int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, 
         }
     }
     HIP_TRY(hipStreamSynchronize(e->stream)); // staged host vectors may be reused now
+    mark("batch records");
     e->batch_staged = false;
     ep.id = id;
     e->newest = id;
