@@ -23,6 +23,7 @@
 #include "dppr_idspace.hpp"
 #include "dppr_kernels.hpp"
 #include "dppr_multi.hpp"
+#include "dppr_gpush.hpp"
 
 using namespace dppr;
 
@@ -113,6 +114,13 @@ struct Group {
     dppr_stats_t st{};
     int iter_hint[2] = {0, 0};
     int iter_hist[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; // sweeps the last four loops of each phase took
+    int dense_hist[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; // ... before the frontier was small enough for the push form
+    // the tail of a loop as pushes (dppr_gpush.hpp): vertex lists, scan, control block; allocated on first use
+    int *plist[2] = {nullptr, nullptr};
+    int *ppre = nullptr;
+    GPushCtl *pctl = nullptr;
+    unsigned int *pdone = nullptr;
+    int plist_cap = 0;
     bool converged = false;    // |r| <= conv_eps for every source (state after a completed solve)
     double conv_eps = 0.0;
     double park_eps = 0.0;     // parked rows satisfy |r| <= park_eps
@@ -176,6 +184,11 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
                                     // the configs[1] stand-in, equal on the LiveJournal one)
     bool wide_groups = false;       // ... one of more than 8 sources: its groups hold at most 512 vertices
     bool group_tail_seeding = true; // source groups seed from the batch tails after a converged solve (false: dense Inspect)
+    int gpush_enter_pairs = -1;     // a group's loop switches to the push form below this many frontier pairs (-1: from the
+                                    // sweep's floor, n_ggroups / 16; 0: never) -- dppr_set_group_push
+    int gpush_list_cap = 1 << 20;   // vertices a frontier list of that form holds
+    long long gpush_max_edges = 0;  // in-edges one iteration of that form may have (0: from the sweep's floor, 200 per sweep group)
+    int gpush_auto_factor = 2;      // automatic threshold: this many pairs per sweep group (DPPR_GROUP_PUSH_FACTOR: tuning runs)
     // stream-update scratch
     uint32_t *su_k[2] = {nullptr, nullptr}, *su_v[2] = {nullptr, nullptr};
     double *su_term = nullptr;
@@ -1198,6 +1211,94 @@ int group_multi_capacity(dppr_engine *e, int spl) {
 
 // One frontier loop of a source group. `tails`: the state was converged before the batch's stream
 // update, so only the batch tails (sorted in su_k[1]) can be legal -- no pass over all vertices.
+// The tail of a group's loop in push form (dppr_gpush.hpp). Called between two chunks of sweeps when the frontier is
+// small: g.act[0] / g.x hold the frontier the last sweep left. Returns with *converged set (the loop is over; state as
+// a finished loop leaves it) or cleared (the mode gave up -- an iteration too large for it -- and put the frontier back
+// in sweep form: g.act[0], g.x, frontier sizes in row 0 of g.cnt, the other rows zero), or with *entered false if it
+// did not start (nothing changed). Iterations run are added to *iters and to the group's statistics.
+int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps, int *iters, bool *entered, bool *converged) {
+    *entered = false;
+    *converged = false;
+    const int GWM = GS_MAX;
+    const int cap = std::max(1024, std::min(e->gpush_list_cap, e->V));
+    if (g.plist_cap != cap) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        (void)hipFree(g.plist[0]); (void)hipFree(g.plist[1]); (void)hipFree(g.ppre); (void)hipFree(g.pctl); (void)hipFree(g.pdone);
+        g.plist[0] = g.plist[1] = g.ppre = nullptr;
+        g.pctl = nullptr;
+        g.pdone = nullptr;
+        g.plist_cap = 0;
+        HIP_TRY(hipMalloc((void **)&g.plist[0], sizeof(int) * (size_t)cap));
+        HIP_TRY(hipMalloc((void **)&g.plist[1], sizeof(int) * (size_t)cap));
+        HIP_TRY(hipMalloc((void **)&g.ppre, sizeof(int) * ((size_t)cap + 1)));
+        HIP_TRY(hipMalloc((void **)&g.pctl, sizeof(GPushCtl)));
+        HIP_TRY(hipMalloc((void **)&g.pdone, sizeof(unsigned int)));
+        g.plist_cap = cap;
+    }
+    static thread_local GPushCtl h;
+    HIP_TRY(hipMemsetAsync(g.pctl, 0, sizeof(GPushCtl), e->stream));
+    HIP_TRY(hipMemsetAsync(g.pdone, 0, sizeof(unsigned int), e->stream));
+    const int n_words = (e->n_int + 31) / 32;
+    hipLaunchKernelGGL(k_gpush_list, dim3(grid_for(n_words)), dim3(BLOCK), 0, e->stream, g.act[0], n_words, g.plist[0], cap, g.pctl);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&h, g.pctl, sizeof(int) * 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (h.overflow || h.n[0] >= cap || h.n[0] == 0) return DPPR_OK; // (does not fit this form: the sweeps go on)
+    // the frontier's rows move from the snapshot back to residual[]; its bits stay set (they queue it for iteration 0)
+    if (g.spl == 1) hipLaunchKernelGGL(k_gpush_rows<1>, dim3(grid_for(h.n[0], BLOCK / OCT)), dim3(BLOCK), 0, e->stream, g.plist[0], g.pctl, 0, g.x, g.r, false);
+    else hipLaunchKernelGGL(k_gpush_rows<2>, dim3(grid_for(h.n[0], BLOCK / OCT)), dim3(BLOCK), 0, e->stream, g.plist[0], g.pctl, 0, g.x, g.r, false);
+    HIP_TRY(hipMemsetAsync(g.act[1], 0, g.act_bytes, e->stream));
+    *entered = true;
+    // what an iteration may cost here: a sweep's floor is ~0.02 us per sweep group, a returning f64 atomic ~1 / 20 000 us
+    const long long max_edges = e->gpush_max_edges > 0 ? e->gpush_max_edges : std::max<long long>(4096, 200ll * std::max(ep.n_ggroups, 1));
+    const int grid = 256;
+    static const bool trace = getenv("DPPR_GROUP_TRACE") != nullptr;
+    int it_done = 0;
+    for (;;) {
+        const int m = 8; // iterations per chunk (<= GPUSH_LOG)
+        HIP_TRY(hipMemsetAsync(reinterpret_cast<char *>(g.pctl) + offsetof(GPushCtl, F), 0, sizeof(GPushCtl) - offsetof(GPushCtl, F), e->stream));
+        for (int k = 0; k < m; ++k) {
+            hipLaunchKernelGGL(k_gpush_scan, dim3(1), dim3(1024), 0, e->stream, g.pctl, g.plist[0], g.plist[1], ep.row_ptr, g.ppre, cap - 1, max_edges);
+            if (g.spl == 1) {
+                hipLaunchKernelGGL(k_gpush_snap<1>, dim3(grid), dim3(BLOCK), 0, e->stream, g.plist[0], g.plist[1], g.pctl, g.x, g.r, g.p, g.act[0], phase, eps);
+                hipLaunchKernelGGL(k_gpush_expand<1>, dim3(grid), dim3(BLOCK), 0, e->stream, g.plist[0], g.plist[1], g.pctl, g.ppre, ep.row_ptr, ep.adj,
+                                   ep.hub_degp1, g.x, g.r, g.act[0], g.plist[0], g.plist[1], cap, phase, eps, g.dstats, g.pdone);
+            } else {
+                hipLaunchKernelGGL(k_gpush_snap<2>, dim3(grid), dim3(BLOCK), 0, e->stream, g.plist[0], g.plist[1], g.pctl, g.x, g.r, g.p, g.act[0], phase, eps);
+                hipLaunchKernelGGL(k_gpush_expand<2>, dim3(grid), dim3(BLOCK), 0, e->stream, g.plist[0], g.plist[1], g.pctl, g.ppre, ep.row_ptr, ep.adj,
+                                   ep.hub_degp1, g.x, g.r, g.act[0], g.plist[0], g.plist[1], cap, phase, eps, g.dstats, g.pdone);
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&h, g.pctl, sizeof(GPushCtl), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (int i = it_done; i < h.it; ++i) {
+            long long F = 0;
+            for (int s = 0; s < GWM; ++s) F += h.F[i & (GPUSH_LOG - 1)][s];
+            if (F == 0) continue;
+            g.st.iterations++;
+            g.st.sum_F += F;
+            ++*iters;
+            if (trace)
+                fprintf(stderr, "[gpush ] phase %d iteration +%d  frontier pairs %9lld  adds %lld\n", phase, i, F, h.atomics[i & (GPUSH_LOG - 1)]);
+        }
+        it_done = h.it;
+        if (h.stop) { // an iteration too large for this form: the queued vertices go back to sweep form
+            if (trace) fprintf(stderr, "[gpush ] phase %d: an iteration of %d vertices called itself off after %d iterations\n", phase, h.n[h.it & 1], h.it);
+            HIP_TRY(hipMemsetAsync(g.cnt, 0, sizeof(int) * 3 * GWM, e->stream));
+            if (g.spl == 1) hipLaunchKernelGGL(k_gpush_leave<1>, dim3(grid_for(e->n_int, BLOCK / OCT)), dim3(BLOCK), 0, e->stream, e->n_int, g.act[0], g.x, g.r, g.p, h.it > 0 ? 1 : 0, phase, eps, g.cnt);
+            else hipLaunchKernelGGL(k_gpush_leave<2>, dim3(grid_for(e->n_int, BLOCK / OCT)), dim3(BLOCK), 0, e->stream, e->n_int, g.act[0], g.x, g.r, g.p, h.it > 0 ? 1 : 0, phase, eps, g.cnt);
+            HIP_TRY(hipGetLastError());
+            return DPPR_OK;
+        }
+        if (h.n[h.it & 1] == 0) {
+            *converged = true;
+            return DPPR_OK;
+        }
+        if (it_done >= e->max_iters) return fail(e, DPPR_ERR_NOT_CONVERGED, "iteration cap hit");
+    }
+}
+
 int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps, bool tails) {
     int cur = 0;
     const int GWM = GS_MAX;
@@ -1235,6 +1336,10 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
     int active_iters = 0;
     const int sweep_grid = std::min(std::max(ep.n_ggroups, 1), e->gsweep_grid_cap);
     int follow = 4; // size of the next follow-up chunk of one-sweep launches
+    // the tail of the loop as pushes (dppr_gpush.hpp): below push_thr frontier pairs, one-sweep launches only
+    long long push_thr = e->gpush_enter_pairs == 0 ? 0 : e->gpush_enter_pairs > 0 ? e->gpush_enter_pairs : std::max(64, ep.n_ggroups * e->gpush_auto_factor);
+    bool push_gave_up = false;
+    int dense_len = -1; // sweeps of this loop before the frontier was that small
     const int nvx = ep.ggrp_max_tiles * WAVE; // vertices per sweep group of this epoch's tables: 1024, or 512 once a 16-wide group exists
     for (int it = 0; more;) {
         if (it >= e->max_iters) return fail(e, DPPR_ERR_NOT_CONVERGED, "iteration cap hit");
@@ -1304,9 +1409,16 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
         int n;
         if (it == 0) {
             int lo = 0;
-            for (int h : g.iter_hist[phase]) lo = h > 0 && (lo == 0 || h < lo) ? h : lo;
+            for (int h : (push_thr > 0 ? g.dense_hist : g.iter_hist)[phase]) lo = h > 0 && (lo == 0 || h < lo) ? h : lo;
             n = lo > 0 ? lo : e->chunk_iters;
             follow = 4;
+        } else if (push_thr > 0 && !push_gave_up) {
+            // the push form takes over below push_thr pairs and a sweep of the tail costs its floor whatever it finds: go
+            // only as far as the frontier is sure to stay above the threshold (it shrinks by <= ~4x per sweep down there)
+            long long F = 0;
+            for (int s = 0; s < GWM; ++s) F += e->pinned[cur * GWM + s];
+            n = 1;
+            for (long long f = F / 4; f > push_thr && n < e->chunk_iters; f /= 4) ++n;
         } else {
             n = std::min(follow, e->chunk_iters);
             follow *= 2;
@@ -1337,6 +1449,11 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
         for (int k = 0; k < n; ++k) {
             const int *f = e->pinned + 5 * GWM + k * GWM;
             if (!any_left(f)) continue;
+            if (push_thr > 0 && dense_len < 0) { // (the sweep that FOUND the frontier this small could have been a push iteration)
+                long long F = 0;
+                for (int s = 0; s < GWM; ++s) F += f[s];
+                if (F <= push_thr) dense_len = it + k;
+            }
             g.st.iterations++;
             g.st.pull_iterations++;
             for (int s = 0; s < GWM; ++s) g.st.sum_F += f[s];
@@ -1356,6 +1473,36 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
         }
         more = any_left(e->pinned + cur * GWM);
         it += n;
+        if (more && push_thr > 0 && !push_gave_up) {
+            long long F = 0;
+            for (int s = 0; s < GWM; ++s) F += e->pinned[cur * GWM + s];
+            if (F <= push_thr) {
+                if (dense_len < 0) dense_len = it;
+                int pushed = 0;
+                bool entered = false, conv = false;
+                int rc = group_push_tail(e, g, ep, phase, eps, &pushed, &entered, &conv);
+                if (rc) return rc;
+                if (entered) {
+                    active_iters = it + pushed;
+                    it += pushed;
+                    if (conv) more = false;
+                    else { // back in sweep form: frontier sizes in row 0; the next try waits for a much smaller frontier
+                        cur = 0;
+                        HIP_TRY(hipMemcpyAsync(e->pinned, g.cnt, sizeof(int) * GWM, hipMemcpyDeviceToHost, e->stream));
+                        HIP_TRY(hipStreamSynchronize(e->stream));
+                        more = any_left(e->pinned);
+                        push_thr = std::max<long long>(F / 8, 1);
+                        dense_len = -1;
+                    }
+                } else {
+                    push_gave_up = true;
+                }
+            }
+        }
+    }
+    if (push_thr > 0) {
+        for (int k = 3; k > 0; --k) g.dense_hist[phase][k] = g.dense_hist[phase][k - 1];
+        g.dense_hist[phase][0] = dense_len >= 0 ? std::max(dense_len, 1) : std::max(active_iters, 1);
     }
     g.iter_hint[phase] = active_iters;
     for (int k = 3; k > 0; --k) g.iter_hist[phase][k] = g.iter_hist[phase][k - 1];
@@ -1425,6 +1572,8 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     if (const char *v = getenv("DPPR_RENUMBER")) e->renumber_on = atoi(v) != 0;
     if (const char *v = getenv("DPPR_RENUMBER_PCT")) e->renumber_growth_pct = std::max(1, atoi(v));
     if (const char *v = getenv("DPPR_RENUMBER_MIN")) e->renumber_min_parked = std::max(1, atoi(v));
+    if (const char *v = getenv("DPPR_GROUP_PUSH")) e->gpush_enter_pairs = std::max(-1, atoi(v));
+    if (const char *v = getenv("DPPR_GROUP_PUSH_FACTOR")) e->gpush_auto_factor = std::max(1, atoi(v));
     if (const char *v = getenv("DPPR_GGROUPS_MIN")) e->ggroups_min = std::max(1, atoi(v));
     e->device = device;
     e->V = V;
@@ -1588,6 +1737,14 @@ int dppr_set_sweep_bitmap(dppr_engine *e, int on) {
 int dppr_set_group_resident(dppr_engine *e, int on) {
     if (!e) return DPPR_ERR_INVALID;
     e->group_resident = on != 0;
+    return DPPR_OK;
+}
+
+int dppr_set_group_push(dppr_engine *e, int enter_pairs, int list_cap, int64_t max_edges) {
+    if (!e || enter_pairs < -1 || list_cap < 0 || max_edges < 0) return fail(e, DPPR_ERR_INVALID, "set_group_push: bad argument");
+    e->gpush_enter_pairs = enter_pairs;
+    if (list_cap > 0) e->gpush_list_cap = list_cap;
+    e->gpush_max_edges = max_edges;
     return DPPR_OK;
 }
 

@@ -55,7 +55,7 @@ EXPORTS = [
     "dppr_trace_get", "dppr_synchronize", "dppr_bench_atomics",
     "dppr_add_source_group", "dppr_group_init_solve", "dppr_group_update", "dppr_group_read", "dppr_group_stats",
     "dppr_group_reset_stats", "dppr_set_group_seeding", "dppr_seed_lists", "dppr_set_sweep_bitmap", "dppr_set_group_resident",
-    "dppr_set_renumbering", "dppr_id_space",
+    "dppr_set_renumbering", "dppr_id_space", "dppr_set_group_push",
 ]
 
 
@@ -82,6 +82,7 @@ def lib():
     L.dppr_set_profiling.argtypes = [vp, C.c_int]
     L.dppr_set_incremental_graph.argtypes = [vp, C.c_int]
     L.dppr_set_renumbering.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.dppr_set_group_push.argtypes = [vp, C.c_int, C.c_int, C.c_int64]
     L.dppr_id_space.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     L.dppr_set_tuning.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.dppr_set_persistent.argtypes = [vp, C.c_int, C.c_int64]
@@ -178,6 +179,10 @@ class Engine:
 
     def set_incremental_graph(self, on):
         self._ck(self._L.dppr_set_incremental_graph(self._h, int(on)), "set_incremental_graph")
+
+    def set_group_push(self, enter_pairs=-1, list_cap=0, max_edges=0):
+        """Tail of a source group's loop as pushes: -1 automatic threshold, 0 never, N below N frontier pairs."""
+        self._ck(self._L.dppr_set_group_push(self._h, int(enter_pairs), int(list_cap), int(max_edges)), "set_group_push")
 
     def set_renumbering(self, on, growth_pct=0, min_parked=0):
         """Renumbering of the internal ids at slide time (include/dppr.h); 0 keeps a threshold as it is."""

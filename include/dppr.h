@@ -236,6 +236,17 @@ int dppr_group_reset_stats(dppr_engine *e, int32_t group);
  * default; 0 = one launch per sweep everywhere. The roll-call / time-out rules are those of
  * dppr_set_persistent. Same results. */
 int dppr_set_group_resident(dppr_engine *e, int on);
+/* The tail of a source group's frontier loop as pushes. A sweep costs at least its floor (every out_col entry, every
+ * sweep group's tables) however few (vertex, source) pairs are still being pushed; below enter_pairs frontier pairs
+ * the loop's remaining iterations run as what the reference does for every iteration (gpu/ExpandRev.cuh:34-77,
+ * :708-743: per frontier vertex and in-neighbour a returning atomic add, all sources of the group at once), same
+ * synchronous schedule, same results up to the order of the sums. enter_pairs: -1 (default) = from the sweep's floor
+ * (sweep groups / 16), 0 = never, N = below N pairs; an iteration with more in-edges than the floor is worth sends
+ * the loop back to sweeps (max_edges: that bound on an iteration's in-edges; 0 = automatic, 200 per sweep group), to
+ * try again on a much smaller frontier. list_cap: vertices a frontier list holds (0: keep; default 2^20). Windows
+ * whose groups run as multi-sweep launches do not use it. */
+int dppr_set_group_push(dppr_engine *e, int enter_pairs, int list_cap, int64_t max_edges);
+
 /* How dppr_group_update seeds its two frontier loops. from_tails (default): after a converged solve
  * only tails of the batch's records can be legal (the argument of cpu/PPRCPUMTCilkRev.h:126-156), so
  * the frontier is read off the batch; 0: a full Inspect pass over all vertices per phase like

@@ -772,12 +772,14 @@ def test_incremental_graph_equals_full_rebuild(directed):
             assert np.array_equal(oa[0], ob[0]) and np.array_equal(oa[1], ob[1])
 
 
-def run_source_group(V, e1, e2, W, c, eps, directed, sources, batches, seeding, tuning=None, resident=True):
+def run_source_group(V, e1, e2, W, c, eps, directed, sources, batches, seeding, tuning=None, resident=True, push=None):
     """Drive a source group and one oracle state per source (synchronous schedule) over the same
     stream; per-source p/r to rounding, summed statistics equal."""
     e = eng.Engine(V, W, directed, c, **(tuning or {}))
     e.set_group_seeding(seeding == "tails")
     e.set_group_resident(resident)
+    if push is not None:
+        e.set_group_push(*push)
     g = orc.Graph(V, e1, e2, directed, W, c)
     states = [orc.State(V, s, eps) for s in sources]
     e.load_window(*g.window_edges())
@@ -871,6 +873,30 @@ def test_source_group_launch_forms(nsrc, mode):
         assert st["persist_launches"] >= 7 and st["persist_aborts"] == 0
         if mode == "multi-sweep-3-at-a-time":
             assert st["persist_launches"] > st["iterations"] / 4
+
+
+@pytest.mark.parametrize("mode", ["automatic", "never", "as-early-as-possible", "as-early-as-possible-chunk2", "tiny-lists", "below-50-pairs",
+                                  "iterations-call-themselves-off"])
+@pytest.mark.parametrize("seeding", ["tails", "dense"])
+@pytest.mark.parametrize("nsrc,directed", [(3, 1), (10, 0), (16, 1)])
+def test_source_group_tail_as_pushes(nsrc, directed, seeding, mode):
+    """The tail of a group's loop in push form (dppr_gpush.hpp), one-sweep launches before it: entered at the automatic
+    threshold, never, at every chunk boundary (iterations too large for the form call themselves off and the loop goes
+    back to sweeps, to try again on a much smaller frontier -- forced with a bound of 3000 in-edges per iteration),
+    with frontier lists of 1024 vertices (longer frontiers do not enter), below 50 pairs. Per-source p / r, sum F and sum E of the oracle's synchronous schedule every time."""
+    V, e1, e2 = datagen.rmat_stream(13, 70000, 21)
+    W, c = 20000, 200
+    sources = [int(x) for x in datagen.top_sources(V, e1, e2, W, directed, nsrc)]
+    push = {"automatic": (-1, 0), "never": (0, 0), "as-early-as-possible": (10**9, 0), "as-early-as-possible-chunk2": (10**9, 0),
+            "tiny-lists": (10**9, 1024), "below-50-pairs": (50, 0), "iterations-call-themselves-off": (10**9, 0, 3000)}[mode]
+    tuning = dict(chunk_iters=2) if mode.endswith("chunk2") or mode.endswith("off") else None
+    e, gid = run_source_group(V, e1, e2, W, c, 1e-9, directed, sources, 4, seeding, tuning=tuning, resident=False, push=push)
+    st = e.group_stats(gid)
+    assert st["persist_launches"] == 0
+    if mode == "never":
+        assert st["pull_iterations"] == st["iterations"]
+    elif mode != "tiny-lists":  # (there a frontier that does not fit the lists simply stays with the sweeps)
+        assert st["pull_iterations"] < st["iterations"]  # some iterations ran as pushes
 
 
 def test_source_group_sources_outside_the_window_and_duplicates():
