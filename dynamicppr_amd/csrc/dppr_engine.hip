@@ -1216,7 +1216,8 @@ int group_multi_capacity(dppr_engine *e, int spl) {
 // a finished loop leaves it) or cleared (the mode gave up -- an iteration too large for it -- and put the frontier back
 // in sweep form: g.act[0], g.x, frontier sizes in row 0 of g.cnt, the other rows zero), or with *entered false if it
 // did not start (nothing changed). Iterations run are added to *iters and to the group's statistics.
-int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps, int *iters, bool *entered, bool *converged) {
+int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps, long long pairs_at_entry, int *iters, bool *entered,
+                    bool *converged) {
     *entered = false;
     *converged = false;
     const int GWM = GS_MAX;
@@ -1255,7 +1256,13 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
     static const bool trace = getenv("DPPR_GROUP_TRACE") != nullptr;
     int it_done = 0;
     for (;;) {
-        const int m = 8; // iterations per chunk (<= GPUSH_LOG)
+        // iterations per chunk (<= GPUSH_LOG): down here the frontier about halves per iteration, so the first chunk is
+        // sized to reach the end (an iteration that finds nothing is three empty dispatches), follow-ups are short
+        int m = 4;
+        if (it_done == 0) {
+            m = 2;
+            for (long long f = pairs_at_entry; f > 1 && m < GPUSH_LOG; f >>= 1) ++m;
+        }
         HIP_TRY(hipMemsetAsync(reinterpret_cast<char *>(g.pctl) + offsetof(GPushCtl, F), 0, sizeof(GPushCtl) - offsetof(GPushCtl, F), e->stream));
         for (int k = 0; k < m; ++k) {
             hipLaunchKernelGGL(k_gpush_scan, dim3(1), dim3(1024), 0, e->stream, g.pctl, g.plist[0], g.plist[1], ep.row_ptr, g.ppre, cap - 1, max_edges);
@@ -1480,7 +1487,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
                 if (dense_len < 0) dense_len = it;
                 int pushed = 0;
                 bool entered = false, conv = false;
-                int rc = group_push_tail(e, g, ep, phase, eps, &pushed, &entered, &conv);
+                int rc = group_push_tail(e, g, ep, phase, eps, F, &pushed, &entered, &conv);
                 if (rc) return rc;
                 if (entered) {
                     active_iters = it + pushed;
