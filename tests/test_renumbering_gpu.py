@@ -320,14 +320,16 @@ def test_every_vertex_has_an_id_and_the_two_zones_touch(directed):
     assert touched and sp["renumberings"] >= 3 and sp["revivals"] > 10, sp
 
 
+@pytest.mark.parametrize("form", ["multi-sweep", "one-sweep"])
 @pytest.mark.parametrize("seed", [2, 3])
-def test_production_mode_soak_against_cilk_oracle(seed):
+def test_production_mode_soak_against_cilk_oracle(seed, form):
     """tools/soak.py, shortened: eager schedule, default launch forms, renumbering at work, one slot and a 10-source group
-    over 120 in-step batches of a medium-size stream; |p - p_cpu| < 1e-9, |r| < eps and the invariant every 10 batches."""
+    over 120 in-step batches of a medium-size stream (the group's loops as multi-sweep launches, or one launch per
+    sweep with the tail as pushes); |p - p_cpu| < 1e-9, |r| < eps and the invariant every 10 batches."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), str(seed), "120", "15"], stdout=subprocess.PIPE,
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), str(seed), "120", "15"] + (["one-sweep"] if form == "one-sweep" else []), stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=900, cwd=root)
     assert r.returncode == 0 and "120 batches ok" in r.stdout, r.stdout[-2000:]

@@ -2,7 +2,8 @@
 """Long randomised soak at medium size, production mode (eager schedule, default launch forms, renumbering on): a single
 source slot and a 10-source group over hundreds of in-step batches, every state compared with the oracle's restatement
 of cpu/PPRCPUMTCilkRev (-t 1) every few batches (|p - p_cpu| < 1e-9, |r| < eps, loop invariant).
-    python tools/soak.py [seed] [batches] [scale]"""
+    python tools/soak.py [seed] [batches] [scale] [one-sweep]      (4th argument: the group's loops as one launch per sweep
+    with the tail as pushes -- what large windows run -- instead of multi-sweep launches)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,6 +23,8 @@ g = orc.Graph(V, e1, e2, directed, W, c)
 states = [orc.State(V, s, eps) for s in srcs]
 e = eng.Engine(V, W, directed, c)
 e.set_renumbering(1, growth_pct=5, min_parked=64)
+if len(sys.argv) > 4:
+    e.set_group_resident(False)
 e.load_window(*g.window_edges())
 slot = e.add_source(srcs[0]); gid = e.add_source_group(srcs)
 for s in states: s.cilk_execute(g)
