@@ -119,7 +119,6 @@ struct Group {
     int *plist[2] = {nullptr, nullptr};
     int *ppre = nullptr;
     GPushCtl *pctl = nullptr;
-    unsigned int *pdone = nullptr;
     int plist_cap = 0;
     bool converged = false;    // |r| <= conv_eps for every source (state after a completed solve)
     double conv_eps = 0.0;
@@ -1224,31 +1223,27 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
     const int cap = std::max(1024, std::min(e->gpush_list_cap, e->V));
     if (g.plist_cap != cap) {
         HIP_TRY(hipStreamSynchronize(e->stream));
-        (void)hipFree(g.plist[0]); (void)hipFree(g.plist[1]); (void)hipFree(g.ppre); (void)hipFree(g.pctl); (void)hipFree(g.pdone);
+        (void)hipFree(g.plist[0]); (void)hipFree(g.plist[1]); (void)hipFree(g.ppre); (void)hipFree(g.pctl);
         g.plist[0] = g.plist[1] = g.ppre = nullptr;
         g.pctl = nullptr;
-        g.pdone = nullptr;
         g.plist_cap = 0;
         HIP_TRY(hipMalloc((void **)&g.plist[0], sizeof(int) * (size_t)cap));
         HIP_TRY(hipMalloc((void **)&g.plist[1], sizeof(int) * (size_t)cap));
         HIP_TRY(hipMalloc((void **)&g.ppre, sizeof(int) * ((size_t)cap + 1)));
         HIP_TRY(hipMalloc((void **)&g.pctl, sizeof(GPushCtl)));
-        HIP_TRY(hipMalloc((void **)&g.pdone, sizeof(unsigned int)));
         g.plist_cap = cap;
     }
     static thread_local GPushCtl h;
+    // no host round trip on the way in: a list that does not fit (overflow) moves nothing and makes the first scan call
+    // the mode off, which the read-back of the first chunk shows
     HIP_TRY(hipMemsetAsync(g.pctl, 0, sizeof(GPushCtl), e->stream));
-    HIP_TRY(hipMemsetAsync(g.pdone, 0, sizeof(unsigned int), e->stream));
     const int n_words = (e->n_int + 31) / 32;
     hipLaunchKernelGGL(k_gpush_list, dim3(grid_for(n_words)), dim3(BLOCK), 0, e->stream, g.act[0], n_words, g.plist[0], cap, g.pctl);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&h, g.pctl, sizeof(int) * 8, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    if (h.overflow || h.n[0] >= cap || h.n[0] == 0) return DPPR_OK; // (does not fit this form: the sweeps go on)
     // the frontier's rows move from the snapshot back to residual[]; its bits stay set (they queue it for iteration 0)
-    if (g.spl == 1) hipLaunchKernelGGL(k_gpush_rows<1>, dim3(grid_for(h.n[0], BLOCK / OCT)), dim3(BLOCK), 0, e->stream, g.plist[0], g.pctl, 0, g.x, g.r, false);
-    else hipLaunchKernelGGL(k_gpush_rows<2>, dim3(grid_for(h.n[0], BLOCK / OCT)), dim3(BLOCK), 0, e->stream, g.plist[0], g.pctl, 0, g.x, g.r, false);
-    HIP_TRY(hipMemsetAsync(g.act[1], 0, g.act_bytes, e->stream));
+    const int rows_grid = grid_for(std::min<long long>(pairs_at_entry, cap), BLOCK / OCT);
+    if (g.spl == 1) hipLaunchKernelGGL(k_gpush_rows<1>, dim3(rows_grid), dim3(BLOCK), 0, e->stream, g.plist[0], g.pctl, 0, g.x, g.r, false);
+    else hipLaunchKernelGGL(k_gpush_rows<2>, dim3(rows_grid), dim3(BLOCK), 0, e->stream, g.plist[0], g.pctl, 0, g.x, g.r, false);
+    HIP_TRY(hipGetLastError());
     *entered = true;
     // what an iteration may cost here: a sweep's floor is ~0.02 us per sweep group, a returning f64 atomic ~1 / 20 000 us
     const long long max_edges = e->gpush_max_edges > 0 ? e->gpush_max_edges : std::max<long long>(4096, 200ll * std::max(ep.n_ggroups, 1));
@@ -1263,17 +1258,16 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
             m = 2;
             for (long long f = pairs_at_entry; f > 1 && m < GPUSH_LOG; f >>= 1) ++m;
         }
-        HIP_TRY(hipMemsetAsync(reinterpret_cast<char *>(g.pctl) + offsetof(GPushCtl, F), 0, sizeof(GPushCtl) - offsetof(GPushCtl, F), e->stream));
         for (int k = 0; k < m; ++k) {
             hipLaunchKernelGGL(k_gpush_scan, dim3(1), dim3(1024), 0, e->stream, g.pctl, g.plist[0], g.plist[1], ep.row_ptr, g.ppre, cap - 1, max_edges);
             if (g.spl == 1) {
                 hipLaunchKernelGGL(k_gpush_snap<1>, dim3(grid), dim3(BLOCK), 0, e->stream, g.plist[0], g.plist[1], g.pctl, g.x, g.r, g.p, g.act[0], phase, eps);
                 hipLaunchKernelGGL(k_gpush_expand<1>, dim3(grid), dim3(BLOCK), 0, e->stream, g.plist[0], g.plist[1], g.pctl, g.ppre, ep.row_ptr, ep.adj,
-                                   ep.hub_degp1, g.x, g.r, g.act[0], g.plist[0], g.plist[1], cap, phase, eps, g.dstats, g.pdone);
+                                   ep.hub_degp1, g.x, g.r, g.act[0], g.plist[0], g.plist[1], cap, phase, eps, g.dstats);
             } else {
                 hipLaunchKernelGGL(k_gpush_snap<2>, dim3(grid), dim3(BLOCK), 0, e->stream, g.plist[0], g.plist[1], g.pctl, g.x, g.r, g.p, g.act[0], phase, eps);
                 hipLaunchKernelGGL(k_gpush_expand<2>, dim3(grid), dim3(BLOCK), 0, e->stream, g.plist[0], g.plist[1], g.pctl, g.ppre, ep.row_ptr, ep.adj,
-                                   ep.hub_degp1, g.x, g.r, g.act[0], g.plist[0], g.plist[1], cap, phase, eps, g.dstats, g.pdone);
+                                   ep.hub_degp1, g.x, g.r, g.act[0], g.plist[0], g.plist[1], cap, phase, eps, g.dstats);
             }
         }
         HIP_TRY(hipGetLastError());
@@ -1290,6 +1284,10 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
                 fprintf(stderr, "[gpush ] phase %d iteration +%d  frontier pairs %9lld  adds %lld\n", phase, i, F, h.atomics[i & (GPUSH_LOG - 1)]);
         }
         it_done = h.it;
+        if (h.stop && h.it == 0 && h.overflow) { // the frontier did not fit the lists: nothing was moved, the sweeps go on
+            *entered = false;
+            return DPPR_OK;
+        }
         if (h.stop) { // an iteration too large for this form: the queued vertices go back to sweep form
             if (trace) fprintf(stderr, "[gpush ] phase %d: an iteration of %d vertices called itself off after %d iterations\n", phase, h.n[h.it & 1], h.it);
             HIP_TRY(hipMemsetAsync(g.cnt, 0, sizeof(int) * 3 * GWM, e->stream));
@@ -1501,8 +1499,9 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
                         push_thr = std::max<long long>(F / 8, 1);
                         dense_len = -1;
                     }
-                } else {
-                    push_gave_up = true;
+                } else { // (the frontier did not fit the lists)
+                    push_thr = std::max<long long>(F / 8, 1);
+                    dense_len = -1;
                 }
             }
         }

@@ -30,7 +30,8 @@ struct GPushCtl {
     int overflow;      // the next list did not hold every queued vertex: the bits do (the host leaves the mode)
     int it;            // iterations run in this mode so far
     int stop;          // set by the scan when an iteration would be too large for this mode: nothing further is changed
-    int pad[2];
+    unsigned int done; // workgroups of the running expand kernel that have finished
+    int pad;
     int F[GPUSH_LOG][GS_MAX]; // legal (vertex, source) pairs each iteration of the chunk pushed, per source
     long long atomics[GPUSH_LOG]; // edge x source adds of each iteration
 };
@@ -56,6 +57,7 @@ template <int SPL>
 __global__ __launch_bounds__(BLOCK) void k_gpush_rows(const int *__restrict__ list, const GPushCtl *__restrict__ ctl, int which,
                                                       double *__restrict__ x, double *__restrict__ r, bool to_x) {
     constexpr int GW = OCT * SPL;
+    if (ctl->overflow) return; // (the list is incomplete: nothing moves, the scan calls the mode off)
     const int n = ctl->n[which];
     const int j = threadIdx.x & (OCT - 1);
     for (int i = (blockIdx.x * BLOCK + threadIdx.x) / OCT; i < n; i += gridDim.x * BLOCK / OCT) {
@@ -126,10 +128,12 @@ __global__ __launch_bounds__(1024) void k_gpush_scan(GPushCtl *ctl, const int *_
     const int n = ctl->n[which];
     const int *list = which ? list1 : list0;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
-    if (n > max_n) {
+    if (n > max_n || ctl->overflow) {
         if (tid == 0) ctl->stop = 1;
         return;
     }
+    if (tid < GS_MAX) ctl->F[ctl->it & (GPUSH_LOG - 1)][tid] = 0; // (this iteration's row of the log: the snapshot adds to it)
+    if (tid == 0) ctl->atomics[ctl->it & (GPUSH_LOG - 1)] = 0;
     if (tid == 0) s_carry = 0;
     __syncthreads();
     for (int base = 0; base < n; base += 1024) {
@@ -173,8 +177,7 @@ __global__ __launch_bounds__(BLOCK) void k_gpush_expand(const int *__restrict__ 
                                                         const Adj *__restrict__ adj, const int *__restrict__ hub_degp1,
                                                         const double *__restrict__ x, double *__restrict__ r,
                                                         uint32_t *__restrict__ bits, int *__restrict__ nlist0, int *__restrict__ nlist1,
-                                                        int cap, int phase, double eps, IterStats *__restrict__ stats,
-                                                        unsigned int *__restrict__ done) {
+                                                        int cap, int phase, double eps, IterStats *__restrict__ stats) {
     constexpr int GW = OCT * SPL;
     __shared__ unsigned long long s_edges;
     if (ctl->stop) return;
@@ -240,8 +243,8 @@ __global__ __launch_bounds__(BLOCK) void k_gpush_expand(const int *__restrict__ 
             atomicAdd(reinterpret_cast<unsigned long long *>(&ctl->atomics[it & (GPUSH_LOG - 1)]), s_edges);
         }
         __threadfence();
-        if (atomicAdd(done, 1u) == gridDim.x - 1) { // everybody's appends are in: the iteration is over
-            *done = 0u;
+        if (atomicAdd(&ctl->done, 1u) == gridDim.x - 1) { // everybody's appends are in: the iteration is over
+            ctl->done = 0u;
             if (ctl->n[which ^ 1] > cap) ctl->n[which ^ 1] = cap; // (overflow is flagged; the bits hold the whole set)
             ctl->it = it + 1;
         }
