@@ -1250,14 +1250,24 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
     const int grid = 256;
     static const bool trace = getenv("DPPR_GROUP_TRACE") != nullptr;
     int it_done = 0;
+    long long known_n = pairs_at_entry; // (an upper bound of the frontier's vertices until the first read-back)
+    bool tiny_declined = false;
     for (;;) {
+        if (known_n <= TINY_N && !tiny_declined) {
+            // a frontier of a few hundred vertices: a run of iterations as ONE single-workgroup launch
+            if (g.spl == 1)
+                hipLaunchKernelGGL(k_gpush_tiny<1>, dim3(1), dim3(1024), 0, e->stream, g.pctl, g.plist[0], g.plist[1], ep.row_ptr, ep.adj, ep.hub_degp1,
+                                   g.r, g.p, g.act[0], phase, eps, g.dstats, GPUSH_LOG);
+            else
+                hipLaunchKernelGGL(k_gpush_tiny<2>, dim3(1), dim3(1024), 0, e->stream, g.pctl, g.plist[0], g.plist[1], ep.row_ptr, ep.adj, ep.hub_degp1,
+                                   g.r, g.p, g.act[0], phase, eps, g.dstats, GPUSH_LOG);
+        } else {
         // iterations per chunk (<= GPUSH_LOG): down here the frontier about halves per iteration, so the first chunk is
-        // sized to reach the end (an iteration that finds nothing is three empty dispatches), follow-ups are short
-        int m = 4;
-        if (it_done == 0) {
-            m = 2;
-            for (long long f = pairs_at_entry; f > 1 && m < GPUSH_LOG; f >>= 1) ++m;
-        }
+        // sized to reach the single-workgroup form (an iteration that finds nothing is three empty dispatches)
+        int m = 2;
+        if (it_done == 0)
+            for (long long f = pairs_at_entry; f > TINY_N && m < GPUSH_LOG; f >>= 1) ++m;
+        tiny_declined = false;
         for (int k = 0; k < m; ++k) {
             hipLaunchKernelGGL(k_gpush_scan, dim3(1), dim3(1024), 0, e->stream, g.pctl, g.plist[0], g.plist[1], ep.row_ptr, g.ppre, cap - 1, max_edges);
             if (g.spl == 1) {
@@ -1269,6 +1279,7 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
                 hipLaunchKernelGGL(k_gpush_expand<2>, dim3(grid), dim3(BLOCK), 0, e->stream, g.plist[0], g.plist[1], g.pctl, g.ppre, ep.row_ptr, ep.adj,
                                    ep.hub_degp1, g.x, g.r, g.act[0], g.plist[0], g.plist[1], cap, phase, eps, g.dstats);
             }
+        }
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(&h, g.pctl, sizeof(GPushCtl), hipMemcpyDeviceToHost, e->stream));
@@ -1283,7 +1294,9 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
             if (trace)
                 fprintf(stderr, "[gpush ] phase %d iteration +%d  frontier pairs %9lld  adds %lld\n", phase, i, F, h.atomics[i & (GPUSH_LOG - 1)]);
         }
+        if (h.it == it_done && !h.stop && known_n <= TINY_N) tiny_declined = true; // (too many vertices or in-edges for one workgroup)
         it_done = h.it;
+        known_n = h.n[h.it & 1];
         if (h.stop && h.it == 0 && h.overflow) { // the frontier did not fit the lists: nothing was moved, the sweeps go on
             *entered = false;
             return DPPR_OK;

@@ -251,6 +251,165 @@ __global__ __launch_bounds__(BLOCK) void k_gpush_expand(const int *__restrict__ 
     }
 }
 
+// A RUN of iterations on a frontier of a few hundred vertices as ONE single-workgroup launch: the scan, the snapshot
+// and the expand of every iteration with workgroup barriers in between, lists, scan and snapshot rows in LDS. What the
+// waves exchange through global memory goes through the L2 only: residual[] is read with agent-scope loads, zeroed with
+// a returning exchange and added to with returning atomics (a wave that waits for the value knows the operation is
+// done), pagerank is credited with an atomic add, the activity bits with returning atomics. Stops -- at an iteration
+// boundary, lists and counters written back for whoever goes on -- when the frontier is empty, when an iteration is too
+// large for it (more than TINY_N vertices or TINY_E in-edges: the three-kernel form takes it) or after max_it
+// iterations; a next list that outgrows TINY_N raises `stop` (the bits hold the set: the host leaves the mode).
+constexpr int TINY_N = 512;
+constexpr int TINY_E = 32768;
+
+template <int SPL>
+__global__ __launch_bounds__(1024) void k_gpush_tiny(GPushCtl *ctl, int *__restrict__ list0, int *__restrict__ list1,
+                                                     const int *__restrict__ in_row_ptr, const Adj *__restrict__ adj,
+                                                     const int *__restrict__ hub_degp1, double *r, double *p, uint32_t *bits, int phase,
+                                                     double eps, IterStats *__restrict__ stats, int max_it) {
+    constexpr int GW = OCT * SPL, NT = 1024, NOCT = NT / OCT;
+    __shared__ int s_list[2][TINY_N];
+    __shared__ int s_pre[TINY_N + 1];
+    __shared__ double s_x[TINY_N * GW];
+    __shared__ int s_w[NT / WAVE];
+    __shared__ int s_n[2];
+    __shared__ int s_cnt[GS_MAX];
+    __shared__ int s_flag; // 1: the next list overflowed
+    __shared__ unsigned long long s_edges;
+    if (ctl->stop || ctl->overflow) return;
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int j = tid & (OCT - 1), oid = tid / OCT;
+    int it = ctl->it, which = it & 1;
+    const int n0 = ctl->n[which];
+    if (n0 > TINY_N) return; // (not a frontier for this kernel)
+    for (int i = tid; i < n0; i += NT) s_list[which][i] = (which ? list1 : list0)[i];
+    if (tid == 0) {
+        s_n[which] = n0;
+        s_n[which ^ 1] = 0;
+        s_flag = 0;
+        s_edges = 0ull;
+    }
+    if (tid < GS_MAX) s_cnt[tid] = 0;
+    unsigned long long edges_before = 0; // (thread 0)
+    for (int step = 0; step < max_it; ++step) {
+        __syncthreads();
+        const int n = s_n[which];
+        if (n == 0 || s_flag) break;
+        // ---- scan of the in-degrees (one vertex per thread: n <= TINY_N <= NT)
+        int d = 0;
+        if (tid < n) {
+            const int u = s_list[which][tid];
+            d = in_row_ptr[u + 1] - in_row_ptr[u];
+        }
+        const int inc = wave_inclusive_scan(d);
+        if (lane == WAVE - 1) s_w[w] = inc;
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int k = 0; k < NT / WAVE; ++k) {
+            woff += k < w ? s_w[k] : 0;
+            tot += s_w[k];
+        }
+        if (tid < n) s_pre[tid] = woff + inc - d;
+        if (tid == 0) s_pre[n] = tot;
+        if (tot > TINY_E) break; // (uniform: every thread computed the same total)
+        // ---- snapshot
+        int nleg[SPL];
+#pragma unroll
+        for (int q = 0; q < SPL; ++q) nleg[q] = 0;
+        for (int i = oid; i < n; i += NOCT) {
+            const int u = s_list[which][i];
+            const size_t base = (size_t)u * GW + j * SPL;
+#pragma unroll
+            for (int q = 0; q < SPL; ++q) {
+                double rv = gs_ld<true>(r + base + q);
+                const bool lg = legal(rv, phase, eps);
+                if (lg) {
+                    rv = atomic_exch(r + base + q, 0.0); // (nobody adds between the load and this: same value)
+                    if (it > 0) (void)__hip_atomic_fetch_add(p + base + q, ALPHA * rv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    nleg[q]++;
+                }
+                s_x[i * GW + j * SPL + q] = lg ? rv : 0.0;
+            }
+            if (j == 0) (void)atomicAnd(&bits[u >> 5], ~(1u << (u & 31)));
+        }
+#pragma unroll
+        for (int q = 0; q < SPL; ++q)
+            if (nleg[q]) atomicAdd(&s_cnt[j * SPL + q], nleg[q]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the credits and bit clears of this wave are at the L2)
+        __syncthreads();
+        if (tid < GS_MAX) {
+            ctl->F[it & (GPUSH_LOG - 1)][tid] = s_cnt[tid];
+            s_cnt[tid] = 0;
+        }
+        // ---- expand
+        const int e_per = (tot + NOCT - 1) / NOCT;
+        int e0 = oid * e_per;
+        const int e1 = min(tot, e0 + e_per);
+        unsigned long long adds = 0;
+        if (e0 < e1) {
+            int lo = 0, hi = n;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_pre[mid] <= e0) lo = mid; else hi = mid;
+            }
+            int i = lo;
+            while (e0 < e1) {
+                while (s_pre[i + 1] <= e0) ++i;
+                const int u = s_list[which][i];
+                double xv[SPL];
+#pragma unroll
+                for (int q = 0; q < SPL; ++q) xv[q] = s_x[i * GW + j * SPL + q];
+                const int row_end = min(s_pre[i + 1], e1);
+                const Adj *row = adj + in_row_ptr[u] + (e0 - s_pre[i]);
+                for (int k = 0; k < row_end - e0; ++k) {
+                    const Adj a = row[k];
+                    const double den = (double)(a.degp1 < 0 ? hub_degp1[~a.degp1] : a.degp1);
+                    bool crossed = false;
+#pragma unroll
+                    for (int q = 0; q < SPL; ++q) {
+                        if (xv[q] != 0.0) {
+                            const double add = ONE_MINUS_ALPHA * xv[q] / den;
+                            const double prer = atomic_add_ret(&r[(size_t)a.v * GW + j * SPL + q], add);
+                            crossed |= !legal(prer, phase, eps) && legal(prer + add, phase, eps);
+                            ++adds;
+                        }
+                    }
+                    if (oct_mask(__ballot(crossed)) && j == 0) {
+                        const uint32_t bit = 1u << (a.v & 31);
+                        const uint32_t old = atomicOr(&bits[a.v >> 5], bit);
+                        if (!(old & bit)) {
+                            const int pos = atomicAdd(&s_n[which ^ 1], 1);
+                            if (pos < TINY_N) s_list[which ^ 1][pos] = a.v;
+                            else s_flag = 1;
+                        }
+                    }
+                }
+                e0 = row_end;
+            }
+        }
+        if (adds) atomicAdd(&s_edges, adds);
+        __syncthreads();
+        if (tid == 0) {
+            ctl->atomics[it & (GPUSH_LOG - 1)] = (long long)(s_edges - edges_before);
+            edges_before = s_edges;
+            s_n[which] = 0; // (becomes the next "next" list)
+        }
+        ++it;
+        which ^= 1;
+    }
+    __syncthreads();
+    // ---- hand over: the live list (which), its size, the iteration count
+    const int n = min(s_n[which], TINY_N);
+    for (int i = tid; i < n; i += NT) (which ? list1 : list0)[i] = s_list[which][i];
+    if (tid == 0) {
+        ctl->n[which] = n;
+        ctl->n[which ^ 1] = 0;
+        ctl->it = it;
+        if (s_flag) ctl->stop = 1; // the list is incomplete, the bits are not: back to sweeps
+        if (s_edges) stats->blk_E[0] += s_edges;
+    }
+}
+
 // Leaving the mode before the loop is over (the frontier grew again): the queued vertices -- exactly the set bits --
 // get their residual rows into the snapshot and their pagerank share (credit: not if no iteration ran here -- then
 // they are the frontier the sweep handed over, credited already), which is what a sweep expects of an active vertex, and the per-source
