@@ -1252,8 +1252,9 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
     int it_done = 0;
     long long known_n = pairs_at_entry; // (an upper bound of the frontier's vertices until the first read-back)
     bool tiny_declined = false;
+    long long last_adds = pairs_at_entry <= 64 ? 0 : -1; // edge x source adds of the last iteration run (-1: not known yet)
     for (;;) {
-        if (known_n <= TINY_N && !tiny_declined) {
+        if (known_n <= TINY_N && last_adds >= 0 && last_adds <= TINY_E / 2 && !tiny_declined) {
             // a frontier of a few hundred vertices: a run of iterations as ONE single-workgroup launch
             if (g.spl == 1)
                 hipLaunchKernelGGL(k_gpush_tiny<1>, dim3(1), dim3(1024), 0, e->stream, g.pctl, g.plist[0], g.plist[1], ep.row_ptr, ep.adj, ep.hub_degp1,
@@ -1266,7 +1267,7 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
         // sized to reach the single-workgroup form (an iteration that finds nothing is three empty dispatches)
         int m = 2;
         if (it_done == 0)
-            for (long long f = pairs_at_entry; f > TINY_N && m < GPUSH_LOG; f >>= 1) ++m;
+            for (long long f = pairs_at_entry; f > 128 && m < GPUSH_LOG; f >>= 2) ++m;
         tiny_declined = false;
         for (int k = 0; k < m; ++k) {
             hipLaunchKernelGGL(k_gpush_scan, dim3(1), dim3(1024), 0, e->stream, g.pctl, g.plist[0], g.plist[1], ep.row_ptr, g.ppre, cap - 1, max_edges);
@@ -1295,6 +1296,7 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
                 fprintf(stderr, "[gpush ] phase %d iteration +%d  frontier pairs %9lld  adds %lld\n", phase, i, F, h.atomics[i & (GPUSH_LOG - 1)]);
         }
         if (h.it == it_done && !h.stop && known_n <= TINY_N) tiny_declined = true; // (too many vertices or in-edges for one workgroup)
+        if (h.it > it_done) last_adds = h.atomics[(h.it - 1) & (GPUSH_LOG - 1)];
         it_done = h.it;
         known_n = h.n[h.it & 1];
         if (h.stop && h.it == 0 && h.overflow) { // the frontier did not fit the lists: nothing was moved, the sweeps go on

@@ -257,10 +257,10 @@ __global__ __launch_bounds__(BLOCK) void k_gpush_expand(const int *__restrict__ 
 // a returning exchange and added to with returning atomics (a wave that waits for the value knows the operation is
 // done), pagerank is credited with an atomic add, the activity bits with returning atomics. Stops -- at an iteration
 // boundary, lists and counters written back for whoever goes on -- when the frontier is empty, when an iteration is too
-// large for it (more than TINY_N vertices or TINY_E in-edges: the three-kernel form takes it) or after max_it
+// large for it (more than TINY_N vertices or TINY_E in-edges: the three-kernel form, with an octet per edge, takes it) or after max_it
 // iterations; a next list that outgrows TINY_N raises `stop` (the bits hold the set: the host leaves the mode).
 constexpr int TINY_N = 512;
-constexpr int TINY_E = 32768;
+constexpr int TINY_E = 1024; // (an octet walks its share of the edges one returning atomic after the other: 8 per octet at most)
 
 template <int SPL>
 __global__ __launch_bounds__(1024) void k_gpush_tiny(GPushCtl *ctl, int *__restrict__ list0, int *__restrict__ list1,
