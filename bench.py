@@ -75,7 +75,8 @@ def parse_args():
                     help="default workload at N = 1 only: do not append the configs[1] (single source, resident path) line")
     ap.add_argument("--group", type=int, default=None, help=argparse.SUPPRESS)  # old spelling of --sources
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
-                    help="engine tuning knob (hub_min_degree, big_row_edges, pull_min_frontier, chunk_iters, pull_block, sweep_bitmap)")
+                    help="engine tuning knob (hub_min_degree, big_row_edges, pull_min_frontier, chunk_iters, pull_block, sweep_bitmap, "
+                         "binned=MODE[,HA_TILES,HB_TILES,TARGET_EDGES,MIN_IDS])")
     return ap.parse_args()
 
 
@@ -158,7 +159,7 @@ def main():
         sources = shard.assign_sources(datagen.top_sources(V, e1, e2, W, directed, 10), rank, world, per_rank=S)
 
     schedule = eng.SCHEDULE_EAGER if a.schedule == "eager" else eng.SCHEDULE_SYNC
-    tune = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.tune}
+    tune = {kv.split("=")[0]: (tuple(int(x) for x in kv.split("=")[1].split(",")) if "," in kv else int(kv.split("=")[1])) for kv in a.tune}
     e = eng.Engine(V, W, directed, c, n_epochs=n_steps + n_prof + 1, device=local_rank, schedule=schedule, **tune)
     ss = st.SlidingStream(V, e1, e2, directed, wl)
     e.load_window(*ss.serialize_edge_stream())

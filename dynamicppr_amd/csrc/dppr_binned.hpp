@@ -1,0 +1,260 @@
+// dppr_binned.hpp -- the dense frontier iteration of ONE source on a window whose snapshot vector is far larger
+// than the L2s: a BINNED (propagation-blocked) sweep.
+//
+// k_pull_iter (dppr_pull.hpp) gathers x[u] for every out-edge (v, u): an 8-byte value out of a 64-byte sector, and once
+// x no longer fits the caches every gather is a random sector from Infinity Cache / HBM (twitter stand-in: 4.4 GB
+// fetched per sweep for 1.2 GB of useful values). The arithmetic does not care in which order the
+// pushes u -> v of gpu/ExpandRev.cuh:70-73 reach residual[v], so the same sums are formed in two STREAMING passes over
+// a per-epoch layout of the window's edges:
+//
+//   * the heads u are cut into A-BLOCKS (consecutive 64-vertex tiles, <= ha_tiles of them, about equal in-edge counts),
+//     the rows v into B-BLOCKS (<= hb_tiles tiles, about equal out-edge counts). The edges of A-block a, ordered by
+//     (B-block of v, v, u), are its A-major run [in_row_ptr[first head of a], in_row_ptr[first head of a + 1]); the edges
+//     of B-block b, ordered by (A-block of u, v, u), are its B-major run [out_row_ptr[first row of b], ...). Both runs
+//     hold the same edges tile by tile (a tile = the edges from A-block a into B-block b) in the same inner order.
+//   * k_bin_scatter (one workgroup per A-block): the block's slice of x is staged in LDS; the A-major run is streamed
+//     (2-byte head index + 4-byte B-major position per edge) and x[u] is written to vals[position]: inside a tile the
+//     positions are consecutive, so a wave's 64 stores are runs of whole lines, not 64 sectors.
+//   * k_bin_reduce (one workgroup per B-block): row accumulators (starting at residual[v]), 1 / (outdeg + 1) and
+//     outdeg + 1 of the block's rows sit in LDS; the B-major run is streamed (8-byte value + 2-byte row index per
+//     edge), add = (1.0-ALPHA) * x[u] / (outdeg(v) + 1) exactly as gpu/ExpandRev.cuh:72 (push_term), runs of one row
+//     inside a wave are summed in registers first (segmented DPP scan) and cost ONE LDS atomic; then repair
+//     (gpu/ExpandRev.cuh:708-743), threshold and the next snapshot per row, as k_pull_iter does them.
+//
+// 24 streamed bytes per edge in lines instead of a 64-byte sector per edge; no global atomics. Results equal
+// k_pull_iter's up to the order of each row's sum.
+#pragma once
+
+#include "dppr_common.hpp"
+
+namespace dppr {
+
+constexpr int BIN_NT = 1024;   // threads of both passes
+#ifndef DPPR_BIN_U
+#define DPPR_BIN_U 8
+#endif
+constexpr int BIN_U = DPPR_BIN_U; // entries in flight per lane
+
+// tile -> block of a cut (cut[k] = first tile of block k, cut[n_blocks] = n_tiles)
+__global__ __launch_bounds__(BLOCK) void k_bin_tile_block(const int *__restrict__ cut, int n_blocks, int n_tiles,
+                                                          int *__restrict__ tile_block) {
+    for (int t = blockIdx.x * BLOCK + threadIdx.x; t < n_tiles; t += gridDim.x * BLOCK) {
+        int lo = 0, hi = n_blocks; // last block whose first tile is <= t
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (cut[mid] <= t) lo = mid; else hi = mid;
+        }
+        tile_block[t] = lo;
+    }
+}
+
+// out-orientation keys (row v << bits | head u, sorted) -> sort key (B-block of v, A-block of u); the value carried
+// through the sort is the edge itself
+__global__ __launch_bounds__(BLOCK) void k_bin_keys(const uint64_t *__restrict__ out_keys, int Ed, int bits,
+                                                    const int *__restrict__ tile_a, const int *__restrict__ tile_b,
+                                                    int abits, uint32_t *__restrict__ k1) {
+    const uint64_t mask = (1ull << bits) - 1;
+    for (int o = blockIdx.x * BLOCK + threadIdx.x; o < Ed; o += gridDim.x * BLOCK) {
+        const uint64_t k = out_keys[o];
+        const int v = (int)(k >> bits), u = (int)(k & mask);
+        k1[o] = ((uint32_t)tile_b[v >> 6] << abits) | (uint32_t)tile_a[u >> 6];
+    }
+}
+
+// B-major order reached: row index of every position, and the keys / values of the second (A-major) sort
+__global__ __launch_bounds__(BLOCK) void k_bin_fill_b(const uint64_t *__restrict__ edges_b, int Ed, int bits,
+                                                      const int *__restrict__ tile_a, const int *__restrict__ tile_b,
+                                                      const int *__restrict__ bcut, uint16_t *__restrict__ dl,
+                                                      uint32_t *__restrict__ k2, uint64_t *__restrict__ v2) {
+    const uint64_t mask = (1ull << bits) - 1;
+    for (int q = blockIdx.x * BLOCK + threadIdx.x; q < Ed; q += gridDim.x * BLOCK) {
+        const uint64_t k = edges_b[q];
+        const int v = (int)(k >> bits), u = (int)(k & mask);
+        dl[q] = (uint16_t)(v - bcut[tile_b[v >> 6]] * WAVE);
+        k2[q] = (uint32_t)tile_a[u >> 6];
+        v2[q] = ((uint64_t)(uint32_t)q << 32) | (uint32_t)u;
+    }
+}
+
+// A-major order reached: head index inside its block and B-major position of every entry
+__global__ __launch_bounds__(BLOCK) void k_bin_fill_a(const uint32_t *__restrict__ k2s, const uint64_t *__restrict__ v2s, int Ed,
+                                                      const int *__restrict__ acut, uint16_t *__restrict__ hl,
+                                                      int *__restrict__ apos) {
+    for (int j = blockIdx.x * BLOCK + threadIdx.x; j < Ed; j += gridDim.x * BLOCK) {
+        const uint64_t qu = v2s[j];
+        apos[j] = (int)(qu >> 32);
+        hl[j] = (uint16_t)((int)(qu & 0xffffffffu) - acut[k2s[j]] * WAVE);
+    }
+}
+
+// Diagnostic build only (-DDPPR_STAMPS, tools/r03/stamps_bin.sh): wall-clock (100 MHz) stamps per workgroup of the last launch
+// whose frontier held at least a third of the vertices
+#ifdef DPPR_STAMPS
+__device__ unsigned long long g_bin_stamps[2][16384 * 6];
+#define BSTAMP(K, i, val)                                                                              \
+    do {                                                                                               \
+        if (threadIdx.x == 0 && blockIdx.x < 16384 && 3 * (long long)*cnt_in >= NV) g_bin_stamps[K][blockIdx.x * 6 + (i)] = (val); \
+    } while (0)
+#else
+#define BSTAMP(K, i, val) ((void)0)
+#endif
+
+// Pass 1: vals[B-major position] = x[head] for every edge of A-block blockIdx.x. LDS: the block's slice of x.
+__global__ __launch_bounds__(BIN_NT) void k_bin_scatter(int NV, const int *__restrict__ cnt_in, const int *__restrict__ acut,
+                                                        const int *__restrict__ in_row_ptr, const uint16_t *__restrict__ hl,
+                                                        const int *__restrict__ apos, const double *__restrict__ x,
+                                                        double *__restrict__ vals) {
+    extern __shared__ double s_x[];
+    if (*cnt_in == 0) return; // empty frontier: nothing is read or written (k_bin_reduce returns as well)
+    const int h0 = acut[blockIdx.x] * WAVE, h1 = min(acut[blockIdx.x + 1] * WAVE, NV);
+    const int j0 = in_row_ptr[h0], j1 = in_row_ptr[h1];
+    BSTAMP(0, 0, wall_clock64());
+    BSTAMP(0, 4, (unsigned long long)(j1 - j0));
+    BSTAMP(0, 1, wall_clock64());
+    BSTAMP(0, 2, wall_clock64());
+    if (j0 == j1) return;
+    for (int i = threadIdx.x; i < h1 - h0; i += BIN_NT) s_x[i] = x[h0 + i];
+    __syncthreads();
+    BSTAMP(0, 1, wall_clock64());
+    for (int j = j0 + (int)threadIdx.x; j < j1; j += BIN_NT * BIN_U) {
+        int h[BIN_U], q[BIN_U];
+#pragma unroll
+        for (int k = 0; k < BIN_U; ++k) {
+            const int jj = j + k * BIN_NT;
+            h[k] = jj < j1 ? (int)hl[jj] : -1;
+            q[k] = jj < j1 ? apos[jj] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < BIN_U; ++k)
+            if (h[k] >= 0) vals[q[k]] = s_x[h[k]];
+    }
+#ifdef DPPR_STAMPS
+    __syncthreads();
+    BSTAMP(0, 2, wall_clock64());
+#endif
+}
+
+// wave64 segmented inclusive sum on the DPP path: `head` marks the first lane of a run; every lane receives the sum
+// of its run up to itself. Same ladder as wave_inclusive_scan; a lane that has seen a head inside its window stops
+// taking from below.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void seg_step(double &x, int &f) {
+    const double y = dpp_take_f64<CTRL, ROW_MASK>(x);
+    const int g = __builtin_amdgcn_update_dpp(0, f, CTRL, ROW_MASK, 0xf, false);
+    if (!f) x += y; // (lanes without a source received 0.0 and 0)
+    f |= g;
+}
+__device__ __forceinline__ double wave_segmented_sum(double x, bool head) {
+    int f = head ? 1 : 0;
+    seg_step<0x111, 0xf>(x, f);
+    seg_step<0x112, 0xf>(x, f);
+    seg_step<0x114, 0xf>(x, f);
+    seg_step<0x118, 0xf>(x, f);
+    seg_step<0x142, 0xa>(x, f);
+    seg_step<0x143, 0xc>(x, f);
+    return x;
+}
+
+// Pass 2: the rows of B-block blockIdx.x. LDS (dynamic): per row accumulator (8) + reciprocal (8) + outdeg + 1 (4).
+// Workgroups beyond the n_b blocks take the rows [NV_bin, NV) in pieces of rows_cap: vertices that received their id after
+// the tables were built (they have no edge in this epoch, but may hold state).
+__global__ __launch_bounds__(BIN_NT) void k_bin_reduce(int NV, int NV_bin, int n_b, const int *__restrict__ cnt_in, const int *__restrict__ bcut,
+                                                       int rows_cap, const int *__restrict__ out_row_ptr,
+                                                       const uint16_t *__restrict__ dl, const double *__restrict__ vals,
+                                                       const double *__restrict__ x, double *__restrict__ x_new,
+                                                       double *__restrict__ r, double *__restrict__ p,
+                                                       int *__restrict__ cnt_out, int *__restrict__ cnt_zero, int phase, double eps,
+                                                       IterStats *__restrict__ stats, int *__restrict__ log_slot) {
+    extern __shared__ double s_bin[];
+    __shared__ int s_cnt[BIN_NT / WAVE];
+    __shared__ unsigned long long s_edges[BIN_NT / WAVE];
+    double *s_acc = s_bin, *s_rcp = s_bin + rows_cap;
+    int *s_den = reinterpret_cast<int *>(s_bin + 2 * rows_cap);
+    const int F = *cnt_in;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *cnt_zero = 0;
+        *log_slot = F;
+    }
+    if (F == 0) return;
+    const int lane = lane_id(), w = wave_id();
+    int v0, v1;
+    if ((int)blockIdx.x < n_b) {
+        v0 = bcut[blockIdx.x] * WAVE;
+        v1 = min(bcut[blockIdx.x + 1] * WAVE, NV_bin);
+    } else {
+        v0 = min(NV_bin + ((int)blockIdx.x - n_b) * rows_cap, NV);
+        v1 = min(v0 + rows_cap, NV);
+    }
+    const int nrows = v1 - v0;
+    for (int i = threadIdx.x; i < nrows; i += BIN_NT) {
+        const int d = out_row_ptr[v0 + i + 1] - out_row_ptr[v0 + i];
+        s_acc[i] = r[v0 + i];
+        s_rcp[i] = 1.0 / (double)(d + 1);
+        s_den[i] = d + 1;
+    }
+    const int e0 = out_row_ptr[v0], e1 = out_row_ptr[v1];
+    BSTAMP(1, 0, wall_clock64());
+    BSTAMP(1, 4, (unsigned long long)(e1 - e0));
+    __syncthreads();
+    BSTAMP(1, 1, wall_clock64());
+    unsigned long long edges = 0;
+    for (int q0 = e0; q0 < e1; q0 += BIN_NT * BIN_U) { // workgroup-uniform trip count (the DPP steps below want whole waves);
+        const int q = q0 + (int)threadIdx.x;           // a wave's lanes hold 64 consecutive entries per k
+        double xv[BIN_U];
+        int row[BIN_U];
+#pragma unroll
+        for (int k = 0; k < BIN_U; ++k) {
+            const int qq = q + k * BIN_NT;
+            xv[k] = qq < e1 ? vals[qq] : 0.0;
+            row[k] = qq < e1 ? (int)dl[qq] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < BIN_U; ++k) {
+            const bool nz = xv[k] != 0.0;
+            const uint64_t any = __ballot(nz);
+            if (any == 0) continue; // wave-uniform
+            edges += (unsigned long long)__popcll(any);
+            const int i = nz ? row[k] : -1 - lane; // a lane without a term is a run of its own
+            const double t = nz ? push_term(xv[k], (double)s_den[row[k]], s_rcp[row[k]]) : 0.0;
+            const int below = __builtin_amdgcn_update_dpp(-0x7fffffff, i, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            const int above = __builtin_amdgcn_update_dpp(-0x7fffffff, i, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+            const double sum = wave_segmented_sum(t, lane == 0 || below != i);
+            if (nz && (lane == WAVE - 1 || above != i)) lds_add(&s_acc[i], sum); // the run's last lane
+        }
+    }
+    __syncthreads();
+    BSTAMP(1, 2, wall_clock64());
+    // repair, threshold, next snapshot (k_pull_iter's `finish`)
+    int n_legal = 0;
+    for (int i = threadIdx.x; i < nrows; i += BIN_NT) {
+        const int v = v0 + i;
+        const double rv = r[v], xvv = x[v];
+        double rn = s_acc[i];
+        if (xvv != 0.0) rn -= xvv;
+        const bool lg = legal(rn, phase, eps);
+        if (rn != rv) r[v] = rn;
+        x_new[v] = lg ? rn : 0.0;
+        if (lg) {
+            p[v] += ALPHA * rn;
+            n_legal++;
+        }
+    }
+    const int cw = wave_inclusive_scan(n_legal);
+    if (lane == WAVE - 1) s_cnt[w] = cw;
+    if (lane == 0) s_edges[w] = edges;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        unsigned long long te = 0;
+#pragma unroll
+        for (int k = 0; k < BIN_NT / WAVE; ++k) {
+            tot += s_cnt[k];
+            te += s_edges[k];
+        }
+        if (tot) atomicAdd(cnt_out, tot);
+        if (te) atomicAdd(&stats->blk_E[blockIdx.x & (STAT_SLOTS - 1)], te); // (more workgroups than slots: slots are shared)
+    }
+    BSTAMP(1, 3, wall_clock64());
+}
+
+} // namespace dppr

@@ -24,6 +24,7 @@
 #include "dppr_kernels.hpp"
 #include "dppr_multi.hpp"
 #include "dppr_gpush.hpp"
+#include "dppr_binned.hpp"
 
 using namespace dppr;
 
@@ -64,6 +65,14 @@ struct Epoch {
     // hub directory of this epoch (vertices whose pushes are aggregated in LDS)
     int *hub_v = nullptr, *hub_degp1 = nullptr;
     int n_hubs = 0;
+    // binned sweep (dppr_binned.hpp): block cuts (first tile of every A- / B-block), per edge the head index inside
+    // its A-block + B-major position (A-major order) and the row index inside its B-block (B-major order)
+    int *acut = nullptr, *bcut = nullptr;
+    int n_a = 0, n_b = 0;
+    uint16_t *hl = nullptr, *dl = nullptr;
+    int *apos = nullptr;
+    bool bin_valid = false;
+    int bin_n_int = 0; // internal ids the tables cover (<= grp_n_int: later ids have no edge in this epoch)
 };
 
 struct Slot {
@@ -188,6 +197,18 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     int gpush_list_cap = 1 << 20;   // vertices a frontier list of that form holds
     long long gpush_max_edges = 0;  // in-edges one iteration of that form may have (0: from the sweep's floor, 200 per sweep group)
     int gpush_auto_factor = 2;      // automatic threshold: this many pairs per sweep group (DPPR_GROUP_PUSH_FACTOR: tuning runs)
+    // binned sweep of single-source loops on windows far beyond the L2s (dppr_binned.hpp, dppr_set_binned_sweep)
+    int bin_mode = 1;               // 0: never, 1: when a source slot exists and the window has >= bin_min_ids vertices, 2: always
+    int bin_ha_tiles = 128, bin_hb_tiles = 64; // most 64-vertex tiles an A-block (heads, 8 B of LDS each) / a B-block (rows, 20 B each) holds
+    long long bin_target = 49152;   // edges a block is cut for
+    long long bin_min_ids = 6ll << 20; // 48 MB of snapshot: beyond what the eight L2s hold together
+    uint32_t *bin_k[2] = {nullptr, nullptr}; // sort keys (Ed each)
+    int *bin_tile_a = nullptr, *bin_tile_b = nullptr; // tile -> block
+    double *bin_vals = nullptr;     // the values in B-major order: what pass 1 hands to pass 2 (one loop runs at a time)
+    void *bin_tmp = nullptr;
+    size_t bin_tmp_bytes = 0;
+    bool bin_ready = false;         // scratch allocated, kernels' LDS sizes registered
+    std::vector<int32_t> h_tiles_in;
     // stream-update scratch
     uint32_t *su_k[2] = {nullptr, nullptr}, *su_v[2] = {nullptr, nullptr};
     double *su_term = nullptr;
@@ -263,6 +284,7 @@ bool translate(dppr_engine *e, const int32_t *src, int n, std::vector<int32_t> &
 }
 
 int cut_sweep_groups(dppr_engine *e, Epoch &ep);
+int build_bins(dppr_engine *e, Epoch &ep);
 
 // A vertex that got its internal id AFTER an epoch was built (a source outside the window, a
 // dppr_write to an unseen vertex) is not covered by that epoch's sweep groups: re-cut them.
@@ -272,6 +294,7 @@ int recut_stale_groups(dppr_engine *e) {
                            (e->wide_groups && ep.ggrp_max_tiles > 512 / WAVE))) {
             int rc = cut_sweep_groups(e, ep);
             if (rc) return rc;
+            // (binned tables stay valid: k_bin_reduce takes the ids beyond bin_n_int, which have no edge in this epoch, on the side)
         }
     return DPPR_OK;
 }
@@ -722,6 +745,90 @@ int cut_sweep_groups(dppr_engine *e, Epoch &ep) {
     return DPPR_OK;
 }
 
+
+// ---- binned sweep tables of an epoch (dppr_binned.hpp). Part of the (untimed) graph build; needs the sorted
+// out-orientation keys, i.e. `ep` must be the epoch the persistent key arrays describe (the newest one).
+bool bin_wanted(const dppr_engine *e) {
+    if (e->bin_mode == 2) return true;
+    return e->bin_mode == 1 && !e->slots.empty() && (long long)e->n_int >= e->bin_min_ids;
+}
+
+int bin_prepare(dppr_engine *e) { // engine-level scratch, once
+    if (e->bin_ready) return DPPR_OK;
+    const size_t Edn = (size_t)std::max(e->Ed, 1), nt = (size_t)e->V / WAVE + 3;
+    for (int k = 0; k < 2; ++k) HIP_TRY(hipMalloc((void **)&e->bin_k[k], sizeof(uint32_t) * Edn));
+    HIP_TRY(hipMalloc((void **)&e->bin_tile_a, sizeof(int) * nt));
+    HIP_TRY(hipMalloc((void **)&e->bin_tile_b, sizeof(int) * nt));
+    HIP_TRY(hipMalloc((void **)&e->bin_vals, sizeof(double) * (Edn + 64)));
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, e->bin_tmp_bytes, e->bin_k[0], e->bin_k[1], e->keys_a, e->keys_b, Edn, 0u, 32u, e->stream));
+    HIP_TRY(hipMalloc(&e->bin_tmp, std::max<size_t>(e->bin_tmp_bytes, 16)));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                e->bin_ha_tiles * WAVE * (int)sizeof(double)));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_reduce), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                e->bin_hb_tiles * WAVE * 20));
+    e->bin_ready = true;
+    return DPPR_OK;
+}
+
+int build_bins(dppr_engine *e, Epoch &ep) {
+    ep.bin_valid = false;
+    if (!bin_wanted(e) || e->Ed <= 0 || ep.grp_n_int <= 0) return DPPR_OK;
+    if (int rc = bin_prepare(e)) return rc;
+    const int Ed = e->Ed, NV = ep.grp_n_int;
+    const int n_tiles = (NV + WAVE - 1) / WAVE;
+    if (!ep.hl) {
+        const size_t Edn = (size_t)Ed, nt = (size_t)e->V / WAVE + 3;
+        HIP_TRY(hipMalloc((void **)&ep.hl, sizeof(uint16_t) * Edn));
+        HIP_TRY(hipMalloc((void **)&ep.dl, sizeof(uint16_t) * Edn));
+        HIP_TRY(hipMalloc((void **)&ep.apos, sizeof(int) * Edn));
+        HIP_TRY(hipMalloc((void **)&ep.acut, sizeof(int) * nt));
+        HIP_TRY(hipMalloc((void **)&ep.bcut, sizeof(int) * nt));
+    }
+    // tile prefixes of both CSRs -> host -> cuts (blocks of about bin_target edges, bounded tile counts)
+    int *scratch = e->hub_slot_of; // V ints (free once the CSRs are built)
+    e->h_tiles.resize((size_t)n_tiles + 2);
+    e->h_tiles_in.resize((size_t)n_tiles + 2);
+    hipLaunchKernelGGL(k_tile_prefix, dim3(grid_for(n_tiles + 1)), dim3(BLOCK), 0, e->stream, ep.out_row_ptr, NV, n_tiles, scratch);
+    HIP_TRY(hipMemcpyAsync(e->h_tiles.data(), scratch, sizeof(int) * ((size_t)n_tiles + 1), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    hipLaunchKernelGGL(k_tile_prefix, dim3(grid_for(n_tiles + 1)), dim3(BLOCK), 0, e->stream, ep.row_ptr, NV, n_tiles, scratch);
+    HIP_TRY(hipMemcpyAsync(e->h_tiles_in.data(), scratch, sizeof(int) * ((size_t)n_tiles + 1), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    std::vector<int32_t> cut_a, cut_b;
+    const long long want = std::max<long long>(1, (long long)Ed / std::max<long long>(e->bin_target, 1));
+    cut_greedy(e->h_tiles_in.data(), n_tiles, e->bin_ha_tiles, want, 2 * WAVE, cut_a);
+    cut_greedy(e->h_tiles.data(), n_tiles, e->bin_hb_tiles, want, 2 * WAVE, cut_b);
+    ep.n_a = (int)cut_a.size() - 1;
+    ep.n_b = (int)cut_b.size() - 1;
+    int abits = 1, bbits = 1;
+    while ((1 << abits) < ep.n_a) abits++;
+    while ((1 << bbits) < ep.n_b) bbits++;
+    if (abits + bbits > 32) return DPPR_OK; // (a window of that many blocks: the sweep stays k_pull_iter)
+    HIP_TRY(hipMemcpyAsync(ep.acut, cut_a.data(), sizeof(int) * cut_a.size(), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(ep.bcut, cut_b.data(), sizeof(int) * cut_b.size(), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_bin_tile_block, dim3(grid_for(n_tiles)), dim3(BLOCK), 0, e->stream, ep.acut, ep.n_a, n_tiles, e->bin_tile_a);
+    hipLaunchKernelGGL(k_bin_tile_block, dim3(grid_for(n_tiles)), dim3(BLOCK), 0, e->stream, ep.bcut, ep.n_b, n_tiles, e->bin_tile_b);
+    const uint64_t *out_keys = e->directed ? e->out_sorted : e->in_sorted;
+    hipLaunchKernelGGL(k_bin_keys, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->stream, out_keys, Ed, e->bits, e->bin_tile_a, e->bin_tile_b,
+                       abits, e->bin_k[0]);
+    HIP_TRY(hipGetLastError());
+    size_t tmp = e->bin_tmp_bytes; // B-major: stable by (B-block, A-block); the keys are in (row, head) order
+    HIP_TRY(rocprim::radix_sort_pairs(e->bin_tmp, tmp, e->bin_k[0], e->bin_k[1], out_keys, e->keys_a, (size_t)Ed, 0u,
+                                      (unsigned)(abits + bbits), e->stream));
+    hipLaunchKernelGGL(k_bin_fill_b, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->stream, e->keys_a, Ed, e->bits, e->bin_tile_a,
+                       e->bin_tile_b, ep.bcut, ep.dl, e->bin_k[0], e->keys_b);
+    HIP_TRY(hipGetLastError());
+    tmp = e->bin_tmp_bytes;        // A-major: the B-major sequence, stable by A-block
+    HIP_TRY(rocprim::radix_sort_pairs(e->bin_tmp, tmp, e->bin_k[0], e->bin_k[1], e->keys_b, e->keys_a, (size_t)Ed, 0u,
+                                      (unsigned)abits, e->stream));
+    hipLaunchKernelGGL(k_bin_fill_a, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->stream, e->bin_k[1], e->keys_a, Ed, ep.acut, ep.hl, ep.apos);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream)); // the cuts are locals
+    ep.bin_n_int = NV;
+    ep.bin_valid = true;
+    return DPPR_OK;
+}
+
 // Hub directory + in-CSR + out-CSR of `ep` from the persistent sorted keys and outdeg.
 int build_epoch(dppr_engine *e, Epoch &ep) {
     const int Ed = e->Ed;
@@ -755,7 +862,8 @@ int build_epoch(dppr_engine *e, Epoch &ep) {
                        e->directed ? e->out_sorted : e->in_sorted, Ed, e->V, e->bits, ep.out_row_ptr, ep.out_col);
     HIP_TRY(hipGetLastError());
     ep.Ed = Ed;
-    return cut_sweep_groups(e, ep);
+    if (int rc = cut_sweep_groups(e, ep)) return rc;
+    return build_bins(e, ep);
 }
 
 int read_count(dppr_engine *e, const int *dptr, int *out) {
@@ -810,7 +918,8 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
     const int push_grid = pull_min == 0x7fffffff ? 2048 : std::min(2048, std::max(64, (pull_min * 4 / WAVE + 3) / 4));
     // Sweeps on a window that cannot run resident carry the activity bitmap of their snapshot (k_pull_iter<.., true>)
     const int pcap0 = persist_capacity(e);
-    const bool use_bits = e->sweep_bits && !entry.dense && (pcap0 <= 0 || ep.n_groups > pcap0);
+    const bool binned = ep.bin_valid && ep.bin_n_int <= ep.grp_n_int && (pcap0 <= 0 || ep.n_groups > pcap0 || e->bin_mode == 2);
+    const bool use_bits = e->sweep_bits && !binned && !entry.dense && (pcap0 <= 0 || ep.n_groups > pcap0);
     bool dense_valid = entry.dense; // s.x holds the snapshot of the current frontier (p already updated)
     bool list_valid = !entry.dense; // s.ft[buf] holds the frontier as a list (sweeps only count it)
     bool any_pull = entry.any_pull;
@@ -940,7 +1049,20 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 dense_valid = true;
             }
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k], e->stream));
-            if (pull) {
+            if (pull && binned) {
+                // the sweep as two streaming passes over the epoch's binned edge layout (dppr_binned.hpp)
+                hipLaunchKernelGGL(k_bin_scatter, dim3(ep.n_a), dim3(BIN_NT), (size_t)e->bin_ha_tiles * WAVE * sizeof(double), e->stream,
+                                   ep.bin_n_int, s.cnt + cur, ep.acut, ep.row_ptr, ep.hl, ep.apos, s.x, e->bin_vals);
+                const int rows_cap = e->bin_hb_tiles * WAVE;
+                hipLaunchKernelGGL(k_bin_reduce, dim3(ep.n_b + (ep.grp_n_int - ep.bin_n_int + rows_cap - 1) / rows_cap), dim3(BIN_NT),
+                                   (size_t)rows_cap * 20, e->stream, ep.grp_n_int, ep.bin_n_int, ep.n_b, s.cnt + cur, ep.bcut, rows_cap,
+                                   ep.out_row_ptr, ep.dl, e->bin_vals, s.x,
+                                   s.x2, s.r, s.p, s.cnt + nxt, s.cnt + zer, phase, eps, s.dstats, log_slot);
+                std::swap(s.x, s.x2);
+                dense_valid = true;
+                list_valid = false;
+                any_pull = true;
+            } else if (pull) {
                 // workgroup size = max tiles per group x 64 (the groups themselves were cut by the builder)
                 const int pb = sweep_block(e);
 #define DPPR_LAUNCH_PULL(PB, BITS)                                                                                    \
@@ -1002,6 +1124,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             s.st.iterations++;
             s.st.sum_F += f;
             if (pull) s.st.pull_iterations++;
+            if (pull && binned) s.st.binned_sweeps++;
             active_iters = it + k + 1;
             if (e->profiling) {
                 float ms = 0;
@@ -1691,7 +1814,10 @@ void dppr_destroy(dppr_engine *e) {
     for (auto &ep : e->epochs) {
         (void)hipFree(ep.row_ptr); (void)hipFree(ep.adj); (void)hipFree(ep.out_row_ptr); (void)hipFree(ep.out_col); (void)hipFree(ep.b1); (void)hipFree(ep.b2);
         (void)hipFree(ep.deg_after); (void)hipFree(ep.ins); (void)hipFree(ep.hub_v); (void)hipFree(ep.hub_degp1); (void)hipFree(ep.grp_tile); (void)hipFree(ep.ggrp_tile); (void)hipFree(ep.gtab);
+        (void)hipFree(ep.acut); (void)hipFree(ep.bcut); (void)hipFree(ep.hl); (void)hipFree(ep.dl); (void)hipFree(ep.apos);
     }
+    for (int k = 0; k < 2; ++k) (void)hipFree(e->bin_k[k]);
+    (void)hipFree(e->bin_tile_a); (void)hipFree(e->bin_tile_b); (void)hipFree(e->bin_vals); (void)hipFree(e->bin_tmp);
     (void)hipFree(e->w1); (void)hipFree(e->w2); (void)hipFree(e->outdeg);
     (void)hipFree(e->bar);
     (void)hipFree(e->hub_slot_of); (void)hipFree(e->hub_hist); (void)hipFree(e->d_ext2int); (void)hipFree(e->d_xfer);
@@ -1752,6 +1878,18 @@ int dppr_set_tuning(dppr_engine *e, int hub_min_degree, int big_row_edges, int p
 int dppr_set_sweep_bitmap(dppr_engine *e, int on) {
     if (!e) return DPPR_ERR_INVALID;
     e->sweep_bits = on != 0;
+    return DPPR_OK;
+}
+
+int dppr_set_binned_sweep(dppr_engine *e, int mode, int ha_tiles, int hb_tiles, int64_t target_edges, int64_t min_ids) {
+    if (!e || mode < 0 || mode > 2 || ha_tiles < 0 || ha_tiles > 288 || hb_tiles < 0 || hb_tiles > 120 || target_edges < 0 || min_ids < 0 ||
+        e->bin_ready || e->loaded)
+        return fail(e, DPPR_ERR_INVALID, "set_binned_sweep: call right after dppr_create; mode 0..2, ha_tiles <= 288, hb_tiles <= 120");
+    e->bin_mode = mode;
+    if (ha_tiles > 0) e->bin_ha_tiles = ha_tiles;
+    if (hb_tiles > 0) e->bin_hb_tiles = hb_tiles;
+    if (target_edges > 0) e->bin_target = target_edges;
+    if (min_ids > 0) e->bin_min_ids = min_ids;
     return DPPR_OK;
 }
 
@@ -2010,6 +2148,9 @@ int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->slots.push_back(std::move(s));
     if (int rc = recut_stale_groups(e)) return rc; // the source may have received a fresh internal id
+    if (Epoch *nw = find_epoch(e, -1)) // a window that sweeps binned: the newest epoch's tables, if it was built before any slot existed
+        if (!nw->bin_valid && bin_wanted(e))
+            if (int rc = build_bins(e, *nw)) return rc;
     if (out_slot) *out_slot = (int)e->slots.size() - 1;
     return DPPR_OK;
 }
@@ -2492,6 +2633,10 @@ int dppr_group_stats(dppr_engine *e, int32_t group, dppr_stats_t *out) {
 
 #ifdef DPPR_STAMPS
 // diagnostic build only: copy the stage stamps of the last sweep (rows x 8 clock values)
+extern "C" int dppr_debug_bin_stamps(unsigned long long *out, int which, int rows) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dppr::g_bin_stamps), sizeof(unsigned long long) * 6 * (size_t)rows,
+                               sizeof(unsigned long long) * 6 * 16384 * (size_t)which) == hipSuccess ? 0 : -2;
+}
 extern "C" int dppr_debug_stamps(unsigned long long *out, int rows) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(dppr::g_stamps), sizeof(unsigned long long) * 8 * (size_t)rows) == hipSuccess
                ? 0 : -2;

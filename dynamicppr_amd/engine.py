@@ -29,7 +29,8 @@ class Stats(C.Structure):
                 ("records", C.c_int64), ("inspected", C.c_int64), ("batches", C.c_int64),
                 ("pull_iterations", C.c_int64),
                 ("algorithmic_bytes", C.c_int64), ("gpu_ms", C.c_double), ("push_ms", C.c_double),
-                ("push_launches", C.c_int64), ("persist_launches", C.c_int64), ("persist_aborts", C.c_int64)]
+                ("push_launches", C.c_int64), ("persist_launches", C.c_int64), ("persist_aborts", C.c_int64),
+                ("binned_sweeps", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -55,7 +56,7 @@ EXPORTS = [
     "dppr_trace_get", "dppr_synchronize", "dppr_bench_atomics",
     "dppr_add_source_group", "dppr_group_init_solve", "dppr_group_update", "dppr_group_read", "dppr_group_stats",
     "dppr_group_reset_stats", "dppr_set_group_seeding", "dppr_seed_lists", "dppr_set_sweep_bitmap", "dppr_set_group_resident",
-    "dppr_set_renumbering", "dppr_id_space", "dppr_set_group_push",
+    "dppr_set_renumbering", "dppr_id_space", "dppr_set_group_push", "dppr_set_binned_sweep",
 ]
 
 
@@ -111,6 +112,7 @@ def lib():
     L.dppr_group_read.argtypes = [vp, C.c_int32, C.c_int32, dp, dp]
     L.dppr_group_stats.argtypes = [vp, C.c_int32, C.POINTER(Stats)]
     L.dppr_set_sweep_bitmap.argtypes = [vp, C.c_int]
+    L.dppr_set_binned_sweep.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64]
     L.dppr_set_group_resident.argtypes = [vp, C.c_int]
     L.dppr_seed_lists.argtypes = [vp, C.c_int32, C.c_int, ip, ip]
     L.dppr_group_reset_stats.argtypes = [vp, C.c_int32]
@@ -140,7 +142,7 @@ class Engine:
 
     def __init__(self, V, W, directed, max_batch, n_epochs=1, device=0, schedule=SCHEDULE_EAGER,
                  hub_min_degree=None, big_row_edges=None, pull_min_frontier=None, chunk_iters=None, pull_block=None,
-                 persistent=None, persist_timeout_us=None, sweep_bitmap=None):
+                 persistent=None, persist_timeout_us=None, sweep_bitmap=None, binned=None):
         self._L = lib()
         self._h = C.c_void_p()
         self.V, self.W, self.directed, self.c = int(V), int(W), int(directed), int(max_batch)
@@ -155,6 +157,10 @@ class Engine:
                                              int(pull_block or 0)), "set_tuning")
         if sweep_bitmap is not None:
             self._ck(self._L.dppr_set_sweep_bitmap(self._h, int(sweep_bitmap)), "set_sweep_bitmap")
+        if binned is not None:   # int mode, or (mode, ha_tiles, hb_tiles, target_edges, min_ids)
+            args = (binned,) if isinstance(binned, int) else tuple(binned)
+            args = tuple(int(a) for a in args) + (0,) * (5 - len(args))
+            self._ck(self._L.dppr_set_binned_sweep(self._h, *args), "set_binned_sweep")
         if persistent is not None or persist_timeout_us is not None:
             self._ck(self._L.dppr_set_persistent(self._h, 1 if persistent is None else int(persistent),
                                                  int(persist_timeout_us or 0)), "set_persistent")

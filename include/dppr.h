@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DPPR_ABI_VERSION 1
+#define DPPR_ABI_VERSION 2
 
 typedef struct dppr_engine dppr_engine; /* opaque */
 
@@ -69,6 +69,7 @@ typedef struct dppr_stats_t {
     int64_t push_launches; /* push-kernel launches timed into push_ms */
     int64_t persist_launches; /* launches of the resident multi-iteration sweep (k_pull_resident) */
     int64_t persist_aborts;   /* of those, launches that stopped at a grid-barrier time-out */
+    int64_t binned_sweeps;    /* pull iterations evaluated as a binned sweep (k_bin_scatter + k_bin_reduce; subset of pull_iterations) */
 } dppr_stats_t;
 
 /* ---- lifetime ----------------------------------------------------------- */
@@ -129,6 +130,20 @@ int dppr_set_persistent(dppr_engine *e, int mode, int64_t timeout_us);
  * extra dependent L2 round trip per edge costs more than the sectors it saves; profiles/r02_pmc_*_bits*).
  * Source groups always use their bitmap (dppr_multi.hpp). Results are identical either way. */
 int dppr_set_sweep_bitmap(dppr_engine *e, int on);
+
+/* Single-source dense iterations on windows whose snapshot vector is far beyond the L2s run as a BINNED
+ * (propagation-blocked) sweep: two streaming passes over a per-epoch layout of the window's edges instead of one
+ * random 64-byte sector per edge (dppr_binned.hpp: k_bin_scatter + k_bin_reduce replace k_pull_iter; the per-edge
+ * term is still gpu/ExpandRev.cuh:72's expression, results equal k_pull_iter's up to the order of each row's sum).
+ *   mode         : 0 never, 1 (default) when a source slot exists and the window has at least min_ids vertices with
+ *                  an id, 2 always (tests: tiny windows)
+ *   ha_tiles     : most 64-vertex tiles of heads per A-block (8 bytes of LDS per head; 0 keeps the default, 128)
+ *   hb_tiles     : most tiles of rows per B-block (20 bytes of LDS per row; 0 keeps 64)
+ *   target_edges : edges a block is cut for (0 keeps 49152)
+ *   min_ids      : mode 1 threshold (0 keeps 6 Mi: 48 MB of snapshot)
+ * The layout costs 8 bytes per window edge and epoch plus 16 bytes per window edge of scratch, and is built in
+ * dppr_slide / dppr_load_window (untimed, like the CSRs). Only valid right after dppr_create. */
+int dppr_set_binned_sweep(dppr_engine *e, int mode, int ha_tiles, int hb_tiles, int64_t target_edges, int64_t min_ids);
 
 /* ---- graph side (UNTIMED in the reference's metric) --------------------- */
 

@@ -41,10 +41,16 @@ TUNINGS = [dict(pull_min_frontier=-1), dict(hub_min_degree=3, big_row_edges=8, p
            dict(pull_min_frontier=1, chunk_iters=3),
            # per-iteration sweeps that test the activity bitmap before each gather (several groups / mixed with push / odd block)
            dict(pull_min_frontier=1, persistent=0, sweep_bitmap=1, pull_block=256, big_row_edges=8),
-           dict(pull_min_frontier=40, persistent=0, sweep_bitmap=1), dict(pull_min_frontier=1, sweep_bitmap=1, pull_block=640)]
+           dict(pull_min_frontier=40, persistent=0, sweep_bitmap=1), dict(pull_min_frontier=1, sweep_bitmap=1, pull_block=640),
+           # binned sweeps (k_bin_scatter + k_bin_reduce instead of k_pull_iter; on by itself only on windows of millions of
+           # vertices): one-tile blocks of ~64 edges (dozens of blocks, every tile a handful of edges), the default
+           # block shape (one block each), and mixed with push iterations in chunks of 3
+           dict(pull_min_frontier=1, persistent=0, binned=(2, 1, 1, 64)), dict(pull_min_frontier=1, persistent=0, binned=2),
+           dict(pull_min_frontier=40, persistent=0, binned=(2, 2, 3, 200), chunk_iters=3)]
 TUNING_IDS = ["push-only", "push-hubs+bigrows", "push-all-hub-all-big", "pull-only", "mixed-pull>=40", "default",
               "mixed-chunk1", "mixed-chunk3", "pull-wg512", "mixed-wg1024", "pull-no-persist", "pull-wg256",
-              "pull-rollcall-fails", "pull-resident-3-sweeps", "pull-bitmap-wg256", "mixed-bitmap", "pull-bitmap-wg640"]
+              "pull-rollcall-fails", "pull-resident-3-sweeps", "pull-bitmap-wg256", "mixed-bitmap", "pull-bitmap-wg640",
+              "binned-tiny-blocks", "binned-one-block", "mixed-binned-chunk3"]
 
 
 def make(directed, schedule=eng.SCHEDULE_EAGER, scale=9, edges=6000, seed=11, W=600, c=6, eps=1e-9, n_epochs=1,
@@ -196,6 +202,10 @@ def test_sync_schedule_frontier_sets_bit_exact(directed, tuning):
         compare()
     st = sc.e.stats(sc.slot)
     assert st["sum_E"] == sc.s.stats()["E"] and st["sum_F"] == sc.s.stats()["F"]
+    if "binned" in tuning:   # every sweep took the binned form
+        assert st["binned_sweeps"] == st["pull_iterations"] > 0
+    else:
+        assert st["binned_sweeps"] == 0
 
 
 @pytest.mark.parametrize("variant", [1, 3])
