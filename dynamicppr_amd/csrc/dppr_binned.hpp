@@ -7,12 +7,12 @@
 // pushes u -> v of gpu/ExpandRev.cuh:70-73 reach residual[v], so the same sums are formed in two STREAMING passes over
 // a per-epoch layout of the window's edges:
 //
-//   * the heads u are cut into A-BLOCKS (consecutive 64-vertex tiles, <= ha_tiles of them, about equal in-edge counts),
-//     the rows v into B-BLOCKS (<= hb_tiles tiles, about equal out-edge counts). The edges of A-block a, ordered by
+//   * the heads u are cut into A-BLOCKS (consecutive vertices, at most 64 ha_tiles of them), the rows v into B-BLOCKS
+//     (at most 64 hb_tiles rows, about `target` out-edges, a hub row alone). The edges of A-block a, ordered by
 //     (B-block of v, v, u), are its A-major run [in_row_ptr[first head of a], in_row_ptr[first head of a + 1]); the edges
 //     of B-block b, ordered by (A-block of u, v, u), are its B-major run [out_row_ptr[first row of b], ...). Both runs
 //     hold the same edges tile by tile (a tile = the edges from A-block a into B-block b) in the same inner order.
-//   * k_bin_scatter (one workgroup per A-block): the block's slice of x is staged in LDS; the A-major run is streamed
+//   * k_bin_scatter (workgroups take chunks of an A-block's run): the block's slice of x is staged in LDS; the run is streamed
 //     (2-byte head index + 4-byte B-major position per edge) and x[u] is written to vals[position]: inside a tile the
 //     positions are consecutive, so a wave's 64 stores are runs of whole lines, not 64 sectors.
 //   * k_bin_reduce (one workgroup per B-block): row accumulators (starting at residual[v]), 1 / (outdeg + 1) and
@@ -31,47 +31,74 @@ namespace dppr {
 
 constexpr int BIN_NT = 1024;   // threads of both passes
 #ifndef DPPR_BIN_U
-#define DPPR_BIN_U 8
+#define DPPR_BIN_U 4           // (8, and a software-pipelined loop, were measured: 3-5 % slower on the twitter stand-in)
 #endif
 constexpr int BIN_U = DPPR_BIN_U; // entries in flight per lane
 
-// tile -> block of a cut (cut[k] = first tile of block k, cut[n_blocks] = n_tiles)
-__global__ __launch_bounds__(BLOCK) void k_bin_tile_block(const int *__restrict__ cut, int n_blocks, int n_tiles,
-                                                          int *__restrict__ tile_block) {
-    for (int t = blockIdx.x * BLOCK + threadIdx.x; t < n_tiles; t += gridDim.x * BLOCK) {
-        int lo = 0, hi = n_blocks; // last block whose first tile is <= t
+// ---- block cuts (graph build, untimed). A cut is a list of first VERTICES, cut[0] = 0 < ... < cut[n_blocks] = NV; it holds
+// every multiple of the vertex cap, the first vertex behind every `target` edges of the CSR, and both sides of every row
+// of at least target / 4 edges: blocks of at most cap vertices and about target edges, a hub alone in its block.
+// quant[k - 1] = first vertex with row_ptr[v] >= k * target, k = 1 .. K - 1
+__global__ __launch_bounds__(BLOCK) void k_bin_quantiles(const int *__restrict__ row_ptr, int NV, long long target, int K,
+                                                         int *__restrict__ quant) {
+    for (int k = 1 + blockIdx.x * BLOCK + threadIdx.x; k < K; k += gridDim.x * BLOCK) {
+        const long long want = (long long)k * target;
+        int lo = 0, hi = NV; // first v in [0, NV] with row_ptr[v] >= want
+        while (lo < hi) {
+            const int mid = lo + ((hi - lo) >> 1);
+            if ((long long)row_ptr[mid] < want) lo = mid + 1; else hi = mid;
+        }
+        quant[k - 1] = lo;
+    }
+}
+// rows of at least min_deg edges (first `cap` takers)
+__global__ __launch_bounds__(BLOCK) void k_bin_big_rows(const int *__restrict__ row_ptr, int NV, int min_deg, int cap,
+                                                        int *__restrict__ list, int *__restrict__ count) {
+    for (int v = blockIdx.x * BLOCK + threadIdx.x; v < NV; v += gridDim.x * BLOCK)
+        if (row_ptr[v + 1] - row_ptr[v] >= min_deg) {
+            const int slot = atomicAdd(count, 1);
+            if (slot < cap) list[slot] = v;
+        }
+}
+// vertex -> block of a cut; also start[k] = row_ptr[cut[k]] (the block's first edge), k = 0 .. n_blocks
+__global__ __launch_bounds__(BLOCK) void k_bin_vertex_block(const int *__restrict__ cut, int n_blocks, int NV,
+                                                            const int *__restrict__ row_ptr, int *__restrict__ vblk,
+                                                            int *__restrict__ start) {
+    for (int v = blockIdx.x * BLOCK + threadIdx.x; v < NV; v += gridDim.x * BLOCK) {
+        int lo = 0, hi = n_blocks; // last block whose first vertex is <= v
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if (cut[mid] <= t) lo = mid; else hi = mid;
+            if (cut[mid] <= v) lo = mid; else hi = mid;
         }
-        tile_block[t] = lo;
+        vblk[v] = lo;
     }
+    for (int k = blockIdx.x * BLOCK + threadIdx.x; k <= n_blocks; k += gridDim.x * BLOCK) start[k] = row_ptr[cut[k]];
 }
 
 // out-orientation keys (row v << bits | head u, sorted) -> sort key (B-block of v, A-block of u); the value carried
 // through the sort is the edge itself
 __global__ __launch_bounds__(BLOCK) void k_bin_keys(const uint64_t *__restrict__ out_keys, int Ed, int bits,
-                                                    const int *__restrict__ tile_a, const int *__restrict__ tile_b,
+                                                    const int *__restrict__ vblk_a, const int *__restrict__ vblk_b,
                                                     int abits, uint32_t *__restrict__ k1) {
     const uint64_t mask = (1ull << bits) - 1;
     for (int o = blockIdx.x * BLOCK + threadIdx.x; o < Ed; o += gridDim.x * BLOCK) {
         const uint64_t k = out_keys[o];
         const int v = (int)(k >> bits), u = (int)(k & mask);
-        k1[o] = ((uint32_t)tile_b[v >> 6] << abits) | (uint32_t)tile_a[u >> 6];
+        k1[o] = ((uint32_t)vblk_b[v] << abits) | (uint32_t)vblk_a[u];
     }
 }
 
 // B-major order reached: row index of every position, and the keys / values of the second (A-major) sort
 __global__ __launch_bounds__(BLOCK) void k_bin_fill_b(const uint64_t *__restrict__ edges_b, int Ed, int bits,
-                                                      const int *__restrict__ tile_a, const int *__restrict__ tile_b,
+                                                      const int *__restrict__ vblk_a, const int *__restrict__ vblk_b,
                                                       const int *__restrict__ bcut, uint16_t *__restrict__ dl,
                                                       uint32_t *__restrict__ k2, uint64_t *__restrict__ v2) {
     const uint64_t mask = (1ull << bits) - 1;
     for (int q = blockIdx.x * BLOCK + threadIdx.x; q < Ed; q += gridDim.x * BLOCK) {
         const uint64_t k = edges_b[q];
         const int v = (int)(k >> bits), u = (int)(k & mask);
-        dl[q] = (uint16_t)(v - bcut[tile_b[v >> 6]] * WAVE);
-        k2[q] = (uint32_t)tile_a[u >> 6];
+        dl[q] = (uint16_t)(v - bcut[vblk_b[v]]);
+        k2[q] = (uint32_t)vblk_a[u];
         v2[q] = ((uint64_t)(uint32_t)q << 32) | (uint32_t)u;
     }
 }
@@ -83,36 +110,38 @@ __global__ __launch_bounds__(BLOCK) void k_bin_fill_a(const uint32_t *__restrict
     for (int j = blockIdx.x * BLOCK + threadIdx.x; j < Ed; j += gridDim.x * BLOCK) {
         const uint64_t qu = v2s[j];
         apos[j] = (int)(qu >> 32);
-        hl[j] = (uint16_t)((int)(qu & 0xffffffffu) - acut[k2s[j]] * WAVE);
+        hl[j] = (uint16_t)((int)(qu & 0xffffffffu) - acut[k2s[j]]);
     }
 }
 
-// Diagnostic build only (-DDPPR_STAMPS, tools/r03/stamps_bin.sh): wall-clock (100 MHz) stamps per workgroup of the last launch
-// whose frontier held at least a third of the vertices
+// Diagnostic build only (-DDPPR_STAMPS, tools/r03/stamps_bin.sh): wall-clock (100 MHz) stamps per workgroup of the last
+// launch whose frontier held at least a third of the vertices
 #ifdef DPPR_STAMPS
 __device__ unsigned long long g_bin_stamps[2][16384 * 6];
-#define BSTAMP(K, i, val)                                                                              \
-    do {                                                                                               \
+#define BSTAMP(K, i, val)                                                                                                      \
+    do {                                                                                                                       \
         if (threadIdx.x == 0 && blockIdx.x < 16384 && 3 * (long long)*cnt_in >= NV) g_bin_stamps[K][blockIdx.x * 6 + (i)] = (val); \
     } while (0)
 #else
 #define BSTAMP(K, i, val) ((void)0)
 #endif
 
-// Pass 1: vals[B-major position] = x[head] for every edge of A-block blockIdx.x. LDS: the block's slice of x.
+// Pass 1: vals[B-major position] = x[head] for a CHUNK of an A-block's edges (chunk = {block, first entry, end}: a block of
+// many edges is dealt to several workgroups, each stages the block's slice of x). LDS: that slice.
+struct BinChunk {
+    int blk, j0, j1;
+};
 __global__ __launch_bounds__(BIN_NT) void k_bin_scatter(int NV, const int *__restrict__ cnt_in, const int *__restrict__ acut,
-                                                        const int *__restrict__ in_row_ptr, const uint16_t *__restrict__ hl,
+                                                        const BinChunk *__restrict__ chunks, const uint16_t *__restrict__ hl,
                                                         const int *__restrict__ apos, const double *__restrict__ x,
                                                         double *__restrict__ vals) {
     extern __shared__ double s_x[];
     if (*cnt_in == 0) return; // empty frontier: nothing is read or written (k_bin_reduce returns as well)
-    const int h0 = acut[blockIdx.x] * WAVE, h1 = min(acut[blockIdx.x + 1] * WAVE, NV);
-    const int j0 = in_row_ptr[h0], j1 = in_row_ptr[h1];
+    const BinChunk ch = chunks[blockIdx.x];
+    const int h0 = acut[ch.blk], h1 = acut[ch.blk + 1];
+    const int j0 = ch.j0, j1 = ch.j1;
     BSTAMP(0, 0, wall_clock64());
     BSTAMP(0, 4, (unsigned long long)(j1 - j0));
-    BSTAMP(0, 1, wall_clock64());
-    BSTAMP(0, 2, wall_clock64());
-    if (j0 == j1) return;
     for (int i = threadIdx.x; i < h1 - h0; i += BIN_NT) s_x[i] = x[h0 + i];
     __syncthreads();
     BSTAMP(0, 1, wall_clock64());
@@ -179,8 +208,8 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_reduce(int NV, int NV_bin, int n
     const int lane = lane_id(), w = wave_id();
     int v0, v1;
     if ((int)blockIdx.x < n_b) {
-        v0 = bcut[blockIdx.x] * WAVE;
-        v1 = min(bcut[blockIdx.x + 1] * WAVE, NV_bin);
+        v0 = bcut[blockIdx.x];
+        v1 = bcut[blockIdx.x + 1];
     } else {
         v0 = min(NV_bin + ((int)blockIdx.x - n_b) * rows_cap, NV);
         v1 = min(v0 + rows_cap, NV);
@@ -216,10 +245,18 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_reduce(int NV, int NV_bin, int n
             edges += (unsigned long long)__popcll(any);
             const int i = nz ? row[k] : -1 - lane; // a lane without a term is a run of its own
             const double t = nz ? push_term(xv[k], (double)s_den[row[k]], s_rcp[row[k]]) : 0.0;
+            // Lanes of one row are neighbours (a tile's entries are in (row, head) order). Many short runs: one LDS atomic
+            // per lane (a run of k lanes is a k-way conflict, cheap for small k). Few long runs (a hub's row): the runs are
+            // summed in registers first and cost ONE atomic each -- thousands of atomics on one LDS word would serialise.
             const int below = __builtin_amdgcn_update_dpp(-0x7fffffff, i, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-            const int above = __builtin_amdgcn_update_dpp(-0x7fffffff, i, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-            const double sum = wave_segmented_sum(t, lane == 0 || below != i);
-            if (nz && (lane == WAVE - 1 || above != i)) lds_add(&s_acc[i], sum); // the run's last lane
+            const bool head = lane == 0 || below != i;
+            if (__popcll(__ballot(head)) >= 16) { // wave-uniform
+                if (nz) lds_add(&s_acc[i], t);
+            } else {
+                const int above = __builtin_amdgcn_update_dpp(-0x7fffffff, i, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+                const double sum = wave_segmented_sum(t, head);
+                if (nz && (lane == WAVE - 1 || above != i)) lds_add(&s_acc[i], sum); // the run's last lane
+            }
         }
     }
     __syncthreads();

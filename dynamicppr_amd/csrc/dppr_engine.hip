@@ -35,6 +35,7 @@ static constexpr int MAX_CHUNK = 64;
 static constexpr int CNT_HDR = 16;
 static constexpr int PERSIST_RETRY_BATCHES = 64; // after a failed roll-call: batches on per-iteration launches before the next try
 static constexpr int GMULTI_MAX = 2 * MAX_CHUNK; // sweeps a multi-sweep launch of a source group may run
+static constexpr int BIN_MAX_BLOCKS = 1 << 16, BIN_MAX_BIG = 4096, BIN_SMALL_INTS = BIN_MAX_BLOCKS + BIN_MAX_BIG + 1 + 64; // bin_cut scratch
 static constexpr int RESIDENT_MARGIN = 8; // sweeps a resident launch is given beyond what the last batch needed
 
 namespace {
@@ -67,8 +68,12 @@ struct Epoch {
     int n_hubs = 0;
     // binned sweep (dppr_binned.hpp): block cuts (first tile of every A- / B-block), per edge the head index inside
     // its A-block + B-major position (A-major order) and the row index inside its B-block (B-major order)
-    int *acut = nullptr, *bcut = nullptr;
+    int *acut = nullptr, *bcut = nullptr; // first vertex of every A- / B-block (one allocation; bcut points into it)
+    size_t bin_tab_cap = 0;
     int n_a = 0, n_b = 0;
+    BinChunk *chunks = nullptr;           // work items of k_bin_scatter
+    size_t chunk_cap = 0;
+    int n_chunks = 0;
     uint16_t *hl = nullptr, *dl = nullptr;
     int *apos = nullptr;
     bool bin_valid = false;
@@ -199,11 +204,14 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     int gpush_auto_factor = 2;      // automatic threshold: this many pairs per sweep group (DPPR_GROUP_PUSH_FACTOR: tuning runs)
     // binned sweep of single-source loops on windows far beyond the L2s (dppr_binned.hpp, dppr_set_binned_sweep)
     int bin_mode = 1;               // 0: never, 1: when a source slot exists and the window has >= bin_min_ids vertices, 2: always
-    int bin_ha_tiles = 128, bin_hb_tiles = 64; // most 64-vertex tiles an A-block (heads, 8 B of LDS each) / a B-block (rows, 20 B each) holds
-    long long bin_target = 49152;   // edges a block is cut for
+    int bin_ha_tiles = 288, bin_hb_tiles = 48; // an A-block holds at most 64 x ha_tiles heads (8 B of LDS each), a B-block 64 x hb_tiles rows (20 B each)
+    long long bin_target = 196608;  // edges a B-block is cut for (one workgroup of k_bin_reduce)
+    long long bin_target_a = 4ll << 20; // ... an A-block (its edges are dealt to workgroups of k_bin_scatter in chunks: large, so that tiles are long runs)
     long long bin_min_ids = 6ll << 20; // 48 MB of snapshot: beyond what the eight L2s hold together
     uint32_t *bin_k[2] = {nullptr, nullptr}; // sort keys (Ed each)
-    int *bin_tile_a = nullptr, *bin_tile_b = nullptr; // tile -> block
+    int *bin_vblk_a = nullptr, *bin_vblk_b = nullptr; // vertex -> block (V each)
+    int *bin_small = nullptr;       // quantile vertices | big rows | counter (bin_cut)
+    long long bin_chunk = 32768;    // edges per workgroup of k_bin_scatter
     double *bin_vals = nullptr;     // the values in B-major order: what pass 1 hands to pass 2 (one loop runs at a time)
     void *bin_tmp = nullptr;
     size_t bin_tmp_bytes = 0;
@@ -755,10 +763,11 @@ bool bin_wanted(const dppr_engine *e) {
 
 int bin_prepare(dppr_engine *e) { // engine-level scratch, once
     if (e->bin_ready) return DPPR_OK;
-    const size_t Edn = (size_t)std::max(e->Ed, 1), nt = (size_t)e->V / WAVE + 3;
+    const size_t Edn = (size_t)std::max(e->Ed, 1);
     for (int k = 0; k < 2; ++k) HIP_TRY(hipMalloc((void **)&e->bin_k[k], sizeof(uint32_t) * Edn));
-    HIP_TRY(hipMalloc((void **)&e->bin_tile_a, sizeof(int) * nt));
-    HIP_TRY(hipMalloc((void **)&e->bin_tile_b, sizeof(int) * nt));
+    HIP_TRY(hipMalloc((void **)&e->bin_vblk_a, sizeof(int) * (size_t)e->V));
+    HIP_TRY(hipMalloc((void **)&e->bin_vblk_b, sizeof(int) * (size_t)e->V));
+    HIP_TRY(hipMalloc((void **)&e->bin_small, sizeof(int) * BIN_SMALL_INTS));
     HIP_TRY(hipMalloc((void **)&e->bin_vals, sizeof(double) * (Edn + 64)));
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, e->bin_tmp_bytes, e->bin_k[0], e->bin_k[1], e->keys_a, e->keys_b, Edn, 0u, 32u, e->stream));
     HIP_TRY(hipMalloc(&e->bin_tmp, std::max<size_t>(e->bin_tmp_bytes, 16)));
@@ -770,60 +779,113 @@ int bin_prepare(dppr_engine *e) { // engine-level scratch, once
     return DPPR_OK;
 }
 
+// One cut (dppr_binned.hpp: every multiple of `cap` vertices, the first vertex behind every `target` edges, both sides of
+// every row of >= target / 4 edges); device searches, the merge of the few thousand boundaries on the host.
+int bin_cut(dppr_engine *e, const int *row_ptr, int NV, int cap, long long target, std::vector<int32_t> &cut) {
+    const int Ed = e->Ed;
+    target = std::max<long long>(target, 64);
+    const int K = (int)std::min<long long>((Ed + target - 1) / target, BIN_MAX_BLOCKS);
+    int *d_q = e->bin_small, *d_big = e->bin_small + BIN_MAX_BLOCKS, *d_cnt = d_big + BIN_MAX_BIG;
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int), e->stream));
+    if (K > 1) hipLaunchKernelGGL(k_bin_quantiles, dim3(grid_for(K)), dim3(BLOCK), 0, e->stream, row_ptr, NV, target, K, d_q);
+    hipLaunchKernelGGL(k_bin_big_rows, dim3(grid_for(NV)), dim3(BLOCK), 0, e->stream, row_ptr, NV, (int)std::max<long long>(target / 4, 1),
+                       BIN_MAX_BIG, d_big, d_cnt);
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> h((size_t)BIN_MAX_BLOCKS + BIN_MAX_BIG + 1);
+    HIP_TRY(hipMemcpyAsync(h.data(), e->bin_small, sizeof(int) * h.size(), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    cut.clear();
+    for (long long v = 0; v < NV; v += cap) cut.push_back((int32_t)v);
+    for (int k = 0; k + 1 < K; ++k) cut.push_back(h[(size_t)k]);
+    const int nbig = std::min(h[(size_t)BIN_MAX_BLOCKS + BIN_MAX_BIG], BIN_MAX_BIG);
+    for (int k = 0; k < nbig; ++k) {
+        cut.push_back(h[(size_t)BIN_MAX_BLOCKS + k]);
+        cut.push_back(h[(size_t)BIN_MAX_BLOCKS + k] + 1);
+    }
+    cut.push_back(NV);
+    std::sort(cut.begin(), cut.end());
+    cut.erase(std::unique(cut.begin(), cut.end()), cut.end());
+    while (!cut.empty() && cut.back() > NV) cut.pop_back();
+    if (cut.empty() || cut.front() != 0) cut.insert(cut.begin(), 0);
+    if (cut.back() != NV) cut.push_back(NV);
+    return DPPR_OK;
+}
+
 int build_bins(dppr_engine *e, Epoch &ep) {
     ep.bin_valid = false;
     if (!bin_wanted(e) || e->Ed <= 0 || ep.grp_n_int <= 0) return DPPR_OK;
     if (int rc = bin_prepare(e)) return rc;
     const int Ed = e->Ed, NV = ep.grp_n_int;
-    const int n_tiles = (NV + WAVE - 1) / WAVE;
     if (!ep.hl) {
-        const size_t Edn = (size_t)Ed, nt = (size_t)e->V / WAVE + 3;
+        const size_t Edn = (size_t)Ed;
         HIP_TRY(hipMalloc((void **)&ep.hl, sizeof(uint16_t) * Edn));
         HIP_TRY(hipMalloc((void **)&ep.dl, sizeof(uint16_t) * Edn));
         HIP_TRY(hipMalloc((void **)&ep.apos, sizeof(int) * Edn));
-        HIP_TRY(hipMalloc((void **)&ep.acut, sizeof(int) * nt));
-        HIP_TRY(hipMalloc((void **)&ep.bcut, sizeof(int) * nt));
     }
-    // tile prefixes of both CSRs -> host -> cuts (blocks of about bin_target edges, bounded tile counts)
-    int *scratch = e->hub_slot_of; // V ints (free once the CSRs are built)
-    e->h_tiles.resize((size_t)n_tiles + 2);
-    e->h_tiles_in.resize((size_t)n_tiles + 2);
-    hipLaunchKernelGGL(k_tile_prefix, dim3(grid_for(n_tiles + 1)), dim3(BLOCK), 0, e->stream, ep.out_row_ptr, NV, n_tiles, scratch);
-    HIP_TRY(hipMemcpyAsync(e->h_tiles.data(), scratch, sizeof(int) * ((size_t)n_tiles + 1), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    hipLaunchKernelGGL(k_tile_prefix, dim3(grid_for(n_tiles + 1)), dim3(BLOCK), 0, e->stream, ep.row_ptr, NV, n_tiles, scratch);
-    HIP_TRY(hipMemcpyAsync(e->h_tiles_in.data(), scratch, sizeof(int) * ((size_t)n_tiles + 1), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
     std::vector<int32_t> cut_a, cut_b;
-    const long long want = std::max<long long>(1, (long long)Ed / std::max<long long>(e->bin_target, 1));
-    cut_greedy(e->h_tiles_in.data(), n_tiles, e->bin_ha_tiles, want, 2 * WAVE, cut_a);
-    cut_greedy(e->h_tiles.data(), n_tiles, e->bin_hb_tiles, want, 2 * WAVE, cut_b);
+    if (int rc = bin_cut(e, ep.row_ptr, NV, e->bin_ha_tiles * WAVE, e->bin_target_a, cut_a)) return rc;
+    if (int rc = bin_cut(e, ep.out_row_ptr, NV, e->bin_hb_tiles * WAVE, e->bin_target, cut_b)) return rc;
     ep.n_a = (int)cut_a.size() - 1;
     ep.n_b = (int)cut_b.size() - 1;
     int abits = 1, bbits = 1;
     while ((1 << abits) < ep.n_a) abits++;
     while ((1 << bbits) < ep.n_b) bbits++;
-    if (abits + bbits > 32) return DPPR_OK; // (a window of that many blocks: the sweep stays k_pull_iter)
+    if (abits + bbits > 32 || ep.n_a + 2 > BIN_MAX_BLOCKS || ep.n_b + 2 > BIN_MAX_BLOCKS) return DPPR_OK; // (a window of that many blocks: the sweep stays k_pull_iter)
+    // per epoch: acut | astart | bcut (block tables), then the chunk table
+    const size_t tab_ints = (size_t)2 * (ep.n_a + 1) + (ep.n_b + 1);
+    if (tab_ints > ep.bin_tab_cap) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        (void)hipFree(ep.acut);
+        ep.acut = nullptr;
+        ep.bin_tab_cap = 0;
+        HIP_TRY(hipMalloc((void **)&ep.acut, sizeof(int) * (tab_ints + tab_ints / 4 + 1024)));
+        ep.bin_tab_cap = tab_ints + tab_ints / 4 + 1024;
+    }
+    int *d_astart = ep.acut + (ep.n_a + 1);
+    ep.bcut = d_astart + (ep.n_a + 1);
     HIP_TRY(hipMemcpyAsync(ep.acut, cut_a.data(), sizeof(int) * cut_a.size(), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(ep.bcut, cut_b.data(), sizeof(int) * cut_b.size(), hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(k_bin_tile_block, dim3(grid_for(n_tiles)), dim3(BLOCK), 0, e->stream, ep.acut, ep.n_a, n_tiles, e->bin_tile_a);
-    hipLaunchKernelGGL(k_bin_tile_block, dim3(grid_for(n_tiles)), dim3(BLOCK), 0, e->stream, ep.bcut, ep.n_b, n_tiles, e->bin_tile_b);
+    hipLaunchKernelGGL(k_bin_vertex_block, dim3(grid_for(NV)), dim3(BLOCK), 0, e->stream, ep.acut, ep.n_a, NV, ep.row_ptr, e->bin_vblk_a, d_astart);
+    int *d_bstart = e->bin_small; // (not kept: a B-block's edges are out_row_ptr[bcut[b]] .. out_row_ptr[bcut[b + 1]])
+    hipLaunchKernelGGL(k_bin_vertex_block, dim3(grid_for(NV)), dim3(BLOCK), 0, e->stream, ep.bcut, ep.n_b, NV, ep.out_row_ptr, e->bin_vblk_b, d_bstart);
     const uint64_t *out_keys = e->directed ? e->out_sorted : e->in_sorted;
-    hipLaunchKernelGGL(k_bin_keys, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->stream, out_keys, Ed, e->bits, e->bin_tile_a, e->bin_tile_b,
+    hipLaunchKernelGGL(k_bin_keys, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->stream, out_keys, Ed, e->bits, e->bin_vblk_a, e->bin_vblk_b,
                        abits, e->bin_k[0]);
     HIP_TRY(hipGetLastError());
+    // chunks of the A-major runs (a block of many edges is dealt to several workgroups of k_bin_scatter)
+    std::vector<int32_t> astart((size_t)ep.n_a + 1);
+    HIP_TRY(hipMemcpyAsync(astart.data(), d_astart, sizeof(int) * astart.size(), hipMemcpyDeviceToHost, e->stream));
     size_t tmp = e->bin_tmp_bytes; // B-major: stable by (B-block, A-block); the keys are in (row, head) order
     HIP_TRY(rocprim::radix_sort_pairs(e->bin_tmp, tmp, e->bin_k[0], e->bin_k[1], out_keys, e->keys_a, (size_t)Ed, 0u,
                                       (unsigned)(abits + bbits), e->stream));
-    hipLaunchKernelGGL(k_bin_fill_b, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->stream, e->keys_a, Ed, e->bits, e->bin_tile_a,
-                       e->bin_tile_b, ep.bcut, ep.dl, e->bin_k[0], e->keys_b);
+    hipLaunchKernelGGL(k_bin_fill_b, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->stream, e->keys_a, Ed, e->bits, e->bin_vblk_a,
+                       e->bin_vblk_b, ep.bcut, ep.dl, e->bin_k[0], e->keys_b);
     HIP_TRY(hipGetLastError());
     tmp = e->bin_tmp_bytes;        // A-major: the B-major sequence, stable by A-block
     HIP_TRY(rocprim::radix_sort_pairs(e->bin_tmp, tmp, e->bin_k[0], e->bin_k[1], e->keys_b, e->keys_a, (size_t)Ed, 0u,
                                       (unsigned)abits, e->stream));
     hipLaunchKernelGGL(k_bin_fill_a, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->stream, e->bin_k[1], e->keys_a, Ed, ep.acut, ep.hl, ep.apos);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(e->stream)); // the cuts are locals
+    HIP_TRY(hipStreamSynchronize(e->stream)); // astart has arrived; the cuts are locals
+    std::vector<BinChunk> chunks;
+    const int csize = (int)std::max<long long>(e->bin_chunk, 64);
+    for (int a = 0; a < ep.n_a; ++a) {
+        const int j0 = astart[(size_t)a], j1 = astart[(size_t)a + 1];
+        const int pieces = (j1 - j0 + csize - 1) / csize; // (a block without an edge: no workgroup)
+        for (int k = 0; k < pieces; ++k) {
+            const long long lo = j0 + (long long)(j1 - j0) * k / pieces, hi = j0 + (long long)(j1 - j0) * (k + 1) / pieces;
+            chunks.push_back(BinChunk{a, (int)lo, (int)hi});
+        }
+    }
+    ep.n_chunks = (int)chunks.size();
+    if (chunks.size() > ep.chunk_cap) {
+        (void)hipFree(ep.chunks);
+        ep.chunks = nullptr;
+        ep.chunk_cap = 0;
+        HIP_TRY(hipMalloc((void **)&ep.chunks, sizeof(BinChunk) * (chunks.size() + chunks.size() / 4 + 256)));
+        ep.chunk_cap = chunks.size() + chunks.size() / 4 + 256;
+    }
+    if (!chunks.empty()) HIP_TRY(hipMemcpy(ep.chunks, chunks.data(), sizeof(BinChunk) * chunks.size(), hipMemcpyHostToDevice));
     ep.bin_n_int = NV;
     ep.bin_valid = true;
     return DPPR_OK;
@@ -1051,8 +1113,9 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k], e->stream));
             if (pull && binned) {
                 // the sweep as two streaming passes over the epoch's binned edge layout (dppr_binned.hpp)
-                hipLaunchKernelGGL(k_bin_scatter, dim3(ep.n_a), dim3(BIN_NT), (size_t)e->bin_ha_tiles * WAVE * sizeof(double), e->stream,
-                                   ep.bin_n_int, s.cnt + cur, ep.acut, ep.row_ptr, ep.hl, ep.apos, s.x, e->bin_vals);
+                if (ep.n_chunks > 0)
+                    hipLaunchKernelGGL(k_bin_scatter, dim3(ep.n_chunks), dim3(BIN_NT), (size_t)e->bin_ha_tiles * WAVE * sizeof(double), e->stream,
+                                       ep.bin_n_int, s.cnt + cur, ep.acut, ep.chunks, ep.hl, ep.apos, s.x, e->bin_vals);
                 const int rows_cap = e->bin_hb_tiles * WAVE;
                 hipLaunchKernelGGL(k_bin_reduce, dim3(ep.n_b + (ep.grp_n_int - ep.bin_n_int + rows_cap - 1) / rows_cap), dim3(BIN_NT),
                                    (size_t)rows_cap * 20, e->stream, ep.grp_n_int, ep.bin_n_int, ep.n_b, s.cnt + cur, ep.bcut, rows_cap,
@@ -1814,10 +1877,10 @@ void dppr_destroy(dppr_engine *e) {
     for (auto &ep : e->epochs) {
         (void)hipFree(ep.row_ptr); (void)hipFree(ep.adj); (void)hipFree(ep.out_row_ptr); (void)hipFree(ep.out_col); (void)hipFree(ep.b1); (void)hipFree(ep.b2);
         (void)hipFree(ep.deg_after); (void)hipFree(ep.ins); (void)hipFree(ep.hub_v); (void)hipFree(ep.hub_degp1); (void)hipFree(ep.grp_tile); (void)hipFree(ep.ggrp_tile); (void)hipFree(ep.gtab);
-        (void)hipFree(ep.acut); (void)hipFree(ep.bcut); (void)hipFree(ep.hl); (void)hipFree(ep.dl); (void)hipFree(ep.apos);
+        (void)hipFree(ep.acut); (void)hipFree(ep.chunks); (void)hipFree(ep.hl); (void)hipFree(ep.dl); (void)hipFree(ep.apos);
     }
     for (int k = 0; k < 2; ++k) (void)hipFree(e->bin_k[k]);
-    (void)hipFree(e->bin_tile_a); (void)hipFree(e->bin_tile_b); (void)hipFree(e->bin_vals); (void)hipFree(e->bin_tmp);
+    (void)hipFree(e->bin_vblk_a); (void)hipFree(e->bin_vblk_b); (void)hipFree(e->bin_small); (void)hipFree(e->bin_vals); (void)hipFree(e->bin_tmp);
     (void)hipFree(e->w1); (void)hipFree(e->w2); (void)hipFree(e->outdeg);
     (void)hipFree(e->bar);
     (void)hipFree(e->hub_slot_of); (void)hipFree(e->hub_hist); (void)hipFree(e->d_ext2int); (void)hipFree(e->d_xfer);
@@ -1881,15 +1944,18 @@ int dppr_set_sweep_bitmap(dppr_engine *e, int on) {
     return DPPR_OK;
 }
 
-int dppr_set_binned_sweep(dppr_engine *e, int mode, int ha_tiles, int hb_tiles, int64_t target_edges, int64_t min_ids) {
+int dppr_set_binned_sweep(dppr_engine *e, int mode, int ha_tiles, int hb_tiles, int64_t target_edges, int64_t min_ids, int64_t chunk_edges,
+                          int64_t target_a_edges) {
     if (!e || mode < 0 || mode > 2 || ha_tiles < 0 || ha_tiles > 288 || hb_tiles < 0 || hb_tiles > 120 || target_edges < 0 || min_ids < 0 ||
-        e->bin_ready || e->loaded)
+        chunk_edges < 0 || target_a_edges < 0 || e->bin_ready || e->loaded)
         return fail(e, DPPR_ERR_INVALID, "set_binned_sweep: call right after dppr_create; mode 0..2, ha_tiles <= 288, hb_tiles <= 120");
     e->bin_mode = mode;
     if (ha_tiles > 0) e->bin_ha_tiles = ha_tiles;
     if (hb_tiles > 0) e->bin_hb_tiles = hb_tiles;
     if (target_edges > 0) e->bin_target = target_edges;
     if (min_ids > 0) e->bin_min_ids = min_ids;
+    if (chunk_edges > 0) e->bin_chunk = chunk_edges;
+    if (target_a_edges > 0) e->bin_target_a = target_a_edges;
     return DPPR_OK;
 }
 

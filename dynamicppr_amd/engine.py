@@ -112,7 +112,7 @@ def lib():
     L.dppr_group_read.argtypes = [vp, C.c_int32, C.c_int32, dp, dp]
     L.dppr_group_stats.argtypes = [vp, C.c_int32, C.POINTER(Stats)]
     L.dppr_set_sweep_bitmap.argtypes = [vp, C.c_int]
-    L.dppr_set_binned_sweep.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64]
+    L.dppr_set_binned_sweep.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64]
     L.dppr_set_group_resident.argtypes = [vp, C.c_int]
     L.dppr_seed_lists.argtypes = [vp, C.c_int32, C.c_int, ip, ip]
     L.dppr_group_reset_stats.argtypes = [vp, C.c_int32]
@@ -157,9 +157,9 @@ class Engine:
                                              int(pull_block or 0)), "set_tuning")
         if sweep_bitmap is not None:
             self._ck(self._L.dppr_set_sweep_bitmap(self._h, int(sweep_bitmap)), "set_sweep_bitmap")
-        if binned is not None:   # int mode, or (mode, ha_tiles, hb_tiles, target_edges, min_ids)
+        if binned is not None:   # int mode, or (mode, ha_tiles, hb_tiles, target_edges, min_ids, chunk_edges, target_a_edges)
             args = (binned,) if isinstance(binned, int) else tuple(binned)
-            args = tuple(int(a) for a in args) + (0,) * (5 - len(args))
+            args = tuple(int(a) for a in args) + (0,) * (7 - len(args))
             self._ck(self._L.dppr_set_binned_sweep(self._h, *args), "set_binned_sweep")
         if persistent is not None or persist_timeout_us is not None:
             self._ck(self._L.dppr_set_persistent(self._h, 1 if persistent is None else int(persistent),

@@ -137,13 +137,16 @@ int dppr_set_sweep_bitmap(dppr_engine *e, int on);
  * term is still gpu/ExpandRev.cuh:72's expression, results equal k_pull_iter's up to the order of each row's sum).
  *   mode         : 0 never, 1 (default) when a source slot exists and the window has at least min_ids vertices with
  *                  an id, 2 always (tests: tiny windows)
- *   ha_tiles     : most 64-vertex tiles of heads per A-block (8 bytes of LDS per head; 0 keeps the default, 128)
- *   hb_tiles     : most tiles of rows per B-block (20 bytes of LDS per row; 0 keeps 64)
- *   target_edges : edges a block is cut for (0 keeps 49152)
+ *   ha_tiles     : an A-block holds at most 64 x ha_tiles heads (8 bytes of LDS per head; 0 keeps the default, 288)
+ *   hb_tiles     : a B-block holds at most 64 x hb_tiles rows (20 bytes of LDS per row; 0 keeps 48)
+ *   target_edges : edges a B-block is cut for (0 keeps 196608); a row of a quarter of that is a block of its own
  *   min_ids      : mode 1 threshold (0 keeps 6 Mi: 48 MB of snapshot)
+ *   chunk_edges  : edges per workgroup of k_bin_scatter (0 keeps 32768)
+ *   target_a_edges : edges an A-block is cut for (0 keeps 4 Mi: large, the longer the runs a tile's values are written in)
  * The layout costs 8 bytes per window edge and epoch plus 16 bytes per window edge of scratch, and is built in
  * dppr_slide / dppr_load_window (untimed, like the CSRs). Only valid right after dppr_create. */
-int dppr_set_binned_sweep(dppr_engine *e, int mode, int ha_tiles, int hb_tiles, int64_t target_edges, int64_t min_ids);
+int dppr_set_binned_sweep(dppr_engine *e, int mode, int ha_tiles, int hb_tiles, int64_t target_edges, int64_t min_ids,
+                          int64_t chunk_edges, int64_t target_a_edges);
 
 /* ---- graph side (UNTIMED in the reference's metric) --------------------- */
 

@@ -45,8 +45,8 @@ TUNINGS = [dict(pull_min_frontier=-1), dict(hub_min_degree=3, big_row_edges=8, p
            # binned sweeps (k_bin_scatter + k_bin_reduce instead of k_pull_iter; on by itself only on windows of millions of
            # vertices): one-tile blocks of ~64 edges (dozens of blocks, every tile a handful of edges), the default
            # block shape (one block each), and mixed with push iterations in chunks of 3
-           dict(pull_min_frontier=1, persistent=0, binned=(2, 1, 1, 64)), dict(pull_min_frontier=1, persistent=0, binned=2),
-           dict(pull_min_frontier=40, persistent=0, binned=(2, 2, 3, 200), chunk_iters=3)]
+           dict(pull_min_frontier=1, persistent=0, binned=(2, 1, 1, 64, 0, 64, 64)), dict(pull_min_frontier=1, persistent=0, binned=2),
+           dict(pull_min_frontier=40, persistent=0, binned=(2, 2, 3, 200, 0, 100, 500), chunk_iters=3)]
 TUNING_IDS = ["push-only", "push-hubs+bigrows", "push-all-hub-all-big", "pull-only", "mixed-pull>=40", "default",
               "mixed-chunk1", "mixed-chunk3", "pull-wg512", "mixed-wg1024", "pull-no-persist", "pull-wg256",
               "pull-rollcall-fails", "pull-resident-3-sweeps", "pull-bitmap-wg256", "mixed-bitmap", "pull-bitmap-wg640",

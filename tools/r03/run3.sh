@@ -1,0 +1,4 @@
+cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_engine_gpu.py -x -q -m gpu -k "binned" 2>&1 | tail -3
+bash tools/r03/stamps_bin.sh twitter 1
+bash tools/r03/sweep_bin.sh twitter binned=1 binned=1,288,48,98304 binned=1,288,64,196608 binned=1,288,48,196608,0,65536 binned=1,288,48,196608,0,32768,16777216 binned=1,288,112,393216
