@@ -204,7 +204,7 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     int gpush_auto_factor = 2;      // automatic threshold: this many pairs per sweep group (DPPR_GROUP_PUSH_FACTOR: tuning runs)
     // binned sweep of single-source loops on windows far beyond the L2s (dppr_binned.hpp, dppr_set_binned_sweep)
     int bin_mode = 1;               // 0: never, 1: when a source slot exists and the window has >= bin_min_ids vertices, 2: always
-    int bin_ha_tiles = 288, bin_hb_tiles = 48; // an A-block holds at most 64 x ha_tiles heads (8 B of LDS each), a B-block 64 x hb_tiles rows (20 B each)
+    int bin_ha_tiles = 128, bin_hb_tiles = 48; // an A-block holds at most 64 x ha_tiles heads (8 B of LDS each), a B-block 64 x hb_tiles rows (20 B each)
     long long bin_target = 196608;  // edges a B-block is cut for (one workgroup of k_bin_reduce)
     long long bin_target_a = 4ll << 20; // ... an A-block (its edges are dealt to workgroups of k_bin_scatter in chunks: large, so that tiles are long runs)
     long long bin_min_ids = 6ll << 20; // 48 MB of snapshot: beyond what the eight L2s hold together

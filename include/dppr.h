@@ -137,7 +137,7 @@ int dppr_set_sweep_bitmap(dppr_engine *e, int on);
  * term is still gpu/ExpandRev.cuh:72's expression, results equal k_pull_iter's up to the order of each row's sum).
  *   mode         : 0 never, 1 (default) when a source slot exists and the window has at least min_ids vertices with
  *                  an id, 2 always (tests: tiny windows)
- *   ha_tiles     : an A-block holds at most 64 x ha_tiles heads (8 bytes of LDS per head; 0 keeps the default, 288)
+ *   ha_tiles     : an A-block holds at most 64 x ha_tiles heads (8 bytes of LDS per head; 0 keeps the default, 128)
  *   hb_tiles     : a B-block holds at most 64 x hb_tiles rows (20 bytes of LDS per row; 0 keeps 48)
  *   target_edges : edges a B-block is cut for (0 keeps 196608); a row of a quarter of that is a block of its own
  *   min_ids      : mode 1 threshold (0 keeps 6 Mi: 48 MB of snapshot)

@@ -462,6 +462,40 @@ def test_multi_epoch_prestaging_and_two_sources():
         sc.e.update(sc.slot, sc.eps, epoch=K + 7)
 
 
+def test_binned_sweep_covers_ids_assigned_after_its_tables_were_built():
+    """Epochs staged BEFORE a source outside the window receives its id: their binned tables cover fewer ids than their
+    sweeps must (k_bin_reduce's extra workgroups take the new ids, which have no edge in those epochs). Both sources
+    against the oracle through the staged epochs, synchronous schedule (frontier work equal, p / r to rounding)."""
+    K = 3
+    tuning = dict(pull_min_frontier=1, persistent=0, binned=(2, 1, 1, 64, 0, 64, 64))
+    sc = make(1, schedule=eng.SCHEDULE_SYNC, c=20, n_epochs=K + 1, tuning=tuning)
+    sc.s.sync_execute(sc.g)
+    sc.e.init_solve(sc.slot, sc.eps)
+    want = []
+    for k in range(1, K + 1):
+        assert sc.advance_graphs()
+        sc.s.sync_inc_execute(sc.g)
+        want.append((sc.s.p.copy(), sc.s.r.copy()))
+    used = np.zeros(sc.V, bool)
+    g = sc.g._g.contents
+    used[np.ctypeslib.as_array(g.s1, (g.stream_len,))[:g.pos]] = True
+    used[np.ctypeslib.as_array(g.s2, (g.stream_len,))[:g.pos]] = True
+    lonely = int(np.nonzero(~used)[0][0])            # never seen by the engine: gets a fresh id now
+    ids0 = sc.e.id_space()["ids"]
+    slot2 = sc.e.add_source(lonely)
+    assert sc.e.id_space()["ids"] == ids0 + 1
+    for k in range(1, K + 1):
+        sc.e.update(sc.slot, sc.eps, epoch=k)
+        p, r = sc.e.read(sc.slot)
+        assert np.max(np.abs(p - want[k - 1][0])) < SYNC_TOL and np.max(np.abs(r - want[k - 1][1])) < SYNC_TOL
+    st, w = sc.e.stats(sc.slot), sc.s.stats()
+    assert (st["iterations"], st["sum_F"], st["sum_E"]) == (w["iters"], w["F"], w["E"]) and st["binned_sweeps"] == st["pull_iterations"] > 0
+    sc.e.init_solve(slot2, sc.eps)                   # a source without an edge: one push, p = alpha at the source
+    p2, r2 = sc.e.read(slot2)
+    assert p2[lonely] == 0.15 and np.count_nonzero(p2) == 1 and not r2.any()
+    assert sc.e.stats(slot2)["binned_sweeps"] == 1
+
+
 def test_full_size_youtube_standin_properties():
     """BASELINE.json configs[1] size (com-youtube stand-in): size-independent properties --
     residual bound, loop invariant, stats consistency -- after init and 3 batches."""
