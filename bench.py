@@ -42,16 +42,22 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 NORTH_STAR_TOL = 1e-9   # BASELINE.json: "within the repo's 1e-9 tolerance"
 
-# per config: (sources per GPU, how they are picked)
+# per config: (sources per GPU, how they are picked). The 8-GPU configurations of BASELINE.json (twitter: 8 top-10 sources,
+# friendster: the 10 sources of a top1000 file) are FIXED source sets dealt round-robin over the ranks (0 = "the config's own
+# sources": 8 / 4+4 / 2+2+2+2 / 1 each; friendster 10 / 5+5 / 3+3+2+2 / 2+2+1x6) -- strong scaling, and N = 1 is the
+# "one GPU, one source group" alternative the multi-GPU numbers have to be read against.
 PLANS = {
     "dblp": (1, "top10"), "youtube": (1, "top10"), "livejournal": (10, "top1000"),
-    "twitter": (1, "top10"), "friendster": (2, "top1000"),
+    "twitter": (0, "top10"), "friendster": (0, "top1000"),
 }
+
 # committed rocprofv3 --pmc summaries (tools/prof_pmc.sh) of the dominant kernel per workload
 PMC_FILES = {
     ("youtube", 1): ("profiles/r01_final_pmc_traffic_youtube.json", ("k_pull_resident",)),
     ("livejournal", 10): ("profiles/r02_pmc_traffic_livejournal_group10.json", ("k_gsweep",)),
     ("twitter", 8): ("profiles/r02_pmc_traffic_twitter_group8.json", ("k_gsweep",)),
+    ("twitter", 1): ("profiles/r03_pmc_traffic_tw1_binned.json", ("k_bin_scatter", "k_bin_reduce")),
+    ("friendster", 1): ("profiles/r03_pmc_traffic_fr1_binned.json", ("k_bin_scatter", "k_bin_reduce")),
 }
 
 
@@ -122,7 +128,8 @@ def main():
     S = a.sources or a.group or S
     # a source group's sweeps are event-bracketed on a few FURTHER batches after the timed region (an event
     # pair per launch widens the dispatch gaps from ~4 to ~10 us: it must not sit in the timed batches)
-    n_prof = min(a.steps, 5) if S > 1 else 0
+    S_plan = S if S else -(-shard.CONFIG_SOURCE_SETS[a.config][0] // world)   # (most sources a rank of this run holds)
+    n_prof = min(a.steps, 5) if S_plan > 1 else 0
     pick = a.pick or pick
     if a.bin:
         V, e1, e2 = datagen.read_bin(a.bin)
@@ -146,14 +153,23 @@ def main():
         # the run reads W + n_steps * c stream edges: only that prefix of the seeded stream is generated
         # (rank 0 writes the file, the others wait and read it)
         need = min(stream_len, W + (n_steps + n_prof + 1) * c)
-        if rank == 0:
-            datagen.ensure_stand_in(a.config, a.data_dir, need)
+        if rank == 0:   # rank 0 generates (or finds) the file; its record of that is the one the line carries
+            path = datagen.ensure_stand_in(a.config, a.data_dir, need)
         if D:
             D.barrier()
-        path = datagen.ensure_stand_in(a.config, a.data_dir, need)
+        if rank != 0:
+            path = datagen.ensure_stand_in(a.config, a.data_dir, need)
         provenance = datagen.PROVENANCE[path]
         V, e1, e2 = datagen.read_bin(path)
-    if pick == "top1000":   # 10 ids sampled from degree ranks [10, 1000): a "top1000" file; every rank its own draw
+    scaling = "weak"
+    if S == 0:              # an 8-GPU configuration: ITS sources, dealt round-robin over the ranks (shard.assign_sources)
+        pool = shard.config_source_pool(a.config, V, e1, e2, W, directed)
+        sources = shard.assign_sources(pool, rank, world)
+        if not sources:
+            sys.exit(f"--gpus {world}: more ranks than the configuration has sources ({len(pool)})")
+        S = len(sources)
+        scaling = "strong"
+    elif pick == "top1000":   # 10 ids sampled from degree ranks [10, 1000): a "top1000" file; every rank its own draw
         sources = [int(s) for s in datagen.ranked_sources(V, e1, e2, W, directed, 10, 1000, max(S, 10), seed=1 + rank)[:S]]
     else:                   # the top-10 file, dealt round-robin over the ranks
         sources = shard.assign_sources(datagen.top_sources(V, e1, e2, W, directed, 10), rank, world, per_rank=S)
@@ -180,14 +196,15 @@ def main():
         torch.cuda.synchronize()
         e.synchronize()
 
-    # ---------------- warmup (untimed); the first batches' results are kept for the parity block ----------------
-    cpu_batches = a.cpu_batches if a.cpu_batches is not None else (12 if stream_len < 10_000_000 else 2)
+    # ---------------- warmup (untimed) ----------------
+    # CPU leg: on streams the -t 1 oracle follows in seconds per batch, it follows TWO sources through every batch up to the end of
+    # the timed region (multi-threaded port for positioning, -t 1 for the last two batches) and p is compared THERE; on larger
+    # streams (a twitter batch is minutes at -t 1) the comparison lives in tests/test_fullsize_golden_gpu.py and the leg is a short sample
+    cpu_follow = stream_len < 100_000_000
+    cpu_batches = a.cpu_batches if a.cpu_batches is not None else (n_steps if cpu_follow else 2)
     want_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline
-    snaps = []
     for k in range(1, a.warmup + 1):
         solver.update(a.eps, k)
-        if want_cpu and k <= cpu_batches:
-            snaps.append(solver.read(0)[0])
     solver.begin_timed()
 
     # ---------------- timed region: exactly K steps, barrier + synchronize on both sides ----------------
@@ -201,6 +218,7 @@ def main():
     ev_ms = ev[0]
     stats = solver.stats()
     units = shard.aggregate_units(S * c * a.steps, D)
+    total_sources = shard.aggregate_units(S, D)
 
     # ---------------- parity at the end of the timed region: every source of this rank ----------------
     w1, w2 = w_end
@@ -213,6 +231,7 @@ def main():
     parity = {"eps": a.eps, "max_abs_residual": max_r, "invariant_max_err": max_inv, "sources_checked": len(sources),
               "max_abs_dp_vs_cpu_t1": None, "tolerance": NORTH_STAR_TOL,
               "ok": bool(max_r < a.eps and max_inv < 1e-12)}
+    p_end = [solver.read(i)[0] for i in range(min(2, len(sources)))] if want_cpu else []   # p at the END of the timed region
 
     # ---------------- roofline of the dominant kernel ----------------
     roof = cpu = None
@@ -221,10 +240,16 @@ def main():
         push_bytes = 72 * ps["sum_F"] + 24 * ps["sum_E"] + 4 * ps["sum_N"]
         achieved = push_bytes / (ps["push_ms"] * 1e-3) / 1e9 if ps["push_ms"] > 0 else 0.0
         traffic, traffic_src = pmc_traffic_per_launch(a.config if not a.bin else None, S)
+        launch_s = 1e-3 * ps["push_ms"] / max(ps["push_launches"], 1)
+        # SURVEY.md 8(d)'s 24 bytes per traversed edge were written for ONE source (4 out_col + 4 degree + 16 residual); a
+        # group of S sources reads the column entry and the degree once for all of them: 16 + 8 / S per edge and source
+        adj_bytes = 72 * ps["sum_F"] + (16 + 8 / S) * ps["sum_E"] + 4 * ps["sum_N"]
         roof = {
             "bound": "hbm", "kernel": solver.kernel_name(ps),
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 5),
+            "frac_group_adjusted": round(adj_bytes / (ps["push_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if ps["push_ms"] > 0 else None,
+            "frac_traffic": round(traffic / launch_s / 1e9 / HBM_PEAK_GBPS, 5) if traffic and launch_s > 0 else None,
             "traffic": traffic, "traffic_source": traffic_src,
             "iterations_per_launch": round(ps["iterations"] / max(ps["push_launches"], 1), 2),
             "launches": ps["push_launches"], "avg_launch_us": round(1e3 * ps["push_ms"] / max(ps["push_launches"], 1), 3),
@@ -232,16 +257,19 @@ def main():
             "whole_batch_algorithmic_GBps": round(stats["algorithmic_bytes"] / (ev_ms * 1e-3) / 1e9, 2),
             "launches_from": ("a replay of the timed batches from the saved state" if S == 1 else
                               f"the {n_prof} batches that follow the timed region on the same stream"),
-            "note": "achieved = SURVEY.md 8(d) bytes (72 F + 24 E + 4 N, summed over the sources) of the hipEvent-"
-                    "bracketed launches / their time; sparse random 8-byte traffic: the kernel is bound by random-"
-                    "sector throughput of L2 / Infinity Cache / HBM, not by streaming bandwidth (DESIGN.md section 6)",
+            "note": "achieved / frac = SURVEY.md 8(d) bytes (72 F + 24 E + 4 N, summed over the sources) of the hipEvent-"
+                    "bracketed launches / their time: a WORK rate in the survey's unit. frac_group_adjusted prices a traversed "
+                    "edge at 16 + 8 / S bytes (a group reads the column entry once for its S sources); frac_traffic = the HBM bytes "
+                    "the counters saw per launch (traffic, from the committed rocprofv3 --pmc passes of this workload) / the "
+                    "launch time measured here / peak: what the memory system actually moved (DESIGN.md section 6)",
         }
         if want_cpu:
-            cpu = cpu_baseline(V, e1, e2, directed, W, c, sources[0], a.eps, cpu_batches, snaps, stream_len)
-            if cpu.get("max_abs_dp") is not None:
-                parity["max_abs_dp_vs_cpu_t1"] = cpu.pop("max_abs_dp")
-                parity["cpu_batches_compared"] = cpu.pop("compared")
-                parity["ok"] = bool(parity["ok"] and parity["max_abs_dp_vs_cpu_t1"] < NORTH_STAR_TOL)
+            cpu = cpu_baseline(V, e1, e2, directed, W, c, sources[:len(p_end)], a.eps, cpu_batches, p_end if cpu_batches == n_steps else [], stream_len)
+            worst = cpu.pop("max_abs_dp")
+            if worst is not None:
+                parity["max_abs_dp_vs_cpu_t1"] = worst
+                parity["cpu_compared"] = cpu.pop("compared")
+                parity["ok"] = bool(parity["ok"] and worst < NORTH_STAR_TOL)
             if stream_len < 10_000_000 and not a.bin:   # the reference's own FIFO binary needs the whole file
                 full = datagen.ensure_stand_in(a.config, a.data_dir)
                 cpu["reference_fifo"] = reference_fifo_baseline(full, directed, flags, sources[0], a.eps, c)
@@ -251,23 +279,34 @@ def main():
         line = {
             "metric": "edge-updates/sec (ppr_throughput, summed over sources); ms_per_step = mean per-batch PPR update time",
             "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{name}, {'directed' if directed else 'undirected'}, -a 0 -y 1 -w 0.1 {flags} "
-                                   f"-e {a.eps:g}, {S} source(s) per GPU from degree ranks "
-                                   f"{'[10,1000) (a top1000 file)' if pick == 'top1000' else '[0,10) (the top10 file)'}"
-                                   + (", streamed together as one source group over one graph replica" if S > 1 else ""),
+                                   f"-e {a.eps:g}, "
+                                   + (f"the configuration's {total_sources} sources" if scaling == "strong" else f"{S} source(s) per GPU")
+                                   + f" from degree ranks {'[10,1000) (a top1000 file)' if pick == 'top1000' else '[0,10) (the top10 file)'}"
+                                   + (f", dealt round-robin over {world} GPU(s)" if scaling == "strong" else "")
+                                   + (", a GPU's sources streamed together as one source group over one graph replica" if S > 1 else ""),
                        "V": V, "stream_edges": int(stream_len), "window": W, "batch_c": c, "records_L": L,
                        "sources": sources, "schedule": a.schedule,
-                       "parallelism": f"{S} source(s) per GPU x {world} GPU(s), replicated graph, no collective",
+                       "parallelism": (f"{total_sources} sources dealt round-robin over {world} GPU(s) (rank 0: {S}), replicated graph, no collective"
+                                       if scaling == "strong" else f"{S} source(s) per GPU x {world} GPU(s), replicated graph, no collective"),
                        "stream_file": provenance},
             "event_ms_per_step": round(ev_ms / a.steps, 4), "init_solve_ms": round(init_ms, 3),
-            "per_source_edges_per_s": round(value / (S * world), 1),
+            "per_source_edges_per_s": round(value / total_sources, 1),
             "iterations_per_step": round(stats["iterations"] / a.steps, 2),
             "pull_iterations_per_step": round(stats["pull_iterations"] / a.steps, 2),
             "edges_pushed_per_step": round(stats["sum_E"] / a.steps, 1),
             "parity": parity, "roofline": roof, "cpu_baseline": cpu,
         }
+        if scaling == "strong":
+            # what the multi-GPU value has to be read against: ALL of the configuration's sources as one source group on ONE GPU
+            # (this very script at --gpus 1; the committed line of that run is quoted when this is an N > 1 run)
+            alt = os.path.join(ROOT, "profiles", f"r03_bench_{a.config}_group_1gpu.json")
+            line["single_gpu_group_alternative"] = (
+                {"this_run": True, "ms_per_step": line["ms_per_step"], "value": line["value"]} if world == 1 else
+                ({k: json.load(open(alt)).get(k) for k in ("ms_per_step", "value", "unit", "steps")} | {"source": os.path.relpath(alt, ROOT)})
+                if os.path.exists(alt) else None)
         # the default run also reports configs[1] (com-youtube stand-in, one top-10 source: the single-source resident
         # path) under its own key: a second, short run of this script as a child process once this one's numbers are in
         if world == 1 and a.config == "livejournal" and not a.bin and not a.no_extra and not a.no_cpu_baseline:
@@ -336,8 +375,11 @@ class SingleSolver:
         return e.stats(slot)
 
     def kernel_name(self, ps):
-        return ("k_pull_resident (one launch = a run of frontier iterations, state kept on chip)"
-                if ps["persist_launches"] else "k_pull_iter / k_push_iter (one frontier iteration)")
+        if ps["persist_launches"]:
+            return "k_pull_resident (one launch = a run of frontier iterations, state kept on chip)"
+        if ps.get("binned_sweeps"):
+            return "k_bin_scatter + k_bin_reduce (one frontier iteration as two streaming passes; a launch = the pair) / k_push_iter"
+        return "k_pull_iter / k_push_iter (one frontier iteration)"
 
 
 class GroupSolver:
@@ -400,54 +442,53 @@ def pmc_traffic_per_launch(config, S):
     return (round(total / launches, 1), f"committed profile {rel}") if launches else (None, None)
 
 
-def cpu_baseline(V, e1, e2, directed, W, c, source, eps, batches, snaps, stream_len):
-    """CPU leg (kind "port"): the oracle's restatement of cpu/PPRCPUMTCilkRev, timed with the
-    reference's scope (IncExecuteImpl only, cpu/PPRCPUMTCilk.h:131-137) on a bounded sample of
-    the same workload: one source, the first `batches` batches after the from-scratch solve, at
-    -t 1 and with OpenMP workers (in place of Cilk Plus, which this toolchain lacks). The -t 1 run's
-    p after every batch is compared with the GPU's (parity block)."""
+def cpu_baseline(V, e1, e2, directed, W, c, sources, eps, batches, p_end, stream_len):
+    """CPU leg (kind "port"): the oracle's restatement of cpu/PPRCPUMTCilkRev, timed with the reference's scope
+    (IncExecuteImpl only, cpu/PPRCPUMTCilk.h:131-137) on the same stream. `sources` (one or two of the rank's) are
+    solved from scratch and followed through `batches` batches: with OpenMP workers (in place of Cilk Plus, which this
+    toolchain lacks) up to the last two, which run at -t 1. When `p_end` is given (the GPU's p of those sources at the
+    end of the timed region, `batches` = every batch up to there), the -t 1 state is compared with it."""
     from oracle import oracle as orc
-    threads = max(1, min(orc.max_threads(), os.cpu_count() or 1))
-
-    def run(nthreads, nb, compare=False):
-        g = orc.Graph(V, e1, e2, directed, W, c)
-        s = orc.State(V, source, eps)
-        s.cilk_execute(g)
-        total, done, worst = 0.0, 0, None
-        for k in range(nb):
-            if g.stream_updates():
-                break
-            g.inc_construct(1)
+    threads = max(1, min(orc.max_threads(), os.cpu_count() or 1, 16))
+    g = orc.Graph(V, e1, e2, directed, W, c)
+    states = [orc.State(V, s, eps) for s in sources]
+    for s in states:            # from-scratch solve (untimed here, like INIT_GRAPH_CALC_TIME in the reference)
+        s.cilk_init()
+        s.cilk_main_loop_mt(g, 0, threads)
+    t_mt = t_1 = 0.0
+    n_mt = n_1 = done = 0
+    for k in range(batches):
+        if g.stream_updates():
+            break
+        g.inc_construct(1)
+        done += 1
+        serial = k >= batches - 2 or threads == 1
+        for s in states:
             t = time.perf_counter()
-            if nthreads == 1:
+            if serial:
                 s.cilk_inc_execute(g)
             else:
-                s.cilk_inc_execute_mt(g, nthreads)
-            total += time.perf_counter() - t
-            done += 1
-            if compare and k < len(snaps):
-                worst = max(worst or 0.0, float(np.max(np.abs(snaps[k] - s.p))))
-        return total, done, worst
-
-    t1, n1, worst = run(1, batches, compare=True)
-    # the parallel schedule does not scale monotonically (CAS contention on hub vertices, tiny per-iteration
-    # work on small windows): on small streams try a few worker counts on a short sample and time the best
-    best = min(threads, 16)
-    if stream_len < 10_000_000:
-        cands = sorted({t for t in (8, 16, 32, 40, 64) if t <= threads} | ({threads} if threads <= 16 else set()))
-        best, best_rate = 1, n1 / t1 if t1 > 0 else 0.0
-        for t in cands:
-            tt, nn, _ = run(t, max(2, batches // 4))
-            if tt > 0 and nn / tt > best_rate:
-                best, best_rate = t, nn / tt
-    tm, nm, _ = run(best, batches) if best > 1 else (t1, n1, None)
-    return {"value": round(c * nm / tm, 1) if tm > 0 else None, "unit": "edges/s", "cores": best,
-            "kind": "port", "ms_per_step": round(1e3 * tm / max(nm, 1), 2),
-            "t1_value": round(c * n1 / t1, 1) if t1 > 0 else None, "t1_ms_per_step": round(1e3 * t1 / max(n1, 1), 2),
-            "max_abs_dp": worst, "compared": min(n1, len(snaps)),
-            "sample": f"ONE source ({source}; the GPU value sums all of a rank's sources), first {nm} batches of the same "
-                      f"stream after the from-scratch solve; oracle restatement of cpu/PPRCPUMTCilkRev with OpenMP "
-                      f"workers ({best} threads) and at -t 1, gcc -O2"}
+                s.cilk_inc_execute_mt(g, threads)
+            dt = time.perf_counter() - t
+            if serial:
+                t_1, n_1 = t_1 + dt, n_1 + 1
+            else:
+                t_mt, n_mt = t_mt + dt, n_mt + 1
+    worst = None
+    if p_end and done == batches:
+        worst = max(float(np.max(np.abs(pe - s.p))) for pe, s in zip(p_end, states))
+    had_mt = n_mt > 0
+    if not had_mt:
+        t_mt, n_mt = t_1, n_1
+    return {"value": round(c * n_mt / t_mt, 1) if t_mt > 0 else None, "unit": "edges/s", "cores": threads if had_mt else 1,
+            "kind": "port", "ms_per_step": round(1e3 * t_mt / max(n_mt, 1), 2),
+            "t1_value": round(c * n_1 / t_1, 1) if t_1 > 0 else None, "t1_ms_per_step": round(1e3 * t_1 / max(n_1, 1), 2),
+            "max_abs_dp": worst,
+            "compared": (f"p of {len(states)} source(s) after batch {done} (the end of the timed region), CPU state reached with the "
+                         f"{threads}-thread port and the last two batches at -t 1") if worst is not None else None,
+            "sample": f"{len(states)} source(s) ({', '.join(str(s) for s in sources)}; value is per source and batch -- the GPU value sums all of a "
+                      f"rank's sources), {done} batches of the same stream after the from-scratch solve: {n_mt} source-batches with "
+                      f"{threads} OpenMP workers, {n_1} at -t 1; oracle restatement of cpu/PPRCPUMTCilkRev, gcc -O2"}
 
 
 def reference_fifo_baseline(bin_path, directed, flags, source, eps, c, batches=4):

@@ -17,6 +17,21 @@ def assign_sources(sources: Sequence[int], rank: int, world: int, per_rank: int 
     return [int(sources[(rank + k * world) % len(sources)]) for k in range(per_rank)]
 
 
+# The 8-GPU configurations of BASELINE.json are FIXED source sets: configs[3] twitter-2010 = 8 of the top-10 file,
+# configs[4] com-friendster = the 10 ids of a top1000 file. bench.py deals them over its ranks with
+# assign_sources(pool, rank, world): 8 / 4+4 / 2+2+2+2 / 1 each, and 10 / 5+5 / 3+3+2+2 / 2+2+1x6.
+CONFIG_SOURCE_SETS = {"twitter": (8, "top10"), "friendster": (10, "top1000")}
+
+
+def config_source_pool(key: str, V: int, e1, e2, W: int, directed: int) -> list[int]:
+    """The source set of an 8-GPU configuration on the given stream (every rank computes the same list)."""
+    from . import datagen
+    n, pick = CONFIG_SOURCE_SETS[key]
+    ids = (datagen.ranked_sources(V, e1, e2, W, directed, 10, 1000, 10, seed=1) if pick == "top1000"
+           else datagen.top_sources(V, e1, e2, W, directed, 10))
+    return [int(x) for x in ids[:n]]
+
+
 def timed_region(run_steps: Callable[[], None], device_sync: Callable[[], None], dist=None):
     """Barrier + device sync on both sides of ``run_steps``; returns (max-over-ranks seconds, world)."""
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1

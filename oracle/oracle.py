@@ -240,6 +240,7 @@ class State:
         return [v[off[i]:off[i + 1]].copy() for i in range(n)]
 
     # schedules
+    def cilk_init(self): lib().orc_cilk_init(self._s)
     def cilk_execute(self, g): lib().orc_cilk_execute(self._s, g._g)
     def cilk_inc_execute(self, g): lib().orc_cilk_inc_execute(self._s, g._g)
     def cilk_inc_execute_mt(self, g, threads): lib().orc_cilk_inc_execute_mt(self._s, g._g, int(threads))

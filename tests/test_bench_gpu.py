@@ -14,8 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("extra,sources", [([], 1), (["--sources", "3"], 3), (["--sources", "10"], 10)])
 def test_bench_line_contract(extra, sources):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "dblp", "--steps", "4", "--warmup", "2",
-                        "--cpu-batches", "1"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "dblp", "--steps", "4", "--warmup", "2"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout
@@ -32,8 +31,11 @@ def test_bench_line_contract(extra, sources):
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and 0 < rf["frac"] < 1
+    assert 0 < rf["frac_group_adjusted"] <= rf["frac"] and "frac_traffic" in rf     # (a group reads a column entry once for its S sources)
+    assert (rf["frac_group_adjusted"] == rf["frac"]) == (sources == 1)
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     pr = d["parity"]
     assert pr["ok"] is True and pr["max_abs_residual"] < pr["eps"] and pr["invariant_max_err"] < 1e-12
     assert pr["max_abs_dp_vs_cpu_t1"] is not None and pr["max_abs_dp_vs_cpu_t1"] < pr["tolerance"]
+    assert "end of the timed region" in pr["cpu_compared"] and f"{min(sources, 2)} source(s)" in pr["cpu_compared"]

@@ -21,6 +21,9 @@ def test_assign_sources_round_robin():
     one = [shard.assign_sources(src, r, 8, per_rank=1) for r in range(8)]
     assert [g[0] for g in one] == src[:8]                  # config 4: one top-10 source per GPU
     assert shard.assign_sources(src[:2], 3, 4, per_rank=2) == [src[1], src[1]]
+    assert [len(shard.assign_sources(src[:8], r, 4)) for r in range(4)] == [2, 2, 2, 2]   # config 4 on 4 GPUs
+    assert [len(shard.assign_sources(src, r, 4)) for r in range(4)] == [3, 3, 2, 2]
+    assert shard.CONFIG_SOURCE_SETS == {"twitter": (8, "top10"), "friendster": (10, "top1000")}
 
 
 WORKER = textwrap.dedent("""
@@ -41,21 +44,25 @@ WORKER = textwrap.dedent("""
     assert rank == 0 or datagen.PROVENANCE[path]["origin"] == "cached"
     V, e1, e2 = datagen.read_bin(path)
     wl = st.workload_config(len(e1), 0.1, 0, 0.01, 5)
-    mine = [int(x) for x in datagen.ranked_sources(V, e1, e2, wl.window, 1, 10, 200, 10, seed=1 + rank)[:1]]
+    # bench.py --config friendster --gpus 2: the configuration's OWN 10 sources (a top1000 file), dealt round-robin
+    pool = shard.config_source_pool("friendster", V, e1, e2, wl.window, 1)
+    mine = shard.assign_sources(pool, rank, world)
     checksum = datagen.PROVENANCE[path]["checksum"]
     g = orc.Graph(V, e1, e2, 1, wl.window, wl.per_batch)
-    s = orc.State(V, mine[0], 1e-9)
-    s.cilk_execute(g)
+    states = [orc.State(V, v, 1e-9) for v in mine]
+    for s in states:
+        s.cilk_execute(g)
     steps = 3
     def run():
         for _ in range(steps):
             assert not g.stream_updates()
             g.inc_construct(1)
-            s.cilk_inc_execute(g)
+            for s in states:
+                s.cilk_inc_execute(g)
         time.sleep(0.05 * (rank + 1))          # rank 1 is the slow one
     dt, w = shard.timed_region(run, lambda: None, dist)
     units = shard.aggregate_units(wl.per_batch * steps * len(mine), dist)
-    json.dump(dict(rank=rank, world=w, source=mine[0], dt=dt, units=units, psum=float(s.p.sum()), checksum=checksum),
+    json.dump(dict(rank=rank, world=w, sources=mine, pool=pool, dt=dt, units=units, psum=float(sum(s.p.sum() for s in states)), checksum=checksum),
               open(os.path.join({out!r}, "rank%d.json" % rank), "w"))
     dist.barrier()
     dist.destroy_process_group()
@@ -77,8 +84,9 @@ def test_two_rank_gloo_run(tmp_path):
     a = json.load(open(tmp_path / "rank0.json"))
     b = json.load(open(tmp_path / "rank1.json"))
     assert a["world"] == b["world"] == 2
-    assert a["source"] != b["source"]                       # independent sources, one per rank
+    assert a["pool"] == b["pool"] and len(set(a["pool"])) == 10      # every rank derives the same source set ...
+    assert a["sources"] == a["pool"][0::2] and b["sources"] == a["pool"][1::2]   # ... and takes its round-robin share: 5 + 5
     assert a["dt"] == b["dt"] and a["dt"] >= 0.1            # MAX over ranks: the slow rank's time
-    assert a["units"] == b["units"] == 2 * 6 * 3            # SUM over ranks of c * steps
+    assert a["units"] == b["units"] == 10 * 6 * 3           # SUM over ranks of sources * c * steps
     assert a["psum"] != b["psum"]
     assert a["checksum"] == b["checksum"]                   # one stream file, written once
