@@ -167,6 +167,7 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     int *w1 = nullptr, *w2 = nullptr;
     int head = 0;
     bool loaded = false;
+    bool broken = false; // a renumbering failed half way (HIP error after the host maps changed): every call but dppr_destroy is refused
     int *outdeg = nullptr;
     int *hub_slot_of = nullptr; // V, scratch of the CSR build
     int *hub_hist = nullptr;    // 32 + 1 ints (histogram, hub counter)
@@ -197,8 +198,8 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
                                     // the configs[1] stand-in, equal on the LiveJournal one)
     bool wide_groups = false;       // ... one of more than 8 sources: its groups hold at most 512 vertices
     bool group_tail_seeding = true; // source groups seed from the batch tails after a converged solve (false: dense Inspect)
-    int gpush_enter_pairs = -1;     // a group's loop switches to the push form below this many frontier pairs (-1: from the
-                                    // sweep's floor, n_ggroups / 16; 0: never) -- dppr_set_group_push
+    int gpush_enter_pairs = -1;     // a group's loop switches to the push form below this many frontier pairs (-1: automatic,
+                                    // max(64, gpush_auto_factor pairs per sweep group); 0: never) -- dppr_set_group_push
     int gpush_list_cap = 1 << 20;   // vertices a frontier list of that form holds
     long long gpush_max_edges = 0;  // in-edges one iteration of that form may have (0: from the sweep's floor, 200 per sweep group)
     int gpush_auto_factor = 2;      // automatic threshold: this many pairs per sweep group (DPPR_GROUP_PUSH_FACTOR: tuning runs)
@@ -279,6 +280,13 @@ int fail(dppr_engine *e, int code, const char *msg) {
 }
 
 inline int to_int(dppr_engine *e, int ext) { return e->to_int(ext); } // (IdSpace: assigns, or revives a parked vertex)
+
+// ids inside [0, V)? (no side effect: a rejected call must not assign ids, revive parked vertices or queue row moves)
+bool ids_in_range(const dppr_engine *e, const int32_t *src, int n) {
+    for (int i = 0; i < n; ++i)
+        if (src[i] < 0 || src[i] >= e->V) return false;
+    return true;
+}
 
 // translate an id array; returns false if any id is outside [0, V)
 bool translate(dppr_engine *e, const int32_t *src, int n, std::vector<int32_t> &dst) {
@@ -517,35 +525,47 @@ int compact_ids(dppr_engine *e, bool *did) {
     // tail of low-degree late-comers next to each other unbalances the sweep groups (configs[1] stand-in in step,
     // survivors kept in their old order instead: 0.52 ms per batch at the start, 0.61 after 400 batches of the
     // same work). The order is computed on the device (hash + in-degree blocks as keys, one radix sort).
-    std::vector<int32_t> perm, order;
-    if (int rc = device_numbering_order(e, live, n_old, n_live, order)) return rc;
-    mark("numbering order (device)");
-    e->renumber(live, order, perm); // (IdSpace: perm, the maps, n_int, n_parked)
-    mark("host maps");
-    // device side
+    // Renumbering is an optimisation: whatever can fail for lack of memory is obtained BEFORE anything is changed, and
+    // then the slide simply goes on in the old numbering (and looks again after some more growth).
     int *d_perm = nullptr;
     double *tmp = nullptr;
     int maxw = 1;
     for (const auto &g : e->groups) maxw = std::max(maxw, g.gw);
-    HIP_TRY(hipMalloc((void **)&d_perm, sizeof(int) * (size_t)V));
-    if (hipMalloc((void **)&tmp, sizeof(double) * (size_t)V * (size_t)maxw) != hipSuccess) {
-        (void)hipFree(d_perm);
-        return fail(e, DPPR_ERR_NOMEM, "renumbering: no memory for the row scratch");
-    }
     auto cleanup = [&]() {
         (void)hipFree(d_perm);
         (void)hipFree(tmp);
     };
+    if (hipMalloc((void **)&d_perm, sizeof(int) * (size_t)V) != hipSuccess ||
+        hipMalloc((void **)&tmp, sizeof(double) * (size_t)V * (size_t)maxw) != hipSuccess) {
+        (void)hipGetLastError();
+        cleanup();
+        e->renumber_next = renumber_threshold(n_old, 12);
+        return DPPR_OK;
+    }
+    mark("scratch allocation");
+    std::vector<int32_t> perm, order;
+    if (int rc = device_numbering_order(e, live, n_old, n_live, order)) {
+        cleanup();
+        if (rc != DPPR_ERR_NOMEM) return rc;
+        e->renumber_next = renumber_threshold(n_old, 12);
+        return DPPR_OK;
+    }
+    mark("numbering order (device)");
+    e->renumber(live, order, perm); // (IdSpace: perm, the maps, n_int, n_parked)
+    mark("host maps");
+    // From here on the host maps are in the NEW numbering: a failure below leaves ring, degrees and state rows part old,
+    // part new -- the engine refuses all further work (`broken`).
 #define RN_TRY(call)                                                     \
     do {                                                                 \
         hipError_t _e = (call);                                          \
         if (_e != hipSuccess) {                                          \
             cleanup();                                                   \
-            e->err = std::string("renumbering: ") + hipGetErrorString(_e); \
+            e->broken = true;                                            \
+            for (auto &ep : e->epochs) ep.id = -1;                       \
+            e->err = std::string("renumbering failed half way (") + hipGetErrorString(_e) + "): the engine is unusable, destroy it"; \
             return DPPR_ERR_HIP;                                         \
         }                                                                \
     } while (0)
-    mark("scratch allocation");
     RN_TRY(hipMemcpyAsync(d_perm, perm.data(), sizeof(int) * (size_t)V, hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(k_remap_ids, dim3(grid_for(e->W)), dim3(BLOCK), 0, e->stream, e->w1, e->W, d_perm);
     hipLaunchKernelGGL(k_remap_ids, dim3(grid_for(e->W)), dim3(BLOCK), 0, e->stream, e->w2, e->W, d_perm);
@@ -1755,6 +1775,11 @@ const char *dppr_strerror(int status) {
 
 const char *dppr_last_error(const dppr_engine *e) { return e ? e->err.c_str() : ""; }
 
+int dppr_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directed, int32_t c, int32_t n_epochs) {
     if (!out || V <= 0 || W < 0 || c < 0 || n_epochs < 1) return DPPR_ERR_INVALID;
     *out = nullptr;
@@ -2075,9 +2100,9 @@ int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32
 }
 
 int dppr_set_batch(dppr_engine *e, const int32_t *b1, const int32_t *b2, const uint8_t *ins, int32_t L) {
-    if (!e || L < 0 || L > 4 * e->c || (L > 0 && (!b1 || !b2 || !ins)))
+    if (!e || e->broken || L < 0 || L > 4 * e->c || (L > 0 && (!b1 || !b2 || !ins)))
         return fail(e, DPPR_ERR_INVALID, "set_batch: length exceeds 4*max_batch");
-    if (!translate(e, b1, L, e->st_b1) || !translate(e, b2, L, e->st_b2))
+    if (!ids_in_range(e, b1, L) || !ids_in_range(e, b2, L) || !translate(e, b1, L, e->st_b1) || !translate(e, b2, L, e->st_b2))
         return fail(e, DPPR_ERR_INVALID, "set_batch: vertex id out of range");
     e->st_b1.resize((size_t)L);
     e->st_b2.resize((size_t)L);
@@ -2090,8 +2115,10 @@ int dppr_set_batch(dppr_engine *e, const int32_t *b1, const int32_t *b2, const u
 int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, int32_t *out_epoch) {
     // c is bounded by max_batch of dppr_create: the batch key buffers (2 * max_batch keys each) and the
     // merge scratch are sized for it
-    if (!e || !e->loaded || c < 0 || c > e->W || c > e->c || (c > 0 && (!n1 || !n2)))
+    if (!e || e->broken || !e->loaded || c < 0 || c > e->W || c > e->c || (c > 0 && (!n1 || !n2)))
         return fail(e, DPPR_ERR_INVALID, "slide: window not loaded, or c exceeds the window / max_batch of dppr_create");
+    if (!ids_in_range(e, n1, c) || !ids_in_range(e, n2, c)) // before anything is touched: a rejected slide is a no-op
+        return fail(e, DPPR_ERR_INVALID, "slide: vertex id out of range");
     HIP_TRY(hipSetDevice(e->device));
     const int W = e->W;
     static const bool slide_trace = getenv("DPPR_SLIDE_TRACE") != nullptr; // (diagnostic: phases of a slide; each mark synchronises)
@@ -2178,7 +2205,7 @@ int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, 
 }
 
 int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
-    if (!e || source < 0 || source >= e->V) return fail(e, DPPR_ERR_INVALID, "add_source: vertex out of range");
+    if (!e || e->broken || source < 0 || source >= e->V) return fail(e, DPPR_ERR_INVALID, "add_source: vertex out of range");
     HIP_TRY(hipSetDevice(e->device));
     Slot s;
     s.source_ext = source;
@@ -2223,6 +2250,7 @@ int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
 
 #define GET_SLOT(e, slot)                                                                       \
     if (!(e) || (slot) < 0 || (slot) >= (int)(e)->slots.size()) return fail((e), DPPR_ERR_INVALID, "bad slot"); \
+    if ((e)->broken) return fail((e), DPPR_ERR_INVALID, "engine unusable after a failed renumbering");            \
     Slot &s = (e)->slots[(size_t)(slot)]
 #define GET_EPOCH(e, epoch)                                                       \
     Epoch *epp = find_epoch((e), (epoch));                                        \
@@ -2556,44 +2584,61 @@ int dppr_trace_get(dppr_engine *e, int32_t slot, int64_t *n_iters, int64_t *n_id
 
 #define GET_GROUP(e, gid)                                                                             \
     if (!(e) || (gid) < 0 || (gid) >= (int)(e)->groups.size()) return fail((e), DPPR_ERR_INVALID, "bad group"); \
+    if ((e)->broken) return fail((e), DPPR_ERR_INVALID, "engine unusable after a failed renumbering");           \
     Group &g = (e)->groups[(size_t)(gid)]
 
 int dppr_add_source_group(dppr_engine *e, const int32_t *sources, int32_t n, int32_t *out_group) {
-    if (!e || !sources || n < 1 || n > GS_MAX) return fail(e, DPPR_ERR_INVALID, "add_source_group: 1..16 sources");
+    if (!e || e->broken || !sources || n < 1 || n > GS_MAX) return fail(e, DPPR_ERR_INVALID, "add_source_group: 1..16 sources");
+    if (!ids_in_range(e, sources, n)) return fail(e, DPPR_ERR_INVALID, "add_source_group: vertex out of range"); // before anything is touched
     HIP_TRY(hipSetDevice(e->device));
     Group g;
     g.n = n;
     g.spl = n > OCT ? 2 : 1;
     g.gw = OCT * g.spl;
-    e->any_groups = true; // (recut_stale_groups below adds the second group table to resident epochs)
-    if (g.spl == 2) e->wide_groups = true;
     for (int s = 0; s < GS_MAX; ++s) g.src.s[s] = -1;
-    for (int s = 0; s < n; ++s) {
-        if (sources[s] < 0 || sources[s] >= e->V) return fail(e, DPPR_ERR_INVALID, "add_source_group: vertex out of range");
-        g.src_ext[s] = sources[s];
-    }
-    for (int s = 0; s < n; ++s) (void)to_int(e, sources[s]);
-    for (int s = 0; s < n; ++s) g.src.s[s] = e->ext2int[(size_t)sources[s]]; // (after ALL revivals: one may move another)
-    if (int rc = flush_moves(e)) return rc;
+    for (int s = 0; s < n; ++s) g.src_ext[s] = sources[s];
     const size_t V = (size_t)e->V, row = sizeof(double) * (size_t)g.gw;
     g.act_bytes = (V / 32 + 1024 / 32 + 4) * sizeof(uint32_t);
-    HIP_TRY(hipMalloc((void **)&g.p, row * V));
-    HIP_TRY(hipMalloc((void **)&g.r, row * V));
-    HIP_TRY(hipMalloc((void **)&g.x, row * V));
-    HIP_TRY(hipMalloc((void **)&g.x2, row * V));
-    HIP_TRY(hipMalloc((void **)&g.act[0], g.act_bytes));
-    HIP_TRY(hipMalloc((void **)&g.act[1], g.act_bytes));
-    HIP_TRY(hipMalloc((void **)&g.cnt, sizeof(int) * (5 * GS_MAX + MAX_CHUNK * GS_MAX))); // rows 3, 4: scratch of multi-sweep launches
-    HIP_TRY(hipMalloc((void **)&g.mlog, sizeof(int) * (size_t)(GMULTI_MAX + 2) * GS_MAX));
-    HIP_TRY(hipMalloc((void **)&g.dstats, sizeof(IterStats)));
-    HIP_TRY(hipMemsetAsync(g.act[0], 0, g.act_bytes, e->stream));
-    HIP_TRY(hipMemsetAsync(g.act[1], 0, g.act_bytes, e->stream));
-    HIP_TRY(hipMemsetAsync(g.cnt, 0, sizeof(int) * (5 * GS_MAX + MAX_CHUNK * GS_MAX), e->stream));
-    HIP_TRY(hipMemsetAsync(g.dstats, 0, sizeof(IterStats), e->stream));
+    auto release = [&]() { // (an allocation failed: nothing of this group stays behind)
+        (void)hipFree(g.p); (void)hipFree(g.r); (void)hipFree(g.x); (void)hipFree(g.x2); (void)hipFree(g.act[0]); (void)hipFree(g.act[1]);
+        (void)hipFree(g.cnt); (void)hipFree(g.mlog); (void)hipFree(g.dstats);
+    };
+#define GRP_TRY(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (call);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            release();                                                                                  \
+            e->err = std::string("add_source_group: ") + hipGetErrorString(_e);                         \
+            return _e == hipErrorOutOfMemory ? DPPR_ERR_NOMEM : DPPR_ERR_HIP;                           \
+        }                                                                                               \
+    } while (0)
+    GRP_TRY(hipMalloc((void **)&g.p, row * V));
+    GRP_TRY(hipMalloc((void **)&g.r, row * V));
+    GRP_TRY(hipMalloc((void **)&g.x, row * V));
+    GRP_TRY(hipMalloc((void **)&g.x2, row * V));
+    GRP_TRY(hipMalloc((void **)&g.act[0], g.act_bytes));
+    GRP_TRY(hipMalloc((void **)&g.act[1], g.act_bytes));
+    GRP_TRY(hipMalloc((void **)&g.cnt, sizeof(int) * (5 * GS_MAX + MAX_CHUNK * GS_MAX))); // rows 3, 4: scratch of multi-sweep launches
+    GRP_TRY(hipMalloc((void **)&g.mlog, sizeof(int) * (size_t)(GMULTI_MAX + 2) * GS_MAX));
+    GRP_TRY(hipMalloc((void **)&g.dstats, sizeof(IterStats)));
+    GRP_TRY(hipMemsetAsync(g.act[0], 0, g.act_bytes, e->stream));
+    GRP_TRY(hipMemsetAsync(g.act[1], 0, g.act_bytes, e->stream));
+    GRP_TRY(hipMemsetAsync(g.cnt, 0, sizeof(int) * (5 * GS_MAX + MAX_CHUNK * GS_MAX), e->stream));
+    GRP_TRY(hipMemsetAsync(g.dstats, 0, sizeof(IterStats), e->stream));
+    // the memory is there: now the ids (a source outside the window receives one; a parked one is revived)
+    for (int s = 0; s < n; ++s) (void)to_int(e, sources[s]);
+    for (int s = 0; s < n; ++s) g.src.s[s] = e->ext2int[(size_t)sources[s]]; // (after ALL revivals: one may move another)
+    if (int rc = flush_moves(e)) {
+        release();
+        return rc;
+    }
     hipLaunchKernelGGL(k_ginit, dim3(grid_for((int64_t)e->V * g.gw)), dim3(BLOCK), 0, e->stream, g.p, g.r, e->V, g.gw, g.src);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    GRP_TRY(hipGetLastError());
+    GRP_TRY(hipStreamSynchronize(e->stream));
+#undef GRP_TRY
     e->groups.push_back(g);
+    e->any_groups = true; // (recut_stale_groups below adds the second group table to resident epochs)
+    if (g.spl == 2) e->wide_groups = true;
     if (int rc = recut_stale_groups(e)) return rc;
     if (out_group) *out_group = (int)e->groups.size() - 1;
     return DPPR_OK;

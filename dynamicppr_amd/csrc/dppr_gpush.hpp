@@ -261,6 +261,10 @@ __global__ __launch_bounds__(BLOCK) void k_gpush_expand(const int *__restrict__ 
 // iterations; a next list that outgrows TINY_N raises `stop` (the bits hold the set: the host leaves the mode).
 constexpr int TINY_N = 512;
 constexpr int TINY_E = 1024; // (an octet walks its share of the edges one returning atomic after the other: 8 per octet at most)
+// gfx950 only: the 16-wide form keeps TINY_N snapshot rows of 128 bytes in LDS (64 KB) next to the lists and the scan,
+// about 70 KB of static LDS -- beyond the 64 KB of earlier targets, within the 160 KB of a CDNA4 CU
+static_assert(sizeof(double) * TINY_N * 16 + sizeof(int) * (3 * TINY_N + 1) + 1024 <= 160 * 1024,
+              "k_gpush_tiny: TINY_N snapshot rows + lists + scan must fit the 160 KB LDS of a gfx950 CU");
 
 template <int SPL>
 __global__ __launch_bounds__(1024) void k_gpush_tiny(GPushCtl *ctl, int *__restrict__ list0, int *__restrict__ list1,

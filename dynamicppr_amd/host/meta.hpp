@@ -40,6 +40,7 @@ inline int gNumGpus = 1;              // -g : devices; sources are dealt round-r
 inline std::string gSourcesFile;      // --sources : file with one source vertex id per line
 inline std::string gDumpPath;         // --dump : write p/r of every source after the last batch
 inline bool gValidate = false;        // --validate : the reference's -DVALIDATE checks at run time
+inline bool gShareDevice = false;     // --share-device (or DPPR_DEVICE_ALIAS=1): the -g N device threads share the devices that exist (d % count)
 inline bool gSplitInterface = false;  // --split : drive the timed region through the 3 virtual calls
 inline int gSchedule = 0;             // --sync : deterministic synchronous schedule
 inline bool gProfile = false;         // --profile : the reference's -DPROFILE output (per-iteration frontier lines, phase times)

@@ -42,6 +42,9 @@ int main(int argc, char *argv[]) {
 
     // Every device thread streams the same file through its own SlidingGraphVec (a position in
     // a shared read-only mapping of the page cache) and owns one engine.
+    // --share-device / DPPR_DEVICE_ALIAS=1: the N device threads (each with its own engine, stream and graph replica) run on the
+    // devices that exist -- the thread-per-device flow of -g N on a node with fewer GPUs (one, on the test pool)
+    const int present = gShareDevice ? std::max(dppr_device_count(), 1) : 0;
     std::vector<std::unique_ptr<SlidingGraphVec>> graphs((size_t)ngpu);
     std::vector<std::unique_ptr<PPRGPU>> drivers((size_t)ngpu);
     for (int d = 0; d < ngpu; ++d) {
@@ -54,7 +57,7 @@ int main(int argc, char *argv[]) {
             }
         }
         graphs[(size_t)d].reset(new SlidingGraphVec(gDataFileName, gIsDirected != 0));
-        drivers[(size_t)d].reset(new PPRRevPushGPU(graphs[(size_t)d].get(), d, mine, /*quiet=*/d != 0 && ngpu > 1));
+        drivers[(size_t)d].reset(new PPRRevPushGPU(graphs[(size_t)d].get(), present ? d % present : d, mine, /*quiet=*/d != 0 && ngpu > 1));
     }
     const auto t0 = std::chrono::steady_clock::now();
     if (ngpu == 1) {

@@ -74,6 +74,10 @@ typedef struct dppr_stats_t {
 
 /* ---- lifetime ----------------------------------------------------------- */
 
+/* HIP devices visible to the process (0 when there is none or the runtime fails): lets a host program that has no HIP of
+ * its own map `-g N` device threads onto the devices that exist. No reference counterpart (single implicit device 0). */
+int dppr_device_count(void);
+
 /* Replaces: DeviceMemory ctor + CudaAllocAppData + InitForDynamicGraph
  * (gpu/DeviceMemory.cuh:9-74) and SlidingGraphBuilder ctor
  * (gpu/SlidingGraphBuilder.cuh:64-76), as called from PPRGPU ctor
@@ -258,8 +262,9 @@ int dppr_set_group_resident(dppr_engine *e, int on);
  * sweep group's tables) however few (vertex, source) pairs are still being pushed; below enter_pairs frontier pairs
  * the loop's remaining iterations run as what the reference does for every iteration (gpu/ExpandRev.cuh:34-77,
  * :708-743: per frontier vertex and in-neighbour a returning atomic add, all sources of the group at once), same
- * synchronous schedule, same results up to the order of the sums. enter_pairs: -1 (default) = from the sweep's floor
- * (sweep groups / 16), 0 = never, N = below N pairs; an iteration with more in-edges than the floor is worth sends
+ * synchronous schedule, same results up to the order of the sums. enter_pairs: -1 (default) = automatic: below
+ * max(64, 2 pairs per sweep group) -- the factor 2 can be changed for tuning runs with the environment variable
+ * DPPR_GROUP_PUSH_FACTOR, read in dppr_create --, 0 = never, N = below N pairs; an iteration with more in-edges than the floor is worth sends
  * the loop back to sweeps (max_edges: that bound on an iteration's in-edges; 0 = automatic, 200 per sweep group), to
  * try again on a much smaller frontier. list_cap: vertices a frontier list holds (0: keep; default 2^20). Windows
  * whose groups run as multi-sweep launches do not use it. */

@@ -125,6 +125,52 @@ def test_cli_multiple_sources_one_gpu(pagerank, small_bin, tmp_path, extra, nsrc
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ngpu,nsrc", [(2, 5), (3, 10)])
+def test_cli_device_threads_share_the_device(pagerank, small_bin, tmp_path, ngpu, nsrc):
+    """`./pagerank -g N --sources f --share-device`: the thread-per-device flow of pagerank_main.cpp (N host threads, each with
+    its own SlidingGraphVec, engine, stream and replica of the window graph; sources dealt round-robin) on the devices that
+    exist -- one on this pool. Every device thread's dump against the oracle, and the aggregate_* lines against the
+    per-device figures."""
+    path, V, e1, e2 = small_bin
+    W, c = 600, 6
+    sources = [int(x) for x in datagen.top_sources(V, e1, e2, W, 0, nsrc)]
+    srcfile = tmp_path / "sources.txt"
+    srcfile.write_text("\n".join(str(s) for s in sources) + "\n")
+    dump = str(tmp_path / "out.bin")
+    r = run([pagerank, "-d", path, "-a", "0", "-i", "0", "-y", "1", "-n", "0", "-r", "0.01", "-b", "6", "-g", str(ngpu), "--share-device",
+             "--sources", str(srcfile), "--dump", dump])
+    assert r.returncode == 0, r.stdout
+    assert f"gpus {ngpu} sources {nsrc}" in r.stdout
+    kv = {k: float(v) for k, v in re.findall(r"^(aggregate_\w+|wall_ms) ([-+0-9.e]+)$", r.stdout, re.M)}
+    assert kv["aggregate_edge_num"] == c * 6 * nsrc
+    assert kv["aggregate_ppr_time_slowest_gpu"] > 0
+    assert abs(kv["aggregate_ppr_throughput"] - kv["aggregate_edge_num"] / kv["aggregate_ppr_time_slowest_gpu"] * 1000.0) <= 1e-4 * kv["aggregate_ppr_throughput"]   # (printed with six significant digits)
+    g = orc.Graph(V, e1, e2, 0, W, c)
+    states = {s: orc.State(V, s, 1e-9) for s in sources}
+    for s in states.values():
+        s.cilk_execute(g)
+    for _ in range(6):
+        assert not g.stream_updates()
+        g.inc_construct(1)
+        for s in states.values():
+            s.cilk_inc_execute(g)
+    seen = []
+    for d in range(ngpu):                                  # one dump per device thread: its round-robin share of the sources
+        got = read_dump(f"{dump}.{d}")
+        assert sorted(got) == sorted(sources[d::ngpu])
+        seen += list(got)
+        for s, (p, res) in got.items():
+            assert np.max(np.abs(res)) < 1e-9
+            assert np.max(np.abs(p - states[s].p)) < 1e-9
+    assert sorted(seen) == sorted(sources)
+    # without the flag, device 1 does not exist on a one-GPU box: a loud failure, not a silent fallback
+    from dynamicppr_amd import engine as eng
+    if eng.lib().dppr_device_count() < 2:
+        r = run([pagerank, "-d", path, "-a", "0", "-i", "0", "-y", "1", "-n", "0", "-r", "0.01", "-b", "2", "-g", "2", "--sources", str(srcfile)])
+        assert r.returncode != 0 and "no usable HIP device" in r.stdout
+
+
+@pytest.mark.gpu
 def test_sweep_tool_scrapes_the_stdout_contract(pagerank, small_bin, tmp_path):
     """tools/sweep.py = scripts/gpu.sh + scripts/extract_gpu.py: runs the variant sweep and scrapes
     ppr_latency / ppr_throughput from the logs."""

@@ -435,6 +435,37 @@ def test_error_paths():
         sc.e.load_window(np.zeros(3, np.int32), np.zeros(3, np.int32))  # n != W
 
 
+def test_rejected_calls_change_nothing():
+    """A call that returns DPPR_ERR_INVALID is a no-op: ids out of range are detected BEFORE any id is assigned, any parked
+    vertex revived or any epoch dropped -- the stream goes on afterwards as if the call had not been made."""
+    sc = make(1, c=10)
+    sc.s.cilk_execute(sc.g)
+    sc.e.init_solve(sc.slot, sc.eps)
+    g = sc.g._g.contents
+    seen = np.zeros(sc.V, bool)
+    seen[np.ctypeslib.as_array(g.s1, (g.stream_len,))[:g.pos]] = True
+    seen[np.ctypeslib.as_array(g.s2, (g.stream_len,))[:g.pos]] = True
+    fresh = np.nonzero(~seen)[0][:4].astype(np.int32)   # vertices without an id: a valid prefix of the rejected arrays
+    before = sc.e.id_space()
+    bad = np.concatenate([fresh, np.array([sc.V], np.int32)])
+    with pytest.raises(eng.DpprError):
+        sc.e.set_batch(bad, np.zeros(5, np.int32), np.ones(5, np.uint8))
+    with pytest.raises(eng.DpprError):
+        sc.e.slide(bad, np.zeros(5, np.int32))
+    with pytest.raises(eng.DpprError):
+        sc.e.slide(np.zeros(5, np.int32), np.concatenate([fresh, np.array([-1], np.int32)]))
+    with pytest.raises(eng.DpprError):
+        sc.e.add_source_group(bad)
+    assert sc.e.id_space() == before
+    for _ in range(3):                                   # the newest epoch is still there, the stream goes on
+        assert sc.advance_graphs()
+        sc.s.cilk_inc_execute(sc.g)
+        sc.e.update(sc.slot, sc.eps)
+        p, r = sc.e.read(sc.slot)
+        assert np.max(np.abs(p - sc.s.p)) < NORTH_STAR_TOL and np.max(np.abs(r)) < sc.eps
+    check_csr(sc)
+
+
 def test_multi_epoch_prestaging_and_two_sources():
     """K epochs staged in HBM first, then the timed path run back to back; two sources share the graph."""
     K = 5
