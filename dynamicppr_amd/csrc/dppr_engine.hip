@@ -288,15 +288,10 @@ bool ids_in_range(const dppr_engine *e, const int32_t *src, int n) {
     return true;
 }
 
-// translate an id array; returns false if any id is outside [0, V)
+// translate an id array; returns false (nothing changed) if any id is outside [0, V)
 bool translate(dppr_engine *e, const int32_t *src, int n, std::vector<int32_t> &dst) {
     dst.resize((size_t)std::max(n, 1));
-    for (int i = 0; i < n; ++i) {
-        const int v = src[i];
-        if (v < 0 || v >= e->V) return false;
-        dst[(size_t)i] = to_int(e, v);
-    }
-    return true;
+    return e->translate(src, (size_t)std::max(n, 0), dst.data());
 }
 
 int cut_sweep_groups(dppr_engine *e, Epoch &ep);

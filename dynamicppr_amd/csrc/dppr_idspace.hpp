@@ -14,11 +14,35 @@
 #include <cstddef>
 #include <functional>
 #include <cstdint>
+#include <atomic>
+#include <thread>
 #include <unordered_map>
 #include <utility>
 #include <vector>
 
 namespace dppr {
+
+// [0, n) in contiguous pieces on up to 8 host threads (small n: inline). The loops handed to it touch disjoint elements
+// (a permutation's targets, one output per input): at twitter scale the id maps are 134 MB tables, and a serial pass
+// of random reads / writes over them was most of a slide's host time (profiles/r03_slide_*).
+#ifndef DPPR_PAR_MIN_PIECE
+#define DPPR_PAR_MIN_PIECE 0 // (tests: a tiny piece size so that toy arrays take the threaded path too)
+#endif
+template <class F>
+inline void parallel_pieces(size_t n, size_t min_piece, F &&fn) {
+    if (DPPR_PAR_MIN_PIECE) min_piece = DPPR_PAR_MIN_PIECE;
+    static const size_t hw = std::thread::hardware_concurrency(); // (asked once: the call reads /sys)
+    size_t nt = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 8), n / std::max<size_t>(min_piece, 1));
+    if (nt <= 1) {
+        fn((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve(nt - 1);
+    for (size_t t = 1; t < nt; ++t) th.emplace_back([&fn, n, nt, t] { fn(n * t / nt, n * (t + 1) / nt); });
+    fn((size_t)0, n / nt);
+    for (auto &x : th) x.join();
+}
 
 struct IdSpace {
     int cap = 0; // id capacity = the external id range V
@@ -41,6 +65,34 @@ struct IdSpace {
     }
 
     bool is_parked(int pos) const { return pos >= cap - n_parked; }
+
+    // External ids -> internal ids for a whole array. False (and NOTHING changed) if an id lies outside [0, cap).
+    // The lookups run in parallel and only read; ids that are new or parked -- rare -- then go through to_int one by one
+    // in array order (a revival may move another parked vertex: parked entries are all resolved in that serial pass).
+    bool translate(const int32_t *src, size_t n, int32_t *dst) {
+        const int32_t lo_parked = cap - n_parked;
+        std::atomic<int> bad{0}, slow{0};
+        parallel_pieces(n, 1 << 16, [&](size_t a, size_t b) {
+            bool any_bad = false, any_slow = false;
+            for (size_t i = a; i < b; ++i) {
+                const int32_t v = src[i];
+                if (v < 0 || v >= cap) {
+                    any_bad = true;
+                    continue;
+                }
+                const int32_t m = ext2int[(size_t)v];
+                dst[i] = (m >= 0 && m < lo_parked) ? m : -1;
+                any_slow |= dst[i] < 0;
+            }
+            if (any_bad) bad.store(1, std::memory_order_relaxed);
+            if (any_slow) slow.store(1, std::memory_order_relaxed);
+        });
+        if (bad.load()) return false;
+        if (slow.load())
+            for (size_t i = 0; i < n; ++i)
+                if (dst[i] < 0) dst[i] = to_int(src[i]);
+        return true;
+    }
 
     // external -> internal id, assigning a new one on first sight, bringing a parked vertex back to the live zone
     int to_int(int ext) {
@@ -110,28 +162,35 @@ struct IdSpace {
         int n_live = 0;
         for (int v = 0; v < n_old; ++v) n_live += live[(size_t)v] ? 1 : 0;
         const int R_new = R_old + (n_old - n_live), base = cap - R_new;
-        perm.assign((size_t)cap, -1);
-        int nl = 0, np = 0;
+        perm.resize((size_t)cap);
+        parallel_pieces((size_t)cap, 1 << 18, [&](size_t a, size_t b) { std::fill(perm.begin() + (std::ptrdiff_t)a, perm.begin() + (std::ptrdiff_t)b, -1); });
         if (!order.empty()) {
-            for (int32_t v : order) perm[(size_t)v] = nl++;
+            parallel_pieces(order.size(), 1 << 16, [&](size_t a, size_t b) {
+                for (size_t k = a; k < b; ++k) perm[(size_t)order[k]] = (int32_t)k;
+            });
+            int np = 0;
             for (int v = 0; v < n_old; ++v)
                 if (!live[(size_t)v]) perm[(size_t)v] = base + np++;
         } else {
+            int nl = 0, np = 0;
             for (int v = 0; v < n_old; ++v) perm[(size_t)v] = live[(size_t)v] ? nl++ : base + np++;
         }
-        for (int v = cap - R_old; v < cap; ++v) perm[(size_t)v] = base + np++;
+        const int np_live = n_old - n_live; // parked out of the live zone; the old parked zone follows in its order
+        for (int i = 0; i < R_old; ++i) perm[(size_t)(cap - R_old + i)] = base + np_live + i;
         // the maps: only the two old zones hold vertices (the rest of int2ext is -1 already and stays so, except where
         // the parked zone grows into it)
         std::vector<int32_t> old_live(int2ext.begin(), int2ext.begin() + n_old);
         std::vector<int32_t> old_parked(int2ext.begin() + (cap - R_old), int2ext.end());
         std::fill(int2ext.begin(), int2ext.begin() + n_old, -1);
         std::fill(int2ext.begin() + (cap - R_old), int2ext.end(), -1);
-        auto place = [&](int v, int ext) {
+        auto place = [&](int v, int ext) { // (perm is a bijection of the occupied positions: every thread writes its own targets)
             const int m = perm[(size_t)v];
             int2ext[(size_t)m] = ext;
             ext2int[(size_t)ext] = m;
         };
-        for (int v = 0; v < n_old; ++v) place(v, old_live[(size_t)v]);
+        parallel_pieces((size_t)n_old, 1 << 16, [&](size_t a, size_t b) {
+            for (size_t v = a; v < b; ++v) place((int)v, old_live[v]);
+        });
         for (int i = 0; i < R_old; ++i) place(cap - R_old + i, old_parked[(size_t)i]);
         n_int = n_live;
         n_parked = R_new;

@@ -83,6 +83,29 @@ int main(int argc, char **argv) {
             const int n = 1 + (int)(rng() % 6);
             std::vector<int> named;
             const long long before = ids.revivals;
+            if (rng() & 1) { // the whole array at once (IdSpace::translate: parallel lookups, the new / parked ids serially) ...
+                std::vector<int32_t> in, out, want;
+                for (int i = 0; i < n + 8; ++i) in.push_back((int32_t)(rng() % (unsigned)cap));
+                dppr::IdSpace ref = ids; // ... must equal one to_int after the other
+                for (int32_t x : in) (void)ref.to_int(x);
+                for (int32_t x : in) want.push_back(ref.ext2int[(size_t)x]);
+                out.assign(in.size(), -7);
+                CHECK(ids.translate(in.data(), in.size(), out.data()), "translate refused ids in range");
+                for (size_t i = 0; i < in.size(); ++i) { // (an id named early may have moved when a later one was revived: compare at the end)
+                    CHECK(ids.ext2int[(size_t)in[i]] == want[i], "translate: ext %d -> %d, one by one %d", in[i], ids.ext2int[(size_t)in[i]], want[i]);
+                    CHECK(out[i] >= 0 && out[i] < ids.n_int, "translate gave %d for ext %d (n_int %d)", out[i], in[i], ids.n_int);
+                }
+                CHECK(ids.ext2int == ref.ext2int && ids.int2ext == ref.int2ext && ids.n_int == ref.n_int && ids.n_parked == ref.n_parked &&
+                      ids.mv_origin == ref.mv_origin, "translate and to_int leave different maps");
+                for (int32_t x : in) named.push_back(x);
+                // an id out of range: refused, nothing changed
+                std::vector<int32_t> bad = in;
+                bad.push_back(rng() & 1 ? cap : -1);
+                const dppr::IdSpace snap = ids;
+                std::vector<int32_t> o2(bad.size());
+                CHECK(!ids.translate(bad.data(), bad.size(), o2.data()), "translate accepted an id out of range");
+                CHECK(ids.ext2int == snap.ext2int && ids.n_int == snap.n_int && ids.n_parked == snap.n_parked && ids.revivals == snap.revivals, "a refused translate changed the maps");
+            }
             for (int i = 0; i < n; ++i) {
                 const int x = (int)(rng() % (unsigned)cap);
                 const int m = ids.to_int(x);

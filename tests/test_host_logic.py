@@ -9,12 +9,29 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def build_idspace_driver(exe, extra):
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-Wall",
+                           "-Werror", "-pthread"] + extra + ["-o", exe, os.path.join(ROOT, "tests", "native", "idspace_test.cpp")])
+    return exe
+
+
 @pytest.fixture(scope="module")
 def driver(tmp_path_factory):
-    exe = str(tmp_path_factory.mktemp("native") / "idspace_test")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-Wall",
-                           "-Werror", "-o", exe, os.path.join(ROOT, "tests", "native", "idspace_test.cpp")])
-    return exe
+    return build_idspace_driver(str(tmp_path_factory.mktemp("native") / "idspace_test"), [])
+
+
+@pytest.fixture(scope="module")
+def threaded_driver(tmp_path_factory):
+    # translate / renumber split their loops over host threads in pieces of >= 64 K ids; with a piece size of 3 the toy
+    # arrays of the test take those paths too (a thread start per call: fewer operations)
+    return build_idspace_driver(str(tmp_path_factory.mktemp("native") / "idspace_test_mt"), ["-DDPPR_PAR_MIN_PIECE=3"])
+
+
+@pytest.mark.parametrize("seed,cap,ops", [(11, 40, 1500), (12, 7, 1000), (13, 500, 2000)])
+def test_threaded_paths_of_translate_and_renumber(threaded_driver, seed, cap, ops):
+    r = subprocess.run([threaded_driver, str(seed), str(cap), str(ops)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " 0 failures" in r.stdout
 
 
 # (capacity, operations): tiny ranges keep the live and the parked zone touching nearly all the time
