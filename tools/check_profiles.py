@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Keeps the committed profile artefacts honest with each other.
+
+    check_profiles.py --cut <kernel_trace.csv> <kernel_stats.csv> <outdir>    (used by tools/prof_timeline.sh)
+        writes kernel_stats.csv (short kernel names), timeline.json and timeline.txt from ONE profiler run
+    check_profiles.py [profiles/]                                              (CPU test suite: tests/test_profiles.py)
+        for every pair r*_kernel_stats_<tag>.csv / r*_batch_timeline_<tag>.json: the timeline's whole-run totals per
+        kernel must equal the stats file's within 10 % (two files of one run), and every kernel's average launch inside
+        the chosen batch must lie within the stats file's [min, max] for that kernel (a batch from another build, or a
+        pathological one, does not). Exit status 1 on any disagreement.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    n = name.split("(")[0].replace("void ", "").strip()
+    n = re.sub(r"rocprim::ROCPRIM_\d+_NS::detail::", "rocprim::", n)
+    if n.startswith("rocprim::trampoline_kernel"):
+        m = re.search(r"(radix_sort_onesweep\w*|partition_impl|merge_impl|radix_sort_block_sort\w*|radix_sort_merge\w*|lookback_scan\w*|scan\w*|histogram\w*)", name)
+        n = "rocprim::" + (m.group(1) if m else "kernel")
+    return n.replace("dppr::", "")[:60]
+
+
+def cut(trace_csv, stats_csv, outdir):
+    rows = list(csv.DictReader(open(trace_csv)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    ev = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows]
+    whole = defaultdict(lambda: [0, 0, 10**18, 0])
+    for n, s, e in ev:
+        w = whole[n]
+        w[0] += 1; w[1] += e - s; w[2] = min(w[2], e - s); w[3] = max(w[3], e - s)
+    with open(os.path.join(outdir, "kernel_stats.csv"), "w") as f:
+        f.write("Name,Calls,TotalDurationNs,AverageNs,MinNs,MaxNs\n")
+        for n, w in sorted(whole.items(), key=lambda kv: -kv[1][1]):
+            f.write(f'"{n}",{w[0]},{w[1]},{w[1] / w[0]:.1f},{w[2]},{w[3]}\n')
+    marks = [i for i, (n, _, _) in enumerate(ev) if n == "k_su_keys"]          # first kernel of every batch's timed region
+    batches = [(marks[i], marks[i + 1]) for i in range(len(marks) - 1)]
+    spans = []
+    for lo, hi in batches:                                                       # a batch ends with its last iteration kernel: cut at the next slide's kernels
+        seg = [x for x in ev[lo:hi] if not x[0].startswith(("k_make", "k_deg", "k_mark", "k_build", "k_assign", "k_tile", "k_gather_deg", "k_gtables", "k_bin_keys", "k_bin_fill", "k_bin_vertex", "k_bin_quant", "k_bin_big", "k_in_degree", "k_number", "k_live", "k_remap", "k_permute", "k_rows"))]
+        spans.append((seg[-1][2] - seg[0][1], lo, seg))
+    spans.sort(key=lambda t: t[0])
+    span, lo, seg = spans[len(spans) // 2]
+    busy = sum(e - s for _, s, e in seg)
+    per = defaultdict(lambda: [0, 0])
+    for n, s, e in seg:
+        per[n][0] += 1; per[n][1] += e - s
+    gaps = sorted(((seg[i + 1][1] - seg[i][2]) / 1e3 for i in range(len(seg) - 1)))
+    tl = {"batches_in_run": len(batches), "batch_spans_us": [round(s[0] / 1e3, 1) for s in sorted(spans, key=lambda t: t[1])],
+          "chosen": "the batch of median span", "span_us": round(span / 1e3, 1), "busy_us": round(busy / 1e3, 1), "dispatches": len(seg),
+          "median_gap_us": round(gaps[len(gaps) // 2], 2) if gaps else None,
+          "kernels": {n: {"launches": c, "total_us": round(t / 1e3, 1), "avg_us": round(t / c / 1e3, 2)} for n, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1])},
+          "iteration_kernel_durations_us": [round((e - s) / 1e3, 1) for n, s, e in seg if n.startswith(("k_gsweep", "k_pull_iter", "k_bin_reduce", "k_pull_resident"))],
+          "whole_run": {n: {"launches": w[0], "total_us": round(w[1] / 1e3, 1)} for n, w in whole.items()}}
+    json.dump(tl, open(os.path.join(outdir, "timeline.json"), "w"), indent=1)
+    with open(os.path.join(outdir, "timeline.txt"), "w") as f:
+        f.write(f"{len(batches)} batches in the run, spans us: {tl['batch_spans_us']}\n")
+        f.write(f"batch of median span: {tl['dispatches']} dispatches, span {tl['span_us']} us, busy {tl['busy_us']} us, median gap {tl['median_gap_us']} us\n")
+        for n, v in tl["kernels"].items():
+            f.write(f"  {n:44s} x{v['launches']:4d}  total {v['total_us']:10.1f} us  avg {v['avg_us']:9.2f} us\n")
+        f.write(f"iteration kernels in launch order (us): {tl['iteration_kernel_durations_us']}\n")
+
+
+def check(directory):
+    bad = 0
+    pairs = 0
+    for tl_path in sorted(glob.glob(os.path.join(directory, "r*_batch_timeline_*.json"))):
+        tag = re.sub(r"^r\d+_batch_timeline_", "", os.path.basename(tl_path))[:-5]
+        rnd = os.path.basename(tl_path).split("_")[0]
+        st_path = os.path.join(directory, f"{rnd}_kernel_stats_{tag}.csv")
+        if not os.path.exists(st_path):
+            print(f"FAIL {os.path.basename(tl_path)}: no {os.path.basename(st_path)} next to it")
+            bad += 1
+            continue
+        pairs += 1
+        tl = json.load(open(tl_path))
+        stats = {r["Name"]: r for r in csv.DictReader(open(st_path))}
+        for n, w in tl["whole_run"].items():
+            if n not in stats:
+                print(f"FAIL {tag}: {n} is in the timeline's run but not in the stats file")
+                bad += 1
+                continue
+            tot = float(stats[n]["TotalDurationNs"]) / 1e3
+            if w["total_us"] > 50 and abs(tot - w["total_us"]) > 0.10 * max(tot, w["total_us"]):
+                print(f"FAIL {tag}: {n}: {w['total_us']:.0f} us in the timeline's run, {tot:.0f} us in the stats file")
+                bad += 1
+        for n, v in tl["kernels"].items():
+            if n in stats and not (float(stats[n]["MinNs"]) / 1e3 * 0.999 <= v["avg_us"] <= float(stats[n]["MaxNs"]) / 1e3 * 1.001):
+                print(f"FAIL {tag}: {n}: average {v['avg_us']} us in the chosen batch, outside [{float(stats[n]['MinNs']) / 1e3:.1f}, {float(stats[n]['MaxNs']) / 1e3:.1f}] of the stats file")
+                bad += 1
+        if tl["busy_us"] > tl["span_us"] * 1.001:
+            print(f"FAIL {tag}: busy {tl['busy_us']} us exceeds the span {tl['span_us']} us")
+            bad += 1
+    print(f"{pairs} timeline / stats pair(s) checked, {bad} disagreement(s)")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--cut":
+        cut(sys.argv[2], sys.argv[3], sys.argv[4])
+    else:
+        sys.exit(check(sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")))
