@@ -77,6 +77,7 @@ def parse_args():
     ap.add_argument("--directed", type=int, default=None)
     ap.add_argument("--cpu-batches", type=int, default=None, help="batches timed on the CPU oracle (bounded sample)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-merged", action="store_true", help="skip the extra pass with the merged loop (N = 1 only)")
     ap.add_argument("--no-extra", action="store_true",
                     help="default workload at N = 1 only: do not append the configs[1] (single source, resident path) line")
     ap.add_argument("--group", type=int, default=None, help=argparse.SUPPRESS)  # old spelling of --sources
@@ -176,6 +177,8 @@ def main():
 
     schedule = eng.SCHEDULE_EAGER if a.schedule == "eager" else eng.SCHEDULE_SYNC
     tune = {kv.split("=")[0]: (tuple(int(x) for x in kv.split("=")[1].split(",")) if "," in kv else int(kv.split("=")[1])) for kv in a.tune}
+    if "merge_phases" in tune:
+        a.no_merged = True   # (the whole run is on the merged loop: tuning / A-B runs)
     e = eng.Engine(V, W, directed, c, n_epochs=n_steps + n_prof + 1, device=local_rank, schedule=schedule, **tune)
     ss = st.SlidingStream(V, e1, e2, directed, wl)
     e.load_window(*ss.serialize_edge_stream())
@@ -234,7 +237,7 @@ def main():
     p_end = [solver.read(i)[0] for i in range(min(2, len(sources)))] if want_cpu else []   # p at the END of the timed region
 
     # ---------------- roofline of the dominant kernel ----------------
-    roof = cpu = None
+    roof = cpu = p_cpu = None
     if rank == 0:
         ps = solver.profile(a, n_steps)
         push_bytes = 72 * ps["sum_F"] + 24 * ps["sum_E"] + 4 * ps["sum_N"]
@@ -265,6 +268,7 @@ def main():
         }
         if want_cpu:
             cpu = cpu_baseline(V, e1, e2, directed, W, c, sources[:len(p_end)], a.eps, cpu_batches, p_end if cpu_batches == n_steps else [], stream_len)
+            p_cpu = cpu.pop("p_cpu")
             worst = cpu.pop("max_abs_dp")
             if worst is not None:
                 parity["max_abs_dp_vs_cpu_t1"] = worst
@@ -274,6 +278,37 @@ def main():
                 full = datagen.ensure_stand_in(a.config, a.data_dir)
                 cpu["reference_fifo"] = reference_fifo_baseline(full, directed, flags, sources[0], a.eps, c)
 
+    # ---------------- the same K steps once more with the MERGED loop (include/dppr.h dppr_set_phase_merge) ----------------
+    # not the reference's schedule, therefore not `value`: one loop for residuals of both signs, run to eps / 4. A second solver
+    # state over the same pre-staged epochs; its p is compared with the same CPU -t 1 states at the end of the timed region.
+    merged = None
+    if rank == 0 and world == 1 and not a.no_merged and a.schedule == "eager":
+        e.set_phase_merge(True, 4)
+        solver2 = GroupSolver(e, sources) if S > 1 else SingleSolver(e, sources[0])
+        solver2.init_solve(a.eps, epoch=0)   # (the epochs of the run are all resident: start from the first)
+        for k in range(1, a.warmup + 1):
+            solver2.update(a.eps, k)
+        solver2.begin_timed()
+
+        def run_steps2():
+            for k in range(a.warmup + 1, n_steps + 1):
+                solver2.update(a.eps, k)
+
+        dt2, _ = shard.timed_region(run_steps2, device_sync, None)
+        st2 = solver2.stats()
+        mr, mi, md = 0.0, 0.0, None
+        for i, sv in enumerate(sources):
+            p2, r2 = solver2.read(i)
+            mr = max(mr, float(np.max(np.abs(r2))))
+            mi = max(mi, invariant_max_err(p2, r2, src_e, dst_e, V, sv))
+            if want_cpu and cpu is not None and i < len(p_cpu or []):
+                md = max(md or 0.0, float(np.max(np.abs(p2 - p_cpu[i]))))
+        e.set_phase_merge(False, 0)
+        merged = {"schedule": "one loop for residuals of both signs, |r| > eps / 4 (dppr_set_phase_merge; NOT the reference's two loops: reported beside `value`, never as it)",
+                  "ms_per_step": round(1e3 * dt2 / a.steps, 4), "value": round(S * c * a.steps / dt2, 1), "unit": "edges/s",
+                  "iterations_per_step": round(st2["iterations"] / a.steps, 2), "speedup_vs_value": round(dt / dt2, 3),
+                  "parity": {"max_abs_residual": mr, "invariant_max_err": mi, "max_abs_dp_vs_cpu_t1": md, "tolerance": NORTH_STAR_TOL,
+                             "ok": bool(mr <= a.eps / 4 and mi < 1e-12 and (md is None or md < NORTH_STAR_TOL))}}
     if rank == 0:
         value = units / dt
         line = {
@@ -297,7 +332,7 @@ def main():
             "iterations_per_step": round(stats["iterations"] / a.steps, 2),
             "pull_iterations_per_step": round(stats["pull_iterations"] / a.steps, 2),
             "edges_pushed_per_step": round(stats["sum_E"] / a.steps, 1),
-            "parity": parity, "roofline": roof, "cpu_baseline": cpu,
+            "parity": parity, "roofline": roof, "cpu_baseline": cpu, "merged_loop": merged,
         }
         if scaling == "strong":
             # what the multi-GPU value has to be read against: ALL of the configuration's sources as one source group on ONE GPU
@@ -330,7 +365,9 @@ def extra_line(args):
         d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         return {"workload": d["config"]["workload"], "ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"],
                 "steps": d["steps"], "warmup": d["warmup"], "roofline_kernel": d["roofline"]["kernel"],
-                "roofline_frac": d["roofline"]["frac"], "avg_launch_us": d["roofline"]["avg_launch_us"], "parity_ok": d["parity"]["ok"]}
+                "roofline_frac": d["roofline"]["frac"], "avg_launch_us": d["roofline"]["avg_launch_us"], "parity_ok": d["parity"]["ok"],
+                "merged_loop": ({k: d["merged_loop"][k] for k in ("ms_per_step", "value", "iterations_per_step")} | {"parity_ok": d["merged_loop"]["parity"]["ok"]})
+                if d.get("merged_loop") else None}
     except Exception as ex:  # the extra line never takes the headline down with it
         return {"error": f"{type(ex).__name__}: {ex}"}
 
@@ -342,8 +379,8 @@ class SingleSolver:
         self.e, self.source = e, source
         self.slot = e.add_source(source)
 
-    def init_solve(self, eps):
-        return self.e.init_solve(self.slot, eps)
+    def init_solve(self, eps, epoch=-1):
+        return self.e.init_solve(self.slot, eps, epoch)
 
     def update(self, eps, epoch):
         return self.e.update(self.slot, eps, epoch=epoch)
@@ -389,8 +426,8 @@ class GroupSolver:
         self.e, self.sources = e, sources
         self.gid = e.add_source_group(sources)
 
-    def init_solve(self, eps):
-        return self.e.group_init_solve(self.gid, eps)
+    def init_solve(self, eps, epoch=-1):
+        return self.e.group_init_solve(self.gid, eps, epoch)
 
     def update(self, eps, epoch):
         return self.e.group_update(self.gid, eps, epoch=epoch)
@@ -452,9 +489,9 @@ def cpu_baseline(V, e1, e2, directed, W, c, sources, eps, batches, p_end, stream
     threads = max(1, min(orc.max_threads(), os.cpu_count() or 1, 16))
     g = orc.Graph(V, e1, e2, directed, W, c)
     states = [orc.State(V, s, eps) for s in sources]
-    for s in states:            # from-scratch solve (untimed here, like INIT_GRAPH_CALC_TIME in the reference)
-        s.cilk_init()
-        s.cilk_main_loop_mt(g, 0, threads)
+    for st in states:            # from-scratch solve (untimed here, like INIT_GRAPH_CALC_TIME in the reference)
+        st.cilk_init()
+        st.cilk_main_loop_mt(g, 0, threads)
     t_mt = t_1 = 0.0
     n_mt = n_1 = done = 0
     for k in range(batches):
@@ -463,12 +500,12 @@ def cpu_baseline(V, e1, e2, directed, W, c, sources, eps, batches, p_end, stream
         g.inc_construct(1)
         done += 1
         serial = k >= batches - 2 or threads == 1
-        for s in states:
+        for st in states:
             t = time.perf_counter()
             if serial:
-                s.cilk_inc_execute(g)
+                st.cilk_inc_execute(g)
             else:
-                s.cilk_inc_execute_mt(g, threads)
+                st.cilk_inc_execute_mt(g, threads)
             dt = time.perf_counter() - t
             if serial:
                 t_1, n_1 = t_1 + dt, n_1 + 1
@@ -476,17 +513,17 @@ def cpu_baseline(V, e1, e2, directed, W, c, sources, eps, batches, p_end, stream
                 t_mt, n_mt = t_mt + dt, n_mt + 1
     worst = None
     if p_end and done == batches:
-        worst = max(float(np.max(np.abs(pe - s.p))) for pe, s in zip(p_end, states))
+        worst = max(float(np.max(np.abs(pe - st.p))) for pe, st in zip(p_end, states))
     had_mt = n_mt > 0
     if not had_mt:
         t_mt, n_mt = t_1, n_1
     return {"value": round(c * n_mt / t_mt, 1) if t_mt > 0 else None, "unit": "edges/s", "cores": threads if had_mt else 1,
             "kind": "port", "ms_per_step": round(1e3 * t_mt / max(n_mt, 1), 2),
             "t1_value": round(c * n_1 / t_1, 1) if t_1 > 0 else None, "t1_ms_per_step": round(1e3 * t_1 / max(n_1, 1), 2),
-            "max_abs_dp": worst,
+            "max_abs_dp": worst, "p_cpu": [np.array(st.p) for st in states] if done == batches else None,
             "compared": (f"p of {len(states)} source(s) after batch {done} (the end of the timed region), CPU state reached with the "
                          f"{threads}-thread port and the last two batches at -t 1") if worst is not None else None,
-            "sample": f"{len(states)} source(s) ({', '.join(str(s) for s in sources)}; value is per source and batch -- the GPU value sums all of a "
+            "sample": f"{len(states)} source(s) ({', '.join(str(v) for v in sources)}; value is per source and batch -- the GPU value sums all of a "
                       f"rank's sources), {done} batches of the same stream after the from-scratch solve: {n_mt} source-batches with "
                       f"{threads} OpenMP workers, {n_1} at -t 1; oracle restatement of cpu/PPRCPUMTCilkRev, gcc -O2"}
 

@@ -20,9 +20,11 @@ struct Adj { // one in-CSR entry: edge src -> (row vertex)
     int32_t degp1;  // outdeg(v) + 1 at this epoch
 };
 
-// gpu/PPRCommon.cuh:6-11 IsLegalRevPush (strict inequalities)
+// gpu/PPRCommon.cuh:6-11 IsLegalRevPush (strict inequalities). phase 2 is not the reference's: the MERGED loop of
+// dppr_set_phase_merge pushes residuals of both signs in one loop (|r| > eps).
+constexpr int PHASE_BOTH = 2;
 __device__ __forceinline__ bool legal(double r, int phase, double eps) {
-    return phase == 0 ? (r > eps) : (r < -eps);
+    return phase == 0 ? (r > eps) : phase == 1 ? (r < -eps) : (r > eps || r < -eps);
 }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }

@@ -148,6 +148,8 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     int Ed = 0;   // directed edges in the window
     int bits = 1; // bits of a vertex id
     int schedule = DPPR_SCHEDULE_EAGER;
+    bool merge_phases = false; // dppr_set_phase_merge: one loop for residuals of both signs (eager schedule only)
+    int merge_div = 4;         // ... run to eps / merge_div
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t evpool[2 * 64] = {};
@@ -988,6 +990,7 @@ void rotate_snapshots(Slot &s, int sweeps) { // three vectors, x_g lives in vect
 
 int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, double eps, int buf, int cur,
                       LoopEntry entry = LoopEntry()) {
+    const int hp = phase == PHASE_BOTH ? 0 : phase; // (loop histories: the merged loop uses slot 0)
     const int pull_min = pull_min_frontier(e);
     const bool sync_sched = e->schedule == DPPR_SCHEDULE_SYNC;
     const HubTable hubs{ep.hub_v, ep.hub_degp1, ep.n_hubs};
@@ -1014,8 +1017,8 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
     int rc = DPPR_OK;
     if (F < 0 && (rc = read_count(e, s.cnt + cur, &F))) return rc;
     if (entry.it == 0) {
-        s.start_dense[phase] = F >= pull_min;
-        s.last_F0[phase] = F;
+        s.start_dense[hp] = F >= pull_min;
+        s.last_F0[hp] = F;
     }
     for (int it = entry.it; F > 0;) {
         if (it >= e->max_iters) return fail(e, DPPR_ERR_NOT_CONVERGED, "iteration cap hit");
@@ -1033,18 +1036,18 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
         int n;
         if (s.trace || e->chunk_iters <= 1) n = 1;
         else if (pull) // consecutive batches take almost the same number of iterations: aim just past the end
-            n = s.iter_hint[phase] > it ? s.iter_hint[phase] - it + 1 : e->chunk_iters;
+            n = s.iter_hint[hp] > it ? s.iter_hint[hp] - it + 1 : e->chunk_iters;
         else if ((long long)F * 4 >= pull_min) n = 1;          // about to turn dense: re-decide next iteration
         else n = F > prevF ? 2 : e->chunk_iters;                // growing: short chunks; decaying tail: long
         const int pcap = persist_capacity(e);
         const bool resident = pull && n >= 2 && !s.trace && pcap > 0 && ep.n_groups > 0 && ep.n_groups <= pcap;
-        if (resident && s.iter_hint[phase] > it) n += RESIDENT_MARGIN - 1;
+        if (resident && s.iter_hint[hp] > it) n += RESIDENT_MARGIN - 1;
         if (!resident && pull && n > 1) {
             // per-iteration sweeps: a launch that finds the frontier empty is still a dispatch, a chunk boundary (read-back
             // + relaunch) costs about three of them -- go as far as the SHORTEST of the last four loops of this phase went
             // (almost surely needed in full), then in chunks that double from 4 (group_loop sizes its chunks the same way)
             int lo = 0;
-            for (int h : s.iter_hist[phase]) lo = h > 0 && (lo == 0 || h < lo) ? h : lo;
+            for (int h : s.iter_hist[hp]) lo = h > 0 && (lo == 0 || h < lo) ? h : lo;
             if (lo > it) n = lo - it;
             else if (lo > 0) {
                 n = std::min(follow, e->chunk_iters);
@@ -1058,7 +1061,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             // ---- a run of dense iterations as ONE resident launch (dppr_resident.hpp)
             if (!dense_valid) {
                 hipLaunchKernelGGL(k_snapshot_dense, dim3(std::min(grid_for(std::max(F, 1 << 14)), 1024)), dim3(BLOCK), 0,
-                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x, (uint32_t *)nullptr);
+                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x, (uint32_t *)nullptr, phase == PHASE_BOTH ? 1 : 0);
                 dense_valid = true;
             }
             HIP_TRY(hipMemsetAsync(e->bar, 0, sizeof(GridBar), e->stream));
@@ -1122,7 +1125,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 const bool bm = use_bits && pull;
                 if (bm) HIP_TRY(hipMemsetAsync(s.act[0], 0, s.act_bytes, e->stream));
                 hipLaunchKernelGGL(k_snapshot_dense, dim3(std::min(grid_for(std::max(F, 1 << 14)), 1024)), dim3(BLOCK), 0,
-                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x, bm ? s.act[0] : (uint32_t *)nullptr);
+                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x, bm ? s.act[0] : (uint32_t *)nullptr, phase == PHASE_BOTH ? 1 : 0);
                 dense_valid = true;
             }
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k], e->stream));
@@ -1215,9 +1218,9 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
         F = e->pinned[cur];
         it += n;
     }
-    s.iter_hint[phase] = active_iters;
-    for (int k = 3; k > 0; --k) s.iter_hist[phase][k] = s.iter_hist[phase][k - 1];
-    s.iter_hist[phase][0] = active_iters;
+    s.iter_hint[hp] = active_iters;
+    for (int k = 3; k > 0; --k) s.iter_hist[hp][k] = s.iter_hist[hp][k - 1];
+    s.iter_hist[hp][0] = active_iters;
     if (any_pull && !x_clean) { // leave both dense vectors all-zero for the next loop
         // only internal ids below n_int are ever written
         HIP_TRY(hipMemsetAsync(s.x, 0, sizeof(double) * (size_t)e->n_int, e->stream));
@@ -1521,6 +1524,7 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
 }
 
 int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps, bool tails) {
+    const int hp = phase == PHASE_BOTH ? 0 : phase; // (loop histories: the merged loop uses slot 0)
     int cur = 0;
     const int GWM = GS_MAX;
     HIP_TRY(hipMemsetAsync(g.cnt, 0, sizeof(int) * 3 * GWM, e->stream));
@@ -1567,7 +1571,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
         // ---- a window whose sweep groups are all resident at once: a run of sweeps as ONE launch (k_gsweep<.., true>)
         const int mcap = e->group_resident && e->persist_mode && e->persist_ok && e->chunk_iters > 1 ? group_multi_capacity(e, g.spl) : 0;
         if (mcap > 0 && ep.n_ggroups > 0 && ep.n_ggroups <= mcap) {
-            int n = g.iter_hint[phase] > it ? g.iter_hint[phase] - it + RESIDENT_MARGIN : 2 * e->chunk_iters;
+            int n = g.iter_hint[hp] > it ? g.iter_hint[hp] - it + RESIDENT_MARGIN : 2 * e->chunk_iters;
             n = std::max(2, std::min(n, GMULTI_MAX));
             if (e->chunk_explicit) n = std::min(n, std::max(e->chunk_iters, 2)); // (tests: launches that stop mid-loop and are resumed)
             HIP_TRY(hipMemsetAsync(g.mlog, 0, sizeof(int) * (size_t)(n + 2) * GWM, e->stream));
@@ -1630,7 +1634,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
         int n;
         if (it == 0) {
             int lo = 0;
-            for (int h : (push_thr > 0 ? g.dense_hist : g.iter_hist)[phase]) lo = h > 0 && (lo == 0 || h < lo) ? h : lo;
+            for (int h : (push_thr > 0 ? g.dense_hist : g.iter_hist)[hp]) lo = h > 0 && (lo == 0 || h < lo) ? h : lo;
             n = lo > 0 ? lo : e->chunk_iters;
             follow = 4;
         } else if (push_thr > 0 && !push_gave_up) {
@@ -1723,12 +1727,12 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
         }
     }
     if (push_thr > 0) {
-        for (int k = 3; k > 0; --k) g.dense_hist[phase][k] = g.dense_hist[phase][k - 1];
-        g.dense_hist[phase][0] = dense_len >= 0 ? std::max(dense_len, 1) : std::max(active_iters, 1);
+        for (int k = 3; k > 0; --k) g.dense_hist[hp][k] = g.dense_hist[hp][k - 1];
+        g.dense_hist[hp][0] = dense_len >= 0 ? std::max(dense_len, 1) : std::max(active_iters, 1);
     }
-    g.iter_hint[phase] = active_iters;
-    for (int k = 3; k > 0; --k) g.iter_hist[phase][k] = g.iter_hist[phase][k - 1];
-    g.iter_hist[phase][0] = active_iters;
+    g.iter_hint[hp] = active_iters;
+    for (int k = 3; k > 0; --k) g.iter_hist[hp][k] = g.iter_hist[hp][k - 1];
+    g.iter_hist[hp][0] = active_iters;
     return DPPR_OK;
 }
 
@@ -1922,6 +1926,13 @@ void dppr_destroy(dppr_engine *e) {
 int dppr_set_schedule(dppr_engine *e, int schedule) {
     if (!e || (schedule != DPPR_SCHEDULE_EAGER && schedule != DPPR_SCHEDULE_SYNC)) return DPPR_ERR_INVALID;
     e->schedule = schedule;
+    return DPPR_OK;
+}
+
+int dppr_set_phase_merge(dppr_engine *e, int on, int eps_divisor) {
+    if (!e || eps_divisor < 0 || eps_divisor > 1024) return fail(e, DPPR_ERR_INVALID, "set_phase_merge: eps_divisor 1..1024 (0 keeps it)");
+    e->merge_phases = on != 0;
+    if (eps_divisor > 0) e->merge_div = eps_divisor;
     return DPPR_OK;
 }
 
@@ -2252,9 +2263,11 @@ int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
     if (!epp) return fail((e), DPPR_ERR_INVALID, "epoch not resident (evicted or never built)"); \
     Epoch &ep = *epp
 
-int dppr_init_solve(dppr_engine *e, int32_t slot, double eps, float *out_ms) {
+int dppr_init_solve(dppr_engine *e, int32_t slot, double eps, float *out_ms) { return dppr_init_solve_at(e, slot, -1, eps, out_ms); }
+
+int dppr_init_solve_at(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *out_ms) {
     GET_SLOT(e, slot);
-    GET_EPOCH(e, -1);
+    GET_EPOCH(e, epoch);
     if (!(eps > 0)) return fail(e, DPPR_ERR_INVALID, "eps must be positive");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
@@ -2322,15 +2335,29 @@ int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *
     s.seed_lists_valid = false;
     // Seeding from the batch tails is exact only if every |r| <= eps beforehand
     // (the state a completed solve leaves). Otherwise fall back to full Inspect passes.
+    // Merged loop (dppr_set_phase_merge, eager schedule): residuals of both signs are pushed in ONE loop, to eps / merge_div.
+    const bool merged = e->merge_phases && e->schedule == DPPR_SCHEDULE_EAGER;
+    const double eps_caller = eps;
+    if (merged) eps = eps / e->merge_div;
     const bool seeded = s.converged && s.conv_eps <= eps;
-    const bool ahead = seeded && can_batch_ahead(e, s, ep);
+    const bool ahead = !merged && seeded && can_batch_ahead(e, s, ep);
     int rc = settle_parked(e, s.p, s.r, 1, eps, &s.park_eps, &s.st);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
     rc = stream_update(e, s, ep, eps, seeded, ahead);
     if (rc) return rc;
     s.converged = false;
-    if (seeded) {
+    if (merged) {
+        if (seeded) { // the frontier: the tails the update left above eps (ft[0]) and those it left below -eps (the candidates)
+            hipLaunchKernelGGL(k_filter, dim3(grid_for(std::max(ep.L, 1))), dim3(BLOCK), 0, e->stream, s.neg, s.cnt + 3, s.r, 1, eps,
+                               s.ft[0], s.cnt + 0);
+            HIP_TRY(hipGetLastError());
+            rc = run_frontier_loop(e, s, ep, PHASE_BOTH, eps, 0, 0);
+        } else {
+            rc = main_loop_inspect(e, s, ep, PHASE_BOTH, eps);
+        }
+        if (rc) return rc;
+    } else if (seeded) {
         int stage = 0;
         bool p1_seeded = false;
         LoopEntry en0, en1;
@@ -2366,7 +2393,8 @@ int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *
     s.st.gpu_ms += ms;
     s.st.batches++;
     s.converged = true;
-    s.conv_eps = eps;
+    s.conv_eps = eps; // (the merged loop's eps / merge_div)
+    (void)eps_caller;
     s.last_epoch = ep.id;
     return DPPR_OK;
 }
@@ -2640,8 +2668,12 @@ int dppr_add_source_group(dppr_engine *e, const int32_t *sources, int32_t n, int
 }
 
 int dppr_group_init_solve(dppr_engine *e, int32_t group, double eps, float *out_ms) {
+    return dppr_group_init_solve_at(e, group, -1, eps, out_ms);
+}
+
+int dppr_group_init_solve_at(dppr_engine *e, int32_t group, int32_t epoch, double eps, float *out_ms) {
     GET_GROUP(e, group);
-    GET_EPOCH(e, -1);
+    GET_EPOCH(e, epoch);
     if (!(eps > 0)) return fail(e, DPPR_ERR_INVALID, "eps must be positive");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
@@ -2669,6 +2701,8 @@ int dppr_group_update(dppr_engine *e, int32_t group, int32_t epoch, double eps, 
     if (!epoch_in_sequence(g.last_epoch, ep.id)) return fail(e, DPPR_ERR_INVALID, "epoch out of sequence for this group");
     HIP_TRY(hipSetDevice(e->device));
     // seeding from the batch tails is exact only if every |r| <= eps beforehand (dppr_update has the same rule)
+    const bool merged = e->merge_phases && e->schedule == DPPR_SCHEDULE_EAGER; // (dppr_set_phase_merge)
+    if (merged) eps = eps / e->merge_div;
     const bool tails = g.converged && g.conv_eps <= eps && e->group_tail_seeding;
     int rc = settle_parked(e, g.p, g.r, g.gw, eps, &g.park_eps, &g.st);
     if (rc) return rc;
@@ -2676,10 +2710,15 @@ int dppr_group_update(dppr_engine *e, int32_t group, int32_t epoch, double eps, 
     rc = group_stream_update(e, g, ep);
     if (rc) return rc;
     g.converged = false;
-    rc = group_loop(e, g, ep, 0, eps, tails);
-    if (rc) return rc;
-    rc = group_loop(e, g, ep, 1, eps, tails);
-    if (rc) return rc;
+    if (merged) {
+        rc = group_loop(e, g, ep, PHASE_BOTH, eps, tails);
+        if (rc) return rc;
+    } else {
+        rc = group_loop(e, g, ep, 0, eps, tails);
+        if (rc) return rc;
+        rc = group_loop(e, g, ep, 1, eps, tails);
+        if (rc) return rc;
+    }
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
     HIP_TRY(hipEventSynchronize(e->ev1));
     float ms = 0;

@@ -64,14 +64,22 @@ __global__ __launch_bounds__(BLOCK) void k_inspect(const double *__restrict__ r,
 // Used by the synchronous schedule and when a sparse (push) iteration is followed by a
 // dense (pull) one.
 // ---------------------------------------------------------------------------
+// `dedup`: the list may name a vertex twice (merged loop: adds of both signs can take a residual across the threshold,
+// back, and across again within one push iteration, and every crossing appends): the entry that claims x[u] -- all zero
+// before a snapshot -- with a compare-and-swap credits pagerank, the others do nothing.
 __global__ __launch_bounds__(BLOCK) void k_snapshot_dense(const int *__restrict__ ft, const int *__restrict__ cnt_in,
                                                           const double *__restrict__ r, double *__restrict__ p,
-                                                          double *__restrict__ x, uint32_t *__restrict__ act) {
+                                                          double *__restrict__ x, uint32_t *__restrict__ act, int dedup) {
     const int F = *cnt_in;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < F; i += gridDim.x * BLOCK) {
         const int u = ft[i];
         const double ru = r[u];
-        x[u] = ru;
+        if (dedup) {
+            if (ru == 0.0 || atomicCAS(reinterpret_cast<unsigned long long *>(&x[u]), 0ull, (unsigned long long)__double_as_longlong(ru)) != 0ull)
+                continue;
+        } else {
+            x[u] = ru;
+        }
         p[u] += ALPHA * ru;
         if (act && ru != 0.0) atomicOr(&act[u >> 5], 1u << (u & 31)); // activity bitmap of the snapshot (cleared by the host)
     }

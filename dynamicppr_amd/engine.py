@@ -56,7 +56,7 @@ EXPORTS = [
     "dppr_trace_get", "dppr_synchronize", "dppr_bench_atomics",
     "dppr_add_source_group", "dppr_group_init_solve", "dppr_group_update", "dppr_group_read", "dppr_group_stats",
     "dppr_group_reset_stats", "dppr_set_group_seeding", "dppr_seed_lists", "dppr_set_sweep_bitmap", "dppr_set_group_resident",
-    "dppr_set_renumbering", "dppr_id_space", "dppr_set_group_push", "dppr_set_binned_sweep", "dppr_device_count",
+    "dppr_set_renumbering", "dppr_id_space", "dppr_set_group_push", "dppr_set_binned_sweep", "dppr_device_count", "dppr_set_phase_merge", "dppr_init_solve_at", "dppr_group_init_solve_at",
 ]
 
 
@@ -92,6 +92,8 @@ def lib():
     L.dppr_slide.argtypes = [vp, ip, ip, C.c_int32, ip]
     L.dppr_add_source.argtypes = [vp, C.c_int32, ip]
     L.dppr_init_solve.argtypes = [vp, C.c_int32, C.c_double, fp]
+    L.dppr_init_solve_at.argtypes = [vp, C.c_int32, C.c_int32, C.c_double, fp]
+    L.dppr_group_init_solve_at.argtypes = [vp, C.c_int32, C.c_int32, C.c_double, fp]
     L.dppr_update.argtypes = [vp, C.c_int32, C.c_int32, C.c_double, fp]
     L.dppr_incremental_batch_update.argtypes = [vp, C.c_int32, C.c_int32]
     L.dppr_execute_main_loop.argtypes = [vp, C.c_int32, C.c_int32, C.c_int, C.c_double]
@@ -112,6 +114,7 @@ def lib():
     L.dppr_group_read.argtypes = [vp, C.c_int32, C.c_int32, dp, dp]
     L.dppr_group_stats.argtypes = [vp, C.c_int32, C.POINTER(Stats)]
     L.dppr_set_sweep_bitmap.argtypes = [vp, C.c_int]
+    L.dppr_set_phase_merge.argtypes = [vp, C.c_int, C.c_int]
     L.dppr_set_binned_sweep.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64]
     L.dppr_set_group_resident.argtypes = [vp, C.c_int]
     L.dppr_seed_lists.argtypes = [vp, C.c_int32, C.c_int, ip, ip]
@@ -142,7 +145,7 @@ class Engine:
 
     def __init__(self, V, W, directed, max_batch, n_epochs=1, device=0, schedule=SCHEDULE_EAGER,
                  hub_min_degree=None, big_row_edges=None, pull_min_frontier=None, chunk_iters=None, pull_block=None,
-                 persistent=None, persist_timeout_us=None, sweep_bitmap=None, binned=None):
+                 persistent=None, persist_timeout_us=None, sweep_bitmap=None, binned=None, merge_phases=None):
         self._L = lib()
         self._h = C.c_void_p()
         self.V, self.W, self.directed, self.c = int(V), int(W), int(directed), int(max_batch)
@@ -157,6 +160,8 @@ class Engine:
                                              int(pull_block or 0)), "set_tuning")
         if sweep_bitmap is not None:
             self._ck(self._L.dppr_set_sweep_bitmap(self._h, int(sweep_bitmap)), "set_sweep_bitmap")
+        if merge_phases is not None:   # True / divisor
+            self.set_phase_merge(bool(merge_phases), 0 if merge_phases is True or not merge_phases else int(merge_phases))
         if binned is not None:   # int mode, or (mode, ha_tiles, hb_tiles, target_edges, min_ids, chunk_edges, target_a_edges)
             args = (binned,) if isinstance(binned, int) else tuple(binned)
             args = tuple(int(a) for a in args) + (0,) * (7 - len(args))
@@ -182,6 +187,10 @@ class Engine:
 
     def set_schedule(self, schedule):
         self._ck(self._L.dppr_set_schedule(self._h, int(schedule)), "set_schedule")
+
+    def set_phase_merge(self, on, eps_divisor=0):
+        """One loop for residuals of both signs, run to eps / eps_divisor (include/dppr.h); eager schedule only."""
+        self._ck(self._L.dppr_set_phase_merge(self._h, int(on), int(eps_divisor)), "set_phase_merge")
 
     def set_incremental_graph(self, on):
         self._ck(self._L.dppr_set_incremental_graph(self._h, int(on)), "set_incremental_graph")
@@ -226,9 +235,9 @@ class Engine:
         self._ck(self._L.dppr_add_source(self._h, int(s), C.byref(slot)), "add_source")
         return slot.value
 
-    def init_solve(self, slot, eps):
+    def init_solve(self, slot, eps, epoch=-1):
         ms = C.c_float(0)
-        self._ck(self._L.dppr_init_solve(self._h, slot, float(eps), C.byref(ms)), "init_solve")
+        self._ck(self._L.dppr_init_solve_at(self._h, slot, int(epoch), float(eps), C.byref(ms)), "init_solve")
         return ms.value
 
     def update(self, slot, eps, epoch=-1):
@@ -317,9 +326,9 @@ class Engine:
         self._ck(self._L.dppr_add_source_group(self._h, pa, len(a), C.byref(gid)), "add_source_group")
         return gid.value
 
-    def group_init_solve(self, group, eps):
+    def group_init_solve(self, group, eps, epoch=-1):
         ms = C.c_float(0)
-        self._ck(self._L.dppr_group_init_solve(self._h, group, float(eps), C.byref(ms)), "group_init_solve")
+        self._ck(self._L.dppr_group_init_solve_at(self._h, group, int(epoch), float(eps), C.byref(ms)), "group_init_solve")
         return ms.value
 
     def group_update(self, group, eps, epoch=-1):

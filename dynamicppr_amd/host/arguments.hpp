@@ -61,6 +61,7 @@ inline void PrintUsage() {
               << "--split: drive each batch through IncrementalBatchUpdate/ExecuteMainLoop(0)/(1)\n"
               << "--sync: synchronous (deterministic) push schedule\n"
               << "--share-device: with -g N on a node of fewer devices, device thread d uses device d % (devices present) (also DPPR_DEVICE_ALIAS=1)\n"
+              << "--merge-phases: push the residuals of both signs in ONE loop, to eps / 4 (not the reference's schedule; same pushes, |p - p_reference| < 1e-9)\n"
               << "--no-groups: with several sources per GPU, solve them one at a time (default: up to 16 together)\n"
               << "--profile: per-iteration frontier lines and the phase-time report of the reference's -DPROFILE build (implies --split)\n"
               << "EXAMPLE: ./pagerank -d ../data/com-dblp.ungraph.bin -a 0 -i 0 -y 1 -w 0.1 -n 0 -r 0.01 -b 1000 -s 1\n"
@@ -123,6 +124,7 @@ inline void ArgumentsParser(int argc, char **argv) {
     gSplitInterface = has(argc, argv, "--split");
     gSchedule = has(argc, argv, "--sync") ? 1 : 0;
     gNoGroups = has(argc, argv, "--no-groups");
+    gMergePhases = has(argc, argv, "--merge-phases");
     gShareDevice = has(argc, argv, "--share-device") || (getenv("DPPR_DEVICE_ALIAS") && atoi(getenv("DPPR_DEVICE_ALIAS")) != 0);
     gProfile = has(argc, argv, "--profile");
     if (gProfile) gSplitInterface = true; // the phases are timed and traced around the three virtual calls

@@ -70,6 +70,7 @@ public:
             std::exit(-1);
         }
         DPPR_CHECK(engine, dppr_set_schedule(engine, gSchedule));
+        if (gMergePhases) DPPR_CHECK(engine, dppr_set_phase_merge(engine, 1, 0)); // (--merge-phases: include/dppr.h; not the reference's schedule)
         ppr_time.assign(sources.size(), 0.0f);
     }
     virtual ~PPRGPU() { dppr_destroy(engine); }

@@ -78,6 +78,18 @@ typedef struct dppr_stats_t {
  * its own map `-g N` device threads onto the devices that exist. No reference counterpart (single implicit device 0). */
 int dppr_device_count(void);
 
+/* MERGED LOOP (off by default; not the reference's schedule). The reference pushes the positive residuals of a batch to
+ * convergence (ExecuteMainLoop(0)) and then the negative ones (ExecuteMainLoop(1), gpu/PPRGPU.cuh:138-164). Both loops
+ * spread the same batch's disturbance over the same part of the graph, and most of what they move cancels: with
+ * on != 0, dppr_update / dppr_group_update (eager schedule) run ONE loop that pushes every residual with |r| > eps',
+ * eps' = eps / eps_divisor (0 keeps the divisor; default 4). Every push is the reference's push (gpu/ExpandRev.cuh:70-77,
+ * :708-743), the loop invariant of SURVEY.md section 0 holds after every iteration, and the state it ends in satisfies
+ * |r| <= eps' < eps -- a state the reference's own Validate() accepts (cpu/PPRCPUMTCilkRev.h:291-309), closer to the
+ * fixed point than the reference's result (LiveJournal stand-in, eps 1e-9: max |p - p_cilk| 4.8e-10 with divisor 4;
+ * 7.7e-10 with divisor 1) in a third to a half of the sweeps. The split interface (dppr_incremental_batch_update +
+ * dppr_execute_main_loop(0 / 1)) and the synchronous schedule always run the reference's two loops. */
+int dppr_set_phase_merge(dppr_engine *e, int on, int eps_divisor);
+
 /* Replaces: DeviceMemory ctor + CudaAllocAppData + InitForDynamicGraph
  * (gpu/DeviceMemory.cuh:9-74) and SlidingGraphBuilder ctor
  * (gpu/SlidingGraphBuilder.cuh:64-76), as called from PPRGPU ctor
@@ -204,6 +216,9 @@ int dppr_add_source(dppr_engine *e, int32_t source_vertex, int32_t *out_slot);
 /* Replaces: Init<<<>>> + ExecuteMainLoop(0) of PPRGPU::DynamicExecute
  * (gpu/PPRGPU.cuh:85-89, gpu/PPRCommon.cuh:12-22). Runs on the newest epoch. */
 int dppr_init_solve(dppr_engine *e, int32_t slot, double eps, float *out_ms);
+/* ... on a given resident epoch (-1: the newest, as dppr_init_solve): a source added after several epochs were pre-staged starts
+ * from the first of them and follows them with dppr_update in sequence. */
+int dppr_init_solve_at(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *out_ms);
 
 /* THE TIMED REGION of the reference (gpu/PPRGPU.cuh:138-164):
  * IncrementalBatchUpdate + ExecuteMainLoop(0) + ExecuteMainLoop(1) for one batch.
@@ -248,6 +263,7 @@ int dppr_reset_stats(dppr_engine *e, int32_t slot);
  * counterpart (one source per process, gpu/PPRGPU.cuh:24). */
 int dppr_add_source_group(dppr_engine *e, const int32_t *sources, int32_t n /* 1..16 */, int32_t *out_group);
 int dppr_group_init_solve(dppr_engine *e, int32_t group, double eps, float *out_ms);
+int dppr_group_init_solve_at(dppr_engine *e, int32_t group, int32_t epoch, double eps, float *out_ms); /* (as dppr_init_solve_at) */
 /* timed region for all sources of the group at once (same scope as dppr_update) */
 int dppr_group_update(dppr_engine *e, int32_t group, int32_t epoch, double eps, float *out_ms);
 int dppr_group_read(dppr_engine *e, int32_t group, int32_t index, double *p, double *r);

@@ -647,6 +647,68 @@ void orc_sync_execute(orc_state *s, const orc_graph *g) {
     orc_sync_main_loop(s, g, 0);
 }
 
+/* NOT a schedule of the reference: the checker of the engine's MERGED loop (include/dppr.h dppr_set_phase_merge).
+ * One synchronous loop over residuals of BOTH signs: frontier = {u : |r[u]| > eps}; every frontier vertex is
+ * snapshotted and credited (cpu/PPRCPUMTCilkRev.h:208-257's push, gpu/ExpandRev.cuh:34-42), every push lands, the
+ * repair follows (gpu/ExpandRev.cuh:708-743); the next frontier is every vertex the iteration left with |r| > eps
+ * (adds of both signs may take a residual across the threshold more than once: a mark keeps the list free of
+ * duplicates). Same push rule, same invariant, |r| <= eps at the end. */
+void orc_merged_main_loop(orc_state *s, const orc_graph *g, double eps) {
+    double *residual = s->r, *pagerank = s->p;
+    const int *deg = g->deg;
+    int *mark = (int *)calloc((size_t)s->V + 1, sizeof(int));
+    int n0 = 0;
+    for (int u = 0; u < s->V; ++u)
+        if (residual[u] > eps || residual[u] < -eps) s->ft[n0++] = u;
+    s->ft_count = n0;
+    int stamp = 0;
+    for (;;) {
+        int F = s->ft_count;
+        if (F == 0) break;
+        trace_frontier(s, s->ft, F);
+        ++stamp;
+        for (int i = 0; i < F; ++i) {
+            int u = s->ft[i];
+            double ru = residual[u];
+            s->ft_r[i] = ru;
+            pagerank[u] += ORC_ALPHA * ru;
+        }
+        int n = 0;
+        int64_t E = 0;
+        for (int i = 0; i < F; ++i) {
+            int u = s->ft[i];
+            double ru = s->ft_r[i];
+            const orc_vec *nb = &g->in[u];
+            E += nb->n;
+            for (int j = 0; j < nb->n; ++j) {
+                int v = vec_at(nb, j);
+                residual[v] += (1.0 - ORC_ALPHA) * ru / (deg[v] + 1);
+                if (mark[v] != stamp) { mark[v] = stamp; s->ft2[n++] = v; } /* touched: decided below */
+            }
+        }
+        for (int i = 0; i < F; ++i) {
+            int u = s->ft[i];
+            residual[u] -= s->ft_r[i];
+            if (mark[u] != stamp) { mark[u] = stamp; s->ft2[n++] = u; }
+        }
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            int v = s->ft2[i];
+            if (residual[v] > eps || residual[v] < -eps) s->ft2[m++] = v;
+        }
+        s->stat_iters++; s->stat_F += F; s->stat_E += E; s->stat_N += m;
+        int *t = s->ft; s->ft = s->ft2; s->ft2 = t;
+        s->ft_count = m;
+        ++s->iteration_id;
+    }
+    free(mark);
+}
+void orc_merged_inc_execute(orc_state *s, const orc_graph *g, double eps) {
+    orc_copy_revert_out_degree(s, g);
+    orc_stream_update(s, g);
+    orc_merged_main_loop(s, g, eps);
+}
+
 void orc_sync_inc_execute(orc_state *s, const orc_graph *g) {
     orc_copy_revert_out_degree(s, g);
     orc_stream_update(s, g);

@@ -149,6 +149,9 @@ void orc_fifo_inc_execute(orc_state *s, const orc_graph *g); /* :36-62 */
  * iteration by iteration (frontier sets bit-exact). */
 void orc_sync_main_loop(orc_state *s, const orc_graph *g, int phase);
 void orc_sync_execute(orc_state *s, const orc_graph *g);
+/* checker of the engine's merged loop (dppr_set_phase_merge): NOT a schedule of the reference, see dppr_oracle.c */
+void orc_merged_main_loop(orc_state *s, const orc_graph *g, double eps);
+void orc_merged_inc_execute(orc_state *s, const orc_graph *g, double eps);
 void orc_sync_inc_execute(orc_state *s, const orc_graph *g);
 
 /* ---- variants 1-3 of the CPU path at -t 1: cpu/PPRCPUMTCilkRevVariants.h (FF :224-326, Eager

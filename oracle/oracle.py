@@ -98,6 +98,9 @@ def lib():
         getattr(L, name).argtypes = [SP, GP, C.c_int]
         getattr(L, name).restype = None
     L.orc_cilk_init.argtypes = [SP]
+    for name in ("orc_merged_main_loop", "orc_merged_inc_execute"):
+        getattr(L, name).argtypes = [SP, GP, C.c_double]
+        getattr(L, name).restype = None
     L.orc_cilk_inc_execute_mt.argtypes = [SP, GP, C.c_int]
     L.orc_cilk_inc_execute_mt.restype = None
     L.orc_cilk_main_loop_mt.argtypes = [SP, GP, C.c_int, C.c_int]
@@ -249,6 +252,8 @@ class State:
     def fifo_inc_execute(self, g): lib().orc_fifo_inc_execute(self._s, g._g)
     def sync_execute(self, g): lib().orc_sync_execute(self._s, g._g)
     def sync_inc_execute(self, g): lib().orc_sync_inc_execute(self._s, g._g)
+    def merged_main_loop(self, g, eps): lib().orc_merged_main_loop(self._s, g._g, float(eps))
+    def merged_inc_execute(self, g, eps): lib().orc_merged_inc_execute(self._s, g._g, float(eps))
     def sync_main_loop(self, g, phase): lib().orc_sync_main_loop(self._s, g._g, phase)
     def cilk_main_loop(self, g, phase): lib().orc_cilk_main_loop(self._s, g._g, phase)
     def variant_execute(self, g, variant): lib().orc_variant_execute(self._s, g._g, int(variant))

@@ -38,4 +38,7 @@ def test_bench_line_contract(extra, sources):
     pr = d["parity"]
     assert pr["ok"] is True and pr["max_abs_residual"] < pr["eps"] and pr["invariant_max_err"] < 1e-12
     assert pr["max_abs_dp_vs_cpu_t1"] is not None and pr["max_abs_dp_vs_cpu_t1"] < pr["tolerance"]
+    ml = d["merged_loop"]     # the same steps with the merged loop, reported BESIDE the headline (never as it)
+    assert ml["parity"]["ok"] is True and ml["parity"]["max_abs_residual"] <= pr["eps"] / 4 and ml["parity"]["max_abs_dp_vs_cpu_t1"] < pr["tolerance"]
+    assert ml["ms_per_step"] > 0 and abs(ml["speedup_vs_value"] - d["ms_per_step"] / ml["ms_per_step"]) < 0.02 * ml["speedup_vs_value"]
     assert "end of the timed region" in pr["cpu_compared"] and f"{min(sources, 2)} source(s)" in pr["cpu_compared"]

@@ -847,6 +847,89 @@ def test_incremental_graph_equals_full_rebuild(directed):
             assert np.array_equal(oa[0], ob[0]) and np.array_equal(oa[1], ob[1])
 
 
+MERGE_TUNINGS = [dict(pull_min_frontier=-1), dict(hub_min_degree=3, big_row_edges=8, pull_min_frontier=-1), dict(pull_min_frontier=1, persistent=0),
+                 dict(pull_min_frontier=1), dict(pull_min_frontier=40, chunk_iters=3), dict(pull_min_frontier=1, pull_block=256, persist_timeout_us=-1),
+                 dict(pull_min_frontier=1, persistent=0, binned=(2, 1, 1, 64, 0, 64, 64)), dict(pull_min_frontier=1, persistent=0, sweep_bitmap=1, pull_block=256)]
+MERGE_IDS = ["push-only", "push-hubs+bigrows", "pull-no-persist", "pull-resident", "mixed-chunk3", "pull-rollcall-fails", "binned", "pull-bitmap"]
+
+
+@pytest.mark.parametrize("tuning", MERGE_TUNINGS, ids=MERGE_IDS)
+@pytest.mark.parametrize("directed", [1, 0])
+def test_merged_loop_single_source(directed, tuning):
+    """dppr_set_phase_merge: residuals of both signs in ONE loop, to eps / 4 (not the reference's schedule; every push is the
+    reference's). The state it ends in satisfies the reference's Validate() with room to spare (|r| <= eps / 4), the loop
+    invariant to rounding, and p is within the north-star tolerance of cpu/PPRCPUMTCilkRev's result at eps AND of the
+    oracle's own merged loop (orc_merged_inc_execute) -- on every launch form."""
+    eps, div = 1e-9, 4
+    sc = make(directed, c=30, eps=eps, tuning=dict(tuning, merge_phases=div))
+    m = orc.State(sc.V, sc.source, eps)
+    sc.s.cilk_execute(sc.g)
+    m.cilk_execute(sc.g)
+    sc.e.init_solve(sc.slot, eps)
+    for k in range(6):
+        assert sc.advance_graphs()
+        sc.s.cilk_inc_execute(sc.g)
+        m.merged_inc_execute(sc.g, eps / div)
+        sc.e.update(sc.slot, eps)
+        p, r = sc.e.read(sc.slot)
+        assert np.max(np.abs(r)) <= eps / div
+        assert np.max(np.abs(p - sc.s.p)) < NORTH_STAR_TOL and np.max(np.abs(p - m.p)) < NORTH_STAR_TOL
+        pw, _ = orc.pow_rev(sc.g, sc.source)
+        assert np.max(np.abs(p - pw)) < 100 * eps                        # gpu/PPRRevPushGPU.cuh:145-156
+        src, dst = window_directed_edges(sc.g)
+        assert invariant_max_err_np(p, r, src, dst, sc.V, sc.source) < INVARIANT_TOL
+    # the split interface still runs the reference's two loops
+    assert sc.advance_graphs()
+    sc.s.cilk_inc_execute(sc.g)
+    sc.e.incremental_batch_update(sc.slot)
+    sc.e.execute_main_loop(sc.slot, 0, eps)
+    sc.e.execute_main_loop(sc.slot, 1, eps)
+    p, r = sc.e.read(sc.slot)
+    assert np.max(np.abs(r)) < eps and np.max(np.abs(p - sc.s.p)) < NORTH_STAR_TOL
+
+
+@pytest.mark.parametrize("mode", ["sweeps", "push-tail", "multi-sweep"])
+@pytest.mark.parametrize("nsrc,directed", [(3, 1), (10, 0), (16, 1)])
+def test_merged_loop_source_group(nsrc, directed, mode):
+    """The merged loop of a source group is a synchronous schedule like its two loops: per source it equals the oracle's merged
+    loop (orc_merged_inc_execute at eps / 4) to the rounding of the sums, with the same frontier and edge totals; and it is within
+    the north-star tolerance of cpu/PPRCPUMTCilkRev at eps."""
+    V, e1, e2 = datagen.rmat_stream(9, 6000, 11)
+    W, c, eps, div = 600, 25, 1e-9, 4
+    sources = [int(x) for x in datagen.top_sources(V, e1, e2, W, directed, nsrc)]
+    e = eng.Engine(V, W, directed, c, merge_phases=div, **(dict(chunk_iters=3) if mode == "multi-sweep" else {}))
+    e.set_group_resident(mode == "multi-sweep")
+    e.set_group_push(*((40, 0, 0) if mode == "push-tail" else (0, 0, 0)))
+    g = orc.Graph(V, e1, e2, directed, W, c)
+    merged = [orc.State(V, s, eps) for s in sources]
+    cilk = [orc.State(V, s, eps) for s in sources]
+    e.load_window(*g.window_edges())
+    gid = e.add_source_group(sources)
+    for s in merged + cilk:
+        s.sync_execute(g)
+    e.group_init_solve(gid, eps)
+    for s in merged:
+        s.reset_stats()
+    e.group_reset_stats(gid)
+    for k in range(5):
+        assert not g.stream_updates()
+        g.inc_construct(1)
+        e.set_batch(*g.batch())
+        e.slide(*g.new_stream())
+        for s in merged:
+            s.merged_inc_execute(g, eps / div)
+        for s in cilk:
+            s.cilk_inc_execute(g)
+        e.group_update(gid, eps)
+        for i in range(nsrc):
+            p, r = e.group_read(gid, i)
+            assert np.max(np.abs(p - merged[i].p)) < SYNC_TOL and np.max(np.abs(r - merged[i].r)) < SYNC_TOL, (k, i)
+            assert np.max(np.abs(r)) <= eps / div and np.max(np.abs(p - cilk[i].p)) < NORTH_STAR_TOL
+    st = e.group_stats(gid)
+    assert st["sum_F"] == sum(s.stats()["F"] for s in merged) and st["sum_E"] == sum(s.stats()["E"] for s in merged)
+    e.close()
+
+
 def run_source_group(V, e1, e2, W, c, eps, directed, sources, batches, seeding, tuning=None, resident=True, push=None):
     """Drive a source group and one oracle state per source (synchronous schedule) over the same
     stream; per-source p/r to rounding, summed statistics equal."""
