@@ -56,12 +56,12 @@ def check(d, i, k, p, r, eps, n_live):
     return dp
 
 
-def run(key, sources_idx, group):
+def run(key, sources_idx, group, merge=False):
     d, V, e1, e2, cfg, wl = load(key)
     eps = float(d["eps"][0])
     W, c = wl.window, wl.per_batch
     sources = [int(d["sources"][i]) for i in sources_idx]
-    e = eng.Engine(V, W, cfg.directed, c)
+    e = eng.Engine(V, W, cfg.directed, c, merge_phases=4 if merge else None)
     ss = st.SlidingStream(V, e1, e2, cfg.directed, wl)
     e.load_window(*ss.serialize_edge_stream())
     n_live = e.id_space()["ids"]
@@ -83,7 +83,8 @@ def run(key, sources_idx, group):
             worst = max(worst, check(d, i, k, p, r, eps, n_live))
     stats = e.group_stats(h) if group else e.stats(h)
     e.close()
-    print(f"[parity] {key} sources {sources_idx} ({'group' if group else 'single-source path'}): max |p_gpu - p_cpu(t=1)| = {worst:.3e}")
+    print(f"[parity] {key} sources {sources_idx} ({'group' if group else 'single-source path'}{', merged loop' if merge else ''}): "
+          f"max |p_gpu - p_cpu(t=1)| = {worst:.3e}, {stats['iterations']} iterations")
     return stats
 
 
@@ -97,6 +98,13 @@ def test_twitter_single_source_matches_cilk_oracle_at_full_size():
 def test_twitter_eight_sources_as_one_group_match_cilk_oracle_at_full_size():
     """All 8 sources of configs[3] as one source group on one GPU (k_gsweep + push tails): every source against its oracle run."""
     run("twitter", list(range(8)), group=True)
+
+
+@pytest.mark.parametrize("group", [False, True])
+def test_twitter_merged_loop_matches_cilk_oracle_at_full_size(group):
+    """dppr_set_phase_merge (one loop for residuals of both signs, to eps / 4 -- not the reference's schedule) against the
+    reference-schedule oracle run at twitter size: within the same 1e-9 (|r| <= eps / 4 < eps)."""
+    run("twitter", list(range(8)) if group else [0], group=group, merge=True)
 
 
 def test_friendster_ten_sources_as_one_group_match_cilk_oracle_at_full_size():

@@ -36,15 +36,17 @@ def window_edges(ss, directed):
     return (w1, w2) if directed else (np.concatenate([w1, w2]), np.concatenate([w2, w1]))
 
 
-@pytest.mark.parametrize("key,batches,pick", [("dblp", 3, "top10"), ("youtube", 3, "top10"), ("livejournal", 2, "top1000")])
-def test_production_mode_matches_cilk_oracle_at_full_size(key, batches, pick):
+@pytest.mark.parametrize("key,batches,pick,merge", [("dblp", 3, "top10", 0), ("youtube", 3, "top10", 0), ("livejournal", 2, "top1000", 0),
+                                                    ("youtube", 3, "top10", 4), ("livejournal", 2, "top1000", 4)])
+def test_production_mode_matches_cilk_oracle_at_full_size(key, batches, pick, merge):
+    """merge = 4: the merged loop (dppr_set_phase_merge, eps / 4; not the reference's schedule) against the same oracle run."""
     V, e1, e2, cfg, wl = stand_in(key, batches)
     W, c, eps = wl.window, wl.per_batch, 1e-9
     if pick == "top10":
         src = int(datagen.top_sources(V, e1, e2, W, cfg.directed, 10)[3])      # scripts/gpu.sh uses index 3 of the top10 file
     else:
         src = int(datagen.ranked_sources(V, e1, e2, W, cfg.directed, 10, 1000, 10)[0])
-    e = eng.Engine(V, W, cfg.directed, c)
+    e = eng.Engine(V, W, cfg.directed, c, merge_phases=merge or None)
     ss = st.SlidingStream(V, e1, e2, cfg.directed, wl)
     e.load_window(*ss.serialize_edge_stream())
     slot = e.add_source(src)
@@ -142,9 +144,11 @@ def test_youtube_eight_sources_as_one_group_matches_cilk_oracle():
 def test_eight_gpu_configs_at_full_size_on_one_gpu_properties(key, nsrc):
     """BASELINE.json configs[3] / configs[4] at their real window sizes (146.8 M / 180.6 M stream edges;
     one rank's share of the sources: one twitter source on the single-source path, two friendster
-    sources as a group). The -t 1 oracle would need minutes per batch here, so the checks are the
-    size-independent ones: the reference's residual bound (gpu/PPRRevPushGPU.cuh:141-143), the loop
-    invariant of SURVEY.md section 0 evaluated from the raw window edges, and the statistics."""
+    sources as a group). The size-independent checks: the reference's residual bound
+    (gpu/PPRRevPushGPU.cuh:141-143), the loop invariant of SURVEY.md section 0 evaluated from the raw window
+    edges, and the statistics. The comparison with the -t 1 oracle at this size (every source of both
+    configurations, the group forms included) is tests/test_fullsize_golden_gpu.py, against fixtures the oracle
+    computed in the build container."""
     V, e1, e2, cfg, wl = stand_in(key, 1)
     W, c, eps = wl.window, wl.per_batch, 1e-9
     if nsrc == 1:

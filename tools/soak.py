@@ -3,7 +3,8 @@
 source slot and a 10-source group over hundreds of in-step batches, every state compared with the oracle's restatement
 of cpu/PPRCPUMTCilkRev (-t 1) every few batches (|p - p_cpu| < 1e-9, |r| < eps, loop invariant).
     python tools/soak.py [seed] [batches] [scale] [one-sweep]      (4th argument: the group's loops as one launch per sweep
-    with the tail as pushes -- what large windows run -- instead of multi-sweep launches)"""
+    with the tail as pushes -- what large windows run -- instead of multi-sweep launches)
+    DPPR_SOAK_MERGE=1: the merged loop (dppr_set_phase_merge, eps / 4) on both states; DPPR_SOAK_TUNE="key=int,...": engine tuning"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,7 +22,11 @@ V, e1, e2 = datagen.rmat_stream(scale, W + (batches + 1) * c, 100 + seed)
 srcs = [int(x) for x in datagen.top_sources(V, e1, e2, W, directed, 10)]
 g = orc.Graph(V, e1, e2, directed, W, c)
 states = [orc.State(V, s, eps) for s in srcs]
-e = eng.Engine(V, W, directed, c)
+tune = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ.get("DPPR_SOAK_TUNE", "").split(",") if kv}
+merge = int(os.environ.get("DPPR_SOAK_MERGE", "0"))
+e = eng.Engine(V, W, directed, c, **tune)
+if merge:
+    e.set_phase_merge(True, 4)
 e.set_renumbering(1, growth_pct=5, min_parked=64)
 if len(sys.argv) > 4:
     e.set_group_resident(False)
@@ -41,7 +46,7 @@ for k in range(1, batches + 1):
         for i, s in enumerate(states):
             for p, r in ([e.read(slot)] if i == 0 else []) + [e.group_read(gid, i)]:
                 dp = float(np.max(np.abs(p - s.p))); worst = max(worst, dp)
-                assert dp < 1e-9 and np.max(np.abs(r)) < eps and invariant_max_err_np(p, r, src, dst, V, srcs[i]) < 1e-13, (k, i, dp)
+                assert dp < 1e-9 and np.max(np.abs(r)) <= (eps / 4 if merge else eps) and invariant_max_err_np(p, r, src, dst, V, srcs[i]) < 1e-13, (k, i, dp)
 st = e.stats(slot); sp = e.id_space()
-print(f"seed {seed}: directed {directed} V {V} W {W} c {c}: {batches} batches ok, max |p - p_cpu| {worst:.3e}, id space {sp}, "
+print(f"seed {seed}{' merged loop' if merge else ''} {tune or ''}: directed {directed} V {V} W {W} c {c}: {batches} batches ok, max |p - p_cpu| {worst:.3e}, id space {sp}, "
       f"resident launches {st['persist_launches']} aborts {st['persist_aborts']}, {time.time() - t0:.0f} s")
