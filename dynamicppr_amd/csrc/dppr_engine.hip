@@ -90,6 +90,7 @@ struct Slot {
     size_t act_bytes = 0;
     int *ft[2] = {nullptr, nullptr};
     int *neg = nullptr;     // phase-1 candidates
+    int *status = nullptr;  // status-array duplicate filter (variants EAGER / VANILLA): launch number that queued the vertex last; allocated on first use
     int *cnt = nullptr;     // [0..2] rotating frontier counters, [3] neg candidates, [4] scratch, [5..6] big-row counters
     BigItem *big = nullptr; // deferred big rows of the current iteration
     int *log = nullptr;     // per-chunk log: frontier size seen by each enqueued iteration
@@ -148,6 +149,9 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     int Ed = 0;   // directed edges in the window
     int bits = 1; // bits of a vertex id
     int schedule = DPPR_SCHEDULE_EAGER;
+    // the reference's variants (-o, gpu/PPRRevPushGPUVariants.cuh) as mechanisms of the push iterations: dppr_set_variant
+    bool status_dedup = false; // duplicate filter of a push iteration: status array (EAGER 2, VANILLA 3) instead of the threshold crossing
+    bool pre_extract = false;  // synchronous push iterations zero residual[u] at the snapshot (InspectExtra: FAST_FRONTIER 1, VANILLA 3) instead of repairing
     bool merge_phases = false; // dppr_set_phase_merge: one loop for residuals of both signs (eager schedule only)
     int merge_div = 4;         // ... run to eps / merge_div
     hipStream_t stream = nullptr;
@@ -1000,6 +1004,11 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
     const int pcap0 = persist_capacity(e);
     const bool binned = ep.bin_valid && ep.bin_n_int <= ep.grp_n_int && (pcap0 <= 0 || ep.n_groups > pcap0 || e->bin_mode == 2);
     const bool use_bits = e->sweep_bits && !binned && !entry.dense && (pcap0 <= 0 || ep.n_groups > pcap0);
+    if (e->status_dedup && !s.status) { // (first use: -1 everywhere = "never queued")
+        HIP_TRY(hipMalloc((void **)&s.status, sizeof(int) * (size_t)e->V));
+        HIP_TRY(hipMemsetAsync(s.status, 0xff, sizeof(int) * (size_t)e->V, e->stream));
+    }
+    bool extracted = false;         // ... and that snapshot zeroed the residuals it took (InspectExtra): the push needs no repair
     bool dense_valid = entry.dense; // s.x holds the snapshot of the current frontier (p already updated)
     bool list_valid = !entry.dense; // s.ft[buf] holds the frontier as a list (sweeps only count it)
     bool any_pull = entry.any_pull;
@@ -1061,7 +1070,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             // ---- a run of dense iterations as ONE resident launch (dppr_resident.hpp)
             if (!dense_valid) {
                 hipLaunchKernelGGL(k_snapshot_dense, dim3(std::min(grid_for(std::max(F, 1 << 14)), 1024)), dim3(BLOCK), 0,
-                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x, (uint32_t *)nullptr, phase == PHASE_BOTH ? 1 : 0);
+                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x, (uint32_t *)nullptr, phase == PHASE_BOTH ? 1 : 0, 0);
                 dense_valid = true;
             }
             HIP_TRY(hipMemsetAsync(e->bar, 0, sizeof(GridBar), e->stream));
@@ -1124,8 +1133,10 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 // the last size the host saw, capped
                 const bool bm = use_bits && pull;
                 if (bm) HIP_TRY(hipMemsetAsync(s.act[0], 0, s.act_bytes, e->stream));
+                extracted = e->pre_extract && !pull; // (a sweep repairs by itself: rn -= x[v])
                 hipLaunchKernelGGL(k_snapshot_dense, dim3(std::min(grid_for(std::max(F, 1 << 14)), 1024)), dim3(BLOCK), 0,
-                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x, bm ? s.act[0] : (uint32_t *)nullptr, phase == PHASE_BOTH ? 1 : 0);
+                                   e->stream, s.ft[buf], s.cnt + cur, s.r, s.p, s.x, bm ? s.act[0] : (uint32_t *)nullptr, phase == PHASE_BOTH ? 1 : 0,
+                                   extracted ? 1 : 0);
                 dense_valid = true;
             }
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k], e->stream));
@@ -1141,6 +1152,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                                    s.x2, s.r, s.p, s.cnt + nxt, s.cnt + zer, phase, eps, s.dstats, log_slot);
                 std::swap(s.x, s.x2);
                 dense_valid = true;
+                extracted = false;
                 list_valid = false;
                 any_pull = true;
             } else if (pull) {
@@ -1173,22 +1185,25 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
 #undef DPPR_LAUNCH_PULL
                 std::swap(s.x, s.x2); // the sweep wrote every entry of x2: it is the next snapshot
                 dense_valid = true;
+                extracted = false;
                 list_valid = false;
                 any_pull = true;
             } else {
                 int *big_cnt = s.cnt + 5 + (int)(s.iter_seq & 1), *big_zero = s.cnt + 5 + (int)((s.iter_seq + 1) & 1);
                 s.iter_seq++;
+                const Dedup dd{e->status_dedup ? s.status : nullptr, (int)(s.iter_seq & 0x3fffffff)};
                 if (dense_valid)
                     hipLaunchKernelGGL(k_push_iter<true>, dim3(push_grid), dim3(BLOCK), 0, e->stream, s.ft[buf],
                                        s.cnt + cur, s.ft[buf ^ 1], s.cnt + nxt, s.cnt + zer, s.x, ep.row_ptr, ep.adj, hubs,
-                                       s.big, big_cnt, big_zero, e->big_row, s.r, s.p, phase, eps, s.dstats, log_slot);
+                                       s.big, big_cnt, big_zero, e->big_row, s.r, s.p, phase, eps, s.dstats, log_slot, dd, extracted ? 1 : 0);
                 else
                     hipLaunchKernelGGL(k_push_iter<false>, dim3(push_grid), dim3(BLOCK), 0, e->stream, s.ft[buf],
                                        s.cnt + cur, s.ft[buf ^ 1], s.cnt + nxt, s.cnt + zer, s.x, ep.row_ptr, ep.adj, hubs,
-                                       s.big, big_cnt, big_zero, e->big_row, s.r, s.p, phase, eps, s.dstats, log_slot);
+                                       s.big, big_cnt, big_zero, e->big_row, s.r, s.p, phase, eps, s.dstats, log_slot, dd, 0);
                 hipLaunchKernelGGL(k_push_big, dim3(512), dim3(BLOCK), 0, e->stream, s.big, big_cnt, s.ft[buf ^ 1],
-                                   s.cnt + nxt, ep.adj, hubs, s.r, phase, eps, s.dstats);
+                                   s.cnt + nxt, ep.adj, hubs, s.r, phase, eps, s.dstats, dd);
                 dense_valid = false; // the push consumed (and zeroed) the snapshot
+                extracted = false;
                 list_valid = true;
             }
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k + 1], e->stream));
@@ -1890,7 +1905,7 @@ void dppr_destroy(dppr_engine *e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto &s : e->slots) {
         (void)hipFree(s.p); (void)hipFree(s.r); (void)hipFree(s.x); (void)hipFree(s.x2); (void)hipFree(s.x3);
-        (void)hipFree(s.ft[0]); (void)hipFree(s.ft[1]); (void)hipFree(s.neg); (void)hipFree(s.act[0]); (void)hipFree(s.act[1]);
+        (void)hipFree(s.ft[0]); (void)hipFree(s.ft[1]); (void)hipFree(s.neg); (void)hipFree(s.status); (void)hipFree(s.act[0]); (void)hipFree(s.act[1]);
         (void)hipFree(s.cnt); (void)hipFree(s.dstats); (void)hipFree(s.big);
     }
     for (auto &g : e->groups) {
@@ -1926,6 +1941,14 @@ void dppr_destroy(dppr_engine *e) {
 int dppr_set_schedule(dppr_engine *e, int schedule) {
     if (!e || (schedule != DPPR_SCHEDULE_EAGER && schedule != DPPR_SCHEDULE_SYNC)) return DPPR_ERR_INVALID;
     e->schedule = schedule;
+    return DPPR_OK;
+}
+
+int dppr_set_variant(dppr_engine *e, int variant) {
+    if (!e || variant < 0 || variant > 3) return fail(e, DPPR_ERR_INVALID, "set_variant: 0 OPTIMIZED, 1 FAST_FRONTIER, 2 EAGER, 3 VANILLA");
+    e->schedule = (variant == 1 || variant == 3) ? DPPR_SCHEDULE_SYNC : DPPR_SCHEDULE_EAGER; // pre-extracted residuals = the synchronous schedule
+    e->pre_extract = variant == 1 || variant == 3;
+    e->status_dedup = variant == 2 || variant == 3;
     return DPPR_OK;
 }
 

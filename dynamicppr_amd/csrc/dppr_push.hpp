@@ -67,13 +67,16 @@ __global__ __launch_bounds__(BLOCK) void k_inspect(const double *__restrict__ r,
 // `dedup`: the list may name a vertex twice (merged loop: adds of both signs can take a residual across the threshold,
 // back, and across again within one push iteration, and every crossing appends): the entry that claims x[u] -- all zero
 // before a snapshot -- with a compare-and-swap credits pagerank, the others do nothing.
+// `extract`: InspectExtra's pre-extraction (gpu/Inspect.cuh:51-65, variants FAST_FRONTIER / VANILLA): residual[u] = 0 at the
+// snapshot, so that the push iteration that follows needs no repair (k_push_iter<true> with extract).
 __global__ __launch_bounds__(BLOCK) void k_snapshot_dense(const int *__restrict__ ft, const int *__restrict__ cnt_in,
-                                                          const double *__restrict__ r, double *__restrict__ p,
-                                                          double *__restrict__ x, uint32_t *__restrict__ act, int dedup) {
+                                                          double *__restrict__ r, double *__restrict__ p,
+                                                          double *__restrict__ x, uint32_t *__restrict__ act, int dedup, int extract) {
     const int F = *cnt_in;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < F; i += gridDim.x * BLOCK) {
         const int u = ft[i];
         const double ru = r[u];
+        if (extract) r[u] = 0.0;
         if (dedup) {
             if (ru == 0.0 || atomicCAS(reinterpret_cast<unsigned long long *>(&x[u]), 0ull, (unsigned long long)__double_as_longlong(ru)) != 0ull)
                 continue;
@@ -164,6 +167,18 @@ struct OutStage {
 };
 
 
+// Does the add that took residual[v] from prer to prer + add queue v for the next frontier? Two duplicate filters, as in the
+// reference's variants: the threshold CROSSING (ExpandUnifiedRev / ExpandFastFrontierRev, gpu/ExpandRev.cuh:75-77,430-432) or the
+// STATUS array (ExpandEagerRev / ExpandVanillaRev, :255,298,340 and :603,646,688): legal(curr) && atomicExch(status[v], level) < level.
+struct Dedup {
+    int *status; // nullptr: crossing test
+    int level;   // number of this push launch (monotonic over the engine's life: stale entries are always smaller)
+};
+__device__ __forceinline__ bool queues(double prer, double add, int v, int phase, double eps, const Dedup &dd) {
+    if (dd.status) return legal(prer + add, phase, eps) && atomicExch(&dd.status[v], dd.level) < dd.level;
+    return !legal(prer, phase, eps) && legal(prer + add, phase, eps);
+}
+
 // issue the push of one edge; returns the pre-add residual (or NaN-free dummy for hubs)
 struct EdgePush {
     int v;
@@ -195,7 +210,7 @@ __device__ __forceinline__ EdgePush push_edge(bool valid, Adj a, double ru, doub
 __device__ __forceinline__ void push_epilogue(OutStage &out, double *s_hub, const HubTable &hubs,
                                               double *__restrict__ r, int phase, double eps, int *s_cnt, int *s_base,
                                               unsigned long long edges, IterStats *stats,
-                                              unsigned long long *s_edges) {
+                                              unsigned long long *s_edges, const Dedup &dd) {
     __syncthreads(); // all LDS hub adds of the workgroup done
     for (int s0 = 0; s0 < hubs.n; s0 += BLOCK) {
         const int slot = s0 + threadIdx.x;
@@ -206,7 +221,7 @@ __device__ __forceinline__ void push_epilogue(OutStage &out, double *s_hub, cons
             if (acc != 0.0) {
                 v = hubs.v[slot];
                 const double prer = atomic_add_ret(&r[v], acc);
-                hit = !legal(prer, phase, eps) && legal(prer + acc, phase, eps);
+                hit = queues(prer, acc, v, phase, eps, dd);
             }
         }
         out.stage(hit, v);
@@ -233,7 +248,7 @@ __global__ __launch_bounds__(BLOCK) void k_push_iter(const int *__restrict__ ft,
                                                      HubTable hubs, BigItem *__restrict__ big, int *__restrict__ big_cnt,
                                                      int *__restrict__ big_zero, int big_row, double *__restrict__ r,
                                                      double *__restrict__ p, int phase, double eps,
-                                                     IterStats *__restrict__ stats, int *__restrict__ log_slot) {
+                                                     IterStats *__restrict__ stats, int *__restrict__ log_slot, Dedup dd, int extract) {
     __shared__ int s_scan[WAVES_PER_BLOCK][WAVE + 1];
     __shared__ int s_start[WAVES_PER_BLOCK][WAVE];
     __shared__ double s_ru[WAVES_PER_BLOCK][WAVE];
@@ -273,9 +288,11 @@ __global__ __launch_bounds__(BLOCK) void k_push_iter(const int *__restrict__ ft,
             if (DENSE) {
                 ru = x[u];
                 x[u] = 0.0; // x is all-zero again once the sparse iteration is over
-                // RepairFrontierRev: residual[u] -= vertex_ft_r[i]; still legal -> next frontier
-                const double prer = atomic_add_ret(&r[u], -ru);
-                requeue = legal(prer - ru, phase, eps);
+                if (!extract) { // (extract: residual[u] was zeroed at the snapshot, InspectExtra -- nothing to repair)
+                    // RepairFrontierRev: residual[u] -= vertex_ft_r[i]; still legal -> next frontier
+                    const double prer = atomic_add_ret(&r[u], -ru);
+                    requeue = legal(prer - ru, phase, eps);
+                }
             } else {
                 ru = atomic_exch(&r[u], 0.0);
                 p[u] += ALPHA * ru;
@@ -331,20 +348,20 @@ __global__ __launch_bounds__(BLOCK) void k_push_iter(const int *__restrict__ ft,
             }
 #pragma unroll
             for (int k = 0; k < UNROLL; ++k) {
-                const bool hit = q[k].direct && !legal(q[k].prer, phase, eps) && legal(q[k].prer + q[k].add, phase, eps);
+                const bool hit = q[k].direct && queues(q[k].prer, q[k].add, q[k].v, phase, eps, dd);
                 out.stage(hit, q[k].v);
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
-    push_epilogue(out, s_hub, hubs, r, phase, eps, s_cnt, &s_base, edges, stats, s_edges);
+    push_epilogue(out, s_hub, hubs, r, phase, eps, s_cnt, &s_base, edges, stats, s_edges, dd);
 }
 
 // Deferred big rows: chunk c of the list goes to workgroup c % gridDim; 256 lanes x 4 edges.
 __global__ __launch_bounds__(BLOCK) void k_push_big(const BigItem *__restrict__ big, const int *__restrict__ big_cnt,
                                                     int *__restrict__ ft_out, int *__restrict__ cnt_out,
                                                     const Adj *__restrict__ adj, HubTable hubs, double *__restrict__ r,
-                                                    int phase, double eps, IterStats *__restrict__ stats) {
+                                                    int phase, double eps, IterStats *__restrict__ stats, Dedup dd) {
     __shared__ int s_out[WAVES_PER_BLOCK][OUT_CAP];
     __shared__ double s_hub[HUB_CAP];
     __shared__ int s_cnt[WAVES_PER_BLOCK];
@@ -377,7 +394,7 @@ __global__ __launch_bounds__(BLOCK) void k_push_big(const BigItem *__restrict__ 
             }
 #pragma unroll
             for (int k = 0; k < UNROLL; ++k) {
-                const bool hit = q[k].direct && !legal(q[k].prer, phase, eps) && legal(q[k].prer + q[k].add, phase, eps);
+                const bool hit = q[k].direct && queues(q[k].prer, q[k].add, q[k].v, phase, eps, dd);
                 out.stage(hit, q[k].v);
             }
             if (wave_id() == 0) {
@@ -387,7 +404,7 @@ __global__ __launch_bounds__(BLOCK) void k_push_big(const BigItem *__restrict__ 
         }
         chunk0 += nch;
     }
-    push_epilogue(out, s_hub, hubs, r, phase, eps, s_cnt, &s_base, edges, stats, s_edges);
+    push_epilogue(out, s_hub, hubs, r, phase, eps, s_cnt, &s_base, edges, stats, s_edges, dd);
 }
 
 } // namespace dppr

@@ -56,7 +56,7 @@ EXPORTS = [
     "dppr_trace_get", "dppr_synchronize", "dppr_bench_atomics",
     "dppr_add_source_group", "dppr_group_init_solve", "dppr_group_update", "dppr_group_read", "dppr_group_stats",
     "dppr_group_reset_stats", "dppr_set_group_seeding", "dppr_seed_lists", "dppr_set_sweep_bitmap", "dppr_set_group_resident",
-    "dppr_set_renumbering", "dppr_id_space", "dppr_set_group_push", "dppr_set_binned_sweep", "dppr_device_count", "dppr_set_phase_merge", "dppr_init_solve_at", "dppr_group_init_solve_at",
+    "dppr_set_renumbering", "dppr_id_space", "dppr_set_group_push", "dppr_set_binned_sweep", "dppr_device_count", "dppr_set_phase_merge", "dppr_init_solve_at", "dppr_group_init_solve_at", "dppr_set_variant",
 ]
 
 
@@ -115,6 +115,7 @@ def lib():
     L.dppr_group_stats.argtypes = [vp, C.c_int32, C.POINTER(Stats)]
     L.dppr_set_sweep_bitmap.argtypes = [vp, C.c_int]
     L.dppr_set_phase_merge.argtypes = [vp, C.c_int, C.c_int]
+    L.dppr_set_variant.argtypes = [vp, C.c_int]
     L.dppr_set_binned_sweep.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64]
     L.dppr_set_group_resident.argtypes = [vp, C.c_int]
     L.dppr_seed_lists.argtypes = [vp, C.c_int32, C.c_int, ip, ip]
@@ -145,7 +146,7 @@ class Engine:
 
     def __init__(self, V, W, directed, max_batch, n_epochs=1, device=0, schedule=SCHEDULE_EAGER,
                  hub_min_degree=None, big_row_edges=None, pull_min_frontier=None, chunk_iters=None, pull_block=None,
-                 persistent=None, persist_timeout_us=None, sweep_bitmap=None, binned=None, merge_phases=None):
+                 persistent=None, persist_timeout_us=None, sweep_bitmap=None, binned=None, merge_phases=None, variant=None):
         self._L = lib()
         self._h = C.c_void_p()
         self.V, self.W, self.directed, self.c = int(V), int(W), int(directed), int(max_batch)
@@ -154,6 +155,8 @@ class Engine:
             self._h = C.c_void_p()
             raise DpprError(f"dppr_create: {self._L.dppr_strerror(rc).decode()}")
         self.set_schedule(schedule)
+        if variant is not None:   # the reference's -o: sets the schedule too (1, 3: synchronous)
+            self._ck(self._L.dppr_set_variant(self._h, int(variant)), "set_variant")
         if any(v is not None for v in (hub_min_degree, big_row_edges, pull_min_frontier, chunk_iters, pull_block)):
             self._ck(self._L.dppr_set_tuning(self._h, int(hub_min_degree or 256), int(big_row_edges or 512),
                                              int(pull_min_frontier or 0), int(chunk_iters or 0),

@@ -61,6 +61,7 @@ inline void PrintUsage() {
               << "--split: drive each batch through IncrementalBatchUpdate/ExecuteMainLoop(0)/(1)\n"
               << "--sync: synchronous (deterministic) push schedule\n"
               << "--share-device: with -g N on a node of fewer devices, device thread d uses device d % (devices present) (also DPPR_DEVICE_ALIAS=1)\n"
+              << "--push-only: every iteration as a push iteration (no pull sweeps): what the -o variants differ in\n"
               << "--merge-phases: push the residuals of both signs in ONE loop, to eps / 4 (not the reference's schedule; same pushes, |p - p_reference| < 1e-9)\n"
               << "--no-groups: with several sources per GPU, solve them one at a time (default: up to 16 together)\n"
               << "--profile: per-iteration frontier lines and the phase-time report of the reference's -DPROFILE build (implies --split)\n"
@@ -125,14 +126,13 @@ inline void ArgumentsParser(int argc, char **argv) {
     gSchedule = has(argc, argv, "--sync") ? 1 : 0;
     gNoGroups = has(argc, argv, "--no-groups");
     gMergePhases = has(argc, argv, "--merge-phases");
+    gPushOnly = has(argc, argv, "--push-only");
     gShareDevice = has(argc, argv, "--share-device") || (getenv("DPPR_DEVICE_ALIAS") && atoi(getenv("DPPR_DEVICE_ALIAS")) != 0);
     gProfile = has(argc, argv, "--profile");
     if (gProfile) gSplitInterface = true; // the phases are timed and traced around the three virtual calls
-    // -o: the reference's four variants are implementation ablations (eager vs pre-extracted residuals,
-    // threshold-crossing vs status-array dedup, gpu/PPRRevPushGPUVariants.cuh); all of them enqueue a
-    // vertex exactly when its residual ends the iteration legal. This engine has two schedules: the
-    // variants that read residuals eagerly (0 OPTIMIZED, 2 EAGER) run the eager schedule, the ones that
-    // pre-extract them with InspectExtra (1 FAST_FRONTIER, 3 VANILLA) run the synchronous one.
+    // -o: the reference's four variants (gpu/PPRRevPushGPUVariants.cuh) = {eager residual read | pre-extracted residuals
+    // (InspectExtra)} x {threshold-crossing | status-array duplicate filter}; the engine has both mechanisms of both kinds
+    // (dppr_set_variant). The pre-extracting variants (1 FAST_FRONTIER, 3 VANILLA) run the synchronous schedule.
     if (gVariant == FAST_FRONTIER || gVariant == VANILLA) gSchedule = 1;
     ArgumentsChecker();
 }

@@ -41,6 +41,7 @@ inline std::string gSourcesFile;      // --sources : file with one source vertex
 inline std::string gDumpPath;         // --dump : write p/r of every source after the last batch
 inline bool gValidate = false;        // --validate : the reference's -DVALIDATE checks at run time
 inline bool gShareDevice = false;     // --share-device (or DPPR_DEVICE_ALIAS=1): the -g N device threads share the devices that exist (d % count)
+inline bool gPushOnly = false;        // --push-only : no pull sweeps (the ablation of the -o variants times their push mechanisms)
 inline bool gMergePhases = false;     // --merge-phases : one loop for residuals of both signs, to eps / 4 (dppr_set_phase_merge; off: the reference's two loops)
 inline bool gSplitInterface = false;  // --split : drive the timed region through the 3 virtual calls
 inline int gSchedule = 0;             // --sync : deterministic synchronous schedule

@@ -69,7 +69,9 @@ public:
             std::cout << "dppr_create: " << dppr_strerror(rc) << std::endl;
             std::exit(-1);
         }
-        DPPR_CHECK(engine, dppr_set_schedule(engine, gSchedule));
+        DPPR_CHECK(engine, dppr_set_variant(engine, gVariant)); // (-o: the variant's mechanisms and its schedule)
+        if (gSchedule) DPPR_CHECK(engine, dppr_set_schedule(engine, gSchedule)); // (--sync on an eager variant)
+        if (gPushOnly) DPPR_CHECK(engine, dppr_set_tuning(engine, 256, 512, -1, 0, 0)); // (--push-only: every iteration through the push kernels)
         if (gMergePhases) DPPR_CHECK(engine, dppr_set_phase_merge(engine, 1, 0)); // (--merge-phases: include/dppr.h; not the reference's schedule)
         ppr_time.assign(sources.size(), 0.0f);
     }

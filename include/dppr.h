@@ -78,6 +78,18 @@ typedef struct dppr_stats_t {
  * its own map `-g N` device threads onto the devices that exist. No reference counterpart (single implicit device 0). */
 int dppr_device_count(void);
 
+/* The reference's four variants (-o, Meta.h; gpu/PPRRevPushGPUVariants.cuh:6-150) as MECHANISMS of the push iterations:
+ *   0 OPTIMIZED     eager residual read + threshold-crossing duplicate filter (ExpandUnifiedRev + RepairFrontierRev)      [default]
+ *   1 FAST_FRONTIER residuals pre-extracted and zeroed at the snapshot (InspectExtra, gpu/Inspect.cuh:51-65), crossing filter, no repair
+ *   2 EAGER         eager read + STATUS-ARRAY filter: legal(curr) && atomicExch(status[v], level) < level (gpu/ExpandRev.cuh:255,298,340)
+ *   3 VANILLA       pre-extracted + status-array filter (gpu/ExpandRev.cuh:603,646,688)
+ * 1 and 3 imply the synchronous schedule, 0 and 2 the eager one (dppr_set_schedule may be called afterwards). Dense iterations
+ * run as sweeps in every variant (a sweep computes the next frontier directly and needs neither filter): to time the four
+ * mechanisms against each other, as the paper's ablation does, pin the push form (dppr_set_tuning pull_min_frontier = -1,
+ * ./pagerank --push-only). Results: the variants' frontier SETS per iteration equal the oracle's restatements of the reference's
+ * variants (tests); p / r as for the two schedules. */
+int dppr_set_variant(dppr_engine *e, int variant);
+
 /* MERGED LOOP (off by default; not the reference's schedule). The reference pushes the positive residuals of a batch to
  * convergence (ExecuteMainLoop(0)) and then the negative ones (ExecuteMainLoop(1), gpu/PPRGPU.cuh:138-164). Both loops
  * spread the same batch's disturbance over the same part of the graph, and most of what they move cancels: with

@@ -69,7 +69,7 @@ def read_dump(path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("directed", [1, 0])
-@pytest.mark.parametrize("extra", [[], ["--split"], ["--sync"], ["-o", "1"], ["-o", "2"], ["-o", "3"], ["--merge-phases"]])
+@pytest.mark.parametrize("extra", [[], ["--split"], ["--sync"], ["-o", "1"], ["-o", "2"], ["-o", "3"], ["--merge-phases"], ["-o", "2", "--push-only"], ["-o", "3", "--push-only"]])
 def test_cli_end_to_end_matches_oracle(pagerank, small_bin, tmp_path, directed, extra):
     path, V, e1, e2 = small_bin
     W, c = 600, 6

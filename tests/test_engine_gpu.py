@@ -208,13 +208,21 @@ def test_sync_schedule_frontier_sets_bit_exact(directed, tuning):
         assert st["binned_sweeps"] == 0
 
 
+VARIANT_TUNINGS = [dict(), dict(hub_min_degree=3, big_row_edges=8, pull_min_frontier=-1), dict(hub_min_degree=1, big_row_edges=1, pull_min_frontier=-1),
+                   dict(pull_min_frontier=40, persistent=0), dict(pull_min_frontier=40, chunk_iters=3)]
+VARIANT_IDS = ["default", "hubs+bigrows", "all-hub-all-big", "mixed-with-sweeps", "mixed-resident-chunk3"]
+
+
+@pytest.mark.parametrize("tuning", VARIANT_TUNINGS, ids=VARIANT_IDS)
 @pytest.mark.parametrize("variant", [1, 3])
 @pytest.mark.parametrize("directed", [1, 0])
-def test_sync_schedule_is_the_reference_fast_frontier_variant(directed, variant):
-    """`./pagerank -o 1|3` runs DPPR_SCHEDULE_SYNC: its per-iteration frontier sets, iteration count and
-    traversed edges equal the oracle's restatement of PPRCPUMTCilkRevFF / ...Vanilla
-    (cpu/PPRCPUMTCilkRevVariants.h) at -t 1, batch after batch."""
-    sc = make(directed, schedule=eng.SCHEDULE_SYNC, c=20)
+def test_sync_schedule_is_the_reference_fast_frontier_variant(directed, variant, tuning):
+    """`./pagerank -o 1|3` = dppr_set_variant(1 FAST_FRONTIER | 3 VANILLA): residuals pre-extracted and zeroed at the snapshot
+    (InspectExtra), duplicates filtered by the threshold crossing (1) or the status array (3), no repair -- the reference's
+    mechanisms (gpu/PPRRevPushGPUVariants.cuh:58-150) in the push kernels, on the synchronous schedule. Per-iteration frontier
+    sets, iteration count and traversed edges equal the oracle's restatement of PPRCPUMTCilkRevFF / ...Vanilla
+    (cpu/PPRCPUMTCilkRevVariants.h) at -t 1, batch after batch, also through hub tables, big rows and between sweeps."""
+    sc = make(directed, c=20, tuning=dict(tuning, variant=variant))
     sc.s.trace(True)
     sc.e.trace_enable(sc.slot, True)
     sc.s.variant_execute(sc.g, variant)
@@ -845,6 +853,32 @@ def test_incremental_graph_equals_full_rebuild(directed):
             assert np.array_equal(ra, rb) and np.array_equal(ca, cb) and np.array_equal(da, db)
             oa, ob = a.e.read_out_graph(), b.e.read_out_graph()
             assert np.array_equal(oa[0], ob[0]) and np.array_equal(oa[1], ob[1])
+
+
+@pytest.mark.parametrize("tuning", VARIANT_TUNINGS, ids=VARIANT_IDS)
+@pytest.mark.parametrize("directed", [1, 0])
+def test_eager_variant_with_status_array_filter(directed, tuning):
+    """dppr_set_variant(2 EAGER): eager residual reads, next frontier through the status array
+    (legal(curr) && atomicExch(status[v], level) < level, gpu/ExpandRev.cuh:255,298,340) instead of the crossing test. Against
+    the oracle's restatement of PPRCPUMTCilkRevEager and of the default variant (bit-identical to each other at -t 1) within the
+    north-star tolerance, plus the reference's Validate() criteria."""
+    eps = 1e-9
+    sc = make(directed, c=30, eps=eps, tuning=dict(tuning, variant=2))
+    v2 = orc.State(sc.V, sc.source, eps)
+    sc.s.cilk_execute(sc.g)
+    v2.variant_execute(sc.g, 2)
+    sc.e.init_solve(sc.slot, eps)
+    for k in range(6):
+        if k:
+            assert sc.advance_graphs()
+            sc.s.cilk_inc_execute(sc.g)
+            v2.variant_inc_execute(sc.g, 2)
+            sc.e.update(sc.slot, eps)
+        p, r = sc.e.read(sc.slot)
+        assert np.array_equal(v2.p, sc.s.p)                       # the reference's variants 0 and 2 are one schedule
+        assert np.max(np.abs(r)) < eps and np.max(np.abs(p - v2.p)) < NORTH_STAR_TOL
+        src, dst = window_directed_edges(sc.g)
+        assert invariant_max_err_np(p, r, src, dst, sc.V, sc.source) < INVARIANT_TOL
 
 
 MERGE_TUNINGS = [dict(pull_min_frontier=-1), dict(hub_min_degree=3, big_row_edges=8, pull_min_frontier=-1), dict(pull_min_frontier=1, persistent=0),

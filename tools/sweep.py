@@ -4,7 +4,9 @@ vary the batch size (-n 1 -c C -l TOTAL), the variant (-o), or epsilon (-e), log
 scrape the last `ppr_latency` / `ppr_throughput` lines (the stdout contract of gpu/PPRGPU.cuh:170-176).
 
     tools/sweep.py batch_size --data g.bin --directed 0 --source 1 [--log-dir log]
-    tools/sweep.py variant    --data g.bin --directed 0 --source 1
+    tools/sweep.py variant    --data g.bin --directed 0 --source 1        (each -o 0..3 as the engine runs it AND with --push-only: the
+                                                                            variants are mechanisms of the push iterations -- gpu/ExpandRev.cuh's
+                                                                            four Expand kernels --, which the pull sweeps otherwise replace)
     tools/sweep.py epsilon    --data g.bin --directed 0 --source 1
 """
 import argparse
@@ -51,10 +53,13 @@ def main():
                     os.path.join(a.log_dir, f"batch_size_{name}_{c}_{a.source}.txt"))
             rows.append({"batch_size": c, **r})
     elif a.what == "variant":
+        names = ["OPTIMIZED (eager read, crossing filter)", "FAST_FRONTIER (pre-extracted, crossing filter)",
+                 "EAGER (eager read, status-array filter)", "VANILLA (pre-extracted, status-array filter)"]
         for v in range(4):
-            r = run(base + ["-n", "0", "-r", "0.01", "-b", "100", "-o", str(v)],
-                    os.path.join(a.log_dir, f"op_gpu_{name}_{v}_{a.source}.txt"))
-            rows.append({"variant": v, **r})
+            for extra in ([], ["--push-only"]):
+                r = run(base + ["-n", "0", "-r", "0.01", "-b", "100", "-o", str(v)] + extra,
+                        os.path.join(a.log_dir, f"op_gpu_{name}_{v}_{a.source}{'_push_only' if extra else ''}.txt"))
+                rows.append({"variant": v, "name": names[v], "push_only": bool(extra), **r})
     else:
         for e in EPSILONS:
             r = run(base + ["-n", "0", "-r", "0.01", "-b", "100", "-e", e],
