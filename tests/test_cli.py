@@ -181,9 +181,9 @@ def test_sweep_tool_scrapes_the_stdout_contract(pagerank, small_bin, tmp_path):
              "--source", str(src), "--log-dir", str(tmp_path / "log")])
     assert r.returncode == 0, r.stdout
     rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert [x["variant"] for x in rows] == [0, 1, 2, 3]
+    assert [(x["variant"], x["push_only"]) for x in rows] == [(v, po) for v in range(4) for po in (False, True)]   # the ablation table
     assert all(x["ppr_latency_ms"] and x["ppr_throughput"] and x["ppr_throughput"] > 0 for x in rows)
-    assert len(os.listdir(tmp_path / "log")) == 4
+    assert len(os.listdir(tmp_path / "log")) == 8
 
 
 @pytest.mark.gpu
