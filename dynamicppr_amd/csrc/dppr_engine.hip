@@ -36,6 +36,7 @@ static constexpr int CNT_HDR = 16;
 static constexpr int PERSIST_RETRY_BATCHES = 64; // after a failed roll-call: batches on per-iteration launches before the next try
 static constexpr int GMULTI_MAX = 2 * MAX_CHUNK; // sweeps a multi-sweep launch of a source group may run
 static constexpr int BIN_MAX_BLOCKS = 1 << 16, BIN_MAX_BIG = 4096, BIN_SMALL_INTS = BIN_MAX_BLOCKS + BIN_MAX_BIG + 1 + 64; // bin_cut scratch
+static constexpr int SU_SPLIT_MIN = 1 << 16;  // batch records from which IncrementalBatchUpdate runs as k_su_terms + k_su_apply (stream_update)
 static constexpr int RESIDENT_MARGIN = 8; // sweeps a resident launch is given beyond what the last batch needed
 
 namespace {
@@ -1395,8 +1396,21 @@ int stream_update(dppr_engine *e, Slot &s, const Epoch &ep, double eps, bool see
                                    zero_bars ? (int)(sizeof(GridBar) / sizeof(unsigned long long)) : 0, s.cnt, 5);
     if (rc) return rc;
     // without seeding the lists go to scratch space (cnt[4] / neg) and are ignored
-    hipLaunchKernelGGL(k_su_apply_fused, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, e->su_k[1], e->su_v[1], ep.b2, ep.ins,
-                       ep.deg_after, L, s.p, s.r, s.source, seed ? eps : 1e300, s.ft[0], s.cnt + 0, s.neg, s.cnt + 3);
+    if (L >= SU_SPLIT_MIN) {
+        // Large batches: a hub's tail owns thousands of records, and the fused kernel's leader walks what lies beyond its
+        // 1 024-record LDS window through three dependent gathers per record (twitter stand-in, 2.9 M records: 3.0 ms of a batch).
+        // The terms of ALL records are computed in parallel first; the leaders then walk contiguous arrays (same expressions,
+        // same order: bit-identical, the form source groups use).
+        SuSources srcs{};
+        srcs.s[0] = s.source;
+        hipLaunchKernelGGL(k_su_terms, dim3(grid_for(L), 1), dim3(BLOCK), 0, e->stream, e->su_k[1], e->su_v[1], ep.b2, ep.ins, L, s.p, 1,
+                           e->su_term, e->su_ins);
+        hipLaunchKernelGGL(k_su_apply, dim3(grid_for(L), 1), dim3(BLOCK), 0, e->stream, e->su_k[1], e->su_v[1], e->su_term, e->su_ins,
+                           ep.deg_after, L, s.r, 1, srcs, seed ? eps : 1e300, s.ft[0], s.cnt + 0, s.neg, s.cnt + 3);
+    } else {
+        hipLaunchKernelGGL(k_su_apply_fused, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, e->su_k[1], e->su_v[1], ep.b2, ep.ins,
+                           ep.deg_after, L, s.p, s.r, s.source, seed ? eps : 1e300, s.ft[0], s.cnt + 0, s.neg, s.cnt + 3);
+    }
     HIP_TRY(hipGetLastError());
     s.st.records += L;
     return DPPR_OK;

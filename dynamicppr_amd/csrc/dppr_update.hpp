@@ -67,48 +67,104 @@ __global__ __launch_bounds__(BLOCK) void k_su_terms(const uint32_t *__restrict__
 struct SuSources {
     int s[16]; // source vertex per lane (blockIdx.y)
 };
+// A tail's records are applied one after the other (the order is the point). Short groups: by their leader's lane. A group of
+// more than SU_LONG records (a hub's tail in a batch of millions: thousands) would leave that one lane walking global memory at
+// one load latency per record: its leader only notes it, and the WAVE then walks it together -- 64 terms per coalesced load,
+// the recurrence evaluated uniformly by all lanes (same operations in the same order: bit-identical).
+constexpr int SU_LONG = 96;
 __global__ __launch_bounds__(BLOCK) void k_su_apply(const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ svals,
                                                     const double *__restrict__ term_base, const uint8_t *__restrict__ sins,
                                                     const int *__restrict__ deg_after, int L, double *__restrict__ r_base,
                                                     int stride, SuSources srcs, double eps, int *__restrict__ ft_pos,
                                                     int *__restrict__ cnt_pos, int *__restrict__ ft_neg,
                                                     int *__restrict__ cnt_neg) {
+    __shared__ int s_long[WAVES_PER_BLOCK][WAVE][2]; // (first record, end) of the long groups a wave's lanes lead
     double *r = r_base + blockIdx.y;
     const double *term = term_base + (size_t)blockIdx.y * (size_t)L;
     const int source = srcs.s[blockIdx.y];
     const bool seed = ft_pos != nullptr; // groups seed densely instead (k_gseed)
     const int nthreads = gridDim.x * BLOCK;
+    const int lane = lane_id(), w = wave_id();
     for (int j0 = blockIdx.x * BLOCK; j0 < L; j0 += nthreads) {
         const int j = j0 + threadIdx.x;
-        bool pos = false, neg = false;
-        int u = 0;
+        bool pos = false, neg = false, is_long = false;
+        int u = 0, end = 0;
         if (j < L) {
             u = (int)skeys[j];
             const bool leader = (j == 0) || ((int)skeys[j - 1] != u);
             if (leader) {
-                int end = j;
-                int delta = 0; // post-batch degree minus pre-batch degree
-                while (end < L && (int)skeys[end] == u) {
-                    delta += sins[end] ? 1 : -1;
-                    ++end;
+                int lo = j, hi = L; // end of the group: first record behind j whose tail is not u (the keys are sorted)
+                while (hi - lo > 1) {
+                    const int mid = lo + ((hi - lo) >> 1);
+                    if ((int)skeys[mid] == u) lo = mid; else hi = mid;
                 }
-                int d = deg_after[svals[j]] - delta; // RevertOutDegree (gpu/StreamUpdate.cuh:18-33)
-                double ru = r[(size_t)u * stride];
-                const double src_term = ALPHA * (source == u ? 1.0 : 0.0);
-                for (int k = j; k < end; ++k) {
-                    const double add = term[k] - ALPHA * ru + src_term;
-                    if (sins[k]) {
-                        d++;
-                        ru += add / (double)(d + 1) / ALPHA;
-                    } else {
-                        d--;
-                        ru -= add / (double)(d + 1) / ALPHA;
+                end = hi;
+                is_long = end - j > SU_LONG;
+                if (!is_long) {
+                    int delta = 0; // post-batch degree minus pre-batch degree
+                    for (int k = j; k < end; ++k) delta += sins[k] ? 1 : -1;
+                    int d = deg_after[svals[j]] - delta; // RevertOutDegree (gpu/StreamUpdate.cuh:18-33)
+                    double ru = r[(size_t)u * stride];
+                    const double src_term = ALPHA * (source == u ? 1.0 : 0.0);
+                    for (int k = j; k < end; ++k) {
+                        const double add = term[k] - ALPHA * ru + src_term;
+                        if (sins[k]) {
+                            d++;
+                            ru += add / (double)(d + 1) / ALPHA;
+                        } else {
+                            d--;
+                            ru -= add / (double)(d + 1) / ALPHA;
+                        }
+                    }
+                    r[(size_t)u * stride] = ru;
+                    pos = seed && ru > eps;
+                    neg = seed && ru < -eps;
+                }
+            }
+        }
+        // ---- the wave's long groups, one after the other, all lanes together
+        const uint64_t ml = __ballot(is_long);
+        if (ml) { // wave-uniform
+            if (is_long) {
+                s_long[w][mbcnt(ml)][0] = j;
+                s_long[w][mbcnt(ml)][1] = end;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int n_long = __popcll(ml);
+            for (int g = 0; g < n_long; ++g) {
+                const int gj = s_long[w][g][0], gend = s_long[w][g][1];
+                const int gu = (int)skeys[gj];
+                int part = 0;
+                for (int k = gj + lane; k < gend; k += WAVE) part += sins[k] ? 1 : -1;
+                const int delta = __builtin_amdgcn_readlane(wave_inclusive_scan(part), WAVE - 1);
+                int d = deg_after[svals[gj]] - delta;
+                double ru = r[(size_t)gu * stride];
+                const double src_term = ALPHA * (source == gu ? 1.0 : 0.0);
+                for (int base = gj; base < gend; base += WAVE) {
+                    const int k = base + lane;
+                    const double tk = k < gend ? term[k] : 0.0;
+                    const int ik = k < gend ? (int)sins[k] : 0;
+                    const int n = min(WAVE, gend - base);
+                    for (int i = 0; i < n; ++i) { // wave-uniform: every lane evaluates the same recurrence
+                        const double t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tk), i), __builtin_amdgcn_readlane(__double2loint(tk), i));
+                        const int is_ins = __builtin_amdgcn_readlane(ik, i);
+                        const double add = t - ALPHA * ru + src_term;
+                        if (is_ins) {
+                            d++;
+                            ru += add / (double)(d + 1) / ALPHA;
+                        } else {
+                            d--;
+                            ru -= add / (double)(d + 1) / ALPHA;
+                        }
                     }
                 }
-                r[(size_t)u * stride] = ru;
-                pos = seed && ru > eps;
-                neg = seed && ru < -eps;
+                if (lane == 0) {
+                    r[(size_t)gu * stride] = ru;
+                    if (seed && ru > eps) ft_pos[atomicAdd(cnt_pos, 1)] = gu;
+                    if (seed && ru < -eps) ft_neg[atomicAdd(cnt_neg, 1)] = gu;
+                }
             }
+            __builtin_amdgcn_wave_barrier();
         }
         // wave-aggregated appends
         uint64_t m = __ballot(pos);

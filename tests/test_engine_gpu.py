@@ -146,15 +146,19 @@ def test_incremental_batch_update_hub_tail_many_records():
     assert np.array_equal(r, sc.s.r)
 
 
-@pytest.mark.parametrize("shape", ["group-beyond-lds-window", "more-records-than-one-grid-pass"])
+@pytest.mark.parametrize("shape", ["group-beyond-lds-window", "more-records-than-one-grid-pass", "hub-tail-in-a-large-batch"])
 def test_incremental_batch_update_large_batches(shape):
-    """k_su_apply_fused stages 1024 sorted records per workgroup in LDS and covers 2048 x 256
-    records per grid pass: a tail group longer than the window finishes from global memory, and a
-    batch longer than one pass loops -- both still bit-identical to the CPU order."""
+    """k_su_apply_fused stages 1024 sorted records per workgroup in LDS: a tail group longer than the window finishes
+    from global memory. From 65 536 records on, the terms of all records are computed in parallel first and the group leaders
+    walk contiguous arrays (k_su_terms + k_su_apply: a hub's tail owns thousands of records there), over several grid
+    passes -- all still bit-identical to the CPU order."""
     rng = np.random.default_rng(7)
     if shape == "group-beyond-lds-window":
         V, W, c, n = 64, 4000, 3000, 12000          # 70 % of the records share tail 5: a ~4000-record group
         e1 = np.where(rng.random(n) < 0.7, 5, rng.integers(0, V, n)).astype(np.int32)
+    elif shape == "hub-tail-in-a-large-batch":
+        V, W, c, n = 4096, 200000, 60000, 400000    # L = 120 000; 30 % of the records share tail 5: a ~36 000-record group
+        e1 = np.where(rng.random(n) < 0.3, 5, rng.integers(0, V, n)).astype(np.int32)
     else:
         V, W, c, n = 4096, 300000, 270000, 900000   # L = 2c = 540 000 > 524 288
         e1 = rng.integers(0, V, n).astype(np.int32)
