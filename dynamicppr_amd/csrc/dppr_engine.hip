@@ -213,9 +213,10 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     // binned sweep of single-source loops on windows far beyond the L2s (dppr_binned.hpp, dppr_set_binned_sweep)
     int bin_mode = 1;               // 0: never, 1: when a source slot exists and the window has >= bin_min_ids vertices, 2: always
     int bin_ha_tiles = 128, bin_hb_tiles = 48; // an A-block holds at most 64 x ha_tiles heads (8 B of LDS each), a B-block 64 x hb_tiles rows (20 B each)
-    long long bin_target = 196608;  // edges a B-block is cut for (one workgroup of k_bin_reduce)
+    long long bin_target = 0;       // edges a B-block is cut for (one workgroup of k_bin_reduce); 0: from the window, clamp(Ed / 256, 16 K, 192 K)
+                                    // (measured: LiveJournal stand-in best at 16-32 K, twitter / friendster at 192 K)
     long long bin_target_a = 4ll << 20; // ... an A-block (its edges are dealt to workgroups of k_bin_scatter in chunks: large, so that tiles are long runs)
-    long long bin_min_ids = 6ll << 20; // 48 MB of snapshot: beyond what the eight L2s hold together
+    long long bin_min_ids = 1ll << 20; // (smaller windows run resident, or are too small to fill the chip with blocks)
     uint32_t *bin_k[2] = {nullptr, nullptr}; // sort keys (Ed each)
     int *bin_vblk_a = nullptr, *bin_vblk_b = nullptr; // vertex -> block (V each)
     int *bin_small = nullptr;       // quantile vertices | big rows | counter (bin_cut)
@@ -846,7 +847,8 @@ int build_bins(dppr_engine *e, Epoch &ep) {
     }
     std::vector<int32_t> cut_a, cut_b;
     if (int rc = bin_cut(e, ep.row_ptr, NV, e->bin_ha_tiles * WAVE, e->bin_target_a, cut_a)) return rc;
-    if (int rc = bin_cut(e, ep.out_row_ptr, NV, e->bin_hb_tiles * WAVE, e->bin_target, cut_b)) return rc;
+    if (int rc = bin_cut(e, ep.out_row_ptr, NV, e->bin_hb_tiles * WAVE,
+                         e->bin_target > 0 ? e->bin_target : std::min<long long>(std::max<long long>(Ed / 256, 16384), 196608), cut_b)) return rc;
     ep.n_a = (int)cut_a.size() - 1;
     ep.n_b = (int)cut_b.size() - 1;
     int abits = 1, bbits = 1;

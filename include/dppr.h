@@ -167,8 +167,9 @@ int dppr_set_sweep_bitmap(dppr_engine *e, int on);
  *                  an id, 2 always (tests: tiny windows)
  *   ha_tiles     : an A-block holds at most 64 x ha_tiles heads (8 bytes of LDS per head; 0 keeps the default, 128)
  *   hb_tiles     : a B-block holds at most 64 x hb_tiles rows (20 bytes of LDS per row; 0 keeps 48)
- *   target_edges : edges a B-block is cut for (0 keeps 196608); a row of a quarter of that is a block of its own
- *   min_ids      : mode 1 threshold (0 keeps 6 Mi: 48 MB of snapshot)
+ *   target_edges : edges a B-block is cut for (0 keeps the automatic choice, clamp(window edges / 256, 16 Ki, 192 Ki)); a row of a
+ *                  quarter of that is a block of its own
+ *   min_ids      : mode 1 threshold (0 keeps 1 Mi vertices with an id: smaller windows run resident or cannot fill the chip with blocks)
  *   chunk_edges  : edges per workgroup of k_bin_scatter (0 keeps 32768)
  *   target_a_edges : edges an A-block is cut for (0 keeps 4 Mi: large, the longer the runs a tile's values are written in)
  * The layout costs 8 bytes per window edge and epoch plus 16 bytes per window edge of scratch, and is built in
