@@ -794,10 +794,11 @@ int bin_prepare(dppr_engine *e) { // engine-level scratch, once
     HIP_TRY(hipMalloc((void **)&e->bin_vals, sizeof(double) * (Edn + 64)));
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, e->bin_tmp_bytes, e->bin_k[0], e->bin_k[1], e->keys_a, e->keys_b, Edn, 0u, 32u, e->stream));
     HIP_TRY(hipMalloc(&e->bin_tmp, std::max<size_t>(e->bin_tmp_bytes, 16)));
+    // (the attribute belongs to the kernel, not to this engine: the largest shapes dppr_set_binned_sweep admits, so that engines
+    // with different block shapes can share a process)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                e->bin_ha_tiles * WAVE * (int)sizeof(double)));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_reduce), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                e->bin_hb_tiles * WAVE * 20));
+                                272 * WAVE * (int)sizeof(double)));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_reduce), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * WAVE * 20));
     e->bin_ready = true;
     return DPPR_OK;
 }
