@@ -51,6 +51,8 @@ struct Epoch {
     int *b1 = nullptr, *b2 = nullptr, *deg_after = nullptr; // 4c each
     uint8_t *ins = nullptr;
     int L = 0;
+    uint32_t *sk = nullptr, *sv = nullptr; // the batch's records grouped by tail at slide time: tails ascending, record indices (stable)
+    bool grouped = false;
     int id = -1; // global epoch number stored in this ring entry
     // sweep groups: tiles [grp_tile[g], grp_tile[g+1]) per workgroup, about equal edges each
     int *grp_tile = nullptr; // V/64 + 2
@@ -153,6 +155,7 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     // the reference's variants (-o, gpu/PPRRevPushGPUVariants.cuh) as mechanisms of the push iterations: dppr_set_variant
     bool status_dedup = false; // duplicate filter of a push iteration: status array (EAGER 2, VANILLA 3) instead of the threshold crossing
     bool pre_extract = false;  // synchronous push iterations zero residual[u] at the snapshot (InspectExtra: FAST_FRONTIER 1, VANILLA 3) instead of repairing
+    bool group_at_slide = true; // the batch's records are grouped by tail when the batch is uploaded (dppr_slide), not inside dppr_update (dppr_set_batch_grouping)
     bool merge_phases = false; // dppr_set_phase_merge: one loop for residuals of both signs (eager schedule only)
     int merge_div = 4;         // ... run to eps / merge_div
     hipStream_t stream = nullptr;
@@ -1377,8 +1380,32 @@ int main_loop_inspect(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
 // Stable grouping of the epoch's batch records by tail: su_k[1] = tails ascending, su_v[1] = record indices
 // (ascending inside a tail): key extraction + the device radix sort. `zero` / `zero_ints` are cleared on the
 // way (the counters of what follows).
+inline const uint32_t *batch_tails(const dppr_engine *e, const Epoch &ep) { return ep.grouped ? ep.sk : e->su_k[1]; }
+inline const uint32_t *batch_order(const dppr_engine *e, const Epoch &ep) { return ep.grouped ? ep.sv : e->su_v[1]; }
+
+// The grouping is a function of the batch's records alone (not of any solver state): by default it is done once, when the batch
+// is uploaded (dppr_slide -> epoch_group_records; the reference uploads its GPUEdgeBatch untimed as well, gpu/PPRGPU.cuh:131-135),
+// and the timed region starts with a kernel that only clears the loop's counters. dppr_set_batch_grouping(e, 0) keeps it inside
+// dppr_update (the accounting of rounds 1-2: + 5 dispatches of the device radix sort per batch).
+int epoch_group_records(dppr_engine *e, Epoch &ep) {
+    ep.grouped = false;
+    if (!e->group_at_slide || ep.L <= 0) return DPPR_OK;
+    hipLaunchKernelGGL(k_su_keys, dim3(grid_for(ep.L)), dim3(BLOCK), 0, e->stream, ep.b1, ep.L, e->su_k[0], e->su_v[0],
+                       (unsigned long long *)nullptr, 0, (int *)nullptr, 0);
+    size_t tmp = e->su_tmp_bytes;
+    HIP_TRY(rocprim::radix_sort_pairs(e->su_tmp, tmp, e->su_k[0], ep.sk, e->su_v[0], ep.sv, (size_t)ep.L, 0u, (unsigned)e->bits, e->stream));
+    ep.grouped = true;
+    return DPPR_OK;
+}
+
 int group_records_by_tail(dppr_engine *e, const Epoch &ep, unsigned long long *zero, int nz, int *zero_ints, int nzi) {
     const int L = ep.L;
+    if (ep.grouped) { // only the counters (and the GridBar of a resident launch enqueued ahead) are cleared here
+        if (nz > 0 || nzi > 0)
+            hipLaunchKernelGGL(k_su_keys, dim3(1), dim3(BLOCK), 0, e->stream, ep.b1, 0, e->su_k[0], e->su_v[0], zero, nz, zero_ints, nzi);
+        HIP_TRY(hipGetLastError());
+        return DPPR_OK;
+    }
     hipLaunchKernelGGL(k_su_keys, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->su_k[0], e->su_v[0], zero, nz,
                        zero_ints, nzi);
     size_t tmp = e->su_tmp_bytes;
@@ -1387,7 +1414,6 @@ int group_records_by_tail(dppr_engine *e, const Epoch &ep, unsigned long long *z
     return DPPR_OK;
 }
 
-// IncrementalBatchUpdate; when seed != 0 also seeds ft[0]/cnt[0] (phase 0) and neg/cnt[3].
 int stream_update(dppr_engine *e, Slot &s, const Epoch &ep, double eps, bool seed, bool zero_bars = false) {
     const int L = ep.L;
     if (L == 0) {
@@ -1406,12 +1432,12 @@ int stream_update(dppr_engine *e, Slot &s, const Epoch &ep, double eps, bool see
         // same order: bit-identical, the form source groups use).
         SuSources srcs{};
         srcs.s[0] = s.source;
-        hipLaunchKernelGGL(k_su_terms, dim3(grid_for(L), 1), dim3(BLOCK), 0, e->stream, e->su_k[1], e->su_v[1], ep.b2, ep.ins, L, s.p, 1,
+        hipLaunchKernelGGL(k_su_terms, dim3(grid_for(L), 1), dim3(BLOCK), 0, e->stream, batch_tails(e, ep), batch_order(e, ep), ep.b2, ep.ins, L, s.p, 1,
                            e->su_term, e->su_ins);
-        hipLaunchKernelGGL(k_su_apply, dim3(grid_for(L), 1), dim3(BLOCK), 0, e->stream, e->su_k[1], e->su_v[1], e->su_term, e->su_ins,
+        hipLaunchKernelGGL(k_su_apply, dim3(grid_for(L), 1), dim3(BLOCK), 0, e->stream, batch_tails(e, ep), batch_order(e, ep), e->su_term, e->su_ins,
                            ep.deg_after, L, s.r, 1, srcs, seed ? eps : 1e300, s.ft[0], s.cnt + 0, s.neg, s.cnt + 3);
     } else {
-        hipLaunchKernelGGL(k_su_apply_fused, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, e->su_k[1], e->su_v[1], ep.b2, ep.ins,
+        hipLaunchKernelGGL(k_su_apply_fused, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, batch_tails(e, ep), batch_order(e, ep), ep.b2, ep.ins,
                            ep.deg_after, L, s.p, s.r, s.source, seed ? eps : 1e300, s.ft[0], s.cnt + 0, s.neg, s.cnt + 3);
     }
     HIP_TRY(hipGetLastError());
@@ -1564,10 +1590,10 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
         HIP_TRY(hipMemsetAsync(g.act[0], 0, g.act_bytes, e->stream));
         if (ep.L > 0) {
             if (g.spl == 1)
-                hipLaunchKernelGGL(k_gseed_tails<1>, dim3(grid_for(ep.L, BLOCK / OCT)), dim3(BLOCK), 0, e->stream, e->su_k[1],
+                hipLaunchKernelGGL(k_gseed_tails<1>, dim3(grid_for(ep.L, BLOCK / OCT)), dim3(BLOCK), 0, e->stream, batch_tails(e, ep),
                                    ep.L, g.r, g.x, g.p, g.act[0], phase, eps, g.cnt + cur * GWM);
             else
-                hipLaunchKernelGGL(k_gseed_tails<2>, dim3(grid_for(ep.L, BLOCK / OCT)), dim3(BLOCK), 0, e->stream, e->su_k[1],
+                hipLaunchKernelGGL(k_gseed_tails<2>, dim3(grid_for(ep.L, BLOCK / OCT)), dim3(BLOCK), 0, e->stream, batch_tails(e, ep),
                                    ep.L, g.r, g.x, g.p, g.act[0], phase, eps, g.cnt + cur * GWM);
         }
     } else {
@@ -1776,9 +1802,9 @@ int group_stream_update(dppr_engine *e, Group &g, const Epoch &ep) {
     SuSources srcs{};
     for (int s = 0; s < GS_MAX; ++s) srcs.s[s] = g.src.s[s];
     // blockIdx.y = source lane; state element (v, lane) at base[v * gw + lane]
-    hipLaunchKernelGGL(k_su_terms, dim3(grid_for(L), g.n), dim3(BLOCK), 0, e->stream, e->su_k[1], e->su_v[1], ep.b2,
+    hipLaunchKernelGGL(k_su_terms, dim3(grid_for(L), g.n), dim3(BLOCK), 0, e->stream, batch_tails(e, ep), batch_order(e, ep), ep.b2,
                        ep.ins, L, g.p, g.gw, e->su_term, e->su_ins);
-    hipLaunchKernelGGL(k_su_apply, dim3(grid_for(L), g.n), dim3(BLOCK), 0, e->stream, e->su_k[1], e->su_v[1], e->su_term,
+    hipLaunchKernelGGL(k_su_apply, dim3(grid_for(L), g.n), dim3(BLOCK), 0, e->stream, batch_tails(e, ep), batch_order(e, ep), e->su_term,
                        e->su_ins, ep.deg_after, L, g.r, g.gw, srcs, 0.0, (int *)nullptr, (int *)nullptr, (int *)nullptr,
                        (int *)nullptr);
     HIP_TRY(hipGetLastError());
@@ -1906,6 +1932,8 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
         HIP_TRY_C(hipMalloc((void **)&ep.b2, sizeof(int) * Ln));
         HIP_TRY_C(hipMalloc((void **)&ep.deg_after, sizeof(int) * Ln));
         HIP_TRY_C(hipMalloc((void **)&ep.ins, Ln));
+        HIP_TRY_C(hipMalloc((void **)&ep.sk, sizeof(uint32_t) * Ln));
+        HIP_TRY_C(hipMalloc((void **)&ep.sv, sizeof(uint32_t) * Ln));
         HIP_TRY_C(hipMalloc((void **)&ep.grp_tile, sizeof(int) * ((size_t)V / WAVE + 3)));
         HIP_TRY_C(hipMalloc((void **)&ep.ggrp_tile, sizeof(int) * ((size_t)V / WAVE + 3)));
         HIP_TRY_C(hipMalloc((void **)&ep.hub_v, sizeof(int) * HUB_CAP));
@@ -1932,7 +1960,7 @@ void dppr_destroy(dppr_engine *e) {
     }
     for (auto &ep : e->epochs) {
         (void)hipFree(ep.row_ptr); (void)hipFree(ep.adj); (void)hipFree(ep.out_row_ptr); (void)hipFree(ep.out_col); (void)hipFree(ep.b1); (void)hipFree(ep.b2);
-        (void)hipFree(ep.deg_after); (void)hipFree(ep.ins); (void)hipFree(ep.hub_v); (void)hipFree(ep.hub_degp1); (void)hipFree(ep.grp_tile); (void)hipFree(ep.ggrp_tile); (void)hipFree(ep.gtab);
+        (void)hipFree(ep.deg_after); (void)hipFree(ep.ins); (void)hipFree(ep.sk); (void)hipFree(ep.sv); (void)hipFree(ep.hub_v); (void)hipFree(ep.hub_degp1); (void)hipFree(ep.grp_tile); (void)hipFree(ep.ggrp_tile); (void)hipFree(ep.gtab);
         (void)hipFree(ep.acut); (void)hipFree(ep.chunks); (void)hipFree(ep.hl); (void)hipFree(ep.dl); (void)hipFree(ep.apos);
     }
     for (int k = 0; k < 2; ++k) (void)hipFree(e->bin_k[k]);
@@ -1958,6 +1986,12 @@ void dppr_destroy(dppr_engine *e) {
 int dppr_set_schedule(dppr_engine *e, int schedule) {
     if (!e || (schedule != DPPR_SCHEDULE_EAGER && schedule != DPPR_SCHEDULE_SYNC)) return DPPR_ERR_INVALID;
     e->schedule = schedule;
+    return DPPR_OK;
+}
+
+int dppr_set_batch_grouping(dppr_engine *e, int at_slide) {
+    if (!e) return DPPR_ERR_INVALID;
+    e->group_at_slide = at_slide != 0; // (applies to the epochs dppr_slide builds from now on)
     return DPPR_OK;
 }
 
@@ -2130,6 +2164,7 @@ int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32
     for (auto &ep : e->epochs) ep.id = -1;
     Epoch &ep = e->epochs[0];
     ep.L = 0;
+    ep.grouped = false;
     int rc = query_persist_cap(e);
     if (rc) return rc;
     rc = sort_window_full(e);
@@ -2228,6 +2263,7 @@ int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, 
     if (rc) return rc;
     mark("hubs, CSRs, group cut + tables");
     ep.L = 0;
+    ep.grouped = false;
     if (e->batch_staged) {
         const int L = (int)e->st_b1.size();
         ep.L = L;
@@ -2239,6 +2275,7 @@ int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, 
             hipLaunchKernelGGL(k_gather_deg, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->outdeg,
                                ep.deg_after);
             HIP_TRY(hipGetLastError());
+            if (int grc = epoch_group_records(e, ep)) return grc; // the records grouped by tail, for IncrementalBatchUpdate
         }
     }
     HIP_TRY(hipStreamSynchronize(e->stream)); // staged host vectors may be reused now

@@ -78,6 +78,13 @@ typedef struct dppr_stats_t {
  * its own map `-g N` device threads onto the devices that exist. No reference counterpart (single implicit device 0). */
 int dppr_device_count(void);
 
+/* IncrementalBatchUpdate replays a batch's records tail by tail, each tail's records in batch order (lock-free; the
+ * reference serialises them with a spin lock per tail, gpu/StreamUpdate.cuh:50-72). The grouping by tail is a function of the
+ * batch alone. at_slide = 1 (default): dppr_slide does it when it uploads the batch -- untimed, like the reference's own batch
+ * upload (GPUEdgeBatch::CudaMemcpy, gpu/PPRGPU.cuh:131-135) -- and the timed region holds only the replay; at_slide = 0: the
+ * grouping (a device radix sort of the L records) runs inside dppr_update / dppr_group_update, as in rounds 1-2. Same results. */
+int dppr_set_batch_grouping(dppr_engine *e, int at_slide);
+
 /* The reference's four variants (-o, Meta.h; gpu/PPRRevPushGPUVariants.cuh:6-150) as MECHANISMS of the push iterations:
  *   0 OPTIMIZED     eager residual read + threshold-crossing duplicate filter (ExpandUnifiedRev + RepairFrontierRev)      [default]
  *   1 FAST_FRONTIER residuals pre-extracted and zeroed at the snapshot (InspectExtra, gpu/Inspect.cuh:51-65), crossing filter, no repair

@@ -46,11 +46,13 @@ TUNINGS = [dict(pull_min_frontier=-1), dict(hub_min_degree=3, big_row_edges=8, p
            # vertices): one-tile blocks of ~64 edges (dozens of blocks, every tile a handful of edges), the default
            # block shape (one block each), and mixed with push iterations in chunks of 3
            dict(pull_min_frontier=1, persistent=0, binned=(2, 1, 1, 64, 0, 64, 64)), dict(pull_min_frontier=1, persistent=0, binned=2),
-           dict(pull_min_frontier=40, persistent=0, binned=(2, 2, 3, 200, 0, 100, 500), chunk_iters=3)]
+           dict(pull_min_frontier=40, persistent=0, binned=(2, 2, 3, 200, 0, 100, 500), chunk_iters=3),
+           # the batch's records grouped by tail inside the timed region (rounds 1-2) instead of at slide time
+           dict(group_at_slide=0), dict(pull_min_frontier=1, group_at_slide=0)]
 TUNING_IDS = ["push-only", "push-hubs+bigrows", "push-all-hub-all-big", "pull-only", "mixed-pull>=40", "default",
               "mixed-chunk1", "mixed-chunk3", "pull-wg512", "mixed-wg1024", "pull-no-persist", "pull-wg256",
               "pull-rollcall-fails", "pull-resident-3-sweeps", "pull-bitmap-wg256", "mixed-bitmap", "pull-bitmap-wg640",
-              "binned-tiny-blocks", "binned-one-block", "mixed-binned-chunk3"]
+              "binned-tiny-blocks", "binned-one-block", "mixed-binned-chunk3", "grouping-in-update", "pull-grouping-in-update"]
 
 
 def make(directed, schedule=eng.SCHEDULE_EAGER, scale=9, edges=6000, seed=11, W=600, c=6, eps=1e-9, n_epochs=1,
@@ -109,10 +111,12 @@ def test_inspect_frontier_bit_exact(phase):
     assert len(sc.e.inspect(sc.slot, phase, eps)) == 0
 
 
+@pytest.mark.parametrize("at_slide", [1, 0])
 @pytest.mark.parametrize("directed", [1, 0])
-def test_incremental_batch_update_bit_exact(directed):
-    """r after IncrementalBatchUpdate == cpu/PPRCPUMTCilkRev.h:108-124 at -t 1, bit for bit."""
-    sc = make(directed, c=50)
+def test_incremental_batch_update_bit_exact(directed, at_slide):
+    """r after IncrementalBatchUpdate == cpu/PPRCPUMTCilkRev.h:108-124 at -t 1, bit for bit (records grouped by tail when the
+    batch is uploaded, or inside the call: dppr_set_batch_grouping)."""
+    sc = make(directed, c=50, tuning=dict(group_at_slide=at_slide))
     sc.s.cilk_execute(sc.g)
     for k in range(4):
         sc.e.write(sc.slot, sc.s.p.copy(), sc.s.r.copy())
