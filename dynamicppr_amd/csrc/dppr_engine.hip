@@ -285,6 +285,18 @@ inline int grid_for(int64_t n, int per_block = BLOCK, int cap = 2048) {
     return (int)g;
 }
 
+// Wait for the engine's stream from inside a frontier loop (the read-back at the end of a chunk of iterations): polling the
+// stream's completion instead of a blocking hipStreamSynchronize, whose wake-up is part of every chunk boundary's gap
+// (DPPR_SYNC_SPIN=0: the blocking call, for A/B runs).
+inline hipError_t loop_sync(hipStream_t st) {
+    static const bool spin = !(getenv("DPPR_SYNC_SPIN") && atoi(getenv("DPPR_SYNC_SPIN")) == 0);
+    if (!spin) return hipStreamSynchronize(st);
+    hipError_t r;
+    while ((r = hipStreamQuery(st)) == hipErrorNotReady) {
+    }
+    return r;
+}
+
 int fail(dppr_engine *e, int code, const char *msg) {
     if (e) e->err = msg;
     return code;
@@ -958,7 +970,7 @@ int build_epoch(dppr_engine *e, Epoch &ep) {
 
 int read_count(dppr_engine *e, const int *dptr, int *out) {
     HIP_TRY(hipMemcpyAsync(e->pinned, dptr, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(loop_sync(e->stream));
     *out = e->pinned[0];
     return DPPR_OK;
 }
@@ -1044,7 +1056,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             s.trace_ids.resize(old + (size_t)F);
             HIP_TRY(hipMemcpyAsync(s.trace_ids.data() + old, s.ft[buf], sizeof(int) * (size_t)F,
                                    hipMemcpyDeviceToHost, e->stream));
-            HIP_TRY(hipStreamSynchronize(e->stream));
+            HIP_TRY(loop_sync(e->stream));
             for (size_t i = old; i < s.trace_ids.size(); ++i) s.trace_ids[i] = e->int2ext[(size_t)s.trace_ids[i]];
             s.trace_off.push_back((int64_t)s.trace_ids.size());
         }
@@ -1095,7 +1107,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[1], e->stream));
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(e->pinned, s.cnt, sizeof(int) * (size_t)(CNT_HDR + n), hipMemcpyDeviceToHost, e->stream));
-            HIP_TRY(hipStreamSynchronize(e->stream));
+            HIP_TRY(loop_sync(e->stream));
             const int status = e->pinned[7];
             s.st.persist_launches++;
             if (status & PERSIST_FAULT) return fail(e, DPPR_ERR_HIP, "grid barrier of the resident sweep timed out");
@@ -1220,7 +1232,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
         HIP_TRY(hipGetLastError());
         // one read-back per chunk: the new frontier size and the F of each iteration just run
         HIP_TRY(hipMemcpyAsync(e->pinned, s.cnt, sizeof(int) * (size_t)(CNT_HDR + n), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(loop_sync(e->stream));
         for (int k = 0; k < n; ++k) {
             const int f = e->pinned[CNT_HDR + k];
             if (f <= 0) continue; // the frontier emptied inside the chunk: the rest were no-ops
@@ -1302,7 +1314,7 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
     if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[1], e->stream));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e->pinned, s.cnt, sizeof(int) * (size_t)(CNT_HDR + n), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(loop_sync(e->stream));
 
     const int st = e->pinned[7];
     *stage = 0;
@@ -1484,7 +1496,7 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
     const int GWM = GS_MAX;
     const int cap = std::max(1024, std::min(e->gpush_list_cap, e->V));
     if (g.plist_cap != cap) {
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(loop_sync(e->stream));
         (void)hipFree(g.plist[0]); (void)hipFree(g.plist[1]); (void)hipFree(g.ppre); (void)hipFree(g.pctl);
         g.plist[0] = g.plist[1] = g.ppre = nullptr;
         g.pctl = nullptr;
@@ -1546,7 +1558,7 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(&h, g.pctl, sizeof(GPushCtl), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(loop_sync(e->stream));
         for (int i = it_done; i < h.it; ++i) {
             long long F = 0;
             for (int s = 0; s < GWM; ++s) F += h.F[i & (GPUSH_LOG - 1)][s];
@@ -1614,7 +1626,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
         return false;
     };
     HIP_TRY(hipMemcpyAsync(e->pinned, g.cnt + cur * GWM, sizeof(int) * GWM, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(loop_sync(e->stream));
     bool more = any_left(e->pinned);
     int active_iters = 0;
     const int sweep_grid = std::min(std::max(ep.n_ggroups, 1), e->gsweep_grid_cap);
@@ -1648,7 +1660,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[1], e->stream));
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(e->pinned, g.mlog, sizeof(int) * (size_t)(n + 2) * GWM, hipMemcpyDeviceToHost, e->stream));
-            HIP_TRY(hipStreamSynchronize(e->stream));
+            HIP_TRY(loop_sync(e->stream));
             const int st = e->pinned[0];
             g.st.persist_launches++;
             if (st & GSM_FAULT) return fail(e, DPPR_ERR_HIP, "a grid barrier of the multi-sweep group launch timed out");
@@ -1728,7 +1740,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(e->pinned, g.cnt, sizeof(int) * (size_t)(5 * GWM + n * GWM), hipMemcpyDeviceToHost,
                                e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(loop_sync(e->stream));
         for (int k = 0; k < n; ++k) {
             const int *f = e->pinned + 5 * GWM + k * GWM;
             if (!any_left(f)) continue;
@@ -1772,7 +1784,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
                     else { // back in sweep form: frontier sizes in row 0; the next try waits for a much smaller frontier
                         cur = 0;
                         HIP_TRY(hipMemcpyAsync(e->pinned, g.cnt, sizeof(int) * GWM, hipMemcpyDeviceToHost, e->stream));
-                        HIP_TRY(hipStreamSynchronize(e->stream));
+                        HIP_TRY(loop_sync(e->stream));
                         more = any_left(e->pinned);
                         push_thr = std::max<long long>(F / 8, 1);
                         dense_len = -1;
