@@ -1023,7 +1023,11 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
     const int pcap0 = persist_capacity(e);
     const bool binned = ep.bin_valid && ep.bin_n_int <= ep.grp_n_int && (pcap0 <= 0 || ep.n_groups > pcap0 || e->bin_mode == 2);
     const bool use_bits = e->sweep_bits && !binned && !entry.dense && (pcap0 <= 0 || ep.n_groups > pcap0);
-    if (e->status_dedup && !s.status) { // (first use: -1 everywhere = "never queued")
+    // The merged loop always filters through the status array: adds of both signs can take a residual across the threshold more
+    // than once per iteration, and with the crossing test every crossing would append -- the next-frontier list (V entries) could
+    // overflow. One entry per vertex and launch keeps it bounded.
+    const bool use_status = e->status_dedup || phase == PHASE_BOTH;
+    if (use_status && !s.status) { // (first use: -1 everywhere = "never queued")
         HIP_TRY(hipMalloc((void **)&s.status, sizeof(int) * (size_t)e->V));
         HIP_TRY(hipMemsetAsync(s.status, 0xff, sizeof(int) * (size_t)e->V, e->stream));
     }
@@ -1210,7 +1214,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             } else {
                 int *big_cnt = s.cnt + 5 + (int)(s.iter_seq & 1), *big_zero = s.cnt + 5 + (int)((s.iter_seq + 1) & 1);
                 s.iter_seq++;
-                const Dedup dd{e->status_dedup ? s.status : nullptr, (int)(s.iter_seq & 0x3fffffff)};
+                const Dedup dd{use_status ? s.status : nullptr, (int)(s.iter_seq & 0x3fffffff)};
                 if (dense_valid)
                     hipLaunchKernelGGL(k_push_iter<true>, dim3(push_grid), dim3(BLOCK), 0, e->stream, s.ft[buf],
                                        s.cnt + cur, s.ft[buf ^ 1], s.cnt + nxt, s.cnt + zer, s.x, ep.row_ptr, ep.adj, hubs,

@@ -292,6 +292,8 @@ __global__ __launch_bounds__(BLOCK) void k_push_iter(const int *__restrict__ ft,
                     // RepairFrontierRev: residual[u] -= vertex_ft_r[i]; still legal -> next frontier
                     const double prer = atomic_add_ret(&r[u], -ru);
                     requeue = legal(prer - ru, phase, eps);
+                    // (status filter: an add may have queued u for the next frontier already -- one entry per vertex and launch)
+                    if (requeue && dd.status) requeue = atomicExch(&dd.status[u], dd.level) < dd.level;
                 }
             } else {
                 ru = atomic_exch(&r[u], 0.0);

@@ -930,6 +930,36 @@ def test_merged_loop_single_source(directed, tuning):
     assert np.max(np.abs(r)) < eps and np.max(np.abs(p - sc.s.p)) < NORTH_STAR_TOL
 
 
+@pytest.mark.parametrize("tuning", [dict(pull_min_frontier=-1), dict(hub_min_degree=1, big_row_edges=1, pull_min_frontier=-1),
+                                    dict(pull_min_frontier=-1, schedule=eng.SCHEDULE_EAGER, variant=2)], ids=["push", "all-hub-all-big", "variant2"])
+def test_merged_loop_push_iterations_keep_the_frontier_list_bounded(tuning):
+    """A tiny dense window with large batches, every iteration a push iteration: in the merged loop adds of both signs take residuals
+    across the threshold again and again inside one iteration. The next frontier holds every vertex at most once (status-array
+    filter; with the crossing test alone each crossing would append and the V-entry list could overflow): 40 batches against the
+    oracles, the state intact throughout."""
+    V, W, c, eps, div = 64, 600, 150, 1e-9, 4
+    rng = np.random.default_rng(23)
+    n = W + 41 * c
+    e1 = rng.integers(0, V, n).astype(np.int32)
+    e2 = rng.integers(0, V, n).astype(np.int32)
+    e2 = np.where(e2 == e1, (e2 + 1) % V, e2).astype(np.int32)
+    sc = Scenario(V, e1, e2, 1, W, c, 5, eps, **dict(tuning, merge_phases=div))
+    m = orc.State(V, 5, eps)
+    sc.s.cilk_execute(sc.g)
+    m.cilk_execute(sc.g)
+    sc.e.init_solve(sc.slot, eps)
+    for k in range(40):
+        assert sc.advance_graphs()
+        sc.s.cilk_inc_execute(sc.g)
+        m.merged_inc_execute(sc.g, eps / div)
+        sc.e.update(sc.slot, eps)
+        p, r = sc.e.read(sc.slot)
+        assert np.max(np.abs(r)) <= eps / div and np.max(np.abs(p - sc.s.p)) < NORTH_STAR_TOL and np.max(np.abs(p - m.p)) < NORTH_STAR_TOL, k
+        src, dst = window_directed_edges(sc.g)
+        assert invariant_max_err_np(p, r, src, dst, V, 5) < INVARIANT_TOL
+    check_csr(sc)
+
+
 @pytest.mark.parametrize("mode", ["sweeps", "push-tail", "multi-sweep"])
 @pytest.mark.parametrize("nsrc,directed", [(3, 1), (10, 0), (16, 1)])
 def test_merged_loop_source_group(nsrc, directed, mode):
