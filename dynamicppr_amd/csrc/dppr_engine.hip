@@ -1288,6 +1288,8 @@ bool can_batch_ahead(const dppr_engine *e, const Slot &s, const Epoch &ep) {
     // A resident sweep costs the same ~5 us whatever the frontier size, less than one push iteration's
     // launches: with the automatic push/pull threshold a window that can run resident always does.
     // With an explicit threshold (tests) only if the last batch's phases both started above it.
+    if (e->merge_phases && e->schedule == DPPR_SCHEDULE_EAGER) // (the merged loop keeps its history in slot 0)
+        return e->pull_min_frontier == 0 || (s.iter_hint[0] > 0 && s.start_dense[0]);
     return e->pull_min_frontier == 0 ||
            (s.iter_hint[0] > 0 && s.iter_hint[1] > 0 && s.start_dense[0] && s.start_dense[1]);
 }
@@ -1295,11 +1297,14 @@ bool can_batch_ahead(const dppr_engine *e, const Slot &s, const Epoch &ep) {
 // stage (out): 0 = phase 0 still open (resume with en0), 1 = phase 0 done, phase 1 open (resume with
 // en1; *p1_seeded tells whether its snapshot exists), 2 = both phases done
 int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage, LoopEntry *en0, LoopEntry *en1,
-                bool *p1_seeded) {
+                bool *p1_seeded, bool merged = false) {
+    // merged (dppr_set_phase_merge): ONE loop over residuals of both signs -- the launch seeds it (PLAN_SEED) and runs it to the
+    // end; stage 0 + en0 if it ran out of sweeps, stage 2 when it converged (histories in slot 0)
     const int pull_min = pull_min_frontier(e);
     // a resident launch stops by itself when the frontier empties: a generous allowance costs nothing,
     // a short one costs a read-back and another launch (+1: the step that seeds phase 1)
-    int n = s.iter_hint[0] > 0 && s.iter_hint[1] > 0
+    int n = merged ? (s.iter_hint[0] > 0 ? std::min(s.iter_hint[0] + 2 * RESIDENT_MARGIN, 2 * MAX_CHUNK) : 2 * MAX_CHUNK)
+            : s.iter_hint[0] > 0 && s.iter_hint[1] > 0
                       ? std::min(s.iter_hint[0] + s.iter_hint[1] + 1 + 2 * RESIDENT_MARGIN, 2 * MAX_CHUNK)
                       : 2 * MAX_CHUNK; // no history yet
     if (e->chunk_explicit) n = std::min(n, e->chunk_iters); // (tests: launches that stop mid-phase and are resumed)
@@ -1307,8 +1312,9 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
     if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                        \
     hipLaunchKernelGGL(k_pull_resident<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,        \
-                       ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.r, s.p, s.cnt, 0, 0, eps, s.dstats, s.log, n,      \
-                       e->bar, status, e->persist_ticks, e->persist_rollcall_extra, PLAN_SEED | PLAN_BOTH)
+                       ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.r, s.p, s.cnt, 0, merged ? PHASE_BOTH : 0, eps, s.dstats,  \
+                       s.log, n, e->bar, status, e->persist_ticks, e->persist_rollcall_extra,                             \
+                       merged ? PLAN_SEED : (PLAN_SEED | PLAN_BOTH))
     switch (sweep_block(e)) {
     case 256: DPPR_LAUNCH_PERSIST(256); break;
     case 512: DPPR_LAUNCH_PERSIST(512); break;
@@ -1358,6 +1364,21 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
         act[ph]++;
     }
     rotate_snapshots(s, pos);
+    if (merged) {
+        if (!(st & PERSIST_CONVERGED)) { // out of sweeps: the host-driven loop goes on from here
+            en0->it = act[0];
+            en0->F = e->pinned[0];
+            en0->dense = true;
+            en0->any_pull = true;
+            return DPPR_OK;
+        }
+        s.iter_hint[0] = act[0];
+        for (int k = 3; k > 0; --k) s.iter_hist[0][k] = s.iter_hist[0][k - 1];
+        s.iter_hist[0][0] = act[0];
+        if (act[0] == 0) s.start_dense[0] = false;
+        *stage = 2;
+        return DPPR_OK;
+    }
     if (!(st & PERSIST_PHASE1)) { // phase 0 needs more sweeps than the launch had; phase 1 has not started
         en0->it = act[0];
         en0->F = e->pinned[0];
@@ -2433,14 +2454,29 @@ int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *
     const double eps_caller = eps;
     if (merged) eps = eps / e->merge_div;
     const bool seeded = s.converged && s.conv_eps <= eps;
-    const bool ahead = !merged && seeded && can_batch_ahead(e, s, ep);
+    const bool ahead = seeded && can_batch_ahead(e, s, ep);
     int rc = settle_parked(e, s.p, s.r, 1, eps, &s.park_eps, &s.st);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
     rc = stream_update(e, s, ep, eps, seeded, ahead);
     if (rc) return rc;
     s.converged = false;
-    if (merged) {
+    if (merged && ahead) { // a window that runs resident: the whole merged loop as ONE launch that seeds itself
+        int stage = 0;
+        bool p1 = false;
+        LoopEntry en0, en1;
+        rc = batch_ahead(e, s, ep, eps, &stage, &en0, &en1, &p1, true);
+        if (rc) return rc;
+        if (stage != 2) { // out of sweeps, or the roll-call failed (then the update's lists stand: add the negative tails)
+            if (en0.it == 0 && !en0.dense) {
+                hipLaunchKernelGGL(k_filter, dim3(grid_for(std::max(ep.L, 1))), dim3(BLOCK), 0, e->stream, s.neg, s.cnt + 3, s.r, 1, eps,
+                                   s.ft[0], s.cnt + 0);
+                HIP_TRY(hipGetLastError());
+            }
+            rc = run_frontier_loop(e, s, ep, PHASE_BOTH, eps, 0, 0, en0);
+            if (rc) return rc;
+        }
+    } else if (merged) {
         if (seeded) { // the frontier: the tails the update left above eps (ft[0]) and those it left below -eps (the candidates)
             hipLaunchKernelGGL(k_filter, dim3(grid_for(std::max(ep.L, 1))), dim3(BLOCK), 0, e->stream, s.neg, s.cnt + 3, s.r, 1, eps,
                                s.ft[0], s.cnt + 0);
