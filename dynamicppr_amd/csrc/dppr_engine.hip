@@ -2451,7 +2451,6 @@ int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *
     // (the state a completed solve leaves). Otherwise fall back to full Inspect passes.
     // Merged loop (dppr_set_phase_merge, eager schedule): residuals of both signs are pushed in ONE loop, to eps / merge_div.
     const bool merged = e->merge_phases && e->schedule == DPPR_SCHEDULE_EAGER;
-    const double eps_caller = eps;
     if (merged) eps = eps / e->merge_div;
     const bool seeded = s.converged && s.conv_eps <= eps;
     const bool ahead = seeded && can_batch_ahead(e, s, ep);
@@ -2523,7 +2522,6 @@ int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *
     s.st.batches++;
     s.converged = true;
     s.conv_eps = eps; // (the merged loop's eps / merge_div)
-    (void)eps_caller;
     s.last_epoch = ep.id;
     return DPPR_OK;
 }
