@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 NORTH_STAR_TOL = 1e-9   # BASELINE.json: "within the repo's 1e-9 tolerance"
+BIG_WINDOW = 4_000_000  # stream edges in the window from which two sources per GPU are solved one after the other (binned sweeps)
 
 # per config: (sources per GPU, how they are picked). The 8-GPU configurations of BASELINE.json (twitter: 8 top-10 sources,
 # friendster: the 10 sources of a top1000 file) are FIXED source sets dealt round-robin over the ranks (0 = "the config's own
@@ -77,6 +78,7 @@ def parse_args():
     ap.add_argument("--directed", type=int, default=None)
     ap.add_argument("--cpu-batches", type=int, default=None, help="batches timed on the CPU oracle (bounded sample)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-group", action="store_true", help="two sources per GPU on a large window as a source group (default there: one after the other)")
     ap.add_argument("--no-merged", action="store_true", help="skip the extra pass with the merged loop (N = 1 only)")
     ap.add_argument("--no-extra", action="store_true",
                     help="default workload at N = 1 only: do not append the configs[1] (single source, resident path) line")
@@ -182,7 +184,11 @@ def main():
     e = eng.Engine(V, W, directed, c, n_epochs=n_steps + n_prof + 1, device=local_rank, schedule=schedule, **tune)
     ss = st.SlidingStream(V, e1, e2, directed, wl)
     e.load_window(*ss.serialize_edge_stream())
-    solver = GroupSolver(e, sources) if S > 1 else SingleSolver(e, sources[0])
+    # Two sources on a window whose single-source path runs binned sweeps are cheaper one after the other than as a group (a group's
+    # sweep costs about the same for 2 as for 8 sources: twitter stand-in 279 ms against 2 x 91, friendster 494 against 2 x 185;
+    # from 3 sources on the group wins) -- what a rank of the 8-GPU deals of configs[3] / [4] holds
+    pair_as_singles = S == 2 and W >= BIG_WINDOW and not a.force_group
+    solver = (PairSolver(e, sources) if pair_as_singles else GroupSolver(e, sources)) if S > 1 else SingleSolver(e, sources[0])
     init_ms = solver.init_solve(a.eps)
     L = 0
     w_end = None
@@ -246,7 +252,7 @@ def main():
         launch_s = 1e-3 * ps["push_ms"] / max(ps["push_launches"], 1)
         # SURVEY.md 8(d)'s 24 bytes per traversed edge were written for ONE source (4 out_col + 4 degree + 16 residual); a
         # group of S sources reads the column entry and the degree once for all of them: 16 + 8 / S per edge and source
-        adj_bytes = 72 * ps["sum_F"] + (16 + 8 / S) * ps["sum_E"] + 4 * ps["sum_N"]
+        adj_bytes = 72 * ps["sum_F"] + (16 + 8 / (1 if pair_as_singles else S)) * ps["sum_E"] + 4 * ps["sum_N"]
         roof = {
             "bound": "hbm", "kernel": solver.kernel_name(ps),
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -258,7 +264,7 @@ def main():
             "launches": ps["push_launches"], "avg_launch_us": round(1e3 * ps["push_ms"] / max(ps["push_launches"], 1), 3),
             "algorithmic_bytes_per_launch": round(push_bytes / max(ps["push_launches"], 1), 1),
             "whole_batch_algorithmic_GBps": round(stats["algorithmic_bytes"] / (ev_ms * 1e-3) / 1e9, 2),
-            "launches_from": ("a replay of the timed batches from the saved state" if S == 1 else
+            "launches_from": ("a replay of the timed batches from the saved state" if S == 1 or pair_as_singles else
                               f"the {n_prof} batches that follow the timed region on the same stream"),
             "note": "achieved / frac = SURVEY.md 8(d) bytes (72 F + 24 E + 4 N, summed over the sources) of the hipEvent-"
                     "bracketed launches / their time: a WORK rate in the survey's unit. frac_group_adjusted prices a traversed "
@@ -284,7 +290,7 @@ def main():
     merged = None
     if rank == 0 and world == 1 and not a.no_merged and a.schedule == "eager":
         e.set_phase_merge(True, 4)
-        solver2 = GroupSolver(e, sources) if S > 1 else SingleSolver(e, sources[0])
+        solver2 = (PairSolver(e, sources) if pair_as_singles else GroupSolver(e, sources)) if S > 1 else SingleSolver(e, sources[0])
         solver2.init_solve(a.eps, epoch=0)   # (the epochs of the run are all resident: start from the first)
         for k in range(1, a.warmup + 1):
             solver2.update(a.eps, k)
@@ -321,7 +327,8 @@ def main():
                                    + (f"the configuration's {total_sources} sources" if scaling == "strong" else f"{S} source(s) per GPU")
                                    + f" from degree ranks {'[10,1000) (a top1000 file)' if pick == 'top1000' else '[0,10) (the top10 file)'}"
                                    + (f", dealt round-robin over {world} GPU(s)" if scaling == "strong" else "")
-                                   + (", a GPU's sources streamed together as one source group over one graph replica" if S > 1 else ""),
+                                   + (", a GPU's two sources solved one after the other (single-source path)" if pair_as_singles else
+                                      ", a GPU's sources streamed together as one source group over one graph replica" if S > 1 else ""),
                        "V": V, "stream_edges": int(stream_len), "window": W, "batch_c": c, "records_L": L,
                        "sources": sources, "schedule": a.schedule,
                        "parallelism": (f"{total_sources} sources dealt round-robin over {world} GPU(s) (rank 0: {S}), replicated graph, no collective"
@@ -417,6 +424,36 @@ class SingleSolver:
         if ps.get("binned_sweeps"):
             return "k_bin_scatter + k_bin_reduce (one frontier iteration as two streaming passes; a launch = the pair) / k_push_iter"
         return "k_pull_iter / k_push_iter (one frontier iteration)"
+
+
+class PairSolver:
+    """Two sources on the single-source path, one after the other, over the same pre-staged epochs."""
+
+    def __init__(self, e, sources):
+        self.e, self.parts = e, [SingleSolver(e, s) for s in sources]
+
+    def init_solve(self, eps, epoch=-1):
+        return sum(p.init_solve(eps, epoch) for p in self.parts)
+
+    def update(self, eps, epoch):
+        return sum(p.update(eps, epoch) for p in self.parts)
+
+    def read(self, i):
+        return self.parts[i].read(0)
+
+    def begin_timed(self):
+        for p in self.parts:
+            p.begin_timed()
+
+    def stats(self):
+        a, b = (p.stats() for p in self.parts)
+        return {k: a[k] + b[k] for k in a}
+
+    def profile(self, a, n_steps):
+        return self.parts[0].profile(a, n_steps)   # (the kernel is the same for both: the first source's replay)
+
+    def kernel_name(self, ps):
+        return self.parts[0].kernel_name(ps)
 
 
 class GroupSolver:
