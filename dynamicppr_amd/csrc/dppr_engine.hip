@@ -2352,7 +2352,8 @@ int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
     HIP_TRY(hipMalloc((void **)&s.cnt, sizeof(int) * (CNT_HDR + 2 * MAX_CHUNK)));
     s.log = s.cnt + CNT_HDR; // the per-chunk log sits right behind the counters: one read-back fetches both
     // a row is deferred only if it has >= big_row edges, so at most Ed / big_row of them exist
-    HIP_TRY(hipMalloc((void **)&s.big, sizeof(BigItem) * ((size_t)e->Ed / (size_t)std::max(e->big_row, 1) + 64)));
+    // (pieces of <= 1024 edges of rows of >= big_row edges: a row of d edges has ceil(d / 1024) <= d / min(big_row, 512) of them)
+    HIP_TRY(hipMalloc((void **)&s.big, sizeof(BigItem) * ((size_t)e->Ed / (size_t)std::min(std::max(e->big_row, 1), 512) + 64)));
     HIP_TRY(hipMalloc((void **)&s.dstats, sizeof(IterStats)));
     HIP_TRY(hipMemsetAsync(s.cnt, 0, sizeof(int) * (CNT_HDR + 2 * MAX_CHUNK), e->stream));
     HIP_TRY(hipMemsetAsync(s.dstats, 0, sizeof(IterStats), e->stream));

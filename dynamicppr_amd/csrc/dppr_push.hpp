@@ -126,9 +126,9 @@ __global__ __launch_bounds__(BLOCK) void k_snapshot_dense(const int *__restrict_
 // (the counter the NEXT iteration appends to); likewise big_cnt / big_zero. Iteration
 // kernels can therefore be chained without host round trips or memsets.
 // ---------------------------------------------------------------------------
-struct BigItem { // a deferred big row
-    int row_start;
-    int len;
+struct BigItem { // one BIG_CHUNK-edge piece of a deferred big row (the list holds pieces, so that k_push_big finds its work by index)
+    int row_start; // first Adj entry of the piece
+    int len;       // edges in it (<= BIG_CHUNK)
     double ru;
 };
 
@@ -302,21 +302,23 @@ __global__ __launch_bounds__(BLOCK) void k_push_iter(const int *__restrict__ ft,
         }
         if (DENSE) out.stage(requeue, u);
 
-        // big rows: hand (row, ru) to k_push_big
+        // big rows: hand their BIG_CHUNK-edge pieces (row piece, ru) to k_push_big
         const bool is_big = d >= big_row;
         const uint64_t mb = __ballot(is_big);
         if (mb) {
+            const int nch = is_big ? (d + BIG_CHUNK - 1) / BIG_CHUNK : 0;
+            const int incl_ch = wave_inclusive_scan(nch);
             int gb = 0;
-            if (lane == 0) gb = atomicAdd(big_cnt, __popcll(mb));
-            gb = __shfl(gb, 0, WAVE);
-            if (is_big) {
+            if (lane == WAVE - 1) gb = atomicAdd(big_cnt, incl_ch);
+            gb = __shfl(gb, WAVE - 1, WAVE) + incl_ch - nch;
+            for (int c = 0; c < nch; ++c) {
                 BigItem it;
-                it.row_start = rs;
-                it.len = d;
+                it.row_start = rs + c * BIG_CHUNK;
+                it.len = min(BIG_CHUNK, d - c * BIG_CHUNK);
                 it.ru = ru;
-                big[gb + mbcnt(mb)] = it;
-                d = 0;
+                big[gb + c] = it;
             }
+            if (is_big) d = 0;
         }
 
         const int incl = wave_inclusive_scan(d);
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(BLOCK) void k_push_iter(const int *__restrict__ ft,
     push_epilogue(out, s_hub, hubs, r, phase, eps, s_cnt, &s_base, edges, stats, s_edges, dd);
 }
 
-// Deferred big rows: chunk c of the list goes to workgroup c % gridDim; 256 lanes x 4 edges.
+// Deferred big rows: piece c of the list goes to workgroup c % gridDim; 256 lanes x 4 edges.
 __global__ __launch_bounds__(BLOCK) void k_push_big(const BigItem *__restrict__ big, const int *__restrict__ big_cnt,
                                                     int *__restrict__ ft_out, int *__restrict__ cnt_out,
                                                     const Adj *__restrict__ adj, HubTable hubs, double *__restrict__ r,
@@ -376,35 +378,23 @@ __global__ __launch_bounds__(BLOCK) void k_push_big(const BigItem *__restrict__ 
     OutStage out{s_out[wave_id()], 0, ft_out, cnt_out};
     unsigned long long edges = 0;
 
-    int chunk0 = 0; // global index of the first chunk of item `it`
-    for (int it = 0; it < nbig; ++it) {
-        const BigItem item = big[it];
-        const int nch = (item.len + BIG_CHUNK - 1) / BIG_CHUNK;
-        // chunks of this item owned by this workgroup: global chunk id == blockIdx (mod gridDim)
-        int first = (int)blockIdx.x - chunk0 % (int)gridDim.x;
-        if (first < 0) first += gridDim.x;
-        for (int ch = first; ch < nch; ch += gridDim.x) {
-            const int base = ch * BIG_CHUNK;
-            EdgePush q[UNROLL];
+    for (int c = blockIdx.x; c < nbig; c += gridDim.x) { // piece c of the list: 256 lanes x 4 edges
+        const BigItem item = big[c];
+        EdgePush q[UNROLL];
 #pragma unroll
-            for (int k = 0; k < UNROLL; ++k) {
-                const int e = base + k * BLOCK + threadIdx.x;
-                const bool ok = e < item.len;
-                Adj a{0, 1};
-                if (ok) a = adj[item.row_start + e];
-                q[k] = push_edge(ok, a, item.ru, r, s_hub, hubs);
-            }
-#pragma unroll
-            for (int k = 0; k < UNROLL; ++k) {
-                const bool hit = q[k].direct && queues(q[k].prer, q[k].add, q[k].v, phase, eps, dd);
-                out.stage(hit, q[k].v);
-            }
-            if (wave_id() == 0) {
-                const int left = item.len - base;
-                edges += (unsigned long long)(left < BIG_CHUNK ? left : BIG_CHUNK);
-            }
+        for (int k = 0; k < UNROLL; ++k) {
+            const int e = k * BLOCK + threadIdx.x;
+            const bool ok = e < item.len;
+            Adj a{0, 1};
+            if (ok) a = adj[item.row_start + e];
+            q[k] = push_edge(ok, a, item.ru, r, s_hub, hubs);
         }
-        chunk0 += nch;
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) {
+            const bool hit = q[k].direct && queues(q[k].prer, q[k].add, q[k].v, phase, eps, dd);
+            out.stage(hit, q[k].v);
+        }
+        if (wave_id() == 0) edges += (unsigned long long)item.len;
     }
     push_epilogue(out, s_hub, hubs, r, phase, eps, s_cnt, &s_base, edges, stats, s_edges, dd);
 }
