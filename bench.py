@@ -54,9 +54,10 @@ PLANS = {
 
 # committed rocprofv3 --pmc summaries (tools/prof_pmc.sh) of the dominant kernel per workload
 PMC_FILES = {
-    ("youtube", 1): ("profiles/r01_final_pmc_traffic_youtube.json", ("k_pull_resident",)),
-    ("livejournal", 10): ("profiles/r02_pmc_traffic_livejournal_group10.json", ("k_gsweep",)),
-    ("twitter", 8): ("profiles/r02_pmc_traffic_twitter_group8.json", ("k_gsweep",)),
+    ("youtube", 1): ("profiles/r03_pmc_traffic_youtube_1src.json", ("k_pull_resident",)),
+    ("livejournal", 10): ("profiles/r03_pmc_traffic_livejournal_group10.json", ("k_gsweep",)),
+    ("livejournal", 1): ("profiles/r03_pmc_traffic_lj1_binned.json", ("k_bin_scatter", "k_bin_reduce")),
+    ("twitter", 8): ("profiles/r03_pmc_traffic_twitter_group8.json", ("k_gsweep",)),
     ("twitter", 1): ("profiles/r03_pmc_traffic_tw1_binned.json", ("k_bin_scatter", "k_bin_reduce")),
     ("friendster", 1): ("profiles/r03_pmc_traffic_fr1_binned.json", ("k_bin_scatter", "k_bin_reduce")),
 }
@@ -511,9 +512,14 @@ def pmc_traffic_per_launch(config, S):
     if not path or not os.path.exists(path):
         return None, None
     d = json.load(open(path))
-    launches = sum(v["launches"] for k, v in d.items() if k.startswith(heads))
-    total = sum(v["launches"] * v["hbm_bytes_per_launch_corrected"] for k, v in d.items() if k.startswith(heads))
-    return (round(total / launches, 1), f"committed profile {rel}") if launches else (None, None)
+    per_launch = 0.0   # (several heads = the stages of ONE iteration, e.g. k_bin_scatter + k_bin_reduce: their bytes add up)
+    for head in heads:
+        launches = sum(v["launches"] for k, v in d.items() if k.startswith(head))
+        total = sum(v["launches"] * v["hbm_bytes_per_launch_corrected"] for k, v in d.items() if k.startswith(head))
+        if not launches:
+            return None, None
+        per_launch += total / launches
+    return round(per_launch, 1), f"committed profile {rel}"
 
 
 def cpu_baseline(V, e1, e2, directed, W, c, sources, eps, batches, p_end, stream_len):
