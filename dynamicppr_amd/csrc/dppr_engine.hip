@@ -81,6 +81,10 @@ struct Epoch {
     int *apos = nullptr;
     bool bin_valid = false;
     int bin_n_int = 0; // internal ids the tables cover (<= grp_n_int: later ids have no edge in this epoch)
+    // slot table of the resident sweep (dppr_resident.hpp: k_res_slots), rebuilt with every group cut
+    uint32_t *res_pk = nullptr; // Ed entries, group by group, sorted by gather position
+    size_t res_pk_cap = 0;
+    bool res_valid = false;
 };
 
 struct Slot {
@@ -170,6 +174,7 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     bool persist_ok = true;            // cleared when a roll-call gives up: per-iteration launches until re-armed
     int persist_retry = 0;             // dppr_update calls until resident launches are tried again (0: not pending)
     int persist_cap = 0;               // co-resident workgroups of k_pull_resident at the sweep's block size
+    int res_slots = 1;                 // 1: resident launches take their edge slots from the sorted slot table (0: CSR order)
     unsigned long long persist_ticks = 5000000ull; // roll-call time limit in 100 MHz ticks (50 ms)
     int persist_rollcall_extra = 0;    // tests: the roll-call waits for a workgroup that does not exist
     GridBar *bar = nullptr;
@@ -757,6 +762,25 @@ int cut_sweep_groups(dppr_engine *e, Epoch &ep) {
     ep.n_groups = (int)cut.size() - 1;
     ep.grp_n_int = NV;
     HIP_TRY(hipMemcpyAsync(ep.grp_tile, cut.data(), sizeof(int) * cut.size(), hipMemcpyHostToDevice, e->stream));
+    // slot tables for resident launches (a window that got the resident cut; every group must fit the table build's sort)
+    ep.res_valid = false;
+    if (fitted && e->res_slots && ep.Ed > 0 && NV <= RES_ID_LIMIT) {
+        long long largest = 0;
+        for (size_t g = 0; g + 1 < cut.size(); ++g) largest = std::max<long long>(largest, (long long)prefix[cut[g + 1]] - prefix[cut[g]]);
+        if (largest <= RES_SORT_MAX) {
+            if ((size_t)ep.Ed > ep.res_pk_cap) {
+                HIP_TRY(hipStreamSynchronize(e->stream));
+                (void)hipFree(ep.res_pk);
+                ep.res_pk = nullptr;
+                ep.res_pk_cap = 0;
+                HIP_TRY(hipMalloc((void **)&ep.res_pk, sizeof(uint32_t) * ((size_t)ep.Ed + (size_t)ep.Ed / 8 + 1024)));
+                ep.res_pk_cap = (size_t)ep.Ed + (size_t)ep.Ed / 8 + 1024;
+            }
+            hipLaunchKernelGGL(k_res_slots, dim3(ep.n_groups), dim3(1024), 0, e->stream, NV, ep.grp_tile, ep.out_row_ptr, ep.out_col, ep.res_pk);
+            HIP_TRY(hipGetLastError());
+            ep.res_valid = true;
+        }
+    }
     HIP_TRY(hipStreamSynchronize(e->stream)); // `cut` is a local
     ep.n_ggroups = 0;
     if (e->any_groups) { // groups of at most 16 (8) tiles for k_gsweep<1, 1024> (<2, 512>)
@@ -1101,7 +1125,8 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                       \
     hipLaunchKernelGGL(k_pull_resident<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,       \
                        ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.r, s.p, s.cnt, cur, phase, eps, s.dstats, s.log,  \
-                       n, e->bar, s.cnt + 7, e->persist_ticks, e->persist_rollcall_extra, 0)
+                       n, e->bar, s.cnt + 7, e->persist_ticks, e->persist_rollcall_extra, 0,                          \
+                       ep.res_valid ? ep.res_pk : nullptr)
             switch (sweep_block(e)) {
             case 256: DPPR_LAUNCH_PERSIST(256); break;
             case 512: DPPR_LAUNCH_PERSIST(512); break;
@@ -1314,7 +1339,7 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
     hipLaunchKernelGGL(k_pull_resident<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,        \
                        ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.r, s.p, s.cnt, 0, merged ? PHASE_BOTH : 0, eps, s.dstats,  \
                        s.log, n, e->bar, status, e->persist_ticks, e->persist_rollcall_extra,                             \
-                       merged ? PLAN_SEED : (PLAN_SEED | PLAN_BOTH))
+                       merged ? PLAN_SEED : (PLAN_SEED | PLAN_BOTH), ep.res_valid ? ep.res_pk : nullptr)
     switch (sweep_block(e)) {
     case 256: DPPR_LAUNCH_PERSIST(256); break;
     case 512: DPPR_LAUNCH_PERSIST(512); break;
@@ -1999,6 +2024,7 @@ void dppr_destroy(dppr_engine *e) {
         (void)hipFree(ep.row_ptr); (void)hipFree(ep.adj); (void)hipFree(ep.out_row_ptr); (void)hipFree(ep.out_col); (void)hipFree(ep.b1); (void)hipFree(ep.b2);
         (void)hipFree(ep.deg_after); (void)hipFree(ep.ins); (void)hipFree(ep.sk); (void)hipFree(ep.sv); (void)hipFree(ep.hub_v); (void)hipFree(ep.hub_degp1); (void)hipFree(ep.grp_tile); (void)hipFree(ep.ggrp_tile); (void)hipFree(ep.gtab);
         (void)hipFree(ep.acut); (void)hipFree(ep.chunks); (void)hipFree(ep.hl); (void)hipFree(ep.dl); (void)hipFree(ep.apos);
+        (void)hipFree(ep.res_pk);
     }
     for (int k = 0; k < 2; ++k) (void)hipFree(e->bin_k[k]);
     (void)hipFree(e->bin_vblk_a); (void)hipFree(e->bin_vblk_b); (void)hipFree(e->bin_small); (void)hipFree(e->bin_vals); (void)hipFree(e->bin_tmp);
@@ -2098,6 +2124,15 @@ int dppr_set_binned_sweep(dppr_engine *e, int mode, int ha_tiles, int hb_tiles, 
     if (min_ids > 0) e->bin_min_ids = min_ids;
     if (chunk_edges > 0) e->bin_chunk = chunk_edges;
     if (target_a_edges > 0) e->bin_target_a = target_a_edges;
+    return DPPR_OK;
+}
+
+int dppr_set_resident_slots(dppr_engine *e, int sorted) {
+    if (!e) return DPPR_ERR_INVALID;
+    e->res_slots = sorted != 0;
+    // epochs already cut keep their tables until the next cut; switching OFF takes effect at once
+    if (!e->res_slots)
+        for (auto &ep : e->epochs) ep.res_valid = false;
     return DPPR_OK;
 }
 

@@ -84,6 +84,21 @@ constexpr unsigned long long BAR_ABORT = ~0ull;
 constexpr unsigned long long BAR_READY = 1ull;
 constexpr int PERSIST_SLOTS = 4; // edge slots per thread kept in registers (PB * 4 edges per group)
 constexpr unsigned long long X_EMPTY = 0x7FF8DEADBEEFCAFEull;
+// SLOT TABLES (round 3). The gathers are the iteration's cost, and what the fabric moves for them is one 64-byte sector per
+// distinct sector a wave instruction touches -- 0.99 sectors per edge with the slots in CSR order on hashed ids (configs[1]
+// stand-in: the lanes of an instruction walk a few short rows whose columns are spread over the whole id range). Nothing ties
+// a slot to CSR order: every slot carries its owner row. The graph build therefore sorts every group's edge list by gather
+// position (k_res_slots: untimed, with the group cut), so that the lanes of one instruction read neighbouring positions -- the
+// many edges of a group that lead to the same hub become ONE request, neighbours share sectors (0.88 sectors per edge by
+// simulation, tools/r03/resident_slots_sim.py) -- and the lanes of one LDS-atomic instruction belong to different owner rows.
+// Table entry: (gather position << 10) | owner row inside the group. No table (res_pk == nullptr): CSR order, as in round 2.
+// Measured on the configs[1] stand-in: 0.566 -> 0.515 ms per batch. (Giving the 64 .. 16 K vertices of largest in-degree a
+// second, PACKED home behind the vectors -- eight hubs per sector, 0.75 sectors per edge by the same simulation -- was built
+// and measured twice, hub copies stored by their owners and staged through LDS into full-sector stores: 0.56 - 0.59 ms, worse
+// with every hub added. 39 % of all gathers then go to a few hundred consecutive sectors, i.e. to a handful of memory
+// channels; hashed ids spread the hot values over all of them.)
+constexpr int RES_SORT_MAX = 16384;    // edges of one group the table build sorts in LDS (larger groups: no table for the epoch)
+constexpr int RES_ID_LIMIT = 1 << 22;  // ids a table entry can name (22 + 10 bits)
 
 struct alignas(128) BarWord {
     unsigned long long w;
@@ -125,7 +140,7 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
                                                       double *b2, double *r, double *p, int *cnt, int cur0, int phase,
                                                       double eps, IterStats *stats, int *log, int n_iter, GridBar *bar,
                                                       int *status, unsigned long long limit_ticks, int rollcall_extra,
-                                                      int plan) {
+                                                      int plan, const uint32_t *__restrict__ res_pk) {
     constexpr int NW = PB / WAVE;
     constexpr int S = PERSIST_SLOTS;
     __shared__ int s_scan[PB + 1];
@@ -207,6 +222,17 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
         }
         return lo;
     };
+    const int gbase = s_rs[0]; // the group's rows are consecutive: its edges are out_col / res_pk [gbase, gbase + Eg)
+    auto slot_of = [&](int e, int *o, int *c) {
+        if (res_pk) {
+            const uint32_t pk = res_pk[gbase + e];
+            *o = (int)(pk & 1023u);
+            *c = (int)(pk >> 10);
+        } else {
+            *o = owner_of(e);
+            *c = out_col[s_rs[*o] + (e - s_scan[*o])];
+        }
+    };
     int own[S], col[S];
     double den[S];
 #pragma unroll
@@ -216,9 +242,10 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
         col[k] = 0;
         den[k] = 1.0;
         if (e < Eg) {
-            const int o = owner_of(e);
+            int o, c;
+            slot_of(e, &o, &c);
             own[k] = o;
-            col[k] = out_col[s_rs[o] + (e - s_scan[o])];
+            col[k] = c;
             den[k] = (double)(s_scan[o + 1] - s_scan[o] + 1);
         }
     }
@@ -355,8 +382,9 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
             double xe = 0.0;
             int o = 0;
             if (e < Eg) {
-                o = owner_of(e);
-                const double *src = xin + out_col[s_rs[o] + (e - s_scan[o])];
+                int c;
+                slot_of(e, &o, &c);
+                const double *src = xin + c;
                 unsigned long long bits = xb_load(src);
                 unsigned polls = 0;
                 while (bits == X_EMPTY && !s_fault) {
@@ -466,6 +494,48 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
                   ((converged || (!fault && F == 0 && cur_phase == last_phase)) ? PERSIST_CONVERGED : 0);
     }
     stat_add_edges<NW>(stats, edges, s_edges);
+}
+
+// ---- slot table of a resident-size epoch (part of the untimed graph build, next to the group cut) ----
+// k_res_slots (one workgroup per sweep group): the group's edges as (gather position << 10 | owner row), sorted (bitonic, in LDS).
+__global__ __launch_bounds__(1024) void k_res_slots(int NV, const int *__restrict__ grp_tile, const int *__restrict__ out_row_ptr,
+                                                    const int *__restrict__ out_col, uint32_t *__restrict__ res_pk) {
+    __shared__ uint32_t s_key[RES_SORT_MAX];
+    const int tid = threadIdx.x;
+    const int t0 = grp_tile[blockIdx.x], t1 = grp_tile[blockIdx.x + 1];
+    const int va = min(t0 * WAVE, NV), vb = min(t1 * WAVE, NV);
+    const int e0 = out_row_ptr[va], Eg = out_row_ptr[vb] - e0;
+    if (Eg <= 0 || Eg > RES_SORT_MAX) return; // (the host does not use the table of an epoch with such a group)
+    int n2 = 64;
+    while (n2 < Eg) n2 <<= 1;
+    for (int i = tid; i < n2; i += 1024) {
+        uint32_t key = 0xFFFFFFFFu;
+        if (i < Eg) {
+            int lo = va, hi = vb; // owner row: the last v in [va, vb) with out_row_ptr[v] <= e0 + i
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (out_row_ptr[mid] <= e0 + i) lo = mid; else hi = mid;
+            }
+            key = ((uint32_t)out_col[e0 + i] << 10) | (uint32_t)(lo - va);
+        }
+        s_key[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n2; i += 1024) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint32_t a = s_key[i], b = s_key[l];
+                    if (((i & k) == 0) == (a > b)) {
+                        s_key[i] = b;
+                        s_key[l] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < Eg; i += 1024) res_pk[e0 + i] = s_key[i];
 }
 
 } // namespace dppr

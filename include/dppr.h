@@ -294,6 +294,12 @@ int dppr_group_reset_stats(dppr_engine *e, int32_t group);
  * default; 0 = one launch per sweep everywhere. The roll-call / time-out rules are those of
  * dppr_set_persistent. Same results. */
 int dppr_set_group_resident(dppr_engine *e, int on);
+/* Edge slots of the single-source resident sweep (dppr_resident.hpp). sorted = 1 (default): every sweep group's edges are
+ * dealt to the threads in the order of their gather position, so that the lanes of one gather instruction read the same
+ * or neighbouring 64-byte sectors (table built with the group cut, untimed -- the reference builds its CSR untimed as well,
+ * gpu/PPRGPU.cuh:131-135). sorted = 0: slots in CSR order (the form of rounds 1-2). Same pushes, same sums up to the order
+ * of the additions. 1 takes effect with the next epoch built, 0 at once. */
+int dppr_set_resident_slots(dppr_engine *e, int sorted);
 /* The tail of a source group's frontier loop as pushes. A sweep costs at least its floor (every out_col entry, every
  * sweep group's tables) however few (vertex, source) pairs are still being pushed; below enter_pairs frontier pairs
  * the loop's remaining iterations run as what the reference does for every iteration (gpu/ExpandRev.cuh:34-77,

@@ -48,11 +48,15 @@ TUNINGS = [dict(pull_min_frontier=-1), dict(hub_min_degree=3, big_row_edges=8, p
            dict(pull_min_frontier=1, persistent=0, binned=(2, 1, 1, 64, 0, 64, 64)), dict(pull_min_frontier=1, persistent=0, binned=2),
            dict(pull_min_frontier=40, persistent=0, binned=(2, 2, 3, 200, 0, 100, 500), chunk_iters=3),
            # the batch's records grouped by tail inside the timed region (rounds 1-2) instead of at slide time
-           dict(group_at_slide=0), dict(pull_min_frontier=1, group_at_slide=0)]
+           dict(group_at_slide=0), dict(pull_min_frontier=1, group_at_slide=0),
+           # edge slots of the resident sweep in CSR order (rounds 1-2; the default is the table sorted by gather position), also
+           # on several small groups
+           dict(pull_min_frontier=1, resident_slots=0), dict(resident_slots=0, pull_block=256)]
 TUNING_IDS = ["push-only", "push-hubs+bigrows", "push-all-hub-all-big", "pull-only", "mixed-pull>=40", "default",
               "mixed-chunk1", "mixed-chunk3", "pull-wg512", "mixed-wg1024", "pull-no-persist", "pull-wg256",
               "pull-rollcall-fails", "pull-resident-3-sweeps", "pull-bitmap-wg256", "mixed-bitmap", "pull-bitmap-wg640",
-              "binned-tiny-blocks", "binned-one-block", "mixed-binned-chunk3", "grouping-in-update", "pull-grouping-in-update"]
+              "binned-tiny-blocks", "binned-one-block", "mixed-binned-chunk3", "grouping-in-update", "pull-grouping-in-update",
+              "resident-csr-slots", "resident-csr-slots-wg256"]
 
 
 def make(directed, schedule=eng.SCHEDULE_EAGER, scale=9, edges=6000, seed=11, W=600, c=6, eps=1e-9, n_epochs=1,
@@ -641,7 +645,8 @@ def test_full_size_livejournal_standin_two_sources():
     assert st0["batches"] == 2 and st0["pull_iterations"] > 0 and st0["sum_E"] > 10 * len(w1)
 
 
-@pytest.mark.parametrize("mode", ["resident", "per-iteration", "rollcall-fails", "rollcall-fails-whole-batch", "heavy-groups"])
+@pytest.mark.parametrize("mode", ["resident", "per-iteration", "rollcall-fails", "rollcall-fails-whole-batch", "heavy-groups",
+                                  "csr-slots", "heavy-groups-csr-slots"])
 @pytest.mark.parametrize("directed", [1, 0])
 def test_resident_sweeps_same_work_as_per_iteration_launches(directed, mode):
     """Runs of dense iterations as ONE resident launch (k_pull_resident) do exactly the oracle's
@@ -660,9 +665,11 @@ def test_resident_sweeps_same_work_as_per_iteration_launches(directed, mode):
         # first resident launch is a whole batch (seeding inside the kernel) -- and it has to put back
         # what it seeded when its roll-call fails
         tuning = dict(persist_timeout_us=-1)
-    elif mode == "heavy-groups":
+    elif mode.startswith("heavy-groups"):
         tuning["pull_block"] = 256
         edges, W, c = 200000, 40000, 400 # ~80 edges per vertex: a 256-vertex group carries > 4 * 256 edges
+    if mode.endswith("csr-slots"):
+        tuning["resident_slots"] = 0     # slots in CSR order (the default is the sorted slot table)
     V, e1, e2 = datagen.rmat_stream(scale, edges, 21)
     src = int(datagen.top_sources(V, e1, e2, W, directed, 1)[0])
     sc = Scenario(V, e1, e2, directed, W, c, src, 1e-9, schedule=eng.SCHEDULE_SYNC, **tuning)

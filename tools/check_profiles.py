@@ -39,7 +39,17 @@ def cut(trace_csv, stats_csv, outdir):
         f.write("Name,Calls,TotalDurationNs,AverageNs,MinNs,MaxNs\n")
         for n, w in sorted(whole.items(), key=lambda kv: -kv[1][1]):
             f.write(f'"{n}",{w[0]},{w[1]},{w[1] / w[0]:.1f},{w[2]},{w[3]}\n')
-    marks = [i for i, (n, _, _) in enumerate(ev) if n == "k_su_keys"]          # first kernel of every batch's timed region
+    # First kernel of every batch's timed region: the IncrementalBatchUpdate kernel (k_su_apply_fused, or k_su_terms of the
+    # two-kernel form), or the k_su_keys just before it (counter clear; with dppr_set_batch_grouping(0) k_su_keys + the
+    # device sort). The k_su_keys of a slide-time grouping belongs to the SLIDE and is not a mark.
+    marks = []
+    for i, (n, _, _) in enumerate(ev):
+        if n not in ("k_su_apply_fused", "k_su_terms"):
+            continue
+        j = i - 1
+        while j >= 0 and ev[j][0].startswith("rocprim::radix"):
+            j -= 1
+        marks.append(j if j >= 0 and ev[j][0] == "k_su_keys" else i)
     batches = [(marks[i], marks[i + 1]) for i in range(len(marks) - 1)]
     spans = []
     for lo, hi in batches:                                                       # a batch ends with its last iteration kernel: cut at the next slide's kernels
@@ -94,6 +104,9 @@ def check(directory):
             if n in stats and not (float(stats[n]["MinNs"]) / 1e3 * 0.999 <= v["avg_us"] <= float(stats[n]["MaxNs"]) / 1e3 * 1.001):
                 print(f"FAIL {tag}: {n}: average {v['avg_us']} us in the chosen batch, outside [{float(stats[n]['MinNs']) / 1e3:.1f}, {float(stats[n]['MaxNs']) / 1e3:.1f}] of the stats file")
                 bad += 1
+        if not tl.get("iteration_kernel_durations_us"):
+            print(f"FAIL {tag}: the chosen batch holds no iteration kernel -- the cut is not a batch's timed region")
+            bad += 1
         if tl["busy_us"] > tl["span_us"] * 1.001:
             print(f"FAIL {tag}: busy {tl['busy_us']} us exceeds the span {tl['span_us']} us")
             bad += 1
