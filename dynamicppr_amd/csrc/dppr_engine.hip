@@ -92,7 +92,7 @@ struct Slot {
     int source_ext = 0; // id the caller gave
     double *p = nullptr, *r = nullptr;
     double *x = nullptr, *x2 = nullptr; // dense per-iteration push amounts (x) and pull output (x2)
-    double *x3 = nullptr;               // third snapshot vector of the data-flow resident sweep (all zero outside it)
+    double *x3 = nullptr, *x4 = nullptr; // third and fourth snapshot vector of the data-flow resident sweep (all zero outside it)
     uint32_t *act[2] = {nullptr, nullptr}; // activity bitmaps of x / x2 for sweeps on windows that cannot run resident
     size_t act_bytes = 0;
     int *ft[2] = {nullptr, nullptr};
@@ -612,6 +612,7 @@ int compact_ids(dppr_engine *e, bool *did) {
         RN_TRY(hipMemsetAsync(s.x, 0, sizeof(double) * (size_t)V, e->stream));
         RN_TRY(hipMemsetAsync(s.x2, 0, sizeof(double) * (size_t)V, e->stream));
         RN_TRY(hipMemsetAsync(s.x3, 0, sizeof(double) * (size_t)V, e->stream));
+        RN_TRY(hipMemsetAsync(s.x4, 0, sizeof(double) * (size_t)V, e->stream));
         RN_TRY(hipMemsetAsync(s.act[0], 0, s.act_bytes, e->stream));
         RN_TRY(hipMemsetAsync(s.act[1], 0, s.act_bytes, e->stream));
         s.source = perm[(size_t)s.source];
@@ -1028,11 +1029,12 @@ int pull_min_frontier(const dppr_engine *e) {
 
 // after a resident launch of `sweeps` sweeps: make s.x the vector that holds the live snapshot
 // (the other vectors are all zero again)
-void rotate_snapshots(Slot &s, int sweeps) { // three vectors, x_g lives in vector g % 3
-    double *b[3] = {s.x, s.x2, s.x3};
-    s.x = b[sweeps % 3];
-    s.x2 = b[(sweeps + 1) % 3];
-    s.x3 = b[(sweeps + 2) % 3];
+void rotate_snapshots(Slot &s, int sweeps) { // four vectors, x_g lives in vector g % 4
+    double *b[4] = {s.x, s.x2, s.x3, s.x4};
+    s.x = b[sweeps % 4];
+    s.x2 = b[(sweeps + 1) % 4];
+    s.x3 = b[(sweeps + 2) % 4];
+    s.x4 = b[(sweeps + 3) % 4];
 }
 
 int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, double eps, int buf, int cur,
@@ -1124,7 +1126,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                       \
     hipLaunchKernelGGL(k_pull_resident<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,       \
-                       ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.r, s.p, s.cnt, cur, phase, eps, s.dstats, s.log,  \
+                       ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.x4, s.r, s.p, s.cnt, cur, phase, eps, s.dstats, s.log,  \
                        n, e->bar, s.cnt + 7, e->persist_ticks, e->persist_rollcall_extra, 0,                          \
                        ep.res_valid ? ep.res_pk : nullptr)
             switch (sweep_block(e)) {
@@ -1337,7 +1339,8 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
     if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                        \
     hipLaunchKernelGGL(k_pull_resident<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,        \
-                       ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.r, s.p, s.cnt, 0, merged ? PHASE_BOTH : 0, eps, s.dstats,  \
+                       ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.x4, s.r, s.p, s.cnt, 0, merged ? PHASE_BOTH : 0, eps,    \
+                       s.dstats,                                                                                           \
                        s.log, n, e->bar, status, e->persist_ticks, e->persist_rollcall_extra,                             \
                        merged ? PLAN_SEED : (PLAN_SEED | PLAN_BOTH), ep.res_valid ? ep.res_pk : nullptr)
     switch (sweep_block(e)) {
@@ -2011,7 +2014,7 @@ void dppr_destroy(dppr_engine *e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto &s : e->slots) {
-        (void)hipFree(s.p); (void)hipFree(s.r); (void)hipFree(s.x); (void)hipFree(s.x2); (void)hipFree(s.x3);
+        (void)hipFree(s.p); (void)hipFree(s.r); (void)hipFree(s.x); (void)hipFree(s.x2); (void)hipFree(s.x3); (void)hipFree(s.x4);
         (void)hipFree(s.ft[0]); (void)hipFree(s.ft[1]); (void)hipFree(s.neg); (void)hipFree(s.status); (void)hipFree(s.act[0]); (void)hipFree(s.act[1]);
         (void)hipFree(s.cnt); (void)hipFree(s.dstats); (void)hipFree(s.big);
     }
@@ -2373,9 +2376,11 @@ int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
     HIP_TRY(hipMalloc((void **)&s.x, sizeof(double) * V));
     HIP_TRY(hipMalloc((void **)&s.x2, sizeof(double) * V));
     HIP_TRY(hipMalloc((void **)&s.x3, sizeof(double) * V));
+    HIP_TRY(hipMalloc((void **)&s.x4, sizeof(double) * V));
     HIP_TRY(hipMemsetAsync(s.x, 0, sizeof(double) * V, e->stream));
     HIP_TRY(hipMemsetAsync(s.x2, 0, sizeof(double) * V, e->stream));
     HIP_TRY(hipMemsetAsync(s.x3, 0, sizeof(double) * V, e->stream));
+    HIP_TRY(hipMemsetAsync(s.x4, 0, sizeof(double) * V, e->stream));
     s.act_bytes = (V / 32 + 64) * sizeof(uint32_t);
     HIP_TRY(hipMalloc((void **)&s.act[0], s.act_bytes));
     HIP_TRY(hipMalloc((void **)&s.act[1], s.act_bytes));

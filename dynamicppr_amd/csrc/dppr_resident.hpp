@@ -40,23 +40,28 @@ namespace dppr {
 // grid barrier: stores complete ~1.7 K clocks -> arrive -> everybody has arrived ~5.4 K -> only
 // then the next gathers ~8 K; three memory-side round trips in a row.) Here an iteration's
 // gathers wait for exactly what they need -- the values themselves:
-//   * three snapshot vectors B[0..2]; sweep g reads x_g from B[g % 3], writes x_{g+1} to
-//     B[(g+1) % 3], and B[(g+2) % 3] (which held x_{g-1}) is RESET for the sweep after;
+//   * FOUR snapshot vectors B[0..3]; sweep g reads x_g from B[g % 4] and ends with two stores per thread: x_{g+1} into
+//     B[(g+1) % 4], and a RESET of its entry of B[(g+3) % 4] (which held x_{g-1}) for the sweep after next;
 //   * a reset entry holds X_EMPTY, a NaN bit pattern no computed value has; a gather that reads
 //     X_EMPTY is simply repeated until the owner has stored this round's value;
 //   * arrival counters (one memory-side atomic per workgroup and sweep, fire and forget) tell
 //     "every workgroup has finished sweep h" and carry the number of legal vertices it produced.
 //     Nobody waits on them in the common case: during sweep g the first wave of a workgroup looks
 //     at the arrivals of sweep g-1 -- issued a whole gather phase earlier, so normally complete --
-//     to learn (1) that nobody reads x_{g-1} any more, so B[(g+2) % 3] may be reset, and (2) the
+//     to learn (1) that nobody reads x_{g-1} any more: the licence for this sweep's reset, and (2) the
 //     size of the frontier sweep g consumes, i.e. whether the loop is over. Every workgroup
 //     evaluates the same sums at the same iteration number, so all of them stop together.
-// Why a gather never sees a stale value instead of X_EMPTY or the right one: the owner's first
-// wave resets B[(g+2) % 3] for the whole group, waits for those stores to complete (s_waitcnt
-// vmcnt(0)), and only then the workgroup passes the __syncthreads after which any of its waves
-// stores x_{g+1}. A consumer reads B[(g+2) % 3] as x_{g+2} no earlier than its sweep g+2, which it
-// starts after it consumed x_{g+1} of every vertex it depends on -- stored after the reset
-// completed. Progress: sweep g of any workgroup needs only values and arrivals of sweep g-1.
+//     (Rounds 1-2 rotated THREE vectors: the first wave reset the whole group's entries of the vector that held x_{g-1}
+//     as soon as it had seen the arrivals -- sixteen store instructions issued a round trip into the iteration, whose
+//     acknowledgements the workgroup then waited for before it could store x_{g+1} into the vector reset an iteration
+//     earlier... with a fourth vector nothing in an iteration waits for a store issued in the same iteration.)
+// Why a gather never sees a stale value instead of X_EMPTY or the right one: a thread resets its entry of
+// B[(g+3) % 4] at the end of sweep g; in sweep g+1 the workgroup waits for all its outstanding stores (s_waitcnt
+// vmcnt(0)) and only then passes the __syncthreads after which any of its waves stores x_{g+2}. A consumer reads
+// B[(g+3) % 4] as x_{g+3} no earlier than its sweep g+3, which it starts after it consumed x_{g+2} of every vertex it
+// depends on -- stored after the reset completed. And the reset destroys nothing that is still read: x_{g-1} is read in
+// sweep g-1 only, which everybody has left (arrivals of sweep g-1, seen by the first wave before the barrier that
+// precedes the stores). Progress: sweep g of any workgroup needs only values and arrivals of sweep g-1.
 // Accesses to ONE address serialise at the memory side (~10 ns each; 242 workgroups polling the
 // same 16 words took 4 us), so every counter exists BAR_REPS times: a workgroup arrives on all
 // replicas (one 16-lane atomic instruction) and reads only the replica of its own sixteen. Two
@@ -114,7 +119,7 @@ constexpr int PERSIST_ABORTED = 1 << 30;   // the roll-call failed, nothing was 
 constexpr int PERSIST_FAULT = 1 << 29;     // a wait timed out after a successful roll-call
 constexpr int PERSIST_CONVERGED = 1 << 28; // the frontier emptied; all snapshot vectors are all zero again
 constexpr int PERSIST_PHASE1 = 1 << 26;    // a launch that runs both phases had started phase 1
-constexpr int PERSIST_SWEEPS = (1 << 16) - 1; // low bits: loop position g; the live snapshot is vector g % 3
+constexpr int PERSIST_SWEEPS = (1 << 16) - 1; // low bits: loop position g; the live snapshot is vector g % 4
 // plan of a launch
 constexpr int PLAN_SEED = 1;  // take the first snapshot from the registers: {v : legal(residual[v])} (valid after a converged solve)
 constexpr int PLAN_BOTH = 2;  // when phase 0 is over, seed phase 1 the same way and go on
@@ -137,7 +142,7 @@ template <int PB>
 __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restrict__ grp_tile,
                                                       const int *__restrict__ out_row_ptr,
                                                       const int *__restrict__ out_col, double *b0, double *b1,
-                                                      double *b2, double *r, double *p, int *cnt, int cur0, int phase,
+                                                      double *b2, double *b3, double *r, double *p, int *cnt, int cur0, int phase,
                                                       double eps, IterStats *stats, int *log, int n_iter, GridBar *bar,
                                                       int *status, unsigned long long limit_ticks, int rollcall_extra,
                                                       int plan, const uint32_t *__restrict__ res_pk) {
@@ -166,7 +171,12 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
     if (valid) {
         xb_store(b1 + v, X_EMPTY);
         xb_store(b2 + v, X_EMPTY);
+        xb_store(b3 + v, X_EMPTY);
     }
+    auto Bv = [&](int i) { // vector i & 3 (selects, not an indexed private array)
+        const int k = i & 3;
+        return k == 0 ? b0 : k == 1 ? b1 : k == 2 ? b2 : b3;
+    };
     if (tid == 0) s_fault = 0;
     int rs = 0, d = 0;
     double rv = 0.0, xv = 0.0, pv = 0.0;
@@ -289,6 +299,7 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
             if (plan & PLAN_SEED) xb_store(b0 + v, 0ull);
             xb_store(b1 + v, 0ull);
             xb_store(b2 + v, 0ull);
+            xb_store(b3 + v, 0ull);
         }
         if (blockIdx.x == 0 && tid == 0) *status = PERSIST_ABORTED;
         return;
@@ -319,12 +330,11 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
     const int last_phase = (plan & PLAN_BOTH) ? 1 : phase;
     int g = 0;
     for (; g < n_iter; ++g) {
-        const int ri = g % 3;
-        const double *xin = ri == 0 ? b0 : ri == 1 ? b1 : b2;
-        double *xout = ri == 0 ? b1 : ri == 1 ? b2 : b0;
-        double *xrst = ri == 0 ? b2 : ri == 1 ? b0 : b1;
+        const double *xin = Bv(g);
+        double *xout = Bv(g + 1);
         const int it = g; // (PSTAMP)
         PSTAMP(0);
+
         // first wave: the arrivals of sweep g-1, read BEFORE the gathers are issued (loads return in
         // order, so this is back long before they are)
         unsigned long long fw = 0;
@@ -341,14 +351,16 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
                 s_next[1] = fsz;
                 if (!ok) s_fault = 1;
             }
-            if (ok && fsz != 0) { // every workgroup is done with sweep g-1: nobody reads x_{g-1} any more
-                for (int i = lane; i < (t1 - t0) * WAVE; i += WAVE) {
-                    const int vv = t0 * WAVE + i;
-                    if (vv < V) xb_store(xrst + vv, X_EMPTY);
-                }
-            }
+            // (ok: every workgroup is done with sweep g-1, nobody reads x_{g-1} any more -- the licence for the reset at the
+            // head of the NEXT iteration)
         }
         // gathers whose owner has not stored this round's value yet are repeated
+#ifdef DPPR_STAMPS
+        if (it == 10 && tid == PB - 1) { // (last wave: when its first attempt was back)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            g_stamps[blockIdx.x * 8 + 6] = clock64();
+        }
+#endif
         {
             unsigned polls = 0;
             const unsigned long long t_start = wall_clock64();
@@ -366,6 +378,9 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
                 for (int k = 0; k < S; ++k)
                     if (gb[k] == X_EMPTY) gb[k] = xb_load(xin + col[k]);
             }
+#ifdef DPPR_STAMPS
+            if (it == 10 && tid == PB - 1) g_stamps[blockIdx.x * 8 + 7] = polls;
+#endif
         }
         PSTAMP(1);
         double *acc = s_acc[g & 1];
@@ -400,7 +415,7 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
             if (nz) lds_add(&acc[o], ONE_MINUS_ALPHA * xe / (double)(s_scan[o + 1] - s_scan[o] + 1));
             edges += (unsigned long long)__popcll(__ballot(nz));
         }
-        // (first wave: its reset stores are complete before the workgroup goes on to store x_{g+1})
+        // (everybody's reset store is complete before the workgroup goes on to store x_{g+1})
         PSTAMP(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -420,17 +435,8 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
         if (F == 0) {
             // phase 0 is over (x_g is all zero, the gathers above found nothing) and the launch goes on
             // with phase 1: this step seeds it from the registers the way PLAN_SEED does, in place of a
-            // sweep. The vector after next still holds x_{g-1}: the first wave skipped its reset when it
-            // saw the empty frontier, so do it now (everybody is past sweep g-1).
+            // sweep (the vectors rotate as in any other iteration).
             cur_phase = 1;
-            if (w == 0) {
-                for (int i = lane; i < (t1 - t0) * WAVE; i += WAVE) {
-                    const int vv = t0 * WAVE + i;
-                    if (vv < V) xb_store(xrst + vv, X_EMPTY);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __syncthreads();
             rn = rv;
         } else if (xv != 0.0) {
             rn -= xv;
@@ -440,6 +446,10 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
             rv = rn;
             xv = lg ? rn : 0.0;
             xb_store(xout + v, (unsigned long long)__double_as_longlong(xv));
+            // B[(g + 3) & 3] held x_{g-1}; that every workgroup is done with sweep g-1 is what the first wave established
+            // before the barrier above. Everybody resets its own entry, fire and forget next to the snapshot store: the
+            // NEXT iteration's wait for outstanding stores covers both, one iteration before the vector is written.
+            xb_store(Bv(g + 3) + v, X_EMPTY);
             if (lg) pv = pv + ALPHA * rn;
         }
         s_acc[(g + 1) & 1][tid] = rv;
@@ -474,12 +484,10 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
         fault = s_fault != 0;
         F = s_next[1];
     }
-    if (!fault && valid) {
-        const int ri = g % 3; // B[ri] holds x_g (all zero if converged)
-        double *o1 = ri == 0 ? b1 : ri == 1 ? b2 : b0;
-        double *o2 = ri == 0 ? b2 : ri == 1 ? b0 : b1;
-        xb_store(o1 + v, 0ull);
-        xb_store(o2 + v, 0ull);
+    if (!fault && valid) { // B[g & 3] holds x_g (all zero if converged)
+        xb_store(Bv(g + 1) + v, 0ull);
+        xb_store(Bv(g + 2) + v, 0ull);
+        xb_store(Bv(g + 3) + v, 0ull);
     }
     if (valid) {
         r[v] = rv;

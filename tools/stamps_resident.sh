@@ -31,6 +31,8 @@ print("iteration start spread (cycles): median", int(np.median(s[:, 0] - t0)), "
 for i, n in enumerate(names):
     d = s[:, i + 1] - s[:, i]
     print(f"{n:34s} median {int(np.median(d)):7d} cyc   p90 {int(np.percentile(d, 90)):7d}   max {int(d.max()):7d}")
+fa = s[:, 6] - s[:, 0]
+print(f"last wave: first gather attempt back after median {int(np.median(fa))} cyc (p90 {int(np.percentile(fa, 90))}), repeat rounds median {int(np.median(s[:, 7]))} p90 {int(np.percentile(s[:, 7], 90))} max {int(s[:, 7].max())}; workgroups without a repeat: {int((s[:, 7] == 0).sum())}")
 tot = s[:, 5] - s[:, 0]
 print("iteration median", int(np.median(tot)), "max", int(tot.max()), "| span first start -> last end", int(s[:, 5].max() - t0))
 print(e.stats(slot))
