@@ -92,7 +92,6 @@ struct Slot {
     int source_ext = 0; // id the caller gave
     double *p = nullptr, *r = nullptr;
     double *x = nullptr, *x2 = nullptr; // dense per-iteration push amounts (x) and pull output (x2)
-    double *x3 = nullptr, *x4 = nullptr; // third and fourth snapshot vector of the data-flow resident sweep (all zero outside it)
     uint32_t *act[2] = {nullptr, nullptr}; // activity bitmaps of x / x2 for sweeps on windows that cannot run resident
     size_t act_bytes = 0;
     int *ft[2] = {nullptr, nullptr};
@@ -175,6 +174,8 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     int persist_retry = 0;             // dppr_update calls until resident launches are tried again (0: not pending)
     int persist_cap = 0;               // co-resident workgroups of k_pull_resident at the sweep's block size
     int res_slots = 1;                 // 1: resident launches take their edge slots from the sorted slot table (0: CSR order)
+    double *res_arena = nullptr;       // snapshot vectors of a resident launch (resident_arena)
+    long long res_arena_stride = 0;    // doubles per vector
     unsigned long long persist_ticks = 5000000ull; // roll-call time limit in 100 MHz ticks (50 ms)
     int persist_rollcall_extra = 0;    // tests: the roll-call waits for a workgroup that does not exist
     GridBar *bar = nullptr;
@@ -611,8 +612,6 @@ int compact_ids(dppr_engine *e, bool *did) {
         // between two loops the snapshot vectors are all zero and the lists empty: nothing to carry over
         RN_TRY(hipMemsetAsync(s.x, 0, sizeof(double) * (size_t)V, e->stream));
         RN_TRY(hipMemsetAsync(s.x2, 0, sizeof(double) * (size_t)V, e->stream));
-        RN_TRY(hipMemsetAsync(s.x3, 0, sizeof(double) * (size_t)V, e->stream));
-        RN_TRY(hipMemsetAsync(s.x4, 0, sizeof(double) * (size_t)V, e->stream));
         RN_TRY(hipMemsetAsync(s.act[0], 0, s.act_bytes, e->stream));
         RN_TRY(hipMemsetAsync(s.act[1], 0, s.act_bytes, e->stream));
         s.source = perm[(size_t)s.source];
@@ -1002,7 +1001,7 @@ int read_count(dppr_engine *e, const int *dptr, int *out) {
 
 // Frontier loop: PPRRevPushGPU::ExecuteOptimized's while(1) (gpu/PPRRevPushGPU.cuh:106-130).
 // On entry s.ft[buf] holds the frontier and s.cnt[cur] its size; cnt[(cur+1)%3] is zero and
-// the dense vectors s.x / s.x2 / s.x3 are all zero (no snapshot taken yet) -- unless `entry` says
+// the dense vectors s.x / s.x2 are all zero (no snapshot taken yet) -- unless `entry` says
 // otherwise.
 //
 // The reference reads the frontier count back after EVERY iteration (blocking 4-byte D2H,
@@ -1027,14 +1026,20 @@ int pull_min_frontier(const dppr_engine *e) {
     return e->pull_min_frontier > 0 ? e->pull_min_frontier : e->pull_min_frontier < 0 ? 0x7fffffff : std::max(1024, e->Ed / 192);
 }
 
-// after a resident launch of `sweeps` sweeps: make s.x the vector that holds the live snapshot
-// (the other vectors are all zero again)
-void rotate_snapshots(Slot &s, int sweeps) { // four vectors, x_g lives in vector g % 4
-    double *b[4] = {s.x, s.x2, s.x3, s.x4};
-    s.x = b[sweeps % 4];
-    s.x2 = b[(sweeps + 1) % 4];
-    s.x3 = b[(sweeps + 2) % 4];
-    s.x4 = b[(sweeps + 3) % 4];
+// The arena of a resident launch (dppr_resident.hpp, FRESH VECTORS): RES_VECTORS vectors of `stride` doubles, scratch between
+// launches, one per engine (the engine's launches are serial on its stream).
+int resident_arena(dppr_engine *e, const Epoch &ep) {
+    const long long stride = ((long long)ep.grp_n_int + 1023) / 1024 * 1024;
+    if (stride > e->res_arena_stride) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        (void)hipFree(e->res_arena);
+        e->res_arena = nullptr;
+        e->res_arena_stride = 0;
+        const long long want = std::min<long long>(((long long)e->V + 1023) / 1024 * 1024, stride + stride / 4);
+        HIP_TRY(hipMalloc((void **)&e->res_arena, sizeof(double) * (size_t)want * RES_VECTORS));
+        e->res_arena_stride = want;
+    }
+    return DPPR_OK;
 }
 
 int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, double eps, int buf, int cur,
@@ -1123,10 +1128,12 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 dense_valid = true;
             }
             HIP_TRY(hipMemsetAsync(e->bar, 0, sizeof(GridBar), e->stream));
+            if (int arc = resident_arena(e, ep)) return arc;
+            n = std::min(n, RES_MAX_SWEEPS);
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                       \
     hipLaunchKernelGGL(k_pull_resident<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,       \
-                       ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.x4, s.r, s.p, s.cnt, cur, phase, eps, s.dstats, s.log,  \
+                       ep.out_row_ptr, ep.out_col, s.x, e->res_arena, e->res_arena_stride, s.r, s.p, s.cnt, cur, phase, eps, s.dstats, s.log,  \
                        n, e->bar, s.cnt + 7, e->persist_ticks, e->persist_rollcall_extra, 0,                          \
                        ep.res_valid ? ep.res_pk : nullptr)
             switch (sweep_block(e)) {
@@ -1150,7 +1157,6 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 e->persist_retry = PERSIST_RETRY_BATCHES;
                 continue;
             }
-            const int sweeps = status & PERSIST_SWEEPS;
             for (int k = 0; k < n; ++k) {
                 const int f = e->pinned[CNT_HDR + k];
                 if (f <= 0) continue;
@@ -1165,7 +1171,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 s.st.push_ms += ms;
                 s.st.push_launches++;
             }
-            rotate_snapshots(s, sweeps);       // s.x = the snapshot the last sweep wrote
+            // (s.x holds the snapshot the last sweep wrote)
             cur = 0;                              // the launch leaves the live count in cnt[0]
             list_valid = false;
             any_pull = true;
@@ -1335,12 +1341,14 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
                       ? std::min(s.iter_hint[0] + s.iter_hint[1] + 1 + 2 * RESIDENT_MARGIN, 2 * MAX_CHUNK)
                       : 2 * MAX_CHUNK; // no history yet
     if (e->chunk_explicit) n = std::min(n, e->chunk_iters); // (tests: launches that stop mid-phase and are resumed)
+    n = std::min(n, RES_MAX_SWEEPS);
+    if (int arc = resident_arena(e, ep)) return arc;
     int *status = s.cnt + 7; // (the GridBar was zeroed by the batch's first kernel, k_su_keys)
     if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                        \
     hipLaunchKernelGGL(k_pull_resident<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,        \
-                       ep.out_row_ptr, ep.out_col, s.x, s.x2, s.x3, s.x4, s.r, s.p, s.cnt, 0, merged ? PHASE_BOTH : 0, eps,    \
-                       s.dstats,                                                                                           \
+                       ep.out_row_ptr, ep.out_col, s.x, e->res_arena, e->res_arena_stride, s.r, s.p, s.cnt, 0,                  \
+                       merged ? PHASE_BOTH : 0, eps, s.dstats,                                                             \
                        s.log, n, e->bar, status, e->persist_ticks, e->persist_rollcall_extra,                             \
                        merged ? PLAN_SEED : (PLAN_SEED | PLAN_BOTH), ep.res_valid ? ep.res_pk : nullptr)
     switch (sweep_block(e)) {
@@ -1391,7 +1399,6 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
         s.st.sum_F += log[k];
         act[ph]++;
     }
-    rotate_snapshots(s, pos);
     if (merged) {
         if (!(st & PERSIST_CONVERGED)) { // out of sweeps: the host-driven loop goes on from here
             en0->it = act[0];
@@ -2014,7 +2021,7 @@ void dppr_destroy(dppr_engine *e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto &s : e->slots) {
-        (void)hipFree(s.p); (void)hipFree(s.r); (void)hipFree(s.x); (void)hipFree(s.x2); (void)hipFree(s.x3); (void)hipFree(s.x4);
+        (void)hipFree(s.p); (void)hipFree(s.r); (void)hipFree(s.x); (void)hipFree(s.x2);
         (void)hipFree(s.ft[0]); (void)hipFree(s.ft[1]); (void)hipFree(s.neg); (void)hipFree(s.status); (void)hipFree(s.act[0]); (void)hipFree(s.act[1]);
         (void)hipFree(s.cnt); (void)hipFree(s.dstats); (void)hipFree(s.big);
     }
@@ -2033,6 +2040,7 @@ void dppr_destroy(dppr_engine *e) {
     (void)hipFree(e->bin_vblk_a); (void)hipFree(e->bin_vblk_b); (void)hipFree(e->bin_small); (void)hipFree(e->bin_vals); (void)hipFree(e->bin_tmp);
     (void)hipFree(e->w1); (void)hipFree(e->w2); (void)hipFree(e->outdeg);
     (void)hipFree(e->bar);
+    (void)hipFree(e->res_arena);
     (void)hipFree(e->hub_slot_of); (void)hipFree(e->hub_hist); (void)hipFree(e->d_ext2int); (void)hipFree(e->d_xfer);
     (void)hipFree(e->mv_idx); (void)hipFree(e->mv_tmp);
     (void)hipFree(e->keys_a); (void)hipFree(e->keys_b); (void)hipFree(e->sort_tmp);
@@ -2375,12 +2383,8 @@ int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
     HIP_TRY(hipMalloc((void **)&s.r, sizeof(double) * V));
     HIP_TRY(hipMalloc((void **)&s.x, sizeof(double) * V));
     HIP_TRY(hipMalloc((void **)&s.x2, sizeof(double) * V));
-    HIP_TRY(hipMalloc((void **)&s.x3, sizeof(double) * V));
-    HIP_TRY(hipMalloc((void **)&s.x4, sizeof(double) * V));
     HIP_TRY(hipMemsetAsync(s.x, 0, sizeof(double) * V, e->stream));
     HIP_TRY(hipMemsetAsync(s.x2, 0, sizeof(double) * V, e->stream));
-    HIP_TRY(hipMemsetAsync(s.x3, 0, sizeof(double) * V, e->stream));
-    HIP_TRY(hipMemsetAsync(s.x4, 0, sizeof(double) * V, e->stream));
     s.act_bytes = (V / 32 + 64) * sizeof(uint32_t);
     HIP_TRY(hipMalloc((void **)&s.act[0], s.act_bytes));
     HIP_TRY(hipMalloc((void **)&s.act[1], s.act_bytes));

@@ -40,28 +40,35 @@ namespace dppr {
 // grid barrier: stores complete ~1.7 K clocks -> arrive -> everybody has arrived ~5.4 K -> only
 // then the next gathers ~8 K; three memory-side round trips in a row.) Here an iteration's
 // gathers wait for exactly what they need -- the values themselves:
-//   * FOUR snapshot vectors B[0..3]; sweep g reads x_g from B[g % 4] and ends with two stores per thread: x_{g+1} into
-//     B[(g+1) % 4], and a RESET of its entry of B[(g+3) % 4] (which held x_{g-1}) for the sweep after next;
-//   * a reset entry holds X_EMPTY, a NaN bit pattern no computed value has; a gather that reads
+//   * FRESH VECTORS: x_j of a launch lives in its own vector A[j] of an arena (132 vectors; a launch runs at most 128
+//     sweeps). Sweep g reads x_g from A[g] and ends with two stores per thread: x_{g+1} into A[g+1], and the EMPTY mark of
+//     its entry of A[g+3] for the sweep after next (A[1..3] are marked on entry);
+//   * a marked entry holds X_EMPTY, a NaN bit pattern no computed value has; a gather that reads
 //     X_EMPTY is simply repeated until the owner has stored this round's value;
+//   * because every address is written ONCE per launch (after its mark), a gather's first attempt is an ORDINARY load: a copy
+//     of the line in the L1 or in the XCD's L2 -- fetched a moment ago by another workgroup of the same XCD -- holds either
+//     the value or the mark, never an older value. Only a repeat goes to the memory side (agent scope, sc1). The 32
+//     workgroups of an XCD share one fetch of a hub's line instead of pulling it through the fabric 32 times. (Rounds 1-2
+//     rotated three vectors; an address then carried a new value every third sweep, every gather had to be an agent-scope
+//     access that misses the L2 by construction, and the gather phase was bound by the fabric: 0.5 M lines per sweep on
+//     the configs[1] stand-in, 8 K of an iteration's 10.6 K clocks.) The arena's addresses are reused by the next launch;
+//     what an earlier launch left in the L1s / L2s is dropped by the acquire every kernel dispatch begins with -- the
+//     mechanism every per-iteration kernel of this engine relies on when it reads, with ordinary loads, the snapshot vector
+//     the previous kernel's workgroups wrote on other XCDs (an explicit agent-scope acquire by every wave on top of it was
+//     measured: + 35 us per launch);
 //   * arrival counters (one memory-side atomic per workgroup and sweep, fire and forget) tell
 //     "every workgroup has finished sweep h" and carry the number of legal vertices it produced.
 //     Nobody waits on them in the common case: during sweep g the first wave of a workgroup looks
 //     at the arrivals of sweep g-1 -- issued a whole gather phase earlier, so normally complete --
-//     to learn (1) that nobody reads x_{g-1} any more: the licence for this sweep's reset, and (2) the
-//     size of the frontier sweep g consumes, i.e. whether the loop is over. Every workgroup
+//     to learn the size of the frontier sweep g consumes, i.e. whether the loop is over. Every workgroup
 //     evaluates the same sums at the same iteration number, so all of them stop together.
-//     (Rounds 1-2 rotated THREE vectors: the first wave reset the whole group's entries of the vector that held x_{g-1}
-//     as soon as it had seen the arrivals -- sixteen store instructions issued a round trip into the iteration, whose
-//     acknowledgements the workgroup then waited for before it could store x_{g+1} into the vector reset an iteration
-//     earlier... with a fourth vector nothing in an iteration waits for a store issued in the same iteration.)
-// Why a gather never sees a stale value instead of X_EMPTY or the right one: a thread resets its entry of
-// B[(g+3) % 4] at the end of sweep g; in sweep g+1 the workgroup waits for all its outstanding stores (s_waitcnt
-// vmcnt(0)) and only then passes the __syncthreads after which any of its waves stores x_{g+2}. A consumer reads
-// B[(g+3) % 4] as x_{g+3} no earlier than its sweep g+3, which it starts after it consumed x_{g+2} of every vertex it
-// depends on -- stored after the reset completed. And the reset destroys nothing that is still read: x_{g-1} is read in
-// sweep g-1 only, which everybody has left (arrivals of sweep g-1, seen by the first wave before the barrier that
-// precedes the stores). Progress: sweep g of any workgroup needs only values and arrivals of sweep g-1.
+// Why a gather never sees anything but X_EMPTY or the right value: a thread marks its entry of A[g+3] at the end of sweep g;
+// in sweep g+1 the workgroup waits for all its outstanding stores (s_waitcnt vmcnt(0)) and only then passes the
+// __syncthreads after which any of its waves stores x_{g+2}. A consumer reads A[g+3] no earlier than its sweep g+3, which
+// it starts after it consumed x_{g+2} of every vertex it depends on -- stored after the mark completed; and nobody has read
+// (or cached) a line of A[g+3] before that in this launch. A 128-byte line belongs to ONE wave's 512-byte store, so the
+// entries a consumer does not depend on were marked by the same completed store. Progress: sweep g of any workgroup needs
+// only values and arrivals of sweep g-1.
 // Accesses to ONE address serialise at the memory side (~10 ns each; 242 workgroups polling the
 // same 16 words took 4 us), so every counter exists BAR_REPS times: a workgroup arrives on all
 // replicas (one 16-lane atomic instruction) and reads only the replica of its own sixteen. Two
@@ -89,6 +96,8 @@ constexpr unsigned long long BAR_ABORT = ~0ull;
 constexpr unsigned long long BAR_READY = 1ull;
 constexpr int PERSIST_SLOTS = 4; // edge slots per thread kept in registers (PB * 4 edges per group)
 constexpr unsigned long long X_EMPTY = 0x7FF8DEADBEEFCAFEull;
+constexpr int RES_MAX_SWEEPS = 128;               // sweeps of one launch at most
+constexpr int RES_VECTORS = RES_MAX_SWEEPS + 4;   // vectors of the arena: x_0 .. x_128 and the marks three ahead
 // SLOT TABLES (round 3). The gathers are the iteration's cost, and what the fabric moves for them is one 64-byte sector per
 // distinct sector a wave instruction touches -- 0.99 sectors per edge with the slots in CSR order on hashed ids (configs[1]
 // stand-in: the lanes of an instruction walk a few short rows whose columns are spread over the whole id range). Nothing ties
@@ -119,7 +128,7 @@ constexpr int PERSIST_ABORTED = 1 << 30;   // the roll-call failed, nothing was 
 constexpr int PERSIST_FAULT = 1 << 29;     // a wait timed out after a successful roll-call
 constexpr int PERSIST_CONVERGED = 1 << 28; // the frontier emptied; all snapshot vectors are all zero again
 constexpr int PERSIST_PHASE1 = 1 << 26;    // a launch that runs both phases had started phase 1
-constexpr int PERSIST_SWEEPS = (1 << 16) - 1; // low bits: loop position g; the live snapshot is vector g % 4
+constexpr int PERSIST_SWEEPS = (1 << 16) - 1; // low bits: loop position g
 // plan of a launch
 constexpr int PLAN_SEED = 1;  // take the first snapshot from the registers: {v : legal(residual[v])} (valid after a converged solve)
 constexpr int PLAN_BOTH = 2;  // when phase 0 is over, seed phase 1 the same way and go on
@@ -134,6 +143,10 @@ __device__ __forceinline__ bool bar_cas(unsigned long long *p, unsigned long lon
 __device__ __forceinline__ unsigned long long xb_load(const double *p) {
     return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// a gather's FIRST attempt: an ordinary load, which may be served by the L1 / the XCD's L2 (see "FRESH VECTORS" below)
+__device__ __forceinline__ unsigned long long xc_load(const double *p) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
 __device__ __forceinline__ void xb_store(double *p, unsigned long long bits) {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -141,8 +154,8 @@ __device__ __forceinline__ void xb_store(double *p, unsigned long long bits) {
 template <int PB>
 __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restrict__ grp_tile,
                                                       const int *__restrict__ out_row_ptr,
-                                                      const int *__restrict__ out_col, double *b0, double *b1,
-                                                      double *b2, double *b3, double *r, double *p, int *cnt, int cur0, int phase,
+                                                      const int *__restrict__ out_col, double *b0, double *arena,
+                                                      long long stride, double *r, double *p, int *cnt, int cur0, int phase,
                                                       double eps, IterStats *stats, int *log, int n_iter, GridBar *bar,
                                                       int *status, unsigned long long limit_ticks, int rollcall_extra,
                                                       int plan, const uint32_t *__restrict__ res_pk) {
@@ -168,15 +181,12 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
     const int t0 = grp_tile[blockIdx.x], t1 = grp_tile[blockIdx.x + 1];
     const int v = t0 * WAVE + tid;
     const bool valid = tid < (t1 - t0) * WAVE && v < V;
+    auto Av = [&](int j) { return arena + (long long)j * stride; }; // the vector of x_j
     if (valid) {
-        xb_store(b1 + v, X_EMPTY);
-        xb_store(b2 + v, X_EMPTY);
-        xb_store(b3 + v, X_EMPTY);
+        xb_store(Av(1) + v, X_EMPTY);
+        xb_store(Av(2) + v, X_EMPTY);
+        xb_store(Av(3) + v, X_EMPTY);
     }
-    auto Bv = [&](int i) { // vector i & 3 (selects, not an indexed private array)
-        const int k = i & 3;
-        return k == 0 ? b0 : k == 1 ? b1 : k == 2 ? b2 : b3;
-    };
     if (tid == 0) s_fault = 0;
     int rs = 0, d = 0;
     double rv = 0.0, xv = 0.0, pv = 0.0;
@@ -196,10 +206,10 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
         const bool lg0 = valid && legal(rv, phase, eps);
         xv = lg0 ? rv : 0.0;
         if (lg0) pv = pv + ALPHA * rv;
-        if (valid) xb_store(b0 + v, (unsigned long long)__double_as_longlong(xv));
         const int wl = __popcll(__ballot(lg0));
         if (lane == 0) s_cnt[w] = wl;
     }
+    if (valid) xb_store(Av(0) + v, (unsigned long long)__double_as_longlong(xv)); // x_0, given or seeded
     const int incl = wave_inclusive_scan(d);
     if (lane == WAVE - 1) s_wtot[w] = incl;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the EMPTY marks (and seeds) are in place before this workgroup checks in
@@ -294,13 +304,7 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
         }
     }
     __syncthreads();
-    if (!s_next[0]) { // not co-resident: put the vectors back to what they were and leave
-        if (valid) {
-            if (plan & PLAN_SEED) xb_store(b0 + v, 0ull);
-            xb_store(b1 + v, 0ull);
-            xb_store(b2 + v, 0ull);
-            xb_store(b3 + v, 0ull);
-        }
+    if (!s_next[0]) { // not co-resident: nothing the engine looks at was changed (the arena is scratch)
         if (blockIdx.x == 0 && tid == 0) *status = PERSIST_ABORTED;
         return;
     }
@@ -330,8 +334,8 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
     const int last_phase = (plan & PLAN_BOTH) ? 1 : phase;
     int g = 0;
     for (; g < n_iter; ++g) {
-        const double *xin = Bv(g);
-        double *xout = Bv(g + 1);
+        const double *xin = Av(g);
+        double *xout = Av(g + 1);
         const int it = g; // (PSTAMP)
         PSTAMP(0);
 
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
         if (w == 0 && g >= 1 && lane < (int)subs_used) fw = bar_load(&bar->sub[(g - 1) & 1][my_rep][lane].w);
         unsigned long long gb[S];
 #pragma unroll
-        for (int k = 0; k < S; ++k) gb[k] = own[k] >= 0 ? xb_load(xin + col[k]) : 0ull;
+        for (int k = 0; k < S; ++k) gb[k] = own[k] >= 0 ? xc_load(xin + col[k]) : 0ull;
         if (w == 0 && g >= 1) {
             unsigned cum = 0;
             const bool ok = wait_arrivals(g - 1, fw, &cum);
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
                 int c;
                 slot_of(e, &o, &c);
                 const double *src = xin + c;
-                unsigned long long bits = xb_load(src);
+                unsigned long long bits = xc_load(src);
                 unsigned polls = 0;
                 while (bits == X_EMPTY && !s_fault) {
                     // 2^20 polls of >= 2 us each: seconds, like the wall-clock limits of the other waits (reading the
@@ -446,10 +450,9 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
             rv = rn;
             xv = lg ? rn : 0.0;
             xb_store(xout + v, (unsigned long long)__double_as_longlong(xv));
-            // B[(g + 3) & 3] held x_{g-1}; that every workgroup is done with sweep g-1 is what the first wave established
-            // before the barrier above. Everybody resets its own entry, fire and forget next to the snapshot store: the
-            // NEXT iteration's wait for outstanding stores covers both, one iteration before the vector is written.
-            xb_store(Bv(g + 3) + v, X_EMPTY);
+            // The vector of x_{g+3} gets its EMPTY marks now, fire and forget next to the snapshot store: the NEXT iteration's
+            // wait for outstanding stores covers both, one iteration before the vector is written.
+            xb_store(Av(g + 3) + v, X_EMPTY);
             if (lg) pv = pv + ALPHA * rn;
         }
         s_acc[(g + 1) & 1][tid] = rv;
@@ -484,12 +487,8 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
         fault = s_fault != 0;
         F = s_next[1];
     }
-    if (!fault && valid) { // B[g & 3] holds x_g (all zero if converged)
-        xb_store(Bv(g + 1) + v, 0ull);
-        xb_store(Bv(g + 2) + v, 0ull);
-        xb_store(Bv(g + 3) + v, 0ull);
-    }
     if (valid) {
+        if (!fault) b0[v] = xv; // x_g, the live snapshot (all zero if converged)
         r[v] = rv;
         p[v] = pv;
     }
