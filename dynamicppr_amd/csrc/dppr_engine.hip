@@ -325,6 +325,7 @@ bool translate(dppr_engine *e, const int32_t *src, int n, std::vector<int32_t> &
 
 int cut_sweep_groups(dppr_engine *e, Epoch &ep);
 int build_bins(dppr_engine *e, Epoch &ep);
+bool resident_arena(dppr_engine *e, const Epoch &ep);
 
 // A vertex that got its internal id AFTER an epoch was built (a source outside the window, a
 // dppr_write to an unseen vertex) is not covered by that epoch's sweep groups: re-cut them.
@@ -764,6 +765,7 @@ int cut_sweep_groups(dppr_engine *e, Epoch &ep) {
     HIP_TRY(hipMemcpyAsync(ep.grp_tile, cut.data(), sizeof(int) * cut.size(), hipMemcpyHostToDevice, e->stream));
     // slot tables for resident launches (a window that got the resident cut; every group must fit the table build's sort)
     ep.res_valid = false;
+    if (fitted && !e->slots.empty()) (void)resident_arena(e, ep); // (a single-source slot exists: its launches will want the arena)
     if (fitted && e->res_slots && ep.Ed > 0 && NV <= RES_ID_LIMIT) {
         long long largest = 0;
         for (size_t g = 0; g + 1 < cut.size(); ++g) largest = std::max<long long>(largest, (long long)prefix[cut[g + 1]] - prefix[cut[g]]);
@@ -1028,18 +1030,23 @@ int pull_min_frontier(const dppr_engine *e) {
 
 // The arena of a resident launch (dppr_resident.hpp, FRESH VECTORS): RES_VECTORS vectors of `stride` doubles, scratch between
 // launches, one per engine (the engine's launches are serial on its stream).
-int resident_arena(dppr_engine *e, const Epoch &ep) {
+// Grown when a larger window is cut (graph build) or, failing that, before the first launch that needs it; without it (out of
+// memory) the window's sweeps simply run as per-iteration launches.
+bool resident_arena(dppr_engine *e, const Epoch &ep) {
     const long long stride = ((long long)ep.grp_n_int + 1023) / 1024 * 1024;
-    if (stride > e->res_arena_stride) {
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        (void)hipFree(e->res_arena);
+    if (stride <= e->res_arena_stride) return true;
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
+    (void)hipFree(e->res_arena);
+    e->res_arena = nullptr;
+    e->res_arena_stride = 0;
+    const long long want = std::min<long long>(((long long)e->V + 1023) / 1024 * 1024, stride + stride / 4);
+    if (hipMalloc((void **)&e->res_arena, sizeof(double) * (size_t)want * RES_VECTORS) != hipSuccess) {
+        (void)hipGetLastError();
         e->res_arena = nullptr;
-        e->res_arena_stride = 0;
-        const long long want = std::min<long long>(((long long)e->V + 1023) / 1024 * 1024, stride + stride / 4);
-        HIP_TRY(hipMalloc((void **)&e->res_arena, sizeof(double) * (size_t)want * RES_VECTORS));
-        e->res_arena_stride = want;
+        return false;
     }
-    return DPPR_OK;
+    e->res_arena_stride = want;
+    return true;
 }
 
 int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, double eps, int buf, int cur,
@@ -1103,7 +1110,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
         else if ((long long)F * 4 >= pull_min) n = 1;          // about to turn dense: re-decide next iteration
         else n = F > prevF ? 2 : e->chunk_iters;                // growing: short chunks; decaying tail: long
         const int pcap = persist_capacity(e);
-        const bool resident = pull && n >= 2 && !s.trace && pcap > 0 && ep.n_groups > 0 && ep.n_groups <= pcap;
+        const bool resident = pull && n >= 2 && !s.trace && pcap > 0 && ep.n_groups > 0 && ep.n_groups <= pcap && resident_arena(e, ep);
         if (resident && s.iter_hint[hp] > it) n += RESIDENT_MARGIN - 1;
         if (!resident && pull && n > 1) {
             // per-iteration sweeps: a launch that finds the frontier empty is still a dispatch, a chunk boundary (read-back
@@ -1128,7 +1135,6 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 dense_valid = true;
             }
             HIP_TRY(hipMemsetAsync(e->bar, 0, sizeof(GridBar), e->stream));
-            if (int arc = resident_arena(e, ep)) return arc;
             n = std::min(n, RES_MAX_SWEEPS);
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                       \
@@ -1342,7 +1348,6 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
                       : 2 * MAX_CHUNK; // no history yet
     if (e->chunk_explicit) n = std::min(n, e->chunk_iters); // (tests: launches that stop mid-phase and are resumed)
     n = std::min(n, RES_MAX_SWEEPS);
-    if (int arc = resident_arena(e, ep)) return arc;
     int *status = s.cnt + 7; // (the GridBar was zeroed by the batch's first kernel, k_su_keys)
     if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                        \
@@ -2498,7 +2503,7 @@ int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *
     const bool merged = e->merge_phases && e->schedule == DPPR_SCHEDULE_EAGER;
     if (merged) eps = eps / e->merge_div;
     const bool seeded = s.converged && s.conv_eps <= eps;
-    const bool ahead = seeded && can_batch_ahead(e, s, ep);
+    const bool ahead = seeded && can_batch_ahead(e, s, ep) && resident_arena(e, ep);
     int rc = settle_parked(e, s.p, s.r, 1, eps, &s.park_eps, &s.st);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
