@@ -85,6 +85,10 @@ struct Epoch {
     uint32_t *res_pk = nullptr; // Ed entries, group by group, sorted by gather position
     size_t res_pk_cap = 0;
     bool res_valid = false;
+    // the batch's records (sk / sv) cut into the sweep groups' ranges, for IncrementalBatchUpdate inside a resident launch
+    int *su_rng = nullptr;      // n_groups + 1 first-record indices, then two result words of k_res_rec_ranges
+    size_t su_rng_cap = 0;
+    bool su_inline = false;     // every group's range fits the launch's workgroup and no tail lies beyond the groups
 };
 
 struct Slot {
@@ -174,6 +178,7 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     int persist_retry = 0;             // dppr_update calls until resident launches are tried again (0: not pending)
     int persist_cap = 0;               // co-resident workgroups of k_pull_resident at the sweep's block size
     int res_slots = 1;                 // 1: resident launches take their edge slots from the sorted slot table (0: CSR order)
+    int res_update = 1;                // 1: a whole-batch resident launch applies the batch's records itself (PLAN_UPDATE)
     double *res_arena = nullptr;       // snapshot vectors of a resident launch (resident_arena)
     long long res_arena_stride = 0;    // doubles per vector
     unsigned long long persist_ticks = 5000000ull; // roll-call time limit in 100 MHz ticks (50 ms)
@@ -326,6 +331,7 @@ bool translate(dppr_engine *e, const int32_t *src, int n, std::vector<int32_t> &
 int cut_sweep_groups(dppr_engine *e, Epoch &ep);
 int build_bins(dppr_engine *e, Epoch &ep);
 bool resident_arena(dppr_engine *e, const Epoch &ep);
+int res_record_ranges(dppr_engine *e, Epoch &ep);
 
 // A vertex that got its internal id AFTER an epoch was built (a source outside the window, a
 // dppr_write to an unseen vertex) is not covered by that epoch's sweep groups: re-cut them.
@@ -784,6 +790,9 @@ int cut_sweep_groups(dppr_engine *e, Epoch &ep) {
         }
     }
     HIP_TRY(hipStreamSynchronize(e->stream)); // `cut` is a local
+    ep.su_inline = false;
+    if (fitted)
+        if (int rrc = res_record_ranges(e, ep)) return rrc;
     ep.n_ggroups = 0;
     if (e->any_groups) { // groups of at most 16 (8) tiles for k_gsweep<1, 1024> (<2, 512>)
         const int gmax = (e->wide_groups ? 512 : 1024) / WAVE;
@@ -1028,6 +1037,33 @@ int pull_min_frontier(const dppr_engine *e) {
     return e->pull_min_frontier > 0 ? e->pull_min_frontier : e->pull_min_frontier < 0 ? 0x7fffffff : std::max(1024, e->Ed / 192);
 }
 
+// The batch's records, grouped by tail at slide time, cut into the sweep groups' ranges (dppr_resident.hpp, PLAN_UPDATE). Needs
+// both the grouping and a resident-size group cut: called by whichever of the two is made last. Untimed (graph build / slide).
+int res_record_ranges(dppr_engine *e, Epoch &ep) {
+    ep.su_inline = false;
+    const int pb = sweep_block(e);
+    if (!e->res_update || !ep.grouped || ep.L <= 0 || ep.L >= SU_SPLIT_MIN || ep.n_groups <= 0 || ep.n_groups > persist_capacity(e)) return DPPR_OK;
+    const size_t need = (size_t)ep.n_groups + 3;
+    if (need > ep.su_rng_cap) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        (void)hipFree(ep.su_rng);
+        ep.su_rng = nullptr;
+        ep.su_rng_cap = 0;
+        HIP_TRY(hipMalloc((void **)&ep.su_rng, sizeof(int) * (need + 1024)));
+        ep.su_rng_cap = need + 1024;
+    }
+    int *stat = ep.su_rng + ep.n_groups + 1;
+    HIP_TRY(hipMemsetAsync(stat, 0, sizeof(int) * 2, e->stream));
+    hipLaunchKernelGGL(k_res_rec_ranges, dim3((ep.n_groups + 256) / 256), dim3(256), 0, e->stream, ep.sk, ep.L, ep.grp_tile, ep.n_groups,
+                       ep.su_rng, stat);
+    HIP_TRY(hipGetLastError());
+    int h[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(h, stat, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    ep.su_inline = h[0] <= pb && h[1] == ep.L; // (a tail beyond the last group: an id assigned after the cut -- the cut is redone then)
+    return DPPR_OK;
+}
+
 // The arena of a resident launch (dppr_resident.hpp, FRESH VECTORS): RES_VECTORS vectors of `stride` doubles, scratch between
 // launches, one per engine (the engine's launches are serial on its stream).
 // Grown when a larger window is cut (graph build) or, failing that, before the first launch that needs it; without it (out of
@@ -1141,7 +1177,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
     hipLaunchKernelGGL(k_pull_resident<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,       \
                        ep.out_row_ptr, ep.out_col, s.x, e->res_arena, e->res_arena_stride, s.r, s.p, s.cnt, cur, phase, eps, s.dstats, s.log,  \
                        n, e->bar, s.cnt + 7, e->persist_ticks, e->persist_rollcall_extra, 0,                          \
-                       ep.res_valid ? ep.res_pk : nullptr)
+                       ep.res_valid ? ep.res_pk : nullptr, ResUpdate{})
             switch (sweep_block(e)) {
             case 256: DPPR_LAUNCH_PERSIST(256); break;
             case 512: DPPR_LAUNCH_PERSIST(512); break;
@@ -1336,7 +1372,7 @@ bool can_batch_ahead(const dppr_engine *e, const Slot &s, const Epoch &ep) {
 // stage (out): 0 = phase 0 still open (resume with en0), 1 = phase 0 done, phase 1 open (resume with
 // en1; *p1_seeded tells whether its snapshot exists), 2 = both phases done
 int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage, LoopEntry *en0, LoopEntry *en1,
-                bool *p1_seeded, bool merged = false) {
+                bool *p1_seeded, bool merged = false, bool inline_update = false) {
     // merged (dppr_set_phase_merge): ONE loop over residuals of both signs -- the launch seeds it (PLAN_SEED) and runs it to the
     // end; stage 0 + en0 if it ran out of sweeps, stage 2 when it converged (histories in slot 0)
     const int pull_min = pull_min_frontier(e);
@@ -1349,13 +1385,15 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
     if (e->chunk_explicit) n = std::min(n, e->chunk_iters); // (tests: launches that stop mid-phase and are resumed)
     n = std::min(n, RES_MAX_SWEEPS);
     int *status = s.cnt + 7; // (the GridBar was zeroed by the batch's first kernel, k_su_keys)
+    const ResUpdate upd = inline_update ? ResUpdate{ep.su_rng, ep.sk, ep.sv, ep.b2, ep.ins, ep.deg_after, s.source} : ResUpdate{};
+    const int plan = (merged ? PLAN_SEED : (PLAN_SEED | PLAN_BOTH)) | (inline_update ? PLAN_UPDATE : 0);
     if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                        \
     hipLaunchKernelGGL(k_pull_resident<PB>, dim3(ep.n_groups), dim3(PB), 0, e->stream, ep.grp_n_int, ep.grp_tile,        \
                        ep.out_row_ptr, ep.out_col, s.x, e->res_arena, e->res_arena_stride, s.r, s.p, s.cnt, 0,                  \
                        merged ? PHASE_BOTH : 0, eps, s.dstats,                                                             \
                        s.log, n, e->bar, status, e->persist_ticks, e->persist_rollcall_extra,                             \
-                       merged ? PLAN_SEED : (PLAN_SEED | PLAN_BOTH), ep.res_valid ? ep.res_pk : nullptr)
+                       plan, ep.res_valid ? ep.res_pk : nullptr, upd)
     switch (sweep_block(e)) {
     case 256: DPPR_LAUNCH_PERSIST(256); break;
     case 512: DPPR_LAUNCH_PERSIST(512); break;
@@ -1466,13 +1504,14 @@ inline const uint32_t *batch_order(const dppr_engine *e, const Epoch &ep) { retu
 // dppr_update (the accounting of rounds 1-2: + 5 dispatches of the device radix sort per batch).
 int epoch_group_records(dppr_engine *e, Epoch &ep) {
     ep.grouped = false;
+    ep.su_inline = false;
     if (!e->group_at_slide || ep.L <= 0) return DPPR_OK;
     hipLaunchKernelGGL(k_su_keys, dim3(grid_for(ep.L)), dim3(BLOCK), 0, e->stream, ep.b1, ep.L, e->su_k[0], e->su_v[0],
                        (unsigned long long *)nullptr, 0, (int *)nullptr, 0);
     size_t tmp = e->su_tmp_bytes;
     HIP_TRY(rocprim::radix_sort_pairs(e->su_tmp, tmp, e->su_k[0], ep.sk, e->su_v[0], ep.sv, (size_t)ep.L, 0u, (unsigned)e->bits, e->stream));
     ep.grouped = true;
-    return DPPR_OK;
+    return res_record_ranges(e, ep);
 }
 
 int group_records_by_tail(dppr_engine *e, const Epoch &ep, unsigned long long *zero, int nz, int *zero_ints, int nzi) {
@@ -2039,7 +2078,7 @@ void dppr_destroy(dppr_engine *e) {
         (void)hipFree(ep.row_ptr); (void)hipFree(ep.adj); (void)hipFree(ep.out_row_ptr); (void)hipFree(ep.out_col); (void)hipFree(ep.b1); (void)hipFree(ep.b2);
         (void)hipFree(ep.deg_after); (void)hipFree(ep.ins); (void)hipFree(ep.sk); (void)hipFree(ep.sv); (void)hipFree(ep.hub_v); (void)hipFree(ep.hub_degp1); (void)hipFree(ep.grp_tile); (void)hipFree(ep.ggrp_tile); (void)hipFree(ep.gtab);
         (void)hipFree(ep.acut); (void)hipFree(ep.chunks); (void)hipFree(ep.hl); (void)hipFree(ep.dl); (void)hipFree(ep.apos);
-        (void)hipFree(ep.res_pk);
+        (void)hipFree(ep.res_pk); (void)hipFree(ep.su_rng);
     }
     for (int k = 0; k < 2; ++k) (void)hipFree(e->bin_k[k]);
     (void)hipFree(e->bin_vblk_a); (void)hipFree(e->bin_vblk_b); (void)hipFree(e->bin_small); (void)hipFree(e->bin_vals); (void)hipFree(e->bin_tmp);
@@ -2149,6 +2188,14 @@ int dppr_set_resident_slots(dppr_engine *e, int sorted) {
     // epochs already cut keep their tables until the next cut; switching OFF takes effect at once
     if (!e->res_slots)
         for (auto &ep : e->epochs) ep.res_valid = false;
+    return DPPR_OK;
+}
+
+int dppr_set_resident_update(dppr_engine *e, int on) {
+    if (!e) return DPPR_ERR_INVALID;
+    e->res_update = on != 0;
+    if (!e->res_update)
+        for (auto &ep : e->epochs) ep.su_inline = false;
     return DPPR_OK;
 }
 
@@ -2507,14 +2554,34 @@ int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *
     int rc = settle_parked(e, s.p, s.r, 1, eps, &s.park_eps, &s.st);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    rc = stream_update(e, s, ep, eps, seeded, ahead);
+    // A whole-batch resident launch applies the records itself (PLAN_UPDATE): only the counters and the GridBar are cleared
+    // here. Should its roll-call fail, nothing was changed and the update runs as its own kernel after all.
+    bool inline_su = ahead && e->res_update && ep.su_inline && ep.grouped;
+    if (inline_su) {
+        rc = group_records_by_tail(e, ep, reinterpret_cast<unsigned long long *>(e->bar), (int)(sizeof(GridBar) / sizeof(unsigned long long)),
+                                   s.cnt, 5);
+    } else {
+        rc = stream_update(e, s, ep, eps, seeded, ahead);
+    }
     if (rc) return rc;
     s.converged = false;
+    const int64_t aborts_before = s.st.persist_aborts;
+    auto update_after_abort = [&]() -> int { // (inline_su only) the launch gave up at its roll-call
+        if (!inline_su) return DPPR_OK;
+        if (s.st.persist_aborts != aborts_before) {
+            inline_su = false;
+            return stream_update(e, s, ep, eps, seeded, false);
+        }
+        s.st.records += ep.L;
+        return DPPR_OK;
+    };
     if (merged && ahead) { // a window that runs resident: the whole merged loop as ONE launch that seeds itself
         int stage = 0;
         bool p1 = false;
         LoopEntry en0, en1;
-        rc = batch_ahead(e, s, ep, eps, &stage, &en0, &en1, &p1, true);
+        rc = batch_ahead(e, s, ep, eps, &stage, &en0, &en1, &p1, true, inline_su);
+        if (rc) return rc;
+        rc = update_after_abort();
         if (rc) return rc;
         if (stage != 2) { // out of sweeps, or the roll-call failed (then the update's lists stand: add the negative tails)
             if (en0.it == 0 && !en0.dense) {
@@ -2540,14 +2607,20 @@ int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *
         bool p1_seeded = false;
         LoopEntry en0, en1;
         if (ahead) {
-            rc = batch_ahead(e, s, ep, eps, &stage, &en0, &en1, &p1_seeded);
+            rc = batch_ahead(e, s, ep, eps, &stage, &en0, &en1, &p1_seeded, false, inline_su);
+            if (rc) return rc;
+            rc = update_after_abort();
             if (rc) return rc;
         }
         if (stage == 0) {
             rc = run_frontier_loop(e, s, ep, 0, eps, 0, 0, en0);
             if (rc) return rc;
         }
-        if (stage <= 1) {
+        if (stage <= 1 && !p1_seeded && inline_su) {
+            // the update ran inside the launch and recorded no candidates: phase 1 starts from a full Inspect
+            rc = main_loop_inspect(e, s, ep, 1, eps);
+            if (rc) return rc;
+        } else if (stage <= 1) {
             if (!p1_seeded) { // phase 1: candidates recorded by the update, re-checked now
                 HIP_TRY(hipMemsetAsync(s.cnt, 0, sizeof(int) * 3, e->stream));
                 hipLaunchKernelGGL(k_filter, dim3(grid_for(std::max(ep.L, 1))), dim3(BLOCK), 0, e->stream, s.neg,

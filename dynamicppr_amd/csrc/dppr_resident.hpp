@@ -132,6 +132,43 @@ constexpr int PERSIST_SWEEPS = (1 << 16) - 1; // low bits: loop position g
 // plan of a launch
 constexpr int PLAN_SEED = 1;  // take the first snapshot from the registers: {v : legal(residual[v])} (valid after a converged solve)
 constexpr int PLAN_BOTH = 2;  // when phase 0 is over, seed phase 1 the same way and go on
+constexpr int PLAN_UPDATE = 4; // apply the batch's records to the residuals first (IncrementalBatchUpdate inside the launch)
+
+// IncrementalBatchUpdate inside the launch (PLAN_UPDATE). A record changes the residual of its TAIL only, and a tail belongs to
+// exactly one sweep group: the workgroup that owns it applies the group's records -- the batch's records sorted by tail at
+// slide time (dppr_engine.hip: epoch_group_records), cut into the sweep groups' ranges by k_res_rec_ranges -- to the residuals it
+// has just loaded, before it seeds the frontier from them. Same terms, same order per tail, same expressions as k_su_apply_fused
+// (dppr_update.hpp; gpu/StreamUpdate.cuh:34-76, cpu/PPRCPUMTCilkRev.h:108-124): bit-identical residuals. What it saves is a
+// kernel of ~20 us and the gap in front of it -- 6 % of a configs[1] batch, 9 % of a configs[0] one.
+struct ResUpdate {
+    const int *rng;          // per sweep group: first record (n_groups + 1 entries); nullptr: no update
+    const uint32_t *tails;   // the records' tails, ascending
+    const uint32_t *order;   // ... and their indices in the batch (stable)
+    const int *b2;           // heads
+    const uint8_t *ins;      // 1 = insertion
+    const int *deg_after;    // out-degree of the tail after the batch
+    int source;              // the slot's source vertex
+};
+// first record of every sweep group's range (tails[] is sorted); rng[n_groups] = first record whose tail lies beyond the last
+// group; stat[0] = the largest range (atomicMax), stat[1] = rng[n_groups]
+__global__ __launch_bounds__(256) void k_res_rec_ranges(const uint32_t *__restrict__ tails, int L, const int *__restrict__ grp_tile,
+                                                        int n_groups, int *__restrict__ rng, int *__restrict__ stat) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g > n_groups) return;
+    auto lower = [&](int gi) { // first record with tail >= first vertex of group gi
+        const long long key = (long long)grp_tile[gi] * WAVE;
+        int lo = 0, hi = L;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((long long)tails[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    const int a = lower(g);
+    rng[g] = a;
+    if (g < n_groups) atomicMax(&stat[0], lower(g + 1) - a);
+    else stat[1] = a;
+}
 
 __device__ __forceinline__ unsigned long long bar_load(unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -158,7 +195,7 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
                                                       long long stride, double *r, double *p, int *cnt, int cur0, int phase,
                                                       double eps, IterStats *stats, int *log, int n_iter, GridBar *bar,
                                                       int *status, unsigned long long limit_ticks, int rollcall_extra,
-                                                      int plan, const uint32_t *__restrict__ res_pk) {
+                                                      int plan, const uint32_t *__restrict__ res_pk, ResUpdate upd) {
     constexpr int NW = PB / WAVE;
     constexpr int S = PERSIST_SLOTS;
     __shared__ int s_scan[PB + 1];
@@ -169,6 +206,8 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
     __shared__ unsigned long long s_edges[NW];
     __shared__ unsigned s_next[2]; // {roll-call outcome / no fault, size of the frontier of the current sweep}
     __shared__ int s_fault;
+    __shared__ int s_rtail[PB];    // PLAN_UPDATE: the group's records (tail as a row of the group, insertion flag)
+    __shared__ uint8_t s_rins[PB];
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const unsigned G = gridDim.x;
     const unsigned subs_used = G < (unsigned)BAR_SUBS ? G : (unsigned)BAR_SUBS;
@@ -196,6 +235,50 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
         rv = r[v];
         pv = p[v];
         if (!(plan & PLAN_SEED)) xv = b0[v];
+    }
+    if (plan & PLAN_UPDATE) {
+        // the group's records: terms in parallel, then one lane per tail applies its records in batch order
+        const int lo = upd.rng[blockIdx.x], nrec = upd.rng[blockIdx.x + 1] - lo; // <= PB (the host checked)
+        int row = -1, rdeg = 0, u = 0;
+        double term = 0.0;
+        bool rin = false;
+        if (tid < nrec) {
+            u = (int)upd.tails[lo + tid];
+            const int rec = (int)upd.order[lo + tid];
+            rin = upd.ins[rec] != 0;
+            rdeg = upd.deg_after[rec];
+            term = ONE_MINUS_ALPHA * p[upd.b2[rec]] - p[u];
+            row = u - t0 * WAVE;
+        }
+        s_rtail[tid] = row;
+        s_rins[tid] = rin ? 1 : 0;
+        s_acc[1][tid] = term;
+        s_acc[0][tid] = rv;
+        __syncthreads();
+        if (tid < nrec && (tid == 0 || s_rtail[tid - 1] != row)) {
+            int end = tid, delta = 0; // extent of the tail's records and its net degree change (post-batch minus pre-batch)
+            while (end < nrec && s_rtail[end] == row) {
+                delta += s_rins[end] ? 1 : -1;
+                ++end;
+            }
+            int dg = rdeg - delta; // RevertOutDegree (gpu/StreamUpdate.cuh:18-33)
+            double ru = s_acc[0][row];
+            const double src_term = ALPHA * (upd.source == u ? 1.0 : 0.0);
+            for (int k = tid; k < end; ++k) {
+                const double add = s_acc[1][k] - ALPHA * ru + src_term;
+                if (s_rins[k]) {
+                    dg++;
+                    ru += add / (double)(dg + 1) / ALPHA;
+                } else {
+                    dg--;
+                    ru -= add / (double)(dg + 1) / ALPHA;
+                }
+            }
+            s_acc[0][row] = ru;
+        }
+        __syncthreads();
+        rv = s_acc[0][tid];
+        __syncthreads(); // (s_acc is written again below)
     }
     unsigned F = (unsigned)__hip_atomic_load(cnt + cur0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (plan & PLAN_SEED) {

@@ -55,7 +55,7 @@ EXPORTS = [
     "dppr_reset_stats", "dppr_inspect", "dppr_read_graph", "dppr_graph_edges", "dppr_read_out_graph", "dppr_trace_enable",
     "dppr_trace_get", "dppr_synchronize", "dppr_bench_atomics",
     "dppr_add_source_group", "dppr_group_init_solve", "dppr_group_update", "dppr_group_read", "dppr_group_stats",
-    "dppr_group_reset_stats", "dppr_set_group_seeding", "dppr_seed_lists", "dppr_set_sweep_bitmap", "dppr_set_group_resident", "dppr_set_resident_slots",
+    "dppr_group_reset_stats", "dppr_set_group_seeding", "dppr_seed_lists", "dppr_set_sweep_bitmap", "dppr_set_group_resident", "dppr_set_resident_slots", "dppr_set_resident_update",
     "dppr_set_renumbering", "dppr_id_space", "dppr_set_group_push", "dppr_set_binned_sweep", "dppr_device_count", "dppr_set_phase_merge", "dppr_init_solve_at", "dppr_group_init_solve_at", "dppr_set_variant", "dppr_set_batch_grouping",
 ]
 
@@ -120,6 +120,7 @@ def lib():
     L.dppr_set_binned_sweep.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64]
     L.dppr_set_group_resident.argtypes = [vp, C.c_int]
     L.dppr_set_resident_slots.argtypes = [vp, C.c_int]
+    L.dppr_set_resident_update.argtypes = [vp, C.c_int]
     L.dppr_seed_lists.argtypes = [vp, C.c_int32, C.c_int, ip, ip]
     L.dppr_group_reset_stats.argtypes = [vp, C.c_int32]
     L.dppr_set_group_seeding.argtypes = [vp, C.c_int]
@@ -148,7 +149,7 @@ class Engine:
 
     def __init__(self, V, W, directed, max_batch, n_epochs=1, device=0, schedule=SCHEDULE_EAGER,
                  hub_min_degree=None, big_row_edges=None, pull_min_frontier=None, chunk_iters=None, pull_block=None,
-                 persistent=None, persist_timeout_us=None, sweep_bitmap=None, binned=None, merge_phases=None, variant=None, group_at_slide=None, resident_slots=None):
+                 persistent=None, persist_timeout_us=None, sweep_bitmap=None, binned=None, merge_phases=None, variant=None, group_at_slide=None, resident_slots=None, resident_update=None):
         self._L = lib()
         self._h = C.c_void_p()
         self.V, self.W, self.directed, self.c = int(V), int(W), int(directed), int(max_batch)
@@ -169,6 +170,8 @@ class Engine:
             self._ck(self._L.dppr_set_batch_grouping(self._h, int(group_at_slide)), "set_batch_grouping")
         if resident_slots is not None:
             self.set_resident_slots(resident_slots)
+        if resident_update is not None:
+            self._ck(self._L.dppr_set_resident_update(self._h, int(resident_update)), "set_resident_update")
         if merge_phases is not None:   # True / divisor
             self.set_phase_merge(bool(merge_phases), 0 if merge_phases is True or not merge_phases else int(merge_phases))
         if binned is not None:   # int mode, or (mode, ha_tiles, hb_tiles, target_edges, min_ids, chunk_edges, target_a_edges)

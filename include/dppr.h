@@ -300,6 +300,11 @@ int dppr_set_group_resident(dppr_engine *e, int on);
  * gpu/PPRGPU.cuh:131-135). sorted = 0: slots in CSR order (the form of rounds 1-2). Same pushes, same sums up to the order
  * of the additions. 1 takes effect with the next epoch built, 0 at once. */
 int dppr_set_resident_slots(dppr_engine *e, int sorted);
+/* IncrementalBatchUpdate inside the resident launch of a whole batch (dppr_resident.hpp, PLAN_UPDATE; on by default): the
+ * workgroup that owns a tail applies its records -- same terms, same order per tail as the separate kernel
+ * (gpu/StreamUpdate.cuh:34-76), bit-identical residuals -- before it seeds the frontier. dppr_update only (the split calls
+ * dppr_incremental_batch_update + dppr_execute_main_loop always run the update as its own kernel). 0 = always a kernel of its own. */
+int dppr_set_resident_update(dppr_engine *e, int on);
 /* The tail of a source group's frontier loop as pushes. A sweep costs at least its floor (every out_col entry, every
  * sweep group's tables) however few (vertex, source) pairs are still being pushed; below enter_pairs frontier pairs
  * the loop's remaining iterations run as what the reference does for every iteration (gpu/ExpandRev.cuh:34-77,

@@ -51,12 +51,15 @@ TUNINGS = [dict(pull_min_frontier=-1), dict(hub_min_degree=3, big_row_edges=8, p
            dict(group_at_slide=0), dict(pull_min_frontier=1, group_at_slide=0),
            # edge slots of the resident sweep in CSR order (rounds 1-2; the default is the table sorted by gather position), also
            # on several small groups
-           dict(pull_min_frontier=1, resident_slots=0), dict(resident_slots=0, pull_block=256)]
+           dict(pull_min_frontier=1, resident_slots=0), dict(resident_slots=0, pull_block=256),
+           # IncrementalBatchUpdate as a kernel of its own in front of a whole-batch resident launch (the default applies the
+           # records inside the launch)
+           dict(resident_update=0), dict(resident_update=0, pull_block=256)]
 TUNING_IDS = ["push-only", "push-hubs+bigrows", "push-all-hub-all-big", "pull-only", "mixed-pull>=40", "default",
               "mixed-chunk1", "mixed-chunk3", "pull-wg512", "mixed-wg1024", "pull-no-persist", "pull-wg256",
               "pull-rollcall-fails", "pull-resident-3-sweeps", "pull-bitmap-wg256", "mixed-bitmap", "pull-bitmap-wg640",
               "binned-tiny-blocks", "binned-one-block", "mixed-binned-chunk3", "grouping-in-update", "pull-grouping-in-update",
-              "resident-csr-slots", "resident-csr-slots-wg256"]
+              "resident-csr-slots", "resident-csr-slots-wg256", "resident-update-own-kernel", "resident-update-own-kernel-wg256"]
 
 
 def make(directed, schedule=eng.SCHEDULE_EAGER, scale=9, edges=6000, seed=11, W=600, c=6, eps=1e-9, n_epochs=1,
@@ -609,6 +612,45 @@ def test_full_size_resident_sweeps_match_per_iteration_launches():
     st0, st1 = (e.stats(sl) for e, sl in zip(engines, slots))
     assert (st0["iterations"], st0["sum_F"], st0["sum_E"]) == (st1["iterations"], st1["sum_F"], st1["sum_E"])
     assert st0["persist_launches"] == 0 and st1["persist_launches"] >= 15 and st1["persist_aborts"] == 0
+
+
+def test_update_inside_the_resident_launch_equals_the_update_kernel():
+    """configs[1] size: IncrementalBatchUpdate applied by the resident launch itself (PLAN_UPDATE, the default) against the
+    same engine with the update as its own kernel (k_su_apply_fused), batch by batch: the records are applied per tail in
+    the same order with the same expressions, so the states agree to the rounding of the sweeps' LDS sums; iterations,
+    frontier sizes and traversed edges are equal; the records are counted once; and a launch whose roll-call fails
+    (nothing changed) is followed by the update kernel."""
+    V, e1, e2, cfg = datagen.stand_in_stream("youtube", "/tmp/dppr_data")
+    W, c, _, _ = orc.workload_config(len(e1), 0.1, 0, 0.01, 100, 0, 0)
+    src = int(datagen.top_sources(V, e1, e2, W, cfg.directed, 1)[0])
+    eps = 1e-9
+    engines = [eng.Engine(V, W, cfg.directed, c, resident_update=m) for m in (0, 1)]
+    engines.append(eng.Engine(V, W, cfg.directed, c, persist_timeout_us=-1))   # every roll-call fails
+    slots = []
+    for e in engines:
+        e.load_window(e1[:W], e2[:W])
+        slots.append(e.add_source(src))
+        e.init_solve(slots[-1], eps)
+    pos = W
+    for k in range(1, 9):
+        b1 = np.concatenate([e1[pos - W:pos - W + c], e1[pos:pos + c]])
+        b2 = np.concatenate([e2[pos - W:pos - W + c], e2[pos:pos + c]])
+        ins = np.concatenate([np.zeros(c, np.uint8), np.ones(c, np.uint8)])
+        for e, sl in zip(engines, slots):
+            e.set_batch(np.concatenate([b1, b2]), np.concatenate([b2, b1]), np.concatenate([ins, ins]))
+            e.slide(e1[pos:pos + c], e2[pos:pos + c])
+            e.update(sl, eps)
+        pos += c
+        (p0, r0), (p1, r1), (p2, r2) = (e.read(sl) for e, sl in zip(engines, slots))
+        assert np.max(np.abs(p0 - p1)) < 1e-13 and np.max(np.abs(r0 - r1)) < 1e-13, k
+        assert np.max(np.abs(p0 - p2)) < 1e-13 and np.max(np.abs(r0 - r2)) < 1e-13, k
+    st0, st1, st2 = (e.stats(sl) for e, sl in zip(engines, slots))
+    for st in (st1, st2):
+        assert (st0["iterations"], st0["sum_F"], st0["sum_E"], st0["records"]) == (st["iterations"], st["sum_F"], st["sum_E"], st["records"])
+    assert st1["persist_launches"] >= 8 and st1["persist_aborts"] == 0   # (the from-scratch solve's launches count too)
+    assert st2["persist_aborts"] == 1
+    for e in engines:
+        e.close()
 
 
 def test_full_size_livejournal_standin_two_sources():
