@@ -6,9 +6,9 @@ done
 for seed in 7 8; do
   DPPR_SOAK_MERGE=1 timeout 900 python tools/soak.py $seed 250 16 > gpurun_out/soak/soak_m$seed.log 2>&1; echo "soak merged seed $seed rc=$? $(tail -1 gpurun_out/soak/soak_m$seed.log | cut -c1-200)"
 done
-timeout 1200 python bench.py --config youtube --steps 1500 --warmup 5 --no-cpu-baseline > gpurun_out/soak/yt_long.json 2> gpurun_out/soak/yt_long.err; echo "long youtube rc=$?"
+timeout 1200 python bench.py --config youtube --steps 850 --warmup 5 --no-cpu-baseline > gpurun_out/soak/yt_long.json 2> gpurun_out/soak/yt_long.err; echo "long youtube rc=$?"
 python - <<'PY'
 import json
 d=json.loads([l for l in open('gpurun_out/soak/yt_long.json') if l.startswith('{')][-1])
-print('youtube 1500 batches: ms/step', d['ms_per_step'], 'parity', d['parity'], 'merged', (d.get('merged_loop') or {}).get('ms_per_step'))
+print('youtube 850 pre-staged batches: ms/step', d['ms_per_step'], 'parity', d['parity'], 'merged', (d.get('merged_loop') or {}).get('ms_per_step'))
 PY
