@@ -42,8 +42,12 @@ def cut(trace_csv, stats_csv, outdir):
     # First kernel of every batch's timed region: the IncrementalBatchUpdate kernel (k_su_apply_fused, or k_su_terms of the
     # two-kernel form), or the k_su_keys just before it (counter clear; with dppr_set_batch_grouping(0) k_su_keys + the
     # device sort). The k_su_keys of a slide-time grouping belongs to the SLIDE and is not a mark.
+    # With the update applied inside the resident launch (PLAN_UPDATE) a batch is k_su_keys (counter clear) -> k_pull_resident.
     marks = []
     for i, (n, _, _) in enumerate(ev):
+        if n == "k_su_keys" and i + 1 < len(ev) and ev[i + 1][0].startswith("k_pull_resident"):
+            marks.append(i)
+            continue
         if n not in ("k_su_apply_fused", "k_su_terms"):
             continue
         j = i - 1
