@@ -26,3 +26,35 @@ def test_the_checker_catches_a_timeline_from_another_run(tmp_path):
     json.dump(tl, open(tmp_path / "r03_batch_timeline_livejournal_group10.json", "w"))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_profiles.py"), str(tmp_path)], stdout=subprocess.PIPE, text=True)
     assert r.returncode == 1 and "k_gpush_tiny" in r.stdout
+
+
+def test_the_cut_finds_a_batch_in_each_of_its_forms(tmp_path):
+    """tools/check_profiles.py --cut on a synthetic kernel trace: the slide's kernels (incl. the k_su_keys + radix sort of the
+    slide-time grouping) are never taken for a batch; a batch starts at its IncrementalBatchUpdate kernel, at the counter-clearing
+    k_su_keys in front of it, or -- with the update inside the resident launch -- at the k_su_keys in front of k_pull_resident."""
+    import json
+    slide = ["k_make_keys_seg", "rocprim::radix_sort_onesweep", "k_build_csr", "k_su_keys", "rocprim::radix_sort_block_sort"]
+    forms = {"group": ["k_su_terms", "k_su_apply", "k_gsweep<2, 512, false>", "k_gsweep<2, 512, false>", "k_gpush_scan"],
+             "fused": ["k_su_keys", "k_su_apply_fused", "k_pull_resident<1024>", "__amd_rocclr_copyBuffer"],
+             "in-launch": ["k_su_keys", "k_pull_resident<1024>", "__amd_rocclr_copyBuffer"],
+             "grouping-in-update": ["k_su_keys", "rocprim::radix_sort_block_sort", "k_su_apply_fused", "k_pull_iter<1024, false>"]}
+    for form, batch in forms.items():
+        d = tmp_path / form.replace(" ", "_")
+        d.mkdir()
+        t, rows = 1000, []
+        for _ in range(4):
+            for n in slide + batch:
+                dur = 200000 if n.startswith(("k_gsweep", "k_pull")) else 3000
+                rows.append((n, t, t + dur))
+                t += dur + 500
+        with open(d / "trace.csv", "w") as f:
+            f.write('"Kernel_Name","Start_Timestamp","End_Timestamp"\n')
+            for n, s, e in rows:
+                f.write(f'"{n}",{s},{e}\n')
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_profiles.py"), "--cut", str(d / "trace.csv"), "unused", str(d)],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, (form, r.stdout)
+        tl = json.load(open(d / "timeline.json"))
+        assert tl["batches_in_run"] == 3, (form, tl["batches_in_run"])       # four marks delimit three complete batches
+        assert len(tl["iteration_kernel_durations_us"]) == sum(n.startswith(("k_gsweep", "k_pull")) for n in batch), form
+        assert not any(n.startswith(("k_make", "k_build", "rocprim::radix_sort_onesweep")) for n in tl["kernels"]), (form, tl["kernels"])

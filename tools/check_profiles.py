@@ -56,8 +56,14 @@ def cut(trace_csv, stats_csv, outdir):
         marks.append(j if j >= 0 and ev[j][0] == "k_su_keys" else i)
     batches = [(marks[i], marks[i + 1]) for i in range(len(marks) - 1)]
     spans = []
-    for lo, hi in batches:                                                       # a batch ends with its last iteration kernel: cut at the next slide's kernels
-        seg = [x for x in ev[lo:hi] if not x[0].startswith(("k_make", "k_deg", "k_mark", "k_build", "k_assign", "k_tile", "k_gather_deg", "k_gtables", "k_bin_keys", "k_bin_fill", "k_bin_vertex", "k_bin_quant", "k_bin_big", "k_in_degree", "k_number", "k_live", "k_remap", "k_permute", "k_rows"))]
+    slide_kernels = ("k_make", "k_deg", "k_mark", "k_build", "k_assign", "k_tile", "k_gather_deg", "k_gtables", "k_bin_keys", "k_bin_fill", "k_bin_vertex",
+                     "k_bin_quant", "k_bin_big", "k_in_degree", "k_number", "k_live", "k_remap", "k_permute", "k_rows", "k_res_")
+    for lo, hi in batches:                                                       # a batch ends where the next slide's kernels begin
+        seg = []
+        for x in ev[lo:hi]:
+            if x[0].startswith(slide_kernels):
+                break
+            seg.append(x)
         spans.append((seg[-1][2] - seg[0][1], lo, seg))
     spans.sort(key=lambda t: t[0])
     span, lo, seg = spans[len(spans) // 2]
