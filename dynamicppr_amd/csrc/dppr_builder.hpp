@@ -209,6 +209,20 @@ __global__ __launch_bounds__(BLOCK) void k_bench_atomics(double *__restrict__ ta
     }
     if (acc == 123.456) *sink = acc; // keep the returned values live
 }
+// ... and the same adds with the result unused (global_atomic_add_f64 without a return: fire and forget); KIND 1 = plain 8-byte
+// stores at the same addresses, for the rate of scattered stores
+template <int KIND>
+__global__ __launch_bounds__(BLOCK) void k_bench_scatter(double *__restrict__ table, uint64_t mask, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        uint64_t z = (uint64_t)i + 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        if (KIND == 0) (void)__hip_atomic_fetch_add(&table[z & mask], 1e-9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else table[z & mask] = 1e-9;
+    }
+}
 
 // ---------------------------------------------------------------------------
 // Renumbering of the internal ids (dppr_engine.hip: compact_ids / flush_moves). Internal ids are handed out on

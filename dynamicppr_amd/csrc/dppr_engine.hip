@@ -3052,7 +3052,11 @@ int dppr_bench_atomics(int device, int64_t table_elems, int64_t n, int scope, in
     (void)hipEventCreate(&b);
     const int grid = 2048;
     auto launch = [&]() {
-        if (scope == 0)
+        if (scope == 2) // (calibration only) adds whose result is not used
+            hipLaunchKernelGGL(k_bench_scatter<0>, dim3(grid), dim3(BLOCK), 0, 0, table, (uint64_t)table_elems - 1, n);
+        else if (scope == 3) // ... and plain scattered 8-byte stores
+            hipLaunchKernelGGL(k_bench_scatter<1>, dim3(grid), dim3(BLOCK), 0, 0, table, (uint64_t)table_elems - 1, n);
+        else if (scope == 0)
             hipLaunchKernelGGL(k_bench_atomics<__HIP_MEMORY_SCOPE_AGENT>, dim3(grid), dim3(BLOCK), 0, 0, table,
                                (uint64_t)table_elems - 1, n, sink);
         else
