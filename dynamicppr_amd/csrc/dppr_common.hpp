@@ -23,8 +23,13 @@ struct Adj { // one in-CSR entry: edge src -> (row vertex)
 // gpu/PPRCommon.cuh:6-11 IsLegalRevPush (strict inequalities). phase 2 is not the reference's: the MERGED loop of
 // dppr_set_phase_merge pushes residuals of both signs in one loop (|r| > eps).
 constexpr int PHASE_BOTH = 2;
+// Written without a branch on `phase`: the two thresholds are scalar selects the compiler computes once per kernel
+// (+-infinity switches a side off), every test is two compares -- as a three-way conditional each test was a small
+// tree of scalar branches inside the hottest loops.
 __device__ __forceinline__ bool legal(double r, int phase, double eps) {
-    return phase == 0 ? (r > eps) : phase == 1 ? (r < -eps) : (r > eps || r < -eps);
+    const double hi = phase == 1 ? __builtin_huge_val() : eps;   // r > eps counts in phase 0 and in the merged loop
+    const double lo = phase == 0 ? -__builtin_huge_val() : -eps; // r < -eps counts in phase 1 and in the merged loop
+    return (r > hi) | (r < lo);
 }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -126,8 +127,8 @@ struct Slot {
 // f2: up to 16 sources solved together on interleaved state (dppr_multi.hpp)
 struct Group {
     int n = 0;                 // sources in use (1..16)
-    int spl = 1;               // sources per state lane: 1 (<= 8 sources, 64-byte vertex state) or 2 (128-byte)
-    int gw = OCT;              // doubles per vertex = 8 * spl
+    int spl = 1;               // doubles per lane of an octet: 1 (rows of <= 8 doubles) or 2
+    int gw = OCT;              // doubles per vertex = row_width(n): 2, 4, .. 16 (dppr_multi.hpp)
     int src_ext[GS_MAX] = {0}; // ids the caller gave
     SrcN src{};                // internal ids, -1 = unused lane
     double *p = nullptr, *r = nullptr, *x = nullptr, *x2 = nullptr; // [V][gw]
@@ -211,12 +212,14 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     bool sweep_bits = false;        // per-iteration single-source sweeps test an activity bitmap before each gather (dppr_set_sweep_bitmap;
                                     // measured slower on every stand-in, DESIGN.md section 6: off unless asked for)
     bool hot_blocks = true;         // vertex numbering in blocks of falling in-degree (DPPR_HOT_BLOCKS=0: two blocks, hot | rest)
+    int gsweep_hot_rows = 24576;    // k_gsweep: rows below this id are gathered with the default cache policy, the others non-temporal (DPPR_GSWEEP_HOT)
     int gsweep_grid_cap = 2048;     // workgroups of a one-sweep launch of k_gsweep (DPPR_GSWEEP_GRID: tuning runs)
     bool group_resident = true;     // source groups on windows whose sweep groups are all resident run a loop as multi-sweep launches
     int gmulti_cap[2] = {-1, -1};   // co-resident workgroups of k_gsweep<.., true> per state width (-1: not queried yet)
     bool any_groups = false;        // a source group exists: epochs carry the second group table
     int ggroups_min = 256;          // ... of at least this many groups (DPPR_GGROUPS_MIN: tuning runs; 512 / 1008 measured slower on
                                     // the configs[1] stand-in, equal on the LiveJournal one)
+    bool group_full_rows = false;   // (A/B, DPPR_GROUP_FULL_ROWS=1: rows of 64 / 128 bytes whatever the source count, as until round 3)
     bool wide_groups = false;       // ... one of more than 8 sources: its groups hold at most 512 vertices
     bool group_tail_seeding = true; // source groups seed from the batch tails after a converged solve (false: dense Inspect)
     int gpush_enter_pairs = -1;     // a group's loop switches to the push form below this many frontier pairs (-1: automatic,
@@ -1572,13 +1575,30 @@ int pull_device_stats(dppr_engine *e, Slot &s) {
 }
 
 // ---------------------------------------------------------------------------- f2: groups
+// The group kernels are instantiated per row width (dppr_multi.hpp: GW = 2, 4, .. 16 doubles; one double per lane of
+// an octet up to 8, two beyond): f(SPL, GW) is called with the two as compile-time constants.
+template <int N> using IC = std::integral_constant<int, N>;
+template <class F>
+void with_row(int gw, F &&f) {
+    switch (gw) {
+    case 2: f(IC<1>{}, IC<2>{}); break;
+    case 4: f(IC<1>{}, IC<4>{}); break;
+    case 6: f(IC<1>{}, IC<6>{}); break;
+    case 8: f(IC<1>{}, IC<8>{}); break;
+    case 10: f(IC<2>{}, IC<10>{}); break;
+    case 12: f(IC<2>{}, IC<12>{}); break;
+    case 14: f(IC<2>{}, IC<14>{}); break;
+    default: f(IC<2>{}, IC<16>{}); break;
+    }
+}
+
 // workgroups of the multi-sweep form of k_gsweep that the device holds at once
 int group_multi_capacity(dppr_engine *e, int spl) {
     int &cap = e->gmulti_cap[spl - 1];
     if (cap < 0) {
-        int per_cu = 0, cus = 0; // (the 8-wide form on 512-vertex groups needs no more than the 1024-vertex one)
-        hipError_t rc = spl == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gsweep<1, 1024, true>, GNT, 0)
-                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gsweep<2, 512, true>, GNT, 0);
+        int per_cu = 0, cus = 0; // (the widest row of each lane split: narrower ones need no more)
+        hipError_t rc = spl == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gsweep<1, 8, 1024, true>, GNT, 0)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gsweep<2, 16, 512, true>, GNT, 0);
         if (rc != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess)
             per_cu = 0;
         cap = std::min(per_cu * cus, STAT_SLOTS);
@@ -1619,8 +1639,10 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
     hipLaunchKernelGGL(k_gpush_list, dim3(grid_for(n_words)), dim3(BLOCK), 0, e->stream, g.act[0], n_words, g.plist[0], cap, g.pctl);
     // the frontier's rows move from the snapshot back to residual[]; its bits stay set (they queue it for iteration 0)
     const int rows_grid = grid_for(std::min<long long>(pairs_at_entry, cap), BLOCK / OCT);
-    if (g.spl == 1) hipLaunchKernelGGL(k_gpush_rows<1>, dim3(rows_grid), dim3(BLOCK), 0, e->stream, g.plist[0], g.pctl, 0, g.x, g.r, false);
-    else hipLaunchKernelGGL(k_gpush_rows<2>, dim3(rows_grid), dim3(BLOCK), 0, e->stream, g.plist[0], g.pctl, 0, g.x, g.r, false);
+    with_row(g.gw, [&](auto spl, auto gw) {
+        hipLaunchKernelGGL((k_gpush_rows<decltype(spl)::value, decltype(gw)::value>), dim3(rows_grid), dim3(BLOCK), 0, e->stream, g.plist[0],
+                           g.pctl, 0, g.x, g.r, false);
+    });
     HIP_TRY(hipGetLastError());
     *entered = true;
     // what an iteration may cost here: a sweep's floor is ~0.02 us per sweep group, a returning f64 atomic ~1 / 20 000 us
@@ -1634,12 +1656,10 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
     for (;;) {
         if (known_n <= TINY_N && last_adds >= 0 && last_adds <= TINY_E / 2 && !tiny_declined) {
             // a frontier of a few hundred vertices: a run of iterations as ONE single-workgroup launch
-            if (g.spl == 1)
-                hipLaunchKernelGGL(k_gpush_tiny<1>, dim3(1), dim3(1024), 0, e->stream, g.pctl, g.plist[0], g.plist[1], ep.row_ptr, ep.adj, ep.hub_degp1,
-                                   g.r, g.p, g.act[0], phase, eps, g.dstats, GPUSH_LOG);
-            else
-                hipLaunchKernelGGL(k_gpush_tiny<2>, dim3(1), dim3(1024), 0, e->stream, g.pctl, g.plist[0], g.plist[1], ep.row_ptr, ep.adj, ep.hub_degp1,
-                                   g.r, g.p, g.act[0], phase, eps, g.dstats, GPUSH_LOG);
+            with_row(g.gw, [&](auto spl, auto gw) {
+                hipLaunchKernelGGL((k_gpush_tiny<decltype(spl)::value, decltype(gw)::value>), dim3(1), dim3(1024), 0, e->stream, g.pctl, g.plist[0],
+                                   g.plist[1], ep.row_ptr, ep.adj, ep.hub_degp1, g.r, g.p, g.act[0], phase, eps, g.dstats, GPUSH_LOG);
+            });
         } else {
         // iterations per chunk (<= GPUSH_LOG): down here the frontier about halves per iteration, so the first chunk is
         // sized to reach the single-workgroup form (an iteration that finds nothing is three empty dispatches)
@@ -1649,15 +1669,13 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
         tiny_declined = false;
         for (int k = 0; k < m; ++k) {
             hipLaunchKernelGGL(k_gpush_scan, dim3(1), dim3(1024), 0, e->stream, g.pctl, g.plist[0], g.plist[1], ep.row_ptr, g.ppre, cap - 1, max_edges);
-            if (g.spl == 1) {
-                hipLaunchKernelGGL(k_gpush_snap<1>, dim3(grid), dim3(BLOCK), 0, e->stream, g.plist[0], g.plist[1], g.pctl, g.x, g.r, g.p, g.act[0], phase, eps);
-                hipLaunchKernelGGL(k_gpush_expand<1>, dim3(grid), dim3(BLOCK), 0, e->stream, g.plist[0], g.plist[1], g.pctl, g.ppre, ep.row_ptr, ep.adj,
-                                   ep.hub_degp1, g.x, g.r, g.act[0], g.plist[0], g.plist[1], cap, phase, eps, g.dstats);
-            } else {
-                hipLaunchKernelGGL(k_gpush_snap<2>, dim3(grid), dim3(BLOCK), 0, e->stream, g.plist[0], g.plist[1], g.pctl, g.x, g.r, g.p, g.act[0], phase, eps);
-                hipLaunchKernelGGL(k_gpush_expand<2>, dim3(grid), dim3(BLOCK), 0, e->stream, g.plist[0], g.plist[1], g.pctl, g.ppre, ep.row_ptr, ep.adj,
-                                   ep.hub_degp1, g.x, g.r, g.act[0], g.plist[0], g.plist[1], cap, phase, eps, g.dstats);
-            }
+            with_row(g.gw, [&](auto spl, auto gw) {
+                constexpr int SPL = decltype(spl)::value, GW = decltype(gw)::value;
+                hipLaunchKernelGGL((k_gpush_snap<SPL, GW>), dim3(grid), dim3(BLOCK), 0, e->stream, g.plist[0], g.plist[1], g.pctl, g.x, g.r, g.p,
+                                   g.act[0], phase, eps);
+                hipLaunchKernelGGL((k_gpush_expand<SPL, GW>), dim3(grid), dim3(BLOCK), 0, e->stream, g.plist[0], g.plist[1], g.pctl, g.ppre,
+                                   ep.row_ptr, ep.adj, ep.hub_degp1, g.x, g.r, g.act[0], g.plist[0], g.plist[1], cap, phase, eps, g.dstats);
+            });
         }
         }
         HIP_TRY(hipGetLastError());
@@ -1684,8 +1702,10 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
         if (h.stop) { // an iteration too large for this form: the queued vertices go back to sweep form
             if (trace) fprintf(stderr, "[gpush ] phase %d: an iteration of %d vertices called itself off after %d iterations\n", phase, h.n[h.it & 1], h.it);
             HIP_TRY(hipMemsetAsync(g.cnt, 0, sizeof(int) * 3 * GWM, e->stream));
-            if (g.spl == 1) hipLaunchKernelGGL(k_gpush_leave<1>, dim3(grid_for(e->n_int, BLOCK / OCT)), dim3(BLOCK), 0, e->stream, e->n_int, g.act[0], g.x, g.r, g.p, h.it > 0 ? 1 : 0, phase, eps, g.cnt);
-            else hipLaunchKernelGGL(k_gpush_leave<2>, dim3(grid_for(e->n_int, BLOCK / OCT)), dim3(BLOCK), 0, e->stream, e->n_int, g.act[0], g.x, g.r, g.p, h.it > 0 ? 1 : 0, phase, eps, g.cnt);
+            with_row(g.gw, [&](auto spl, auto gw) {
+                hipLaunchKernelGGL((k_gpush_leave<decltype(spl)::value, decltype(gw)::value>), dim3(grid_for(e->n_int, BLOCK / OCT)), dim3(BLOCK), 0,
+                                   e->stream, e->n_int, g.act[0], g.x, g.r, g.p, h.it > 0 ? 1 : 0, phase, eps, g.cnt);
+            });
             HIP_TRY(hipGetLastError());
             return DPPR_OK;
         }
@@ -1705,21 +1725,17 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
     if (tails) {
         HIP_TRY(hipMemsetAsync(g.act[0], 0, g.act_bytes, e->stream));
         if (ep.L > 0) {
-            if (g.spl == 1)
-                hipLaunchKernelGGL(k_gseed_tails<1>, dim3(grid_for(ep.L, BLOCK / OCT)), dim3(BLOCK), 0, e->stream, batch_tails(e, ep),
-                                   ep.L, g.r, g.x, g.p, g.act[0], phase, eps, g.cnt + cur * GWM);
-            else
-                hipLaunchKernelGGL(k_gseed_tails<2>, dim3(grid_for(ep.L, BLOCK / OCT)), dim3(BLOCK), 0, e->stream, batch_tails(e, ep),
-                                   ep.L, g.r, g.x, g.p, g.act[0], phase, eps, g.cnt + cur * GWM);
+            with_row(g.gw, [&](auto spl, auto gw) {
+                hipLaunchKernelGGL((k_gseed_tails<decltype(spl)::value, decltype(gw)::value>), dim3(grid_for(ep.L, BLOCK / OCT)), dim3(BLOCK), 0,
+                                   e->stream, batch_tails(e, ep), ep.L, g.r, g.x, g.p, g.act[0], phase, eps, g.cnt + cur * GWM);
+            });
         }
     } else {
         // dense seeding: every legal vertex of every source enters, snapshot taken
-        if (g.spl == 1)
-            hipLaunchKernelGGL(k_gseed_dense<1>, dim3(grid_for(e->n_int, BLOCK / OCT)), dim3(BLOCK), 0, e->stream, e->n_int,
-                               g.r, g.x, g.p, g.act[0], phase, eps, g.cnt + cur * GWM);
-        else
-            hipLaunchKernelGGL(k_gseed_dense<2>, dim3(grid_for(e->n_int, BLOCK / OCT)), dim3(BLOCK), 0, e->stream, e->n_int,
-                               g.r, g.x, g.p, g.act[0], phase, eps, g.cnt + cur * GWM);
+        with_row(g.gw, [&](auto spl, auto gw) {
+            hipLaunchKernelGGL((k_gseed_dense<decltype(spl)::value, decltype(gw)::value>), dim3(grid_for(e->n_int, BLOCK / OCT)), dim3(BLOCK), 0,
+                               e->stream, e->n_int, g.r, g.x, g.p, g.act[0], phase, eps, g.cnt + cur * GWM);
+        });
         g.st.inspected += (int64_t)e->n_int * g.n;
     }
     HIP_TRY(hipGetLastError());
@@ -1752,14 +1768,17 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
             HIP_TRY(hipMemsetAsync(e->bar, 0, sizeof(GridBar), e->stream));
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
             int *status = g.mlog, *rows = g.mlog + GWM;
-#define DPPR_LAUNCH_GMULTI(SPL, NVX)                                                                                     \
-    hipLaunchKernelGGL((k_gsweep<SPL, NVX, true>), dim3(ep.n_ggroups), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.gtab,       \
-                       ep.n_ggroups, g.cnt + cur * GWM, ep.out_row_ptr, ep.out_col, g.x, g.x2, g.act[0], g.act[1], g.r, g.p, \
+#define DPPR_LAUNCH_GMULTI(SPL, GW, NVX)                                                                                 \
+    hipLaunchKernelGGL((k_gsweep<SPL, GW, NVX, true>), dim3(ep.n_ggroups), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.gtab,   \
+                       ep.n_ggroups, g.cnt + cur * GWM, e->gsweep_hot_rows, ep.out_col, g.x, g.x2, g.act[0], g.act[1], g.r, g.p, \
                        g.cnt + 3 * GWM, g.cnt + 4 * GWM, phase, eps, g.dstats, rows, n, e->bar, status, e->persist_ticks,    \
                        e->persist_rollcall_extra)
-            if (g.spl == 2) DPPR_LAUNCH_GMULTI(2, 512);
-            else if (nvx == 512) DPPR_LAUNCH_GMULTI(1, 512); // (an 8-wide group on an engine that also has a 16-wide one)
-            else DPPR_LAUNCH_GMULTI(1, 1024);
+            with_row(g.gw, [&](auto spl, auto gw) {
+                constexpr int SPL = decltype(spl)::value, GW = decltype(gw)::value;
+                if constexpr (SPL == 2) DPPR_LAUNCH_GMULTI(2, GW, 512);
+                else if (nvx == 512) DPPR_LAUNCH_GMULTI(1, GW, 512); // (a narrow group on an engine that also has a wide one)
+                else DPPR_LAUNCH_GMULTI(1, GW, 1024);
+            });
 #undef DPPR_LAUNCH_GMULTI
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[1], e->stream));
             HIP_TRY(hipGetLastError());
@@ -1827,14 +1846,17 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
         for (int k = 0; k < n; ++k) {
             const int nxt = (cur + 1) % 3, zer = (cur + 2) % 3;
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k], e->stream));
-#define DPPR_LAUNCH_GSWEEP(SPL, NVX)                                                                                      \
-    hipLaunchKernelGGL((k_gsweep<SPL, NVX, false>), dim3(sweep_grid), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.gtab,          \
-                       ep.n_ggroups, g.cnt + cur * GWM, ep.out_row_ptr, ep.out_col, g.x, g.x2, g.act[0], g.act[1], g.r, g.p,  \
+#define DPPR_LAUNCH_GSWEEP(SPL, GW, NVX)                                                                                  \
+    hipLaunchKernelGGL((k_gsweep<SPL, GW, NVX, false>), dim3(sweep_grid), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.gtab,      \
+                       ep.n_ggroups, g.cnt + cur * GWM, e->gsweep_hot_rows, ep.out_col, g.x, g.x2, g.act[0], g.act[1], g.r, g.p,  \
                        g.cnt + nxt * GWM, g.cnt + zer * GWM, phase, eps, g.dstats, log + k * GWM, 1, (GridBar *)nullptr,      \
                        (int *)nullptr, 0ull, 0)
-            if (g.spl == 2) DPPR_LAUNCH_GSWEEP(2, 512);
-            else if (nvx == 512) DPPR_LAUNCH_GSWEEP(1, 512);
-            else DPPR_LAUNCH_GSWEEP(1, 1024);
+            with_row(g.gw, [&](auto spl, auto gw) {
+                constexpr int SPL = decltype(spl)::value, GW = decltype(gw)::value;
+                if constexpr (SPL == 2) DPPR_LAUNCH_GSWEEP(2, GW, 512);
+                else if (nvx == 512) DPPR_LAUNCH_GSWEEP(1, GW, 512);
+                else DPPR_LAUNCH_GSWEEP(1, GW, 1024);
+            });
 #undef DPPR_LAUNCH_GSWEEP
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k + 1], e->stream));
             std::swap(g.x, g.x2);
@@ -1973,6 +1995,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     } while (0)
     if (const char *v = getenv("DPPR_SWEEP_BITS")) e->sweep_bits = atoi(v) != 0; // diagnostic A/B switches
     if (const char *v = getenv("DPPR_HOT_BLOCKS")) e->hot_blocks = atoi(v) != 0;
+    if (const char *v = getenv("DPPR_GSWEEP_HOT")) e->gsweep_hot_rows = std::max(0, atoi(v));
     if (const char *v = getenv("DPPR_GSWEEP_GRID")) e->gsweep_grid_cap = std::max(1, std::min(atoi(v), STAT_SLOTS));
     if (const char *v = getenv("DPPR_RENUMBER")) e->renumber_on = atoi(v) != 0;
     if (const char *v = getenv("DPPR_RENUMBER_PCT")) e->renumber_growth_pct = std::max(1, atoi(v));
@@ -1980,6 +2003,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     if (const char *v = getenv("DPPR_GROUP_PUSH")) e->gpush_enter_pairs = std::max(-1, atoi(v));
     if (const char *v = getenv("DPPR_GROUP_PUSH_FACTOR")) e->gpush_auto_factor = std::max(1, atoi(v));
     if (const char *v = getenv("DPPR_GGROUPS_MIN")) e->ggroups_min = std::max(1, atoi(v));
+    if (const char *v = getenv("DPPR_GROUP_FULL_ROWS")) e->group_full_rows = atoi(v) != 0;
     e->device = device;
     e->V = V;
     e->W = W;
@@ -2866,8 +2890,8 @@ int dppr_add_source_group(dppr_engine *e, const int32_t *sources, int32_t n, int
     HIP_TRY(hipSetDevice(e->device));
     Group g;
     g.n = n;
-    g.spl = n > OCT ? 2 : 1;
-    g.gw = OCT * g.spl;
+    g.gw = e->group_full_rows ? (n > OCT ? 2 * OCT : OCT) : row_width(n); // doubles per vertex: the sources + at most one of padding
+    g.spl = row_spl(g.gw);
     for (int s = 0; s < GS_MAX; ++s) g.src.s[s] = -1;
     for (int s = 0; s < n; ++s) g.src_ext[s] = sources[s];
     const size_t V = (size_t)e->V, row = sizeof(double) * (size_t)g.gw;
@@ -2887,8 +2911,9 @@ int dppr_add_source_group(dppr_engine *e, const int32_t *sources, int32_t n, int
     } while (0)
     GRP_TRY(hipMalloc((void **)&g.p, row * V));
     GRP_TRY(hipMalloc((void **)&g.r, row * V));
-    GRP_TRY(hipMalloc((void **)&g.x, row * V));
-    GRP_TRY(hipMalloc((void **)&g.x2, row * V));
+    const size_t xrow = sizeof(double) * (size_t)x_stride(g.gw); // snapshot rows never straddle a 128-byte line (dppr_multi.hpp)
+    GRP_TRY(hipMalloc((void **)&g.x, xrow * V));
+    GRP_TRY(hipMalloc((void **)&g.x2, xrow * V));
     GRP_TRY(hipMalloc((void **)&g.act[0], g.act_bytes));
     GRP_TRY(hipMalloc((void **)&g.act[1], g.act_bytes));
     GRP_TRY(hipMalloc((void **)&g.cnt, sizeof(int) * (5 * GS_MAX + MAX_CHUNK * GS_MAX))); // rows 3, 4: scratch of multi-sweep launches

@@ -53,19 +53,19 @@ __global__ __launch_bounds__(BLOCK) void k_gpush_list(const uint32_t *__restrict
 
 // rows of the listed vertices between snapshot and residual[] (to_x = false: entering, x -> r; true: leaving, r -> x).
 // An octet per vertex; the snapshot row is GW wide (lanes beyond the sources are zero), the residual row too.
-template <int SPL>
+template <int SPL, int GW>
 __global__ __launch_bounds__(BLOCK) void k_gpush_rows(const int *__restrict__ list, const GPushCtl *__restrict__ ctl, int which,
                                                       double *__restrict__ x, double *__restrict__ r, bool to_x) {
-    constexpr int GW = OCT * SPL;
     if (ctl->overflow) return; // (the list is incomplete: nothing moves, the scan calls the mode off)
     const int n = ctl->n[which];
     const int j = threadIdx.x & (OCT - 1);
+    if (!oct_live<SPL, GW>(j)) return;
     for (int i = (blockIdx.x * BLOCK + threadIdx.x) / OCT; i < n; i += gridDim.x * BLOCK / OCT) {
-        const size_t base = (size_t)list[i] * GW + j * SPL;
+        const size_t base = (size_t)list[i] * GW + j * SPL, xbase = (size_t)list[i] * x_stride(GW) + j * SPL;
 #pragma unroll
         for (int q = 0; q < SPL; ++q) {
-            if (to_x) x[base + q] = r[base + q];
-            else r[base + q] = x[base + q];
+            if (to_x) x[xbase + q] = r[base + q];
+            else r[base + q] = x[xbase + q];
         }
     }
 }
@@ -74,11 +74,10 @@ __global__ __launch_bounds__(BLOCK) void k_gpush_rows(const int *__restrict__ li
 // PPRRevPushGPUFF's snapshot, gpu/Inspect.cuh:51-65): per listed vertex, the legal sources' residuals go to the
 // snapshot row (0 elsewhere), pagerank += ALPHA * residual (iteration 0 excepted), residual = 0; its bit (which queued it) is cleared; its
 // in-degree was scanned by k_gpush_scan, which runs FIRST and may call the iteration off.
-template <int SPL>
+template <int SPL, int GW>
 __global__ __launch_bounds__(BLOCK) void k_gpush_snap(const int *__restrict__ list0, const int *__restrict__ list1, GPushCtl *ctl,
                                                       double *__restrict__ x, double *__restrict__ r, double *__restrict__ p,
                                                       uint32_t *__restrict__ bits, int phase, double eps) {
-    constexpr int GW = OCT * SPL;
     __shared__ int s_cnt[GS_MAX];
     if (ctl->stop) return;
     const int it = ctl->it, which = it & 1;
@@ -90,14 +89,16 @@ __global__ __launch_bounds__(BLOCK) void k_gpush_snap(const int *__restrict__ li
     int nleg[SPL];
 #pragma unroll
     for (int q = 0; q < SPL; ++q) nleg[q] = 0;
+    const bool live = oct_live<SPL, GW>(j);
     for (int i = (blockIdx.x * BLOCK + threadIdx.x) / OCT; i < n; i += gridDim.x * BLOCK / OCT) {
         const int u = list[i];
         const size_t base = (size_t)u * GW + j * SPL;
 #pragma unroll
         for (int q = 0; q < SPL; ++q) {
+            if (!live) continue;
             const double rv = r[base + q];
             const bool lg = legal(rv, phase, eps);
-            x[base + q] = lg ? rv : 0.0;
+            x[(size_t)u * x_stride(GW) + j * SPL + q] = lg ? rv : 0.0;
             if (lg) {
                 // (the frontier a sweep hands over was credited when the sweep took its snapshot in place)
                 if (it > 0) p[base + q] = p[base + q] + ALPHA * rv;
@@ -171,14 +172,13 @@ __global__ __launch_bounds__(1024) void k_gpush_scan(GPushCtl *ctl, const int *_
 // residual[v] += (1.0-ALPHA)*x/(outdeg(v)+1) with a returning atomic; the add that takes residual[v] across the
 // threshold queues v (its activity bit; the first to set it appends v to the next list) -- adds of a phase have one
 // sign, so exactly one add per (v, source) sees the crossing. The last workgroup to finish closes the iteration.
-template <int SPL>
+template <int SPL, int GW>
 __global__ __launch_bounds__(BLOCK) void k_gpush_expand(const int *__restrict__ list0, const int *__restrict__ list1, GPushCtl *ctl,
                                                         const int *__restrict__ pre, const int *__restrict__ in_row_ptr,
                                                         const Adj *__restrict__ adj, const int *__restrict__ hub_degp1,
                                                         const double *__restrict__ x, double *__restrict__ r,
                                                         uint32_t *__restrict__ bits, int *__restrict__ nlist0, int *__restrict__ nlist1,
                                                         int cap, int phase, double eps, IterStats *__restrict__ stats) {
-    constexpr int GW = OCT * SPL;
     __shared__ unsigned long long s_edges;
     if (ctl->stop) return;
     const int it = ctl->it, which = it & 1;
@@ -188,6 +188,7 @@ __global__ __launch_bounds__(BLOCK) void k_gpush_expand(const int *__restrict__ 
     if (threadIdx.x == 0) s_edges = 0ull;
     __syncthreads();
     const int j = threadIdx.x & (OCT - 1);
+    const bool live = oct_live<SPL, GW>(j);
     const long long n_oct = (long long)gridDim.x * (BLOCK / OCT);
     const long long oct = (long long)blockIdx.x * (BLOCK / OCT) + threadIdx.x / OCT;
     const long long per = (etot + n_oct - 1) / n_oct;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(BLOCK) void k_gpush_expand(const int *__restrict__ 
             const int u = list[i];
             double xv[SPL];
 #pragma unroll
-            for (int q = 0; q < SPL; ++q) xv[q] = x[(size_t)u * GW + j * SPL + q];
+            for (int q = 0; q < SPL; ++q) xv[q] = live ? x[(size_t)u * x_stride(GW) + j * SPL + q] : 0.0;
             const long long row_end = pre[i + 1] < (int)e1 ? pre[i + 1] : e1;
             const Adj *row = adj + in_row_ptr[u] + ((int)e0 - pre[i]);
             for (int k = 0; k < (int)(row_end - e0); ++k) {
@@ -266,12 +267,12 @@ constexpr int TINY_E = 1024; // (an octet walks its share of the edges one retur
 static_assert(sizeof(double) * TINY_N * 16 + sizeof(int) * (3 * TINY_N + 1) + 1024 <= 160 * 1024,
               "k_gpush_tiny: TINY_N snapshot rows + lists + scan must fit the 160 KB LDS of a gfx950 CU");
 
-template <int SPL>
+template <int SPL, int GW>
 __global__ __launch_bounds__(1024) void k_gpush_tiny(GPushCtl *ctl, int *__restrict__ list0, int *__restrict__ list1,
                                                      const int *__restrict__ in_row_ptr, const Adj *__restrict__ adj,
                                                      const int *__restrict__ hub_degp1, double *r, double *p, uint32_t *bits, int phase,
                                                      double eps, IterStats *__restrict__ stats, int max_it) {
-    constexpr int GW = OCT * SPL, NT = 1024, NOCT = NT / OCT;
+    constexpr int NT = 1024, NOCT = NT / OCT;
     __shared__ int s_list[2][TINY_N];
     __shared__ int s_pre[TINY_N + 1];
     __shared__ double s_x[TINY_N * GW];
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(1024) void k_gpush_tiny(GPushCtl *ctl, int *__restr
     if (ctl->stop || ctl->overflow) return;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const int j = tid & (OCT - 1), oid = tid / OCT;
+    const bool live = oct_live<SPL, GW>(j);
     int it = ctl->it, which = it & 1;
     const int n0 = ctl->n[which];
     if (n0 > TINY_N) return; // (not a frontier for this kernel)
@@ -325,6 +327,7 @@ __global__ __launch_bounds__(1024) void k_gpush_tiny(GPushCtl *ctl, int *__restr
             const size_t base = (size_t)u * GW + j * SPL;
 #pragma unroll
             for (int q = 0; q < SPL; ++q) {
+                if (!live) continue;
                 double rv = gs_ld<true>(r + base + q);
                 const bool lg = legal(rv, phase, eps);
                 if (lg) {
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(1024) void k_gpush_tiny(GPushCtl *ctl, int *__restr
                 const int u = s_list[which][i];
                 double xv[SPL];
 #pragma unroll
-                for (int q = 0; q < SPL; ++q) xv[q] = s_x[i * GW + j * SPL + q];
+                for (int q = 0; q < SPL; ++q) xv[q] = live ? s_x[i * GW + j * SPL + q] : 0.0;
                 const int row_end = min(s_pre[i + 1], e1);
                 const Adj *row = adj + in_row_ptr[u] + (e0 - s_pre[i]);
                 for (int k = 0; k < row_end - e0; ++k) {
@@ -418,25 +421,25 @@ __global__ __launch_bounds__(1024) void k_gpush_tiny(GPushCtl *ctl, int *__restr
 // get their residual rows into the snapshot and their pagerank share (credit: not if no iteration ran here -- then
 // they are the frontier the sweep handed over, credited already), which is what a sweep expects of an active vertex, and the per-source
 // frontier sizes the sweep's launches look at are counted. An octet per vertex over all ids.
-template <int SPL>
+template <int SPL, int GW>
 __global__ __launch_bounds__(BLOCK) void k_gpush_leave(int V, const uint32_t *__restrict__ bits, double *__restrict__ x,
                                                        const double *__restrict__ r, double *__restrict__ p, int credit, int phase,
                                                        double eps, int *__restrict__ cnt_out) {
-    constexpr int GW = OCT * SPL;
     __shared__ int s_cnt[GS_MAX];
     if (threadIdx.x < GS_MAX) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const int j = threadIdx.x & (OCT - 1);
+    const bool live = oct_live<SPL, GW>(j);
     int nleg[SPL];
 #pragma unroll
     for (int q = 0; q < SPL; ++q) nleg[q] = 0;
     for (int v = (blockIdx.x * BLOCK + threadIdx.x) / OCT; v < V; v += gridDim.x * BLOCK / OCT) {
-        if (!((bits[v >> 5] >> (v & 31)) & 1u)) continue;
+        if (!((bits[v >> 5] >> (v & 31)) & 1u) || !live) continue;
         const size_t base = (size_t)v * GW + j * SPL;
 #pragma unroll
         for (int q = 0; q < SPL; ++q) {
             const double rv = r[base + q];
-            x[base + q] = rv;
+            x[(size_t)v * x_stride(GW) + j * SPL + q] = rv;
             if (legal(rv, phase, eps)) { // a sweep's frontier has its pagerank share already (snapshot in place)
                 if (credit) p[base + q] = p[base + q] + ALPHA * rv;
                 nleg[q]++;

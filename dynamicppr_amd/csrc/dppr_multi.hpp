@@ -1,10 +1,13 @@
 // dppr_multi.hpp -- f2: multi-source batched sweeps.
 //
 // Several source vertices that share one device graph (BASELINE.json configs 3 and 5 run 10 of
-// them) are solved TOGETHER. Their state is interleaved GW-wide, p/r/x[v] = GW doubles: one
-// 64-byte sector for up to 8 sources (SPL = 1), one 128-byte line for up to 16 (SPL = 2). A sweep
-// reads every out_col entry once and one sector (line) per ACTIVE edge for all sources -- a
-// single-source sweep pulls the same sector for 8 useful bytes.
+// them) are solved TOGETHER. Their state is interleaved GW-wide, p/r/x[v] = GW doubles, where
+// GW = 2 * ceil(sources / 2): a row holds the sources and at most one padding double (10 sources:
+// 80-byte rows; until round 3 rows were 64 or 128 bytes whatever the count, so 10 sources moved
+// 37.5 % padding). Eight lanes serve a row: SPL = 1 double per lane up to 8 sources, SPL = 2 beyond;
+// lanes whose doubles lie beyond the row (j * SPL >= GW) issue no memory operation at all. A sweep
+// reads every out_col entry once and one row per ACTIVE edge for all sources -- a single-source
+// sweep pulls a whole sector for 8 useful bytes.
 //
 // Per source the arithmetic is that of k_pull_iter (dppr_pull.hpp), i.e. what the pushes u -> v of
 // gpu/ExpandRev.cuh:70-73 plus the repair of :708-743 leave in residual[v]:
@@ -60,6 +63,26 @@ __device__ __forceinline__ unsigned oct_mask(uint64_t ballot) { // the 8 ballot 
     return (unsigned)(ballot >> (lane_id() & ~(OCT - 1))) & 0xffu;
 }
 
+// Row geometry: GW doubles per vertex (even, 2 .. 16), SPL doubles per lane of the octet. Lane j of an octet owns
+// doubles [j * SPL, j * SPL + SPL) of a row; it is LIVE iff they exist. (A full row -- GW = 8 * SPL -- has no dead lane
+// and the test folds away.)
+__host__ __device__ constexpr int row_width(int n_sources) { return n_sources <= 2 ? 2 : (n_sources + 1) / 2 * 2; }
+__host__ __device__ constexpr int row_spl(int gw) { return gw > OCT ? 2 : 1; }
+// The SNAPSHOT rows (x: the only rows that are gathered at random) keep a power-of-two stride so that a row never
+// straddles a 128-byte line: the L2 fills whole lines from the fabric (TCC_EA0_RDREQ_128B is every read request of
+// a sweep, profiles/r04_pmc_*), and an 80-byte row at an 80-byte stride costs two fills on every other gather.
+// pagerank / residual rows are only ever streamed (consecutive vertices) and stay compact.
+#ifndef DPPR_X_COMPACT
+#define DPPR_X_COMPACT 0 // (A/B: 1 = snapshot rows at the compact stride too)
+#endif
+__host__ __device__ constexpr int x_stride(int gw) { return DPPR_X_COMPACT ? gw : gw > 8 ? 16 : gw > 4 ? 8 : gw; }
+template <int SPL, int GW>
+__device__ __forceinline__ bool oct_live(int j) {
+    static_assert(GW >= 2 && GW <= OCT * SPL && GW % 2 == 0 && (SPL == 1 || GW > OCT), "row width / lane split");
+    if constexpr (GW == OCT * SPL) return true;
+    else return j * SPL < GW;
+}
+
 // r = e_s per source, p = 0. One thread per (vertex, state lane).
 __global__ __launch_bounds__(BLOCK) void k_ginit(double *__restrict__ p, double *__restrict__ r, int V, int gw, SrcN src) {
     const int64_t n = (int64_t)V * gw;
@@ -74,15 +97,15 @@ __global__ __launch_bounds__(BLOCK) void k_ginit(double *__restrict__ p, double 
 // (gpu/ExpandRev.cuh:34-42) for every source at once: where some source is legal, x[v][s] =
 // legal(r) ? r : 0 for all s, p += ALPHA*x, and the vertex's activity bit is set. Writes the
 // complete bitmap (every word up to V). Octet per vertex.
-template <int SPL>
+template <int SPL, int GW>
 __global__ __launch_bounds__(BLOCK) void k_gseed_dense(int V, const double *__restrict__ r, double *__restrict__ x,
                                                        double *__restrict__ p, uint32_t *__restrict__ act, int phase,
                                                        double eps, int *__restrict__ cnt_out) {
-    constexpr int GW = OCT * SPL;
     __shared__ int s_cnt[GS_MAX];
     if (threadIdx.x < GS_MAX) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const int j = threadIdx.x & (OCT - 1);
+    const bool live = oct_live<SPL, GW>(j);
     int nleg[SPL];
 #pragma unroll
     for (int q = 0; q < SPL; ++q) nleg[q] = 0;
@@ -96,18 +119,18 @@ __global__ __launch_bounds__(BLOCK) void k_gseed_dense(int V, const double *__re
         bool lg[SPL];
 #pragma unroll
         for (int q = 0; q < SPL; ++q) {
-            rv[q] = v < V ? r[(size_t)v * GW + j * SPL + q] : 0.0;
-            lg[q] = v < V && legal(rv[q], phase, eps);
+            rv[q] = v < V && live ? r[(size_t)v * GW + j * SPL + q] : 0.0;
+            lg[q] = v < V && live && legal(rv[q], phase, eps);
             any |= lg[q];
             nleg[q] += lg[q] ? 1 : 0;
         }
         const uint64_t bal = __ballot(any);
         const unsigned m = oct_mask(bal);
-        if (m) {
+        if (m && live) {
 #pragma unroll
             for (int q = 0; q < SPL; ++q) {
                 const size_t i = (size_t)v * GW + j * SPL + q;
-                x[i] = rv[q]; // the whole residual row moves to the snapshot (dppr_multi.hpp header)
+                x[(size_t)v * x_stride(GW) + j * SPL + q] = rv[q]; // the whole residual row moves to the snapshot (dppr_multi.hpp header)
                 if (lg[q]) p[i] = p[i] + ALPHA * rv[q];
             }
         }
@@ -131,16 +154,16 @@ __global__ __launch_bounds__(BLOCK) void k_gseed_dense(int V, const double *__re
 // batch records can have left [-eps, eps]; cpu/PPRCPUMTCilkRev.h:126-156 seeds from the batch
 // endpoints for the same reason). skeys = the batch's tails, sorted; an octet takes the first
 // record of each tail. `act` must be all zero on entry.
-template <int SPL>
+template <int SPL, int GW>
 __global__ __launch_bounds__(BLOCK) void k_gseed_tails(const uint32_t *__restrict__ skeys, int L, const double *__restrict__ r,
                                                        double *__restrict__ x, double *__restrict__ p,
                                                        uint32_t *__restrict__ act, int phase, double eps,
                                                        int *__restrict__ cnt_out) {
-    constexpr int GW = OCT * SPL;
     __shared__ int s_cnt[GS_MAX];
     if (threadIdx.x < GS_MAX) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const int j = threadIdx.x & (OCT - 1);
+    const bool live = oct_live<SPL, GW>(j);
     int nleg[SPL];
 #pragma unroll
     for (int q = 0; q < SPL; ++q) nleg[q] = 0;
@@ -158,17 +181,19 @@ __global__ __launch_bounds__(BLOCK) void k_gseed_tails(const uint32_t *__restric
         bool lg[SPL];
 #pragma unroll
         for (int q = 0; q < SPL; ++q) {
-            rv[q] = u >= 0 ? r[(size_t)u * GW + j * SPL + q] : 0.0;
-            lg[q] = u >= 0 && legal(rv[q], phase, eps);
+            rv[q] = u >= 0 && live ? r[(size_t)u * GW + j * SPL + q] : 0.0;
+            lg[q] = u >= 0 && live && legal(rv[q], phase, eps);
             any |= lg[q];
             nleg[q] += lg[q] ? 1 : 0;
         }
         if (oct_mask(__ballot(any))) {
+            if (live) {
 #pragma unroll
-            for (int q = 0; q < SPL; ++q) {
-                const size_t k = (size_t)u * GW + j * SPL + q;
-                x[k] = rv[q];
-                if (lg[q]) p[k] = p[k] + ALPHA * rv[q];
+                for (int q = 0; q < SPL; ++q) {
+                    const size_t k = (size_t)u * GW + j * SPL + q;
+                    x[(size_t)u * x_stride(GW) + j * SPL + q] = rv[q];
+                    if (lg[q]) p[k] = p[k] + ALPHA * rv[q];
+                }
             }
             if (j == 0) atomicOr(&act[u >> 5], 1u << (u & 31));
         }
@@ -277,6 +302,30 @@ __device__ __forceinline__ void gs_stu(uint32_t *p, uint32_t v) {
     else *p = v;
 }
 
+// Cache policy of a one-sweep launch (DPPR_GS_NT, a bit mask; the multi-sweep form keeps its agent-scope accesses).
+// A dense sweep is bound by 128-byte line fills of the XCDs' L2s (tools/r04/gather_probe.hip: ~50 G random lines/s chip-wide
+// whether the table sits in the Infinity Cache or in HBM; 190 G rows/s out of the L2), and an XCD's 4 MiB L2 sees ~25x its
+// size per sweep, so under plain LRU only rows gathered every few microseconds survive. The ids are numbered in blocks of
+// falling in-degree (dppr_idspace.hpp): rows below `hot_rows` take a third to a half of all gathers. They are loaded with
+// the default policy, everything that is touched once per sweep is marked non-temporal so that it does not push them out:
+//   bit 0: gathers of rows >= hot_rows;  bit 1: the vertex phase's row loads;  bit 2: the vertex phase's row stores
+#ifndef DPPR_GS_NT
+#define DPPR_GS_NT 0
+#endif
+#ifndef DPPR_WHATIF
+#define DPPR_WHATIF 0 // (timing experiments that compute WRONG results: 1 = no pagerank traffic, 2 = no own-row read of active vertices)
+#endif
+template <bool COH, int BIT>
+__device__ __forceinline__ double gs_ld_once(const double *p) {
+    if constexpr (!COH && (DPPR_GS_NT & BIT)) return __builtin_nontemporal_load(p);
+    else return gs_ld<COH>(p);
+}
+template <bool COH, int BIT>
+__device__ __forceinline__ void gs_st_once(double *p, double v) {
+    if constexpr (!COH && (DPPR_GS_NT & BIT)) __builtin_nontemporal_store(v, p);
+    else gs_st<COH>(p, v);
+}
+
 // status word of a multi-sweep launch
 constexpr int GSM_ABORTED = 1 << 30;   // the roll-call failed: nothing was changed
 constexpr int GSM_FAULT = 1 << 29;     // a wait timed out after a successful roll-call
@@ -284,8 +333,8 @@ constexpr int GSM_CONVERGED = 1 << 28; // every frontier emptied
 constexpr int GSM_SWEEPS = (1 << 16) - 1;
 
 // One frontier iteration (ExpandUnifiedRev + RepairFrontierRev) for all sources of a group.
-// NVX = vertices per sweep group (the LDS accumulators are NVX x GW doubles: 64 KB for both
-// instantiations, two 1024-thread workgroups per CU).
+// NVX = vertices per sweep group (the LDS accumulators are NVX x GW doubles: at most 64 KB, two
+// 1024-thread workgroups per CU).
 //
 // MULTI = a RUN of iterations as one launch, for windows whose groups are all resident at once (one
 // workgroup per group): the group's row tables are built once and stay in LDS, iterations are
@@ -295,15 +344,16 @@ constexpr int GSM_SWEEPS = (1 << 16) - 1;
 // frontier sizes of all sources are row g of `mlog` (row 0 = cnt_in): the loop ends when a row is
 // all zero. Co-residency is verified by the same roll-call as k_pull_resident's before anything is
 // changed; a failed roll-call leaves everything untouched and the host goes on with one-sweep launches.
-template <int SPL, int NVX, bool MULTI>
+template <int SPL, int GW, int NVX, bool MULTI>
 __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int *__restrict__ gtab, int n_groups,
-                                                   const int *cnt_in, const int *__restrict__ out_row_ptr,
+                                                   const int *cnt_in, int hot_rows,
                                                    const int *__restrict__ out_col, double *x_a, double *x_b,
                                                    uint32_t *act_a, uint32_t *act_b, double *r, double *p, int *cnt_out,
                                                    int *cnt_zero, int phase, double eps, IterStats *__restrict__ stats,
                                                    int *log_slot, int n_iter, GridBar *bar, int *status,
                                                    unsigned long long limit_ticks, int rollcall_extra) {
-    constexpr int GW = OCT * SPL, NOCT = GNT / OCT, WORDS = NVX / 32;
+    constexpr int NOCT = GNT / OCT, WORDS = NVX / 32, XS = x_stride(GW);
+    static_assert(sizeof(double) * NVX * GW <= 64 * 1024, "two workgroups per CU");
     constexpr int EB = 8;        // edges an octet tests per step (one per lane)
     constexpr int GB = EB / SPL; // ... and gathers per sub-step (registers: GB x SPL doubles)
     // vertices an octet finishes per step. A wait for loaded values also waits for every older store, so a second
@@ -322,7 +372,18 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
     __shared__ unsigned long long s_edges;
     __shared__ int s_flag[2]; // MULTI: {go on (roll-call ok / frontier not empty), fault}
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
-    const int j = tid & (OCT - 1), oid = tid / OCT;
+    const int j = tid & (OCT - 1);
+    // Everything a thread derives from its index (LDS addresses of its bitmap words, row bases, masks) is invariant over the
+    // group loop; hoisted out of it, those values were what the 64-register budget spilled (17 VGPRs in round 3), and
+    // every reload from scratch is a vector-memory load behind an `s_waitcnt vmcnt(0)` -- i.e. behind every row load in
+    // flight: the vertex phase's two vertices per step were loaded one after the other. opaque() hides the index from
+    // the optimiser inside the loop: the few integer operations are redone per phase, nothing is kept live.
+    auto opaque = [](int v) {
+#ifndef DPPR_NO_OPAQUE // (A/B switch: the round-3 code generation)
+        asm volatile("" : "+v"(v));
+#endif
+        return v;
+    };
 
     // frontier sizes of the sources; the group iterates while ANY of them is non-empty
     bool stamp_dense = false; // (diagnostic builds: a one-sweep launch is stamped when its frontier is dense)
@@ -409,7 +470,6 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
     // short by asking early: the next group's extents while this one is processed, the next step's bits
     // and the step after's out_col entries while this step's gathers are in flight, pagerank together
     // with the residual.
-    (void)out_row_ptr;
     constexpr int STRIDE = GT_STRIDE(NVX);
     // the next group's header (extents, slice length) is requested while this group is processed
     int hv0 = 0, hnv = 0, hE0 = 0, hEg = 0, hper = 0;
@@ -422,6 +482,9 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
     for (int g = blockIdx.x; g < n_groups; g += gridDim.x) { // workgroup-uniform loop (MULTI: one group per workgroup)
         __syncthreads(); // the previous group's tables are no longer read; the initial fills are in place
         const int *T = gtab + (size_t)g * STRIDE;
+        const int tid_g = opaque(tid);
+        const int j = tid_g & (OCT - 1), oid = tid_g / OCT;
+        const bool live = oct_live<SPL, GW>(j);
         const int v0 = hv0, nv = hnv, E0 = hE0, Eg = hEg, per = hper; // nv <= NVX: the builder cuts these groups for this kernel
         if (g + (int)gridDim.x < n_groups) {
             const int *H = gtab + (size_t)(g + gridDim.x) * STRIDE;
@@ -510,9 +573,24 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
                                 const int ck = __shfl(mycol, (lane & ~(OCT - 1)) + h + k, WAVE);
 #pragma unroll
                                 for (int q = 0; q < SPL; ++q) xv[k][q] = 0.0;
-                                if ((mh >> k) & 1u) {
+#if DPPR_WHATIF & 4
+                                if (((mh >> k) & 1u) && live) { xv[k][0] = 1e-7 * (ck & 7); } // (timing experiment: no gather)
+                                else
+#endif
+#if DPPR_WHATIF & 16
+                                if (((mh >> k) & 1u) && live) { // (timing experiment: every gather goes to one of 4096 rows: always an L2 hit)
 #pragma unroll
-                                    for (int q = 0; q < SPL; ++q) xv[k][q] = gs_ld<MULTI>(x + (size_t)ck * GW + j * SPL + q);
+                                    for (int q = 0; q < SPL; ++q) xv[k][q] = gs_ld<MULTI>(x + (size_t)(ck & 4095) * XS + j * SPL + q);
+                                } else
+#endif
+                                if (((mh >> k) & 1u) && live) {
+                                    if (MULTI || !(DPPR_GS_NT & 1) || ck < hot_rows) {
+#pragma unroll
+                                        for (int q = 0; q < SPL; ++q) xv[k][q] = gs_ld<MULTI>(x + (size_t)ck * XS + j * SPL + q);
+                                    } else {
+#pragma unroll
+                                        for (int q = 0; q < SPL; ++q) xv[k][q] = gs_ld_once<MULTI, 1>(x + (size_t)ck * XS + j * SPL + q);
+                                    }
                                 }
                             }
 #pragma unroll
@@ -552,6 +630,9 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
 
             // ---- vertex phase: repair, threshold, next snapshot for the vertices that were touched
             for (int i0 = 0; i0 < NVX / NOCT; i0 += FU) {
+                const int tid_v = opaque(tid);
+                const int j = tid_v & (OCT - 1), oid = tid_v / OCT;
+                const bool live = oct_live<SPL, GW>(j);
                 int vl[FU];
                 bool tch[FU], wasact[FU];
                 double cur[FU][SPL], pv[FU][SPL]; // cur: the residual row -- from x if the vertex was active, else from r
@@ -566,13 +647,21 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
                         cur[i][q] = 0.0;
                         pv[i][q] = 0.0;
                     }
-                    if (tch[i]) {
+                    if (tch[i] && live) {
                         const size_t base = (size_t)(v0 + vl[i]) * GW + j * SPL;
-                        const double *row = wasact[i] ? x : r;
+                        const double *row = wasact[i] ? x + (size_t)(v0 + vl[i]) * XS + j * SPL : r + base;
 #pragma unroll
                         for (int q = 0; q < SPL; ++q) {
-                            cur[i][q] = gs_ld<MULTI>(row + base + q);
-                            pv[i][q] = gs_ld<MULTI>(p + base + q); // needed only if the vertex ends up legal: asked for now, not after the test
+#if DPPR_WHATIF & 2
+                            if (!wasact[i])
+#endif
+                            cur[i][q] = gs_ld_once<MULTI, 2>(row + q);
+#if DPPR_WHATIF & 2
+                            else cur[i][q] = 1.0; // (timing experiment only: "every source of an active row was pushed")
+#endif
+#if !(DPPR_WHATIF & 1)
+                            pv[i][q] = gs_ld_once<MULTI, 2>(p + base + q);
+#endif // needed only if the vertex ends up legal: asked for now, not after the test
                         }
                     }
                 }
@@ -584,9 +673,12 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
                         bool lg[SPL], any = false, changed = false;
 #pragma unroll
                         for (int q = 0; q < SPL; ++q) {
-                            double *ap = &s_acc[vl[i] * GW + j * SPL + q];
-                            const double a = *ap;
-                            *ap = 0.0;
+                            double a = 0.0;
+                            if (live) {
+                                double *ap = &s_acc[vl[i] * GW + j * SPL + q];
+                                a = *ap;
+                                *ap = 0.0;
+                            }
                             // RepairFrontierRev: a source that was pushed keeps only what arrived during the sweep
                             const bool pushed = wasact[i] && legal(cur[i][q], phase, eps);
                             rn[q] = pushed ? a : cur[i][q] + a;
@@ -596,15 +688,19 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
                             nleg[q] += lg[q] ? 1 : 0;
                         }
                         if (oct_mask(__ballot(any))) { // stays / becomes active: the row lives in the next snapshot
+                            if (live && !(DPPR_WHATIF & 8)) { // (8: timing experiment, no row stores)
 #pragma unroll
-                            for (int q = 0; q < SPL; ++q) {
-                                gs_st<MULTI>(x_new + base + q, rn[q]);
-                                if (lg[q]) p[base + q] = pv[i][q] + ALPHA * rn[q];
+                                for (int q = 0; q < SPL; ++q) {
+                                    gs_st_once<MULTI, 4>(x_new + (size_t)(v0 + vl[i]) * XS + j * SPL + q, rn[q]);
+#if !(DPPR_WHATIF & 1)
+                                    if (lg[q]) gs_st_once<false, 4>(p + base + q, pv[i][q] + ALPHA * rn[q]);
+#endif
+                                }
                             }
                             if (j == 0) atomicOr(&s_actout[vl[i] >> 5], 1u << (vl[i] & 31));
-                        } else if (wasact[i] || changed) { // inactive now: the row goes (back) to residual[]
+                        } else if ((wasact[i] || changed) && live) { // inactive now: the row goes (back) to residual[]
 #pragma unroll
-                            for (int q = 0; q < SPL; ++q) r[base + q] = rn[q];
+                            for (int q = 0; q < SPL; ++q) gs_st_once<false, 4>(r + base + q, rn[q]);
                         }
                     }
                 }

@@ -1089,11 +1089,11 @@ def run_source_group(V, e1, e2, W, c, eps, directed, sources, batches, seeding, 
 
 
 @pytest.mark.parametrize("seeding", ["tails", "dense"])
-@pytest.mark.parametrize("nsrc", [1, 3, 8, 10, 16])
+@pytest.mark.parametrize("nsrc", [1, 2, 3, 5, 6, 8, 9, 10, 11, 12, 13, 16])
 @pytest.mark.parametrize("directed", [1, 0])
 def test_source_group_matches_oracle_per_source(directed, nsrc, seeding):
-    """f2: up to 16 sources solved together on interleaved state (8-wide for <= 8 sources, 16-wide
-    above). Every source's p/r must equal the oracle's synchronous schedule for that source (group
+    """f2: up to 16 sources solved together on interleaved state (rows of 2 * ceil(n / 2) doubles: every
+    row width from 2 to 16 is exercised, with and without a padding double). Every source's p/r must equal the oracle's synchronous schedule for that source (group
     iterations are sweeps), and the summed statistics must equal the sum of the per-source oracle
     runs -- with the frontier seeded from the batch tails and with full Inspect passes."""
     V, e1, e2 = datagen.rmat_stream(9, 6000, 11)
@@ -1107,7 +1107,7 @@ def test_source_group_matches_oracle_per_source(directed, nsrc, seeding):
 
 
 @pytest.mark.parametrize("shape", ["many-groups-hubs", "one-hub-row-spans-all-octets", "tiny-window"])
-@pytest.mark.parametrize("nsrc", [5, 10])
+@pytest.mark.parametrize("nsrc", [5, 9, 10, 12])
 def test_source_group_sweep_shapes(nsrc, shape):
     """k_gsweep splits a sweep group's edges evenly over its 128 octets: windows with several
     sweep groups and hub rows, a window in which one row holds most edges (every octet walks a
@@ -1131,7 +1131,7 @@ def test_source_group_sweep_shapes(nsrc, shape):
 
 
 @pytest.mark.parametrize("mode", ["one-launch-per-sweep", "multi-sweep", "multi-sweep-3-at-a-time", "rollcall-fails"])
-@pytest.mark.parametrize("nsrc", [4, 12])
+@pytest.mark.parametrize("nsrc", [4, 10, 11, 12])
 def test_source_group_launch_forms(nsrc, mode):
     """The frontier loop of a source group as one launch per sweep, as multi-sweep launches (grid barrier
     between sweeps; the default on windows whose groups are all resident), as multi-sweep launches that
@@ -1157,7 +1157,7 @@ def test_source_group_launch_forms(nsrc, mode):
 @pytest.mark.parametrize("mode", ["automatic", "never", "as-early-as-possible", "as-early-as-possible-chunk2", "tiny-lists", "below-50-pairs",
                                   "iterations-call-themselves-off"])
 @pytest.mark.parametrize("seeding", ["tails", "dense"])
-@pytest.mark.parametrize("nsrc,directed", [(3, 1), (10, 0), (16, 1)])
+@pytest.mark.parametrize("nsrc,directed", [(3, 1), (6, 0), (9, 1), (10, 0), (11, 1), (12, 0), (16, 1)])
 def test_source_group_tail_as_pushes(nsrc, directed, seeding, mode):
     """The tail of a group's loop in push form (dppr_gpush.hpp), one-sweep launches before it: entered at the automatic
     threshold, never, at every chunk boundary (iterations too large for the form call themselves off and the loop goes

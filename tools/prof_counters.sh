@@ -40,4 +40,5 @@ for i in range(lo, n):
     print(f"{i:4d} " + " ".join(f"{cols[x][i]:16.1f}" for x in names))
 print("mean " + " ".join(f"{sum(cols[x][lo:n]) / max(n - lo, 1):16.1f}" for x in names))
 PY
+rm -f $OUT/group_*.csv   # (per-dispatch rows of every kernel: tens of MB; the table is what is kept)
 tail -140 $OUT/table.txt

@@ -1,0 +1,23 @@
+#!/bin/bash
+# A/B of library builds on ONE box: tools/r04/ab.sh <tag> "<bench args>" lib1 lib2 ...   (lib = path relative to the repo, or "product")
+# Each library runs the same bench command twice, interleaved (A B A B), so that box-to-box and run-to-run spread are visible.
+TAG=$1; ARGS=$2; shift 2
+cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/ab_$TAG; mkdir -p $OUT
+for rep in 1 2; do
+  for L in "$@"; do
+    N=$(basename $L .so)
+    if [ "$L" = product ]; then unset DPPR_LIB; else export DPPR_LIB=$GRAFT_REPO_ROOT/$L; fi
+    python3 bench.py --no-cpu-baseline --no-extra --no-merged $ARGS > $OUT/${N}_$rep.json 2> $OUT/${N}_$rep.err || echo "FAILED $N"
+  done
+done
+python3 - $OUT <<'PY'
+import json, sys, glob, os
+for f in sorted(glob.glob(sys.argv[1] + "/*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        r = d.get("roofline") or {}
+        print(f"{os.path.basename(f):40s} ms/step {d['ms_per_step']:9.4f}  value {d['value']:14.1f}  launch_us {r.get('avg_launch_us')}  parity_ok {d.get('parity', {}).get('ok')}")
+    except Exception as ex:
+        print(f, "unreadable:", ex)
+PY
