@@ -1613,8 +1613,10 @@ int group_multi_capacity(dppr_engine *e, int spl) {
 // a finished loop leaves it) or cleared (the mode gave up -- an iteration too large for it -- and put the frontier back
 // in sweep form: g.act[0], g.x, frontier sizes in row 0 of g.cnt, the other rows zero), or with *entered false if it
 // did not start (nothing changed). Iterations run are added to *iters and to the group's statistics.
+// *owed: the handed-over snapshot's pagerank share is still to be credited (the last sweep was a deferring one,
+// dppr_multi.hpp); on a return in sweep form it says the same about the snapshot handed back.
 int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps, long long pairs_at_entry, int *iters, bool *entered,
-                    bool *converged) {
+                    bool *converged, bool *owed) {
     *entered = false;
     *converged = false;
     const int GWM = GS_MAX;
@@ -1645,6 +1647,7 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
     });
     HIP_TRY(hipGetLastError());
     *entered = true;
+    const int credit_first = *owed ? 1 : 0; // (iteration 0 of this mode settles it; every later one credits as it snapshots)
     // what an iteration may cost here: a sweep's floor is ~0.02 us per sweep group, a returning f64 atomic ~1 / 20 000 us
     const long long max_edges = e->gpush_max_edges > 0 ? e->gpush_max_edges : std::max<long long>(4096, 200ll * std::max(ep.n_ggroups, 1));
     const int grid = 256;
@@ -1658,7 +1661,7 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
             // a frontier of a few hundred vertices: a run of iterations as ONE single-workgroup launch
             with_row(g.gw, [&](auto spl, auto gw) {
                 hipLaunchKernelGGL((k_gpush_tiny<decltype(spl)::value, decltype(gw)::value>), dim3(1), dim3(1024), 0, e->stream, g.pctl, g.plist[0],
-                                   g.plist[1], ep.row_ptr, ep.adj, ep.hub_degp1, g.r, g.p, g.act[0], phase, eps, g.dstats, GPUSH_LOG);
+                                   g.plist[1], ep.row_ptr, ep.adj, ep.hub_degp1, g.r, g.p, g.act[0], phase, eps, g.dstats, GPUSH_LOG, credit_first);
             });
         } else {
         // iterations per chunk (<= GPUSH_LOG): down here the frontier about halves per iteration, so the first chunk is
@@ -1672,7 +1675,7 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
             with_row(g.gw, [&](auto spl, auto gw) {
                 constexpr int SPL = decltype(spl)::value, GW = decltype(gw)::value;
                 hipLaunchKernelGGL((k_gpush_snap<SPL, GW>), dim3(grid), dim3(BLOCK), 0, e->stream, g.plist[0], g.plist[1], g.pctl, g.x, g.r, g.p,
-                                   g.act[0], phase, eps);
+                                   g.act[0], phase, eps, credit_first);
                 hipLaunchKernelGGL((k_gpush_expand<SPL, GW>), dim3(grid), dim3(BLOCK), 0, e->stream, g.plist[0], g.plist[1], g.pctl, g.ppre,
                                    ep.row_ptr, ep.adj, ep.hub_degp1, g.x, g.r, g.act[0], g.plist[0], g.plist[1], cap, phase, eps, g.dstats);
             });
@@ -1707,6 +1710,7 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
                                    e->stream, e->n_int, g.act[0], g.x, g.r, g.p, h.it > 0 ? 1 : 0, phase, eps, g.cnt);
             });
             HIP_TRY(hipGetLastError());
+            if (h.it > 0) *owed = false; // (iteration 0 settled the hand-over, k_gpush_leave credited what it queued)
             return DPPR_OK;
         }
         if (h.n[h.it & 1] == 0) {
@@ -1751,6 +1755,9 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
     int active_iters = 0;
     const int sweep_grid = std::min(std::max(ep.n_ggroups, 1), e->gsweep_grid_cap);
     int follow = 4; // size of the next follow-up chunk of one-sweep launches
+    // pagerank is credited every other sweep (dppr_multi.hpp): the seeding credited its snapshot, so the first sweep defers;
+    // `owed` = the live snapshot's share has not been added yet, the next sweep is a crediting one
+    bool owed = false;
     // the tail of the loop as pushes (dppr_gpush.hpp): below push_thr frontier pairs, one-sweep launches only
     long long push_thr = e->gpush_enter_pairs == 0 ? 0 : e->gpush_enter_pairs > 0 ? e->gpush_enter_pairs : std::max(64, ep.n_ggroups * e->gpush_auto_factor);
     bool push_gave_up = false;
@@ -1772,7 +1779,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
     hipLaunchKernelGGL((k_gsweep<SPL, GW, NVX, true>), dim3(ep.n_ggroups), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.gtab,   \
                        ep.n_ggroups, g.cnt + cur * GWM, e->gsweep_hot_rows, ep.out_col, g.x, g.x2, g.act[0], g.act[1], g.r, g.p, \
                        g.cnt + 3 * GWM, g.cnt + 4 * GWM, phase, eps, g.dstats, rows, n, e->bar, status, e->persist_ticks,    \
-                       e->persist_rollcall_extra)
+                       e->persist_rollcall_extra, owed ? 1 : 0)
             with_row(g.gw, [&](auto spl, auto gw) {
                 constexpr int SPL = decltype(spl)::value, GW = decltype(gw)::value;
                 if constexpr (SPL == 2) DPPR_LAUNCH_GMULTI(2, GW, 512);
@@ -1810,6 +1817,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
             if (sweeps & 1) {
                 std::swap(g.x, g.x2);
                 std::swap(g.act[0], g.act[1]);
+                owed = !owed;
             }
             it += sweeps;
             if (st & GSM_CONVERGED) break;
@@ -1850,7 +1858,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
     hipLaunchKernelGGL((k_gsweep<SPL, GW, NVX, false>), dim3(sweep_grid), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.gtab,      \
                        ep.n_ggroups, g.cnt + cur * GWM, e->gsweep_hot_rows, ep.out_col, g.x, g.x2, g.act[0], g.act[1], g.r, g.p,  \
                        g.cnt + nxt * GWM, g.cnt + zer * GWM, phase, eps, g.dstats, log + k * GWM, 1, (GridBar *)nullptr,      \
-                       (int *)nullptr, 0ull, 0)
+                       (int *)nullptr, 0ull, 0, owed ? 1 : 0)
             with_row(g.gw, [&](auto spl, auto gw) {
                 constexpr int SPL = decltype(spl)::value, GW = decltype(gw)::value;
                 if constexpr (SPL == 2) DPPR_LAUNCH_GSWEEP(2, GW, 512);
@@ -1862,6 +1870,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
             std::swap(g.x, g.x2);
             std::swap(g.act[0], g.act[1]);
             cur = nxt;
+            owed = !owed; // (if the frontier emptied on the way, the later launches do nothing and nothing is owed: `more` is false below)
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(e->pinned, g.cnt, sizeof(int) * (size_t)(5 * GWM + n * GWM), hipMemcpyDeviceToHost,
@@ -1901,7 +1910,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
                 if (dense_len < 0) dense_len = it;
                 int pushed = 0;
                 bool entered = false, conv = false;
-                int rc = group_push_tail(e, g, ep, phase, eps, F, &pushed, &entered, &conv);
+                int rc = group_push_tail(e, g, ep, phase, eps, F, &pushed, &entered, &conv, &owed);
                 if (rc) return rc;
                 if (entered) {
                     active_iters = it + pushed;

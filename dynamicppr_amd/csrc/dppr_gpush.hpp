@@ -77,7 +77,7 @@ __global__ __launch_bounds__(BLOCK) void k_gpush_rows(const int *__restrict__ li
 template <int SPL, int GW>
 __global__ __launch_bounds__(BLOCK) void k_gpush_snap(const int *__restrict__ list0, const int *__restrict__ list1, GPushCtl *ctl,
                                                       double *__restrict__ x, double *__restrict__ r, double *__restrict__ p,
-                                                      uint32_t *__restrict__ bits, int phase, double eps) {
+                                                      uint32_t *__restrict__ bits, int phase, double eps, int credit_first) {
     __shared__ int s_cnt[GS_MAX];
     if (ctl->stop) return;
     const int it = ctl->it, which = it & 1;
@@ -100,8 +100,9 @@ __global__ __launch_bounds__(BLOCK) void k_gpush_snap(const int *__restrict__ li
             const bool lg = legal(rv, phase, eps);
             x[(size_t)u * x_stride(GW) + j * SPL + q] = lg ? rv : 0.0;
             if (lg) {
-                // (the frontier a sweep hands over was credited when the sweep took its snapshot in place)
-                if (it > 0) p[base + q] = p[base + q] + ALPHA * rv;
+                // (the frontier a sweep hands over was credited when the sweep took its snapshot in place -- unless that was a
+                // deferring sweep, dppr_multi.hpp "pagerank every other sweep": credit_first)
+                if (it > 0 || credit_first) p[base + q] = p[base + q] + ALPHA * rv;
                 r[base + q] = 0.0;
                 nleg[q]++;
             }
@@ -271,7 +272,7 @@ template <int SPL, int GW>
 __global__ __launch_bounds__(1024) void k_gpush_tiny(GPushCtl *ctl, int *__restrict__ list0, int *__restrict__ list1,
                                                      const int *__restrict__ in_row_ptr, const Adj *__restrict__ adj,
                                                      const int *__restrict__ hub_degp1, double *r, double *p, uint32_t *bits, int phase,
-                                                     double eps, IterStats *__restrict__ stats, int max_it) {
+                                                     double eps, IterStats *__restrict__ stats, int max_it, int credit_first) {
     constexpr int NT = 1024, NOCT = NT / OCT;
     __shared__ int s_list[2][TINY_N];
     __shared__ int s_pre[TINY_N + 1];
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(1024) void k_gpush_tiny(GPushCtl *ctl, int *__restr
                 const bool lg = legal(rv, phase, eps);
                 if (lg) {
                     rv = atomic_exch(r + base + q, 0.0); // (nobody adds between the load and this: same value)
-                    if (it > 0) (void)__hip_atomic_fetch_add(p + base + q, ALPHA * rv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (it > 0 || credit_first) (void)__hip_atomic_fetch_add(p + base + q, ALPHA * rv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     nleg[q]++;
                 }
                 s_x[i * GW + j * SPL + q] = lg ? rv : 0.0;

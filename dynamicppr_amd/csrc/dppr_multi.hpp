@@ -46,6 +46,15 @@
 //    residual read and write. For a legal source the new residual is exactly the sum of the sweep's
 //    adds (what PPRRevPushGPUFF's `residual[u] = 0` at the snapshot gives, gpu/Inspect.cuh:51-65);
 //    between loops every bit is clear and residual[] is complete.
+//  * PAGERANK EVERY OTHER SWEEP (round 4). pagerank[v] += ALPHA * x is owed for every snapshot value that is pushed
+//    (gpu/ExpandRev.cuh:42). Crediting it when the snapshot is taken costs a read and a write of the pagerank row per
+//    active vertex and sweep -- 22 % of a dense LiveJournal sweep once the kernel kept its loads in flight. A vertex
+//    phase has TWO consecutive snapshot values of a vertex in registers: the one being pushed in this sweep (cur) and
+//    the one it creates (rn). So sweeps alternate: a DEFERRING sweep does not touch pagerank at all, the next,
+//    CREDITING one adds ALPHA * cur (where cur was pushed) and then ALPHA * rn (where rn will be) -- the same two
+//    additions in the same order as before, bit for bit, with one read-modify-write instead of two. The host tracks
+//    whether the live snapshot is still owed (`credit`); a loop that ends has an empty frontier and owes nothing, a
+//    loop that goes on as pushes (dppr_gpush.hpp) hands the debt to the first push iteration.
 #pragma once
 
 #include "dppr_kernels.hpp"
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
                                                    uint32_t *act_a, uint32_t *act_b, double *r, double *p, int *cnt_out,
                                                    int *cnt_zero, int phase, double eps, IterStats *__restrict__ stats,
                                                    int *log_slot, int n_iter, GridBar *bar, int *status,
-                                                   unsigned long long limit_ticks, int rollcall_extra) {
+                                                   unsigned long long limit_ticks, int rollcall_extra, int credit0) {
     constexpr int NOCT = GNT / OCT, WORDS = NVX / 32, XS = x_stride(GW);
     static_assert(sizeof(double) * NVX * GW <= 64 * 1024, "two workgroups per CU");
     constexpr int EB = 8;        // edges an octet tests per step (one per lane)
@@ -371,8 +380,8 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
     __shared__ int s_cnt[GS_MAX];
     __shared__ unsigned long long s_edges;
     __shared__ int s_flag[2]; // MULTI: {go on (roll-call ok / frontier not empty), fault}
-    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
-    const int j = tid & (OCT - 1);
+    const int tid0 = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int j = tid0 & (OCT - 1);
     // Everything a thread derives from its index (LDS addresses of its bitmap words, row bases, masks) is invariant over the
     // group loop; hoisted out of it, those values were what the 64-register budget spilled (17 VGPRs in round 3), and
     // every reload from scratch is a vector-memory load behind an `s_waitcnt vmcnt(0)` -- i.e. behind every row load in
@@ -389,9 +398,9 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
     bool stamp_dense = false; // (diagnostic builds: a one-sweep launch is stamped when its frontier is dense)
     if constexpr (!MULTI) {
         const int my_cnt = lane < GW ? cnt_in[lane] : 0;
-        if (blockIdx.x == 0 && tid < GW) {
-            cnt_zero[tid] = 0;
-            log_slot[tid] = my_cnt;
+        if (blockIdx.x == 0 && tid0 < GW) {
+            cnt_zero[tid0] = 0;
+            log_slot[tid0] = my_cnt;
         }
         if (__ballot(my_cnt != 0) == 0) return;
 #ifdef DPPR_STAMPS
@@ -405,15 +414,15 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
     (void)stamp_dense;
 #ifdef DPPR_STAMPS
     if (stamp_dense) STAMP(7);
-    if (!MULTI && stamp_dense && tid == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + 5] = wall_clock64(); // (100 MHz, same on every CU)
+    if (!MULTI && stamp_dense && tid0 == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + 5] = wall_clock64(); // (100 MHz, same on every CU)
 #endif
-    for (int k = tid; k < NVX * GW; k += GNT) s_acc[k] = 0.0;
-    if (tid < WORDS) {
-        s_actout[tid] = 0u;
-        s_touched[tid] = 0u;
+    for (int k = tid0; k < NVX * GW; k += GNT) s_acc[k] = 0.0;
+    if (tid0 < WORDS) {
+        s_actout[tid0] = 0u;
+        s_touched[tid0] = 0u;
     }
-    if (tid < GS_MAX) s_cnt[tid] = 0;
-    if (tid == 0) {
+    if (tid0 < GS_MAX) s_cnt[tid0] = 0;
+    if (tid0 == 0) {
         s_edges = 0ull;
         s_flag[0] = 1;
         s_flag[1] = 0;
@@ -431,7 +440,7 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
     if constexpr (MULTI) {
         const unsigned long long t_entry = wall_clock64();
         __syncthreads();
-        if (tid == 0)
+        if (tid0 == 0)
             __hip_atomic_fetch_add(&bar->roll[blockIdx.x % BAR_SUBS].w, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (w == 0) {
             if (blockIdx.x == 0) {
@@ -460,7 +469,7 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
         }
         __syncthreads();
         if (!s_flag[0]) {
-            if (blockIdx.x == 0 && tid == 0) *status = GSM_ABORTED;
+            if (blockIdx.x == 0 && tid0 == 0) *status = GSM_ABORTED;
             return;
         }
     }
@@ -482,8 +491,8 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
     for (int g = blockIdx.x; g < n_groups; g += gridDim.x) { // workgroup-uniform loop (MULTI: one group per workgroup)
         __syncthreads(); // the previous group's tables are no longer read; the initial fills are in place
         const int *T = gtab + (size_t)g * STRIDE;
-        const int tid_g = opaque(tid);
-        const int j = tid_g & (OCT - 1), oid = tid_g / OCT;
+        const int tid = opaque(tid0);
+        const int j = tid & (OCT - 1), oid = tid / OCT;
         const bool live = oct_live<SPL, GW>(j);
         const int v0 = hv0, nv = hnv, E0 = hE0, Eg = hEg, per = hper; // nv <= NVX: the builder cuts these groups for this kernel
         if (g + (int)gridDim.x < n_groups) {
@@ -515,6 +524,7 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
             double *x_new = (it & 1) ? x_a : x_b;
             const uint32_t *act_in = (it & 1) ? act_b : act_a;
             uint32_t *act_out = (it & 1) ? act_a : act_b;
+            const bool credit = ((credit0 ^ it) & 1) != 0; // this sweep settles pagerank for the value it pushes and the one it creates
             if constexpr (MULTI) {
                 // frontier sizes of iteration `it`: row `it` of the log (row 0 = what the seeding left in cnt_in)
                 const int *row = it == 0 ? cnt_in : log_slot + (size_t)it * GS_MAX;
@@ -630,7 +640,7 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
 
             // ---- vertex phase: repair, threshold, next snapshot for the vertices that were touched
             for (int i0 = 0; i0 < NVX / NOCT; i0 += FU) {
-                const int tid_v = opaque(tid);
+                const int tid_v = opaque(tid0);
                 const int j = tid_v & (OCT - 1), oid = tid_v / OCT;
                 const bool live = oct_live<SPL, GW>(j);
                 int vl[FU];
@@ -660,7 +670,7 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
                             else cur[i][q] = 1.0; // (timing experiment only: "every source of an active row was pushed")
 #endif
 #if !(DPPR_WHATIF & 1)
-                            pv[i][q] = gs_ld_once<MULTI, 2>(p + base + q);
+                            if (credit) pv[i][q] = gs_ld_once<MULTI, 2>(p + base + q); // (asked for with the residual, not after the tests)
 #endif // needed only if the vertex ends up legal: asked for now, not after the test
                         }
                     }
@@ -670,7 +680,7 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
                     if (tch[i]) {
                         const size_t base = (size_t)(v0 + vl[i]) * GW + j * SPL;
                         double rn[SPL];
-                        bool lg[SPL], any = false, changed = false;
+                        bool lg[SPL], pushed[SPL], any = false, changed = false;
 #pragma unroll
                         for (int q = 0; q < SPL; ++q) {
                             double a = 0.0;
@@ -680,22 +690,30 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
                                 *ap = 0.0;
                             }
                             // RepairFrontierRev: a source that was pushed keeps only what arrived during the sweep
-                            const bool pushed = wasact[i] && legal(cur[i][q], phase, eps);
-                            rn[q] = pushed ? a : cur[i][q] + a;
+                            pushed[q] = wasact[i] && legal(cur[i][q], phase, eps);
+                            rn[q] = pushed[q] ? a : cur[i][q] + a;
                             lg[q] = legal(rn[q], phase, eps);
                             any |= lg[q];
                             changed |= rn[q] != cur[i][q];
                             nleg[q] += lg[q] ? 1 : 0;
                         }
+#if !(DPPR_WHATIF & 1)
+                        if (credit && live) { // pagerank: what this sweep pushed, then what the next one will (header: every other sweep)
+#pragma unroll
+                            for (int q = 0; q < SPL; ++q) {
+                                if (pushed[q] || lg[q]) {
+                                    double pn = pv[i][q];
+                                    if (pushed[q]) pn = pn + ALPHA * cur[i][q];
+                                    if (lg[q]) pn = pn + ALPHA * rn[q];
+                                    gs_st_once<false, 4>(p + base + q, pn);
+                                }
+                            }
+                        }
+#endif
                         if (oct_mask(__ballot(any))) { // stays / becomes active: the row lives in the next snapshot
                             if (live && !(DPPR_WHATIF & 8)) { // (8: timing experiment, no row stores)
 #pragma unroll
-                                for (int q = 0; q < SPL; ++q) {
-                                    gs_st_once<MULTI, 4>(x_new + (size_t)(v0 + vl[i]) * XS + j * SPL + q, rn[q]);
-#if !(DPPR_WHATIF & 1)
-                                    if (lg[q]) gs_st_once<false, 4>(p + base + q, pv[i][q] + ALPHA * rn[q]);
-#endif
-                                }
+                                for (int q = 0; q < SPL; ++q) gs_st_once<MULTI, 4>(x_new + (size_t)(v0 + vl[i]) * XS + j * SPL + q, rn[q]);
                             }
                             if (j == 0) atomicOr(&s_actout[vl[i] >> 5], 1u << (vl[i] & 31));
                         } else if ((wasact[i] || changed) && live) { // inactive now: the row goes (back) to residual[]
@@ -761,6 +779,7 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
         }
         if constexpr (MULTI) break; // one group per workgroup
     }
+    const int tid = tid0;
     if constexpr (MULTI) {
         if (blockIdx.x == 0 && tid < GS_MAX) { // the live frontier sizes for whoever continues, counters as a one-sweep launch leaves them
             const int f = (tid < GW && !converged && !fault)
