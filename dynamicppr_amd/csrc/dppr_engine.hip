@@ -36,6 +36,7 @@ static constexpr int MAX_CHUNK = 64;
 static constexpr int CNT_HDR = 16;
 static constexpr int PERSIST_RETRY_BATCHES = 64; // after a failed roll-call: batches on per-iteration launches before the next try
 static constexpr int GMULTI_MAX = 2 * MAX_CHUNK; // sweeps a multi-sweep launch of a source group may run
+static constexpr int GQ_PAD = 32;               // ints between the rotating group counters of k_gsweep (own 128-byte line each)
 static constexpr int BIN_MAX_BLOCKS = 1 << 16, BIN_MAX_BIG = 4096, BIN_SMALL_INTS = BIN_MAX_BLOCKS + BIN_MAX_BIG + 1 + 64; // bin_cut scratch
 static constexpr int SU_SPLIT_MIN = 1 << 16;  // batch records from which IncrementalBatchUpdate runs as k_su_terms + k_su_apply (stream_update)
 static constexpr int RESIDENT_MARGIN = 8; // sweeps a resident launch is given beyond what the last batch needed
@@ -135,6 +136,8 @@ struct Group {
     uint32_t *act[2] = {nullptr, nullptr}; // activity bitmaps that go with x / x2
     size_t act_bytes = 0;
     int *cnt = nullptr;        // [3][GS_MAX] rotating frontier sizes, then the per-chunk log [MAX][GS_MAX]
+    int *gq = nullptr;         // one-sweep launches: three rotating group counters (a launch takes tickets from one and zeroes the next), GQ_PAD ints apart
+    unsigned gq_seq = 0;       // one-sweep launches enqueued so far
     int *mlog = nullptr;       // multi-sweep launches: [GS_MAX] status word + padding, then one row of frontier sizes per sweep
     IterStats *dstats = nullptr;
     dppr_stats_t st{};
@@ -213,7 +216,9 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
                                     // measured slower on every stand-in, DESIGN.md section 6: off unless asked for)
     bool hot_blocks = true;         // vertex numbering in blocks of falling in-degree (DPPR_HOT_BLOCKS=0: two blocks, hot | rest)
     int gsweep_hot_rows = 24576;    // k_gsweep: rows below this id are gathered with the default cache policy, the others non-temporal (DPPR_GSWEEP_HOT)
-    int gsweep_grid_cap = 2048;     // workgroups of a one-sweep launch of k_gsweep (DPPR_GSWEEP_GRID: tuning runs)
+    int gsweep_grid_cap = 0;        // workgroups of a one-sweep launch of k_gsweep: 0 = two per CU, what is resident at once (the groups beyond
+                                    // the grid are dealt by a device counter; LiveJournal stand-in, 10 sources: 12.40 ms per batch at 512, 13.1-13.2 at
+                                    // 768 / 1024 / 2048; DPPR_GSWEEP_GRID: tuning runs)
     bool group_resident = true;     // source groups on windows whose sweep groups are all resident run a loop as multi-sweep launches
     int gmulti_cap[2] = {-1, -1};   // co-resident workgroups of k_gsweep<.., true> per state width (-1: not queried yet)
     bool any_groups = false;        // a source group exists: epochs carry the second group table
@@ -1753,6 +1758,11 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
     HIP_TRY(loop_sync(e->stream));
     bool more = any_left(e->pinned);
     int active_iters = 0;
+    if (e->gsweep_grid_cap <= 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus <= 0) cus = 256;
+        e->gsweep_grid_cap = std::min(2 * cus, STAT_SLOTS);
+    }
     const int sweep_grid = std::min(std::max(ep.n_ggroups, 1), e->gsweep_grid_cap);
     int follow = 4; // size of the next follow-up chunk of one-sweep launches
     // pagerank is credited every other sweep (dppr_multi.hpp): the seeding credited its snapshot, so the first sweep defers;
@@ -1779,7 +1789,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
     hipLaunchKernelGGL((k_gsweep<SPL, GW, NVX, true>), dim3(ep.n_ggroups), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.gtab,   \
                        ep.n_ggroups, g.cnt + cur * GWM, e->gsweep_hot_rows, ep.out_col, g.x, g.x2, g.act[0], g.act[1], g.r, g.p, \
                        g.cnt + 3 * GWM, g.cnt + 4 * GWM, phase, eps, g.dstats, rows, n, e->bar, status, e->persist_ticks,    \
-                       e->persist_rollcall_extra, owed ? 1 : 0)
+                       e->persist_rollcall_extra, owed ? 1 : 0, (int *)nullptr, (int *)nullptr)
             with_row(g.gw, [&](auto spl, auto gw) {
                 constexpr int SPL = decltype(spl)::value, GW = decltype(gw)::value;
                 if constexpr (SPL == 2) DPPR_LAUNCH_GMULTI(2, GW, 512);
@@ -1858,7 +1868,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
     hipLaunchKernelGGL((k_gsweep<SPL, GW, NVX, false>), dim3(sweep_grid), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.gtab,      \
                        ep.n_ggroups, g.cnt + cur * GWM, e->gsweep_hot_rows, ep.out_col, g.x, g.x2, g.act[0], g.act[1], g.r, g.p,  \
                        g.cnt + nxt * GWM, g.cnt + zer * GWM, phase, eps, g.dstats, log + k * GWM, 1, (GridBar *)nullptr,      \
-                       (int *)nullptr, 0ull, 0, owed ? 1 : 0)
+                       (int *)nullptr, 0ull, 0, owed ? 1 : 0, g.gq + (g.gq_seq % 3) * GQ_PAD, g.gq + ((g.gq_seq + 1) % 3) * GQ_PAD)
             with_row(g.gw, [&](auto spl, auto gw) {
                 constexpr int SPL = decltype(spl)::value, GW = decltype(gw)::value;
                 if constexpr (SPL == 2) DPPR_LAUNCH_GSWEEP(2, GW, 512);
@@ -1870,6 +1880,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
             std::swap(g.x, g.x2);
             std::swap(g.act[0], g.act[1]);
             cur = nxt;
+            g.gq_seq++;
             owed = !owed; // (if the frontier emptied on the way, the later launches do nothing and nothing is owed: `more` is false below)
         }
         HIP_TRY(hipGetLastError());
@@ -2105,7 +2116,7 @@ void dppr_destroy(dppr_engine *e) {
     for (auto &g : e->groups) {
         (void)hipFree(g.p); (void)hipFree(g.r); (void)hipFree(g.x); (void)hipFree(g.x2);
         (void)hipFree(g.act[0]); (void)hipFree(g.act[1]);
-        (void)hipFree(g.cnt); (void)hipFree(g.mlog); (void)hipFree(g.dstats);
+        (void)hipFree(g.cnt); (void)hipFree(g.mlog); (void)hipFree(g.dstats); (void)hipFree(g.gq);
     }
     for (auto &ep : e->epochs) {
         (void)hipFree(ep.row_ptr); (void)hipFree(ep.adj); (void)hipFree(ep.out_row_ptr); (void)hipFree(ep.out_col); (void)hipFree(ep.b1); (void)hipFree(ep.b2);
@@ -2907,7 +2918,7 @@ int dppr_add_source_group(dppr_engine *e, const int32_t *sources, int32_t n, int
     g.act_bytes = (V / 32 + 1024 / 32 + 4) * sizeof(uint32_t);
     auto release = [&]() { // (an allocation failed: nothing of this group stays behind)
         (void)hipFree(g.p); (void)hipFree(g.r); (void)hipFree(g.x); (void)hipFree(g.x2); (void)hipFree(g.act[0]); (void)hipFree(g.act[1]);
-        (void)hipFree(g.cnt); (void)hipFree(g.mlog); (void)hipFree(g.dstats);
+        (void)hipFree(g.cnt); (void)hipFree(g.mlog); (void)hipFree(g.dstats); (void)hipFree(g.gq);
     };
 #define GRP_TRY(call)                                                                                   \
     do {                                                                                                \
@@ -2928,6 +2939,8 @@ int dppr_add_source_group(dppr_engine *e, const int32_t *sources, int32_t n, int
     GRP_TRY(hipMalloc((void **)&g.cnt, sizeof(int) * (5 * GS_MAX + MAX_CHUNK * GS_MAX))); // rows 3, 4: scratch of multi-sweep launches
     GRP_TRY(hipMalloc((void **)&g.mlog, sizeof(int) * (size_t)(GMULTI_MAX + 2) * GS_MAX));
     GRP_TRY(hipMalloc((void **)&g.dstats, sizeof(IterStats)));
+    GRP_TRY(hipMalloc((void **)&g.gq, sizeof(int) * 3 * GQ_PAD));
+    GRP_TRY(hipMemsetAsync(g.gq, 0, sizeof(int) * 3 * GQ_PAD, e->stream));
     GRP_TRY(hipMemsetAsync(g.act[0], 0, g.act_bytes, e->stream));
     GRP_TRY(hipMemsetAsync(g.act[1], 0, g.act_bytes, e->stream));
     GRP_TRY(hipMemsetAsync(g.cnt, 0, sizeof(int) * (5 * GS_MAX + MAX_CHUNK * GS_MAX), e->stream));

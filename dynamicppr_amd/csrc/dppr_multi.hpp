@@ -360,7 +360,8 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
                                                    uint32_t *act_a, uint32_t *act_b, double *r, double *p, int *cnt_out,
                                                    int *cnt_zero, int phase, double eps, IterStats *__restrict__ stats,
                                                    int *log_slot, int n_iter, GridBar *bar, int *status,
-                                                   unsigned long long limit_ticks, int rollcall_extra, int credit0) {
+                                                   unsigned long long limit_ticks, int rollcall_extra, int credit0,
+                                                   int *q_take, int *q_zero) {
     constexpr int NOCT = GNT / OCT, WORDS = NVX / 32, XS = x_stride(GW);
     static_assert(sizeof(double) * NVX * GW <= 64 * 1024, "two workgroups per CU");
     constexpr int EB = 8;        // edges an octet tests per step (one per lane)
@@ -370,7 +371,10 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
     // requests ALL its rows before any is stored; the one-sweep form has 64 VGPRs and takes steps of 4 / 2.
     // (the one-sweep 16-wide form with 128 VGPRs and all rows at once, one workgroup per CU: 19.05 vs 18.65 ms per
     // LiveJournal batch -- the halved occupancy costs more than the vertex phase gains)
-    constexpr int FU = MULTI ? NVX / NOCT : 4 / SPL;
+#ifndef DPPR_GS_FU
+#define DPPR_GS_FU (4 / SPL)
+#endif
+    constexpr int FU = MULTI ? NVX / NOCT : (DPPR_GS_FU) <= NVX / NOCT ? (DPPR_GS_FU) : NVX / NOCT;
     static_assert(NVX % NOCT == 0 && (NVX / NOCT) % FU == 0, "vertex phase covers the group in whole steps");
     __shared__ double s_acc[NVX * GW];   // per vertex and source: sum of this sweep's adds (zero between groups)
     __shared__ int s_cstart[NVX + 1];    // non-empty rows of the group, compacted: first edge (relative)
@@ -380,6 +384,7 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
     __shared__ int s_cnt[GS_MAX];
     __shared__ unsigned long long s_edges;
     __shared__ int s_flag[2]; // MULTI: {go on (roll-call ok / frontier not empty), fault}
+    __shared__ int s_ticket;  // one-sweep launches: the group this workgroup takes next (groups beyond the grid are dealt by a counter)
     const int tid0 = threadIdx.x, lane = lane_id(), w = wave_id();
     const int j = tid0 & (OCT - 1);
     // Everything a thread derives from its index (LDS addresses of its bitmap words, row bases, masks) is invariant over the
@@ -402,6 +407,7 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
             cnt_zero[tid0] = 0;
             log_slot[tid0] = my_cnt;
         }
+        if (blockIdx.x == 0 && tid0 == 0) *q_zero = 0; // the NEXT launch's group counter (before the early return: a no-op launch keeps the rotation intact)
         if (__ballot(my_cnt != 0) == 0) return;
 #ifdef DPPR_STAMPS
 #ifdef DPPR_STAMP_SPARSE
@@ -488,17 +494,18 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
     }
     int sweeps_done = 0;
     bool converged = false, fault = false;
-    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) { // workgroup-uniform loop (MULTI: one group per workgroup)
+    // One-sweep launches: a workgroup's first group is its block index, every further one a ticket from a device counter
+    // (the groups are cut for equal edge weight, not equal time: with a fixed stride the slots of the last round idle for
+    // a fifth of a sweep; the counter's round trip hides behind the edge phase).
+    for (int g = blockIdx.x; g < n_groups;) { // workgroup-uniform loop (MULTI: one group per workgroup)
         __syncthreads(); // the previous group's tables are no longer read; the initial fills are in place
+        int ticket = 0, g_next = n_groups;
+        if (!MULTI && tid0 == 0) ticket = (int)gridDim.x + atomicAdd(q_take, 1);
         const int *T = gtab + (size_t)g * STRIDE;
         const int tid = opaque(tid0);
         const int j = tid & (OCT - 1), oid = tid / OCT;
         const bool live = oct_live<SPL, GW>(j);
         const int v0 = hv0, nv = hnv, E0 = hE0, Eg = hEg, per = hper; // nv <= NVX: the builder cuts these groups for this kernel
-        if (g + (int)gridDim.x < n_groups) {
-            const int *H = gtab + (size_t)(g + gridDim.x) * STRIDE;
-            hv0 = H[0]; hnv = H[1]; hE0 = H[2]; hEg = H[3]; hper = H[4];
-        }
         // the group's row tables (built once per epoch, k_gtables) -> LDS; the first sweep's activity words and
         // out_col entries are requested in the same round trip
         const int e_begin = oid * per, e_end = min(Eg, e_begin + per);
@@ -634,9 +641,17 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
                 }
                 flush();
             }
+            if (!MULTI && tid0 == 0) s_ticket = ticket;
             GSTAMP(1);
             __syncthreads();
             GSTAMP(2);
+            if constexpr (!MULTI) { // the next group's header (extents, slice length) is requested while this one's vertices are finished
+                g_next = __builtin_amdgcn_readfirstlane(s_ticket);
+                if (g_next < n_groups) {
+                    const int *H = gtab + (size_t)g_next * STRIDE;
+                    hv0 = H[0]; hnv = H[1]; hE0 = H[2]; hEg = H[3]; hper = H[4];
+                }
+            }
 
             // ---- vertex phase: repair, threshold, next snapshot for the vertices that were touched
             for (int i0 = 0; i0 < NVX / NOCT; i0 += FU) {
@@ -778,6 +793,7 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
             }
         }
         if constexpr (MULTI) break; // one group per workgroup
+        g = g_next;
     }
     const int tid = tid0;
     if constexpr (MULTI) {
