@@ -163,6 +163,21 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_scatter(int NV, const int *__res
 #endif
 }
 
+// In-edges of the vertices of a frontier list (what pushing it costs in returning atomics): one thread per vertex.
+__global__ __launch_bounds__(BLOCK) void k_degsum(const int *__restrict__ list, const int *__restrict__ cnt, const int *__restrict__ in_row_ptr,
+                                                  unsigned long long *__restrict__ out) {
+    const int n = *cnt;
+    unsigned long long d = 0;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const int v = list[i];
+        d += (unsigned long long)(in_row_ptr[v + 1] - in_row_ptr[v]);
+    }
+    // wave total (two 32-bit halves through the integer DPP ladder would overflow on hubs: go through LDS-free shuffles)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off, WAVE);
+    if (lane_id() == 0 && d) atomicAdd(out, d);
+}
+
 // wave64 segmented inclusive sum on the DPP path: `head` marks the first lane of a run; every lane receives the sum
 // of its run up to itself. Same ladder as wave_inclusive_scan; a lane that has seen a head inside its window stops
 // taking from below.
@@ -193,9 +208,11 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_reduce(int NV, int NV_bin, int n
                                                        const double *__restrict__ x, double *__restrict__ x_new,
                                                        double *__restrict__ r, double *__restrict__ p,
                                                        int *__restrict__ cnt_out, int *__restrict__ cnt_zero, int phase, double eps,
-                                                       IterStats *__restrict__ stats, int *__restrict__ log_slot) {
+                                                       IterStats *__restrict__ stats, int *__restrict__ log_slot,
+                                                       const int *__restrict__ in_row_ptr, unsigned long long *__restrict__ deg_out) {
     extern __shared__ double s_bin[];
     __shared__ int s_cnt[BIN_NT / WAVE];
+    __shared__ unsigned long long s_deg[BIN_NT / WAVE];
     __shared__ unsigned long long s_edges[BIN_NT / WAVE];
     double *s_acc = s_bin, *s_rcp = s_bin + rows_cap;
     int *s_den = reinterpret_cast<int *>(s_bin + 2 * rows_cap);
@@ -262,7 +279,9 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_reduce(int NV, int NV_bin, int n
     __syncthreads();
     BSTAMP(1, 2, wall_clock64());
     // repair, threshold, next snapshot (k_pull_iter's `finish`)
-    int n_legal = 0;
+    // ... and what the NEXT iteration would cost as a push: the in-edges of the vertices that enter the frontier (one
+    // returning atomic each, gpu/ExpandRev.cuh:70-73) -- the host weighs that against another sweep (dppr_engine.hip)
+    int n_legal = 0, deg = 0;
     for (int i = threadIdx.x; i < nrows; i += BIN_NT) {
         const int v = v0 + i;
         const double rv = r[v], xvv = x[v];
@@ -274,21 +293,28 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_reduce(int NV, int NV_bin, int n
         if (lg) {
             p[v] += ALPHA * rn;
             n_legal++;
+            deg += in_row_ptr ? in_row_ptr[v + 1] - in_row_ptr[v] : s_den[i] - 1; // (undirected: the in-edges are the out-edges)
         }
     }
     const int cw = wave_inclusive_scan(n_legal);
-    if (lane == WAVE - 1) s_cnt[w] = cw;
+    const int dw = wave_inclusive_scan(deg); // (a wave's 64 rows: below 2^31 as long as the epoch's edges are)
+    if (lane == WAVE - 1) {
+        s_cnt[w] = cw;
+        s_deg[w] = (unsigned long long)(unsigned)dw;
+    }
     if (lane == 0) s_edges[w] = edges;
     __syncthreads();
     if (threadIdx.x == 0) {
         int tot = 0;
-        unsigned long long te = 0;
+        unsigned long long te = 0, td = 0;
 #pragma unroll
         for (int k = 0; k < BIN_NT / WAVE; ++k) {
             tot += s_cnt[k];
             te += s_edges[k];
+            td += s_deg[k];
         }
         if (tot) atomicAdd(cnt_out, tot);
+        if (td) atomicAdd(deg_out, td);
         if (te) atomicAdd(&stats->blk_E[blockIdx.x & (STAT_SLOTS - 1)], te); // (more workgroups than slots: slots are shared)
     }
     BSTAMP(1, 3, wall_clock64());

@@ -107,6 +107,8 @@ struct Slot {
     BigItem *big = nullptr; // deferred big rows of the current iteration
     int *log = nullptr;     // per-chunk log: frontier size seen by each enqueued iteration
     long long iter_seq = 0; // running iteration number (selects the big-row counter)
+    double sweep_us = 0;       // binned windows: running mean of a sweep's time (the push / sweep decision)
+    double atomic_ns = 1.0 / 23.5; // ... and of a push iteration's time per in-edge (starts at the chip's rate of returning f64 atomics)
     int iter_hint[2] = {0, 0}; // iterations the last loop of each phase took (sizes the next chunks)
     int iter_hist[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; // ... and the last four
     bool start_dense[2] = {false, false}; // the last loop of each phase began with a frontier worth a sweep
@@ -224,6 +226,7 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     bool any_groups = false;        // a source group exists: epochs carry the second group table
     int ggroups_min = 256;          // ... of at least this many groups (DPPR_GGROUPS_MIN: tuning runs; 512 / 1008 measured slower on
                                     // the configs[1] stand-in, equal on the LiveJournal one)
+    bool cost_model = true;         // binned windows: push or sweep by estimated cost (DPPR_COST_MODEL=0: by the vertex-count threshold)
     bool group_full_rows = false;   // (A/B, DPPR_GROUP_FULL_ROWS=1: rows of 64 / 128 bytes whatever the source count, as until round 3)
     bool wide_groups = false;       // ... one of more than 8 sources: its groups hold at most 512 vertices
     bool group_tail_seeding = true; // source groups seed from the batch tails after a converged solve (false: dense Inspect)
@@ -307,11 +310,24 @@ inline int grid_for(int64_t n, int per_block = BLOCK, int cap = 2048) {
 // Wait for the engine's stream from inside a frontier loop (the read-back at the end of a chunk of iterations): polling the
 // stream's completion instead of a blocking hipStreamSynchronize, whose wake-up is part of every chunk boundary's gap
 // (DPPR_SYNC_SPIN=0: the blocking call, for A/B runs).
+// The poll is bounded: a chunk of sweeps is over within a few hundred microseconds; after LOOP_SPIN_US the
+// thread gives its core back and blocks -- N engines driven by N host threads (./pagerank -g N, two engines on one
+// device) must not hold N cores at 100 % for a wait that has turned long.
+constexpr long LOOP_SPIN_US = 200;
 inline hipError_t loop_sync(hipStream_t st) {
     static const bool spin = !(getenv("DPPR_SYNC_SPIN") && atoi(getenv("DPPR_SYNC_SPIN")) == 0);
     if (!spin) return hipStreamSynchronize(st);
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
     hipError_t r;
+    unsigned polls = 0;
     while ((r = hipStreamQuery(st)) == hipErrorNotReady) {
+        if ((++polls & 15u) == 0) {
+            timespec now;
+            clock_gettime(CLOCK_MONOTONIC, &now);
+            if ((now.tv_sec - t0.tv_sec) * 1000000L + (now.tv_nsec - t0.tv_nsec) / 1000L > LOOP_SPIN_US) return hipStreamSynchronize(st);
+        }
+        __builtin_ia32_pause();
     }
     return r;
 }
@@ -842,22 +858,55 @@ bool bin_wanted(const dppr_engine *e) {
     return e->bin_mode == 1 && !e->slots.empty() && (long long)e->n_int >= e->bin_min_ids;
 }
 
-int bin_prepare(dppr_engine *e) { // engine-level scratch, once
-    if (e->bin_ready) return DPPR_OK;
+// The largest block shapes dppr_set_binned_sweep admits -- ONE pair of constants for the validation, its message and the
+// kernels' dynamic-LDS attribute (the attribute said 272 tiles, the validation 288).
+constexpr int BIN_MAX_HA_TILES = 272, BIN_MAX_HB_TILES = 120;
+static_assert(BIN_MAX_HA_TILES * WAVE * (int)sizeof(double) + 4096 <= 160 * 1024, "k_bin_scatter: the largest A-block's slice of x + static LDS fits a gfx950 CU");
+static_assert(BIN_MAX_HB_TILES * WAVE * 20 + 4096 <= 160 * 1024, "k_bin_reduce: the largest B-block's rows + static LDS fit a gfx950 CU");
+
+// An allocation of the (optional) binned-sweep tables that fails is not an error of the call that wanted them: the
+// partial allocations are released, the sticky HIP error is cleared and the epoch sweeps with k_pull_iter.
+static bool bin_alloc(void **p, size_t bytes) {
+    if (*p) return true;
+    if (hipMalloc(p, bytes) == hipSuccess) return true;
+    *p = nullptr;
+    (void)hipGetLastError();
+    return false;
+}
+
+int bin_prepare(dppr_engine *e, bool *have) { // engine-level scratch, once (idempotent per pointer: a failed attempt may be repeated)
+    *have = false;
+    if (e->bin_ready) {
+        *have = true;
+        return DPPR_OK;
+    }
     const size_t Edn = (size_t)std::max(e->Ed, 1);
-    for (int k = 0; k < 2; ++k) HIP_TRY(hipMalloc((void **)&e->bin_k[k], sizeof(uint32_t) * Edn));
-    HIP_TRY(hipMalloc((void **)&e->bin_vblk_a, sizeof(int) * (size_t)e->V));
-    HIP_TRY(hipMalloc((void **)&e->bin_vblk_b, sizeof(int) * (size_t)e->V));
-    HIP_TRY(hipMalloc((void **)&e->bin_small, sizeof(int) * BIN_SMALL_INTS));
-    HIP_TRY(hipMalloc((void **)&e->bin_vals, sizeof(double) * (Edn + 64)));
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, e->bin_tmp_bytes, e->bin_k[0], e->bin_k[1], e->keys_a, e->keys_b, Edn, 0u, 32u, e->stream));
-    HIP_TRY(hipMalloc(&e->bin_tmp, std::max<size_t>(e->bin_tmp_bytes, 16)));
+    bool ok = true;
+    for (int k = 0; k < 2; ++k) ok = ok && bin_alloc((void **)&e->bin_k[k], sizeof(uint32_t) * Edn);
+    ok = ok && bin_alloc((void **)&e->bin_vblk_a, sizeof(int) * (size_t)e->V);
+    ok = ok && bin_alloc((void **)&e->bin_vblk_b, sizeof(int) * (size_t)e->V);
+    ok = ok && bin_alloc((void **)&e->bin_small, sizeof(int) * BIN_SMALL_INTS);
+    ok = ok && bin_alloc((void **)&e->bin_vals, sizeof(double) * (Edn + 64));
+    if (ok && !e->bin_tmp) {
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, e->bin_tmp_bytes, e->bin_k[0], e->bin_k[1], e->keys_a, e->keys_b, Edn, 0u, 32u, e->stream));
+        ok = bin_alloc(&e->bin_tmp, std::max<size_t>(e->bin_tmp_bytes, 16));
+    }
+    if (!ok) { // out of memory: nothing half-built stays behind, the sweeps of this engine gather (k_pull_iter)
+        for (int k = 0; k < 2; ++k) { (void)hipFree(e->bin_k[k]); e->bin_k[k] = nullptr; }
+        (void)hipFree(e->bin_vblk_a); (void)hipFree(e->bin_vblk_b); (void)hipFree(e->bin_small); (void)hipFree(e->bin_vals); (void)hipFree(e->bin_tmp);
+        e->bin_vblk_a = e->bin_vblk_b = e->bin_small = nullptr;
+        e->bin_vals = nullptr;
+        e->bin_tmp = nullptr;
+        return DPPR_OK;
+    }
     // (the attribute belongs to the kernel, not to this engine: the largest shapes dppr_set_binned_sweep admits, so that engines
     // with different block shapes can share a process)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                272 * WAVE * (int)sizeof(double)));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_reduce), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * WAVE * 20));
+                                BIN_MAX_HA_TILES * WAVE * (int)sizeof(double)));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_reduce), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                BIN_MAX_HB_TILES * WAVE * 20));
     e->bin_ready = true;
+    *have = true;
     return DPPR_OK;
 }
 
@@ -896,13 +945,20 @@ int bin_cut(dppr_engine *e, const int *row_ptr, int NV, int cap, long long targe
 int build_bins(dppr_engine *e, Epoch &ep) {
     ep.bin_valid = false;
     if (!bin_wanted(e) || e->Ed <= 0 || ep.grp_n_int <= 0) return DPPR_OK;
-    if (int rc = bin_prepare(e)) return rc;
+    bool have = false;
+    if (int rc = bin_prepare(e, &have)) return rc;
+    if (!have) return DPPR_OK;
     const int Ed = e->Ed, NV = ep.grp_n_int;
-    if (!ep.hl) {
+    if (!ep.hl || !ep.dl || !ep.apos) { // all three or none (a partial set from a failed attempt is released first)
         const size_t Edn = (size_t)Ed;
-        HIP_TRY(hipMalloc((void **)&ep.hl, sizeof(uint16_t) * Edn));
-        HIP_TRY(hipMalloc((void **)&ep.dl, sizeof(uint16_t) * Edn));
-        HIP_TRY(hipMalloc((void **)&ep.apos, sizeof(int) * Edn));
+        const bool ok = bin_alloc((void **)&ep.hl, sizeof(uint16_t) * Edn) && bin_alloc((void **)&ep.dl, sizeof(uint16_t) * Edn) &&
+                        bin_alloc((void **)&ep.apos, sizeof(int) * Edn);
+        if (!ok) {
+            (void)hipFree(ep.hl); (void)hipFree(ep.dl); (void)hipFree(ep.apos);
+            ep.hl = ep.dl = nullptr;
+            ep.apos = nullptr;
+            return DPPR_OK; // (bin_valid stays false: this epoch's sweeps gather)
+        }
     }
     std::vector<int32_t> cut_a, cut_b;
     if (int rc = bin_cut(e, ep.row_ptr, NV, e->bin_ha_tiles * WAVE, e->bin_target_a, cut_a)) return rc;
@@ -1127,6 +1183,8 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
         return DPPR_OK;
     };
     int F = entry.F, prevF = 0, active_iters = entry.it;
+    long long D = -1; // in-edges of the current frontier (binned windows), -1 = not counted
+    unsigned long long *dsum = reinterpret_cast<unsigned long long *>(s.cnt + 8); // three slots beside the rotating counters
     int follow = 4; // size of the next follow-up chunk of per-iteration sweeps
     int rc = DPPR_OK;
     if (F < 0 && (rc = read_count(e, s.cnt + cur, &F))) return rc;
@@ -1146,9 +1204,40 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             for (size_t i = old; i < s.trace_ids.size(); ++i) s.trace_ids[i] = e->int2ext[(size_t)s.trace_ids[i]];
             s.trace_off.push_back((int64_t)s.trace_ids.size());
         }
-        const bool pull = F >= pull_min;
+        bool pull = F >= pull_min;
+        // a window whose iterations cost hundreds of microseconds and more (twitter / friendster size): decisions per iteration
+        const bool costly = binned && !e->chunk_explicit && (s.sweep_us > 0 ? s.sweep_us : 6.5e-6 * (double)ep.Ed) >= 300.0;
+        if (costly && e->cost_model && !sync_sched && !s.trace && e->pull_min_frontier == 0) {
+            // Push or sweep by what each would cost. A push is one returning atomic per in-edge of the
+            // frontier, executed at the memory side at ~23.5 G/s chip-wide whatever the locality (profiles/r03_atomics_probe.json);
+            // a sweep of this window costs what the last ones did. The frontier's in-edges are counted by the sweep that left it
+            // (k_bin_reduce) or, for a list, by k_degsum. (Round 3 switched on the vertex count: a late frontier of 1.7 M
+            // low-degree vertices is pushed in 0.23 ms and was swept for 2.6, the 156 K batch tails -- hubs -- cost a sweep's time.)
+            if (D < 0 && F >= 1024) {
+                if (!list_valid && (rc = make_list())) return rc;
+                HIP_TRY(hipMemsetAsync(dsum + cur, 0, sizeof(unsigned long long), e->stream));
+                hipLaunchKernelGGL(k_degsum, dim3(grid_for(F)), dim3(BLOCK), 0, e->stream, s.ft[buf], s.cnt + cur, ep.row_ptr, dsum + cur);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(e->pinned, dsum + cur, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+                HIP_TRY(loop_sync(e->stream));
+                unsigned long long d;
+                memcpy(&d, e->pinned, sizeof(d));
+                D = (long long)d;
+            }
+            if (D >= 0 || F < 1024) {
+                const double sweep_us = s.sweep_us > 0 ? s.sweep_us : 6.5e-6 * (double)ep.Ed; // (no sweep timed yet: ~6.5 ps per edge)
+                const double push_us = 15.0 + (double)std::max<long long>(D, 0) * s.atomic_ns * 1e-3; // (measured on this slot's own pushes)
+                pull = F >= 1024 && push_us > 0.9 * sweep_us;
+            }
+        }
         int n;
         if (s.trace || e->chunk_iters <= 1) n = 1;
+        else if (costly)
+            // A window on binned sweeps: an iteration costs milliseconds (friendster stand-in: 2.6 ms a sweep, 11-13 ms the push
+            // of a 3-10 M-vertex frontier), a read-back tens of microseconds. Nothing is enqueued blind: round 3 ran the second
+            // iteration of every loop as a push of ten million vertices (decided at 156 K) and ended every loop with three to
+            // seven sweeps over frontiers of a few hundred vertices (enqueued from the last batches' lengths) -- 40 of 183 ms.
+            n = (!pull && F < 4096 && F <= prevF) ? e->chunk_iters : 1;
         else if (pull) // consecutive batches take almost the same number of iterations: aim just past the end
             n = s.iter_hint[hp] > it ? s.iter_hint[hp] - it + 1 : e->chunk_iters;
         else if ((long long)F * 4 >= pull_min) n = 1;          // about to turn dense: re-decide next iteration
@@ -1245,7 +1334,9 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                                    extracted ? 1 : 0);
                 dense_valid = true;
             }
-            if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k], e->stream));
+            if (binned) HIP_TRY(hipMemsetAsync(dsum + nxt, 0, sizeof(unsigned long long), e->stream));
+            const bool timed = e->profiling || (costly && n == 1); // (the push / sweep decision prices both by what the last ones took)
+            if (timed) HIP_TRY(hipEventRecord(e->evpool[2 * k], e->stream));
             if (pull && binned) {
                 // the sweep as two streaming passes over the epoch's binned edge layout (dppr_binned.hpp)
                 if (ep.n_chunks > 0)
@@ -1255,7 +1346,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 hipLaunchKernelGGL(k_bin_reduce, dim3(ep.n_b + (ep.grp_n_int - ep.bin_n_int + rows_cap - 1) / rows_cap), dim3(BIN_NT),
                                    (size_t)rows_cap * 20, e->stream, ep.grp_n_int, ep.bin_n_int, ep.n_b, s.cnt + cur, ep.bcut, rows_cap,
                                    ep.out_row_ptr, ep.dl, e->bin_vals, s.x,
-                                   s.x2, s.r, s.p, s.cnt + nxt, s.cnt + zer, phase, eps, s.dstats, log_slot);
+                                   s.x2, s.r, s.p, s.cnt + nxt, s.cnt + zer, phase, eps, s.dstats, log_slot, e->directed ? ep.row_ptr : (const int *)nullptr, dsum + nxt);
                 std::swap(s.x, s.x2);
                 dense_valid = true;
                 extracted = false;
@@ -1312,7 +1403,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 extracted = false;
                 list_valid = true;
             }
-            if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k + 1], e->stream));
+            if (timed) HIP_TRY(hipEventRecord(e->evpool[2 * k + 1], e->stream));
             buf ^= 1;
             cur = nxt;
         }
@@ -1333,10 +1424,27 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 HIP_TRY(hipEventElapsedTime(&ms, e->evpool[2 * k], e->evpool[2 * k + 1]));
                 s.st.push_ms += ms;
                 s.st.push_launches++;
+                static const bool trace = getenv("DPPR_LOOP_TRACE") != nullptr; // (diagnostic: one line per iteration of a profiled batch)
+                if (trace)
+                    fprintf(stderr, "[loop  ] phase %d iteration %3d  %-6s frontier %9d  %8.1f us\n", phase, it + k,
+                            pull ? (binned ? "binned" : "sweep") : "push", f, ms * 1e3);
             }
+        }
+        if (costly && n == 1 && e->pinned[CNT_HDR] > 0) { // what a sweep of this window costs / what an atomic of a push does (running means)
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, e->evpool[0], e->evpool[1]));
+            if (pull) s.sweep_us = s.sweep_us > 0 ? 0.75 * s.sweep_us + 0.25 * ms * 1e3 : ms * 1e3;
+            else if (D >= (1 << 20)) s.atomic_ns = 0.75 * s.atomic_ns + 0.25 * std::min(1.0, std::max(0.02, (ms * 1e6 - 15e3) / (double)D));
         }
         prevF = F;
         F = e->pinned[cur];
+        if (binned && pull) { // the sweep counted the in-edges of the frontier it left
+            unsigned long long d;
+            memcpy(&d, e->pinned + 8 + 2 * cur, sizeof(d));
+            D = (long long)d;
+        } else {
+            D = -1;
+        }
         it += n;
     }
     s.iter_hint[hp] = active_iters;
@@ -2023,6 +2131,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     if (const char *v = getenv("DPPR_GROUP_PUSH")) e->gpush_enter_pairs = std::max(-1, atoi(v));
     if (const char *v = getenv("DPPR_GROUP_PUSH_FACTOR")) e->gpush_auto_factor = std::max(1, atoi(v));
     if (const char *v = getenv("DPPR_GGROUPS_MIN")) e->ggroups_min = std::max(1, atoi(v));
+    if (const char *v = getenv("DPPR_COST_MODEL")) e->cost_model = atoi(v) != 0;
     if (const char *v = getenv("DPPR_GROUP_FULL_ROWS")) e->group_full_rows = atoi(v) != 0;
     e->device = device;
     e->V = V;
@@ -2213,9 +2322,9 @@ int dppr_set_sweep_bitmap(dppr_engine *e, int on) {
 
 int dppr_set_binned_sweep(dppr_engine *e, int mode, int ha_tiles, int hb_tiles, int64_t target_edges, int64_t min_ids, int64_t chunk_edges,
                           int64_t target_a_edges) {
-    if (!e || mode < 0 || mode > 2 || ha_tiles < 0 || ha_tiles > 288 || hb_tiles < 0 || hb_tiles > 120 || target_edges < 0 || min_ids < 0 ||
+    if (!e || mode < 0 || mode > 2 || ha_tiles < 0 || ha_tiles > BIN_MAX_HA_TILES || hb_tiles < 0 || hb_tiles > BIN_MAX_HB_TILES || target_edges < 0 || min_ids < 0 ||
         chunk_edges < 0 || target_a_edges < 0 || e->bin_ready || e->loaded)
-        return fail(e, DPPR_ERR_INVALID, "set_binned_sweep: call right after dppr_create; mode 0..2, ha_tiles <= 288, hb_tiles <= 120");
+        return fail(e, DPPR_ERR_INVALID, "set_binned_sweep: call right after dppr_create; mode 0..2, ha_tiles <= 272, hb_tiles <= 120");
     e->bin_mode = mode;
     if (ha_tiles > 0) e->bin_ha_tiles = ha_tiles;
     if (hb_tiles > 0) e->bin_hb_tiles = hb_tiles;
@@ -2344,6 +2453,7 @@ int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32
     Epoch &ep = e->epochs[0];
     ep.L = 0;
     ep.grouped = false;
+    ep.su_inline = false;
     int rc = query_persist_cap(e);
     if (rc) return rc;
     rc = sort_window_full(e);
@@ -2429,6 +2539,9 @@ int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, 
     const int id = e->newest + 1;
     Epoch &ep = e->epochs[id % e->n_epochs];
     ep.id = -1;
+    ep.L = 0;            // (before build_epoch: its group cut looks at the epoch's records, and the ring entry still holds
+    ep.grouped = false;  //  the previous occupant's -- possibly in an older numbering)
+    ep.su_inline = false;
     int rc;
     if (inc) { // f1: merge the batch into the previous sorted keys
         rc = merge_batch_keys(e, e->in_sorted, e->bk[0], e->bks[0], c * per, e->bk[1], e->bks[1], c * per);
