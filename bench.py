@@ -40,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_ACHIEVABLE_GBPS = 6300.0  # ... and what a streaming copy reaches there ("~6.3 TB/s achievable")
 NORTH_STAR_TOL = 1e-9   # BASELINE.json: "within the repo's 1e-9 tolerance"
 BIG_WINDOW = 4_000_000  # stream edges in the window from which two sources per GPU are solved one after the other (binned sweeps)
 
@@ -52,14 +53,15 @@ PLANS = {
     "twitter": (0, "top10"), "friendster": (0, "top1000"),
 }
 
-# committed rocprofv3 --pmc summaries (tools/prof_pmc.sh) of the dominant kernel per workload
+# committed rocprofv3 --pmc summaries (tools/r04/pmc_fabric.sh: requests by size) of the dominant kernel per workload
 PMC_FILES = {
-    ("youtube", 1): ("profiles/r03_pmc_traffic_youtube_1src.json", ("k_pull_resident",)),
-    ("livejournal", 10): ("profiles/r03_pmc_traffic_livejournal_group10.json", ("k_gsweep",)),
-    ("livejournal", 1): ("profiles/r03_pmc_traffic_lj1_binned.json", ("k_bin_scatter", "k_bin_reduce")),
-    ("twitter", 8): ("profiles/r03_pmc_traffic_twitter_group8.json", ("k_gsweep",)),
-    ("twitter", 1): ("profiles/r03_pmc_traffic_tw1_binned.json", ("k_bin_scatter", "k_bin_reduce")),
-    ("friendster", 1): ("profiles/r03_pmc_traffic_fr1_binned.json", ("k_bin_scatter", "k_bin_reduce")),
+    ("youtube", 1): ("profiles/r04_pmc_fabric_youtube_1src.json", ("k_pull_resident",)),
+    ("livejournal", 10): ("profiles/r04_pmc_fabric_livejournal_group10.json", ("k_gsweep",)),
+    ("livejournal", 1): ("profiles/r04_pmc_fabric_livejournal_1src.json", ("k_bin_scatter", "k_bin_reduce")),
+    ("twitter", 8): ("profiles/r04_pmc_fabric_twitter_group8.json", ("k_gsweep",)),
+    ("twitter", 1): ("profiles/r04_pmc_fabric_twitter_1src.json", ("k_bin_scatter", "k_bin_reduce")),
+    ("friendster", 1): ("profiles/r04_pmc_fabric_friendster_1src.json", ("k_bin_scatter", "k_bin_reduce")),
+    ("friendster", 10): ("profiles/r04_pmc_fabric_friendster_group10.json", ("k_gsweep",)),
 }
 
 
@@ -73,6 +75,8 @@ def parse_args():
                     help="sources per GPU (1 = single-source path, 2..16 = one source group); default per config")
     ap.add_argument("--pick", default=None, choices=["top10", "top1000"], help="source ranks: [0,10) or [10,1000)")
     ap.add_argument("--eps", type=float, default=1e-9)
+    ap.add_argument("--batch-edges", type=int, default=None, metavar="C",
+                    help="fixed batch size instead of the config's: the reference's batch-size sweep (-n 1 -c C, scripts/gpu.sh:13)")
     ap.add_argument("--schedule", default="eager", choices=["eager", "sync"])
     ap.add_argument("--data-dir", default=os.environ.get("DPPR_DATA", "/tmp/dppr_data"))
     ap.add_argument("--bin", default=None, help="real reference .bin file to use instead of the stand-in")
@@ -145,6 +149,8 @@ def main():
         stream_len = cfg.edges
         directed = cfg.directed if a.directed is None else a.directed
         name, flags = f"{cfg.name} stand-in (R-MAT scale {cfg.scale}, seed {cfg.seed})", cfg.flags
+    if a.batch_edges:
+        flags = f"-n 1 -c {a.batch_edges} -l {a.batch_edges * (n_steps + n_prof + 2)}"
     f = flags.split()
     opt = {f[i]: f[i + 1] for i in range(0, len(f), 2)}
     wl = st.workload_config(stream_len, 0.1, int(opt.get("-n", 0)), float(opt.get("-r", -1.0)), int(opt.get("-b", 0)),
@@ -212,7 +218,8 @@ def main():
     # streams (a twitter batch is minutes at -t 1) the comparison lives in tests/test_fullsize_golden_gpu.py and the leg is a short sample
     cpu_follow = stream_len < 100_000_000
     cpu_batches = a.cpu_batches if a.cpu_batches is not None else (n_steps if cpu_follow else 2)
-    want_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline
+    blocks = shard.line_blocks(rank, world, a.no_cpu_baseline, a.no_merged, a.schedule)
+    want_cpu = blocks["cpu_baseline"]   # (at N > 1 too: rank 0's line carries the same blocks at every N)
     for k in range(1, a.warmup + 1):
         solver.update(a.eps, k)
     solver.begin_timed()
@@ -229,6 +236,10 @@ def main():
     stats = solver.stats()
     units = shard.aggregate_units(S * c * a.steps, D)
     total_sources = shard.aggregate_units(S, D)
+
+    # what the default accounting keeps out of the bracket (the reference times it: gpu/PPRGPU.cuh:138-164): the out-degree
+    # gather and the grouping of the batch's records by tail, done at slide time (dppr_set_batch_grouping) -- measured on its own
+    grouping_ms = e.time_batch_grouping(epoch=n_steps, reps=5) * (1 if S > 1 and not pair_as_singles else S)
 
     # ---------------- parity at the end of the timed region: every source of this rank ----------------
     w1, w2 = w_end
@@ -247,9 +258,17 @@ def main():
     roof = cpu = p_cpu = None
     if rank == 0:
         ps = solver.profile(a, n_steps)
+        all_iters = {"launches": ps["push_launches"], "avg_launch_us": round(1e3 * ps["push_ms"] / max(ps["push_launches"], 1), 3),
+                     "algorithmic_bytes_per_launch": round((72 * ps["sum_F"] + 24 * ps["sum_E"] + 4 * ps["sum_N"]) / max(ps["push_launches"], 1), 1)}
+        if ps.get("sweep_launches", 0) > 0 and not ps["persist_launches"]:
+            # one launch per sweep (k_gsweep, k_bin_scatter + k_bin_reduce, k_pull_iter): the dominant kernel's OWN launches, bytes
+            # and time -- the push iterations of the same loops (cheap tails, other kernels) are reported beside it, not mixed in,
+            # so that frac can be recomputed from a rocprofv3 kernel-stats file of the same command (tools/check_profiles.py)
+            ps = dict(ps, sum_F=ps["sweep_F"], sum_E=ps["sweep_E"], sum_N=ps["sweep_F"], push_ms=ps["sweep_ms"], push_launches=ps["sweep_launches"],
+                      iterations=ps["sweep_launches"])
         push_bytes = 72 * ps["sum_F"] + 24 * ps["sum_E"] + 4 * ps["sum_N"]
         achieved = push_bytes / (ps["push_ms"] * 1e-3) / 1e9 if ps["push_ms"] > 0 else 0.0
-        traffic, traffic_src = pmc_traffic_per_launch(a.config if not a.bin else None, S)
+        traffic, traffic_src, traffic_detail = pmc_traffic_per_launch(a.config if not a.bin and not a.batch_edges else None, S)
         launch_s = 1e-3 * ps["push_ms"] / max(ps["push_launches"], 1)
         # SURVEY.md 8(d)'s 24 bytes per traversed edge were written for ONE source (4 out_col + 4 degree + 16 residual); a
         # group of S sources reads the column entry and the degree once for all of them: 16 + 8 / S per edge and source
@@ -261,15 +280,21 @@ def main():
             "frac_group_adjusted": round(adj_bytes / (ps["push_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if ps["push_ms"] > 0 else None,
             "frac_traffic": round(traffic / launch_s / 1e9 / HBM_PEAK_GBPS, 5) if traffic and launch_s > 0 else None,
             "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_kind": "L2 <-> fabric bytes per launch (read requests counted by size 32 / 64 / 128 B + write requests 64 / 32 B; "
+                            "Infinity-Cache hits are in them: fabric traffic, an upper bound of HBM traffic)",
+            "traffic_fetch_size_method": traffic_detail,
+            "hbm_achievable": HBM_ACHIEVABLE_GBPS,
+            "frac_traffic_of_achievable": round(traffic / launch_s / 1e9 / HBM_ACHIEVABLE_GBPS, 5) if traffic and launch_s > 0 else None,
             "iterations_per_launch": round(ps["iterations"] / max(ps["push_launches"], 1), 2),
             "launches": ps["push_launches"], "avg_launch_us": round(1e3 * ps["push_ms"] / max(ps["push_launches"], 1), 3),
             "algorithmic_bytes_per_launch": round(push_bytes / max(ps["push_launches"], 1), 1),
+            "all_iteration_launches": all_iters,
             "whole_batch_algorithmic_GBps": round(stats["algorithmic_bytes"] / (ev_ms * 1e-3) / 1e9, 2),
             "launches_from": ("a replay of the timed batches from the saved state" if S == 1 or pair_as_singles else
                               f"the {n_prof} batches that follow the timed region on the same stream"),
             "note": "achieved / frac = SURVEY.md 8(d) bytes (72 F + 24 E + 4 N, summed over the sources) of the hipEvent-"
                     "bracketed launches / their time: a WORK rate in the survey's unit. frac_group_adjusted prices a traversed "
-                    "edge at 16 + 8 / S bytes (a group reads the column entry once for its S sources); frac_traffic = the HBM bytes "
+                    "edge at 16 + 8 / S bytes (a group reads the column entry once for its S sources); frac_traffic = the fabric bytes "
                     "the counters saw per launch (traffic, from the committed rocprofv3 --pmc passes of this workload) / the "
                     "launch time measured here / peak: what the memory system actually moved (DESIGN.md section 6)",
         }
@@ -289,7 +314,7 @@ def main():
     # not the reference's schedule, therefore not `value`: one loop for residuals of both signs, run to eps / 4. A second solver
     # state over the same pre-staged epochs; its p is compared with the same CPU -t 1 states at the end of the timed region.
     merged = None
-    if rank == 0 and world == 1 and not a.no_merged and a.schedule == "eager":
+    if shard.line_blocks(rank, world, a.no_cpu_baseline, a.no_merged, a.schedule)["merged_loop"]:   # (a.no_merged may have been set by --tune above)
         e.set_phase_merge(True, 4)
         solver2 = (PairSolver(e, sources) if pair_as_singles else GroupSolver(e, sources)) if S > 1 else SingleSolver(e, sources[0])
         solver2.init_solve(a.eps, epoch=0)   # (the epochs of the run are all resident: start from the first)
@@ -332,6 +357,15 @@ def main():
                                       ", a GPU's sources streamed together as one source group over one graph replica" if S > 1 else ""),
                        "V": V, "stream_edges": int(stream_len), "window": W, "batch_c": c, "records_L": L,
                        "sources": sources, "schedule": a.schedule,
+                       "timed_region": {
+                           "what": "IncrementalBatchUpdate replay + ExecuteMainLoop(0) + ExecuteMainLoop(1) per batch (gpu/PPRGPU.cuh:138-164), "
+                                   "event-bracketed inside dppr_update / dppr_group_update; batch upload and graph rebuild outside, as in the reference",
+                           "grouping": "at_slide", "copy_out_degree": "at_slide",
+                           "grouping_ms_per_step": round(grouping_ms, 4),
+                           "ms_per_step_grouping_in_region": round(1e3 * dt / a.steps + grouping_ms, 4),
+                           "note": "`value` / `ms_per_step` use the default accounting (the records' grouping by tail and the out-degree gather run "
+                                   "when the batch is uploaded: functions of the batch alone); the reference times both, so the line also carries "
+                                   "the batch time with them put back (measured on the same epoch, 5 repetitions)"},
                        "parallelism": (f"{total_sources} sources dealt round-robin over {world} GPU(s) (rank 0: {S}), replicated graph, no collective"
                                        if scaling == "strong" else f"{S} source(s) per GPU x {world} GPU(s), replicated graph, no collective"),
                        "stream_file": provenance},
@@ -345,7 +379,9 @@ def main():
         if scaling == "strong":
             # what the multi-GPU value has to be read against: ALL of the configuration's sources as one source group on ONE GPU
             # (this very script at --gpus 1; the committed line of that run is quoted when this is an N > 1 run)
-            alt = os.path.join(ROOT, "profiles", f"r03_bench_{a.config}_group_1gpu.json")
+            alt = os.path.join(ROOT, "profiles", f"r04_bench_{a.config}_group_1gpu.json")
+            if not os.path.exists(alt):
+                alt = os.path.join(ROOT, "profiles", f"r03_bench_{a.config}_group_1gpu.json")
             line["single_gpu_group_alternative"] = (
                 {"this_run": True, "ms_per_step": line["ms_per_step"], "value": line["value"]} if world == 1 else
                 ({k: json.load(open(alt)).get(k) for k in ("ms_per_step", "value", "unit", "steps")} | {"source": os.path.relpath(alt, ROOT)})
@@ -423,8 +459,8 @@ class SingleSolver:
         if ps["persist_launches"]:
             return "k_pull_resident (one launch = a run of frontier iterations, state kept on chip)"
         if ps.get("binned_sweeps"):
-            return "k_bin_scatter + k_bin_reduce (one frontier iteration as two streaming passes; a launch = the pair) / k_push_iter"
-        return "k_pull_iter / k_push_iter (one frontier iteration)"
+            return "k_bin_scatter + k_bin_reduce (one frontier iteration as two streaming passes; a launch = the pair)"
+        return "k_pull_iter (one frontier iteration as a gather sweep)" if ps.get("sweep_launches") else "k_push_iter (one frontier iteration)"
 
 
 class PairSolver:
@@ -502,24 +538,28 @@ def invariant_max_err(p, r, src, dst, V, source, alpha=0.15):
 
 
 def pmc_traffic_per_launch(config, S):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this
-    same workload (tools/prof_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate passes, 2 x FETCH + WRITE
-    per the gfx950 correction of MI355X_MICROARCH.md). bench.py cannot run the profiler on itself, so
-    the figure is read back from profiles/ and labelled with its file; (None, None) when there is none
-    for this workload."""
+    """Fabric bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this
+    same workload (tools/r04/pmc_fabric.sh: read requests by size, write requests, FETCH_SIZE / WRITE_SIZE,
+    each in its own pass). bench.py cannot run the profiler on itself, so the figure is read back from
+    profiles/ and labelled with its file; (None, None, None) when there is none for this workload."""
     rel, heads = PMC_FILES.get((config, S), (None, ()))
     path = os.path.join(ROOT, rel) if rel else None
     if not path or not os.path.exists(path):
-        return None, None
+        return None, None, None
     d = json.load(open(path))
-    per_launch = 0.0   # (several heads = the stages of ONE iteration, e.g. k_bin_scatter + k_bin_reduce: their bytes add up)
+    per_launch = raw = corrected = 0.0   # (several heads = the stages of ONE iteration, e.g. k_bin_scatter + k_bin_reduce: their bytes add up)
     for head in heads:
-        launches = sum(v["launches"] for k, v in d.items() if k.startswith(head))
-        total = sum(v["launches"] * v["hbm_bytes_per_launch_corrected"] for k, v in d.items() if k.startswith(head))
+        rows = [v for k, v in d.items() if k.startswith(head)]
+        launches = sum(v["launches"] for v in rows)
         if not launches:
-            return None, None
-        per_launch += total / launches
-    return round(per_launch, 1), f"committed profile {rel}"
+            return None, None, None
+        per_launch += sum(v["launches"] * v["fabric_bytes_per_launch"] for v in rows) / launches
+        raw += sum(v["launches"] * ((v.get("fetch_size_raw_bytes_per_launch") or 0) + (v.get("write_size_bytes_per_launch") or 0)) for v in rows) / launches
+        corrected += sum(v["launches"] * (v.get("hbm_bytes_per_launch_corrected") or 0) for v in rows) / launches
+    detail = {"FETCH_SIZE_plus_WRITE_SIZE_raw": round(raw, 1), "two_x_FETCH_SIZE_plus_WRITE_SIZE": round(corrected, 1),
+              "note": "rounds 1-3 reported 2 x FETCH_SIZE + WRITE_SIZE; FETCH_SIZE tallies 128-byte requests at 64, so the factor is right only "
+                      "where every read request is a 128-byte one -- `traffic` counts the requests by size instead"}
+    return round(per_launch, 1), f"committed profile {rel}", detail
 
 
 def cpu_baseline(V, e1, e2, directed, W, c, sources, eps, batches, p_end, stream_len):

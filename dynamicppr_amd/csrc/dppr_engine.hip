@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <type_traits>
 #include <unordered_map>
@@ -113,7 +114,7 @@ struct Slot {
     int iter_hist[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; // ... and the last four
     bool start_dense[2] = {false, false}; // the last loop of each phase began with a frontier worth a sweep
     int last_F0[2] = {0, 0};   // ... and its size
-    IterStats *dstats = nullptr;
+    IterStats *dstats = nullptr; // two blocks: [0] push iterations (and resident launches), [1] dense sweeps -- the roofline of the sweep kernel counts its own edges
     bool converged = false; // |r| <= eps everywhere (state after a completed solve)
     double conv_eps = 0.0;
     double park_eps = 0.0;  // parked rows satisfy |r| <= park_eps (0: they are exactly zero)
@@ -141,7 +142,7 @@ struct Group {
     int *gq = nullptr;         // one-sweep launches: three rotating group counters (a launch takes tickets from one and zeroes the next), GQ_PAD ints apart
     unsigned gq_seq = 0;       // one-sweep launches enqueued so far
     int *mlog = nullptr;       // multi-sweep launches: [GS_MAX] status word + padding, then one row of frontier sizes per sweep
-    IterStats *dstats = nullptr;
+    IterStats *dstats = nullptr; // two blocks: [0] push iterations (and resident launches), [1] dense sweeps -- the roofline of the sweep kernel counts its own edges
     dppr_stats_t st{};
     int iter_hint[2] = {0, 0};
     int iter_hist[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; // sweeps the last four loops of each phase took
@@ -1346,7 +1347,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 hipLaunchKernelGGL(k_bin_reduce, dim3(ep.n_b + (ep.grp_n_int - ep.bin_n_int + rows_cap - 1) / rows_cap), dim3(BIN_NT),
                                    (size_t)rows_cap * 20, e->stream, ep.grp_n_int, ep.bin_n_int, ep.n_b, s.cnt + cur, ep.bcut, rows_cap,
                                    ep.out_row_ptr, ep.dl, e->bin_vals, s.x,
-                                   s.x2, s.r, s.p, s.cnt + nxt, s.cnt + zer, phase, eps, s.dstats, log_slot, e->directed ? ep.row_ptr : (const int *)nullptr, dsum + nxt);
+                                   s.x2, s.r, s.p, s.cnt + nxt, s.cnt + zer, phase, eps, s.dstats + 1, log_slot, e->directed ? ep.row_ptr : (const int *)nullptr, dsum + nxt);
                 std::swap(s.x, s.x2);
                 dense_valid = true;
                 extracted = false;
@@ -1358,7 +1359,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
 #define DPPR_LAUNCH_PULL(PB, BITS)                                                                                    \
     hipLaunchKernelGGL((k_pull_iter<PB, BITS>), dim3(std::min(std::max(ep.n_groups, 1), 1024)), dim3(PB), 0, e->stream, \
                        ep.grp_n_int, ep.grp_tile, ep.n_groups, s.cnt + cur, ep.out_row_ptr, ep.out_col, s.x, s.x2, s.r, \
-                       s.p, s.cnt + nxt, s.cnt + zer, phase, eps, s.dstats, log_slot,                                   \
+                       s.p, s.cnt + nxt, s.cnt + zer, phase, eps, s.dstats + 1, log_slot,                               \
                        std::min(e->big_row, PULL_BIG_ROW_DEFAULT), s.act[0], s.act[1])
                 if (use_bits) {
                     switch (pb) {
@@ -1417,6 +1418,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             s.st.iterations++;
             s.st.sum_F += f;
             if (pull) s.st.pull_iterations++;
+            if (pull) s.st.sweep_F += f;
             if (pull && binned) s.st.binned_sweeps++;
             active_iters = it + k + 1;
             if (e->profiling) {
@@ -1424,6 +1426,10 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 HIP_TRY(hipEventElapsedTime(&ms, e->evpool[2 * k], e->evpool[2 * k + 1]));
                 s.st.push_ms += ms;
                 s.st.push_launches++;
+                if (pull) {
+                    s.st.sweep_ms += ms;
+                    s.st.sweep_launches++;
+                }
                 static const bool trace = getenv("DPPR_LOOP_TRACE") != nullptr; // (diagnostic: one line per iteration of a profiled batch)
                 if (trace)
                     fprintf(stderr, "[loop  ] phase %d iteration %3d  %-6s frontier %9d  %8.1f us\n", phase, it + k,
@@ -1678,12 +1684,16 @@ int stream_update(dppr_engine *e, Slot &s, const Epoch &ep, double eps, bool see
 }
 
 int pull_device_stats(dppr_engine *e, Slot &s) {
-    static thread_local IterStats h;
-    HIP_TRY(hipMemcpyAsync(&h, s.dstats, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+    static thread_local IterStats h[2];
+    HIP_TRY(hipMemcpyAsync(h, s.dstats, sizeof(h), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    unsigned long long t = 0;
-    for (int i = 0; i < STAT_SLOTS; ++i) t += h.blk_E[i];
-    s.st.sum_E = (int64_t)t;
+    unsigned long long t = 0, ts = 0;
+    for (int i = 0; i < STAT_SLOTS; ++i) {
+        t += h[0].blk_E[i];
+        ts += h[1].blk_E[i];
+    }
+    s.st.sum_E = (int64_t)(t + ts);
+    s.st.sweep_E = (int64_t)ts;
     return DPPR_OK;
 }
 
@@ -1896,7 +1906,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
 #define DPPR_LAUNCH_GMULTI(SPL, GW, NVX)                                                                                 \
     hipLaunchKernelGGL((k_gsweep<SPL, GW, NVX, true>), dim3(ep.n_ggroups), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.gtab,   \
                        ep.n_ggroups, g.cnt + cur * GWM, e->gsweep_hot_rows, ep.out_col, g.x, g.x2, g.act[0], g.act[1], g.r, g.p, \
-                       g.cnt + 3 * GWM, g.cnt + 4 * GWM, phase, eps, g.dstats, rows, n, e->bar, status, e->persist_ticks,    \
+                       g.cnt + 3 * GWM, g.cnt + 4 * GWM, phase, eps, g.dstats + 1, rows, n, e->bar, status, e->persist_ticks,    \
                        e->persist_rollcall_extra, owed ? 1 : 0, (int *)nullptr, (int *)nullptr)
             with_row(g.gw, [&](auto spl, auto gw) {
                 constexpr int SPL = decltype(spl)::value, GW = decltype(gw)::value;
@@ -1924,6 +1934,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
                 g.st.iterations++;
                 g.st.pull_iterations++;
                 for (int s = 0; s < GWM; ++s) g.st.sum_F += f[s];
+                for (int s = 0; s < GWM; ++s) g.st.sweep_F += f[s];
                 active_iters = it + k + 1;
             }
             if (e->profiling) {
@@ -1975,7 +1986,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
 #define DPPR_LAUNCH_GSWEEP(SPL, GW, NVX)                                                                                  \
     hipLaunchKernelGGL((k_gsweep<SPL, GW, NVX, false>), dim3(sweep_grid), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.gtab,      \
                        ep.n_ggroups, g.cnt + cur * GWM, e->gsweep_hot_rows, ep.out_col, g.x, g.x2, g.act[0], g.act[1], g.r, g.p,  \
-                       g.cnt + nxt * GWM, g.cnt + zer * GWM, phase, eps, g.dstats, log + k * GWM, 1, (GridBar *)nullptr,      \
+                       g.cnt + nxt * GWM, g.cnt + zer * GWM, phase, eps, g.dstats + 1, log + k * GWM, 1, (GridBar *)nullptr,      \
                        (int *)nullptr, 0ull, 0, owed ? 1 : 0, g.gq + (g.gq_seq % 3) * GQ_PAD, g.gq + ((g.gq_seq + 1) % 3) * GQ_PAD)
             with_row(g.gw, [&](auto spl, auto gw) {
                 constexpr int SPL = decltype(spl)::value, GW = decltype(gw)::value;
@@ -2006,12 +2017,15 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
             g.st.iterations++;
             g.st.pull_iterations++;
             for (int s = 0; s < GWM; ++s) g.st.sum_F += f[s];
+            for (int s = 0; s < GWM; ++s) g.st.sweep_F += f[s];
             active_iters = it + k + 1;
             if (e->profiling) {
                 float ms = 0;
                 HIP_TRY(hipEventElapsedTime(&ms, e->evpool[2 * k], e->evpool[2 * k + 1]));
                 g.st.push_ms += ms;
                 g.st.push_launches++;
+                g.st.sweep_ms += ms;
+                g.st.sweep_launches++;
                 static const bool trace = getenv("DPPR_GROUP_TRACE") != nullptr; // (diagnostic: one line per sweep)
                 if (trace) {
                     long long F = 0;
@@ -2607,9 +2621,9 @@ int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
     // a row is deferred only if it has >= big_row edges, so at most Ed / big_row of them exist
     // (pieces of <= 1024 edges of rows of >= big_row edges: a row of d edges has ceil(d / 1024) <= d / min(big_row, 512) of them)
     HIP_TRY(hipMalloc((void **)&s.big, sizeof(BigItem) * ((size_t)e->Ed / (size_t)std::min(std::max(e->big_row, 1), 512) + 64)));
-    HIP_TRY(hipMalloc((void **)&s.dstats, sizeof(IterStats)));
+    HIP_TRY(hipMalloc((void **)&s.dstats, 2 * sizeof(IterStats)));
     HIP_TRY(hipMemsetAsync(s.cnt, 0, sizeof(int) * (CNT_HDR + 2 * MAX_CHUNK), e->stream));
-    HIP_TRY(hipMemsetAsync(s.dstats, 0, sizeof(IterStats), e->stream));
+    HIP_TRY(hipMemsetAsync(s.dstats, 0, 2 * sizeof(IterStats), e->stream));
     hipLaunchKernelGGL(k_init, dim3(grid_for(e->V)), dim3(BLOCK), 0, e->stream, s.p, s.r, e->V, source);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -2630,6 +2644,103 @@ int dppr_add_source(dppr_engine *e, int32_t source, int32_t *out_slot) {
     Epoch *epp = find_epoch((e), (epoch));                                        \
     if (!epp) return fail((e), DPPR_ERR_INVALID, "epoch not resident (evicted or never built)"); \
     Epoch &ep = *epp
+
+int dppr_time_batch_grouping(dppr_engine *e, int32_t epoch, int32_t reps, float *out_ms) {
+    if (!e || e->broken || reps < 1 || !out_ms) return fail(e, DPPR_ERR_INVALID, "time_batch_grouping: reps >= 1");
+    GET_EPOCH(e, epoch);
+    HIP_TRY(hipSetDevice(e->device));
+    *out_ms = 0.0f;
+    const int L = ep.L;
+    if (L <= 0) return DPPR_OK;
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    for (int k = 0; k < reps; ++k) {
+        // CopyOutDegree (gpu/StreamUpdate.cuh:7-17) into scratch, then (tail, index) keys and their stable sort, as epoch_group_records does
+        hipLaunchKernelGGL(k_gather_deg, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->outdeg, (int *)e->su_v[1]);
+        hipLaunchKernelGGL(k_su_keys, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->su_k[0], e->su_v[0],
+                           (unsigned long long *)nullptr, 0, (int *)nullptr, 0);
+        size_t tmp = e->su_tmp_bytes;
+        HIP_TRY(rocprim::radix_sort_pairs(e->su_tmp, tmp, e->su_k[0], e->su_k[1], e->su_v[0], e->su_v[1], (size_t)L, 0u, (unsigned)e->bits, e->stream));
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(hipEventSynchronize(e->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    *out_ms = ms / (float)reps;
+    return DPPR_OK;
+}
+
+int dppr_debug_dump(dppr_engine *e, char *buf, int32_t cap) {
+    if (!e || !buf || cap < 2) return 0;
+    std::string o;
+    char line[512];
+#define add(...)                                  \
+    do {                                          \
+        snprintf(line, sizeof(line), __VA_ARGS__); \
+        o += line;                                \
+    } while (0)
+    add("dppr engine %p device %d: V %d W %d c %d directed %d n_int %d newest epoch %d broken %d\n", (void *)e, e->device, e->V, e->W, e->c,
+        e->directed, e->n_int, e->newest, (int)e->broken);
+    add("last error: %s\n", e->err.empty() ? "(none)" : e->err.c_str());
+    add("resident launches: mode %d ok %d retry %d time limit %llu ticks (100 MHz) rollcall_extra %d; schedule %d merge %d\n", e->persist_mode,
+        (int)e->persist_ok, e->persist_retry, e->persist_ticks, e->persist_rollcall_extra, e->schedule, (int)e->merge_phases);
+    // device words through a stream of their own, waited for at most ~2 s
+    hipStream_t side = nullptr;
+    const bool have_side = hipSetDevice(e->device) == hipSuccess && hipStreamCreateWithFlags(&side, hipStreamNonBlocking) == hipSuccess;
+    auto fetch = [&](void *dst, const void *src, size_t bytes) -> bool {
+        if (!have_side || !src) return false;
+        if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, side) != hipSuccess) return false;
+        for (int k = 0; k < 2000; ++k) {
+            const hipError_t q = hipStreamQuery(side);
+            if (q == hipSuccess) return true;
+            if (q != hipErrorNotReady) return false;
+            timespec ts{0, 1000000};
+            nanosleep(&ts, nullptr);
+        }
+        return false;
+    };
+    add("engine stream: %s\n", hipStreamQuery(e->stream) == hipSuccess ? "idle" : "BUSY (work enqueued or running)");
+    {
+        static thread_local GridBar hb;
+        if (fetch(&hb, e->bar, sizeof(GridBar))) {
+            unsigned long long roll = 0, sub[2] = {0, 0};
+            for (int s = 0; s < BAR_SUBS; ++s) roll += hb.roll[s].w >> 32;
+            for (int par = 0; par < 2; ++par)
+                for (int s = 0; s < BAR_SUBS; ++s) sub[par] += hb.sub[par][0][s].w >> 32;
+            add("GridBar: gen %llu (0 pending, %llu ready, %llu abort) roll-call check-ins %llu, arrivals (replica 0) even sweeps %llu odd sweeps %llu\n",
+                hb.gen.w, (unsigned long long)BAR_READY, (unsigned long long)BAR_ABORT, roll, sub[0], sub[1]);
+        } else {
+            add("GridBar: not readable (copy did not complete within 2 s)\n");
+        }
+    }
+    for (size_t i = 0; i < e->slots.size(); ++i) {
+        const Slot &s = e->slots[i];
+        int h[CNT_HDR] = {0};
+        const bool ok = fetch(h, s.cnt, sizeof(h));
+        add("slot %zu: source %d (internal %d) converged %d last_epoch %d iterations %lld persist launches %lld aborts %lld binned sweeps %lld; "
+            "device counters %s[%d %d %d | cand %d | big %d %d | status 0x%x]\n", i, s.source_ext, s.source, (int)s.converged, s.last_epoch,
+            (long long)s.st.iterations, (long long)s.st.persist_launches, (long long)s.st.persist_aborts, (long long)s.st.binned_sweeps,
+            ok ? "" : "(unreadable) ", h[0], h[1], h[2], h[3], h[5], h[6], (unsigned)h[7]);
+    }
+    for (size_t i = 0; i < e->groups.size(); ++i) {
+        const Group &g = e->groups[i];
+        int h[3 * GS_MAX] = {0}, st = 0;
+        const bool ok = fetch(h, g.cnt, sizeof(h)) && fetch(&st, g.mlog, sizeof(int));
+        long long f[3] = {0, 0, 0};
+        for (int r = 0; r < 3; ++r)
+            for (int k = 0; k < GS_MAX; ++k) f[r] += h[r * GS_MAX + k];
+        add("group %zu: %d sources, rows of %d doubles, converged %d last_epoch %d iterations %lld multi-sweep launches %lld aborts %lld; device: %sfrontier "
+            "pairs in the three rotating rows %lld %lld %lld, multi-sweep status 0x%x\n", i, g.n, g.gw, (int)g.converged, g.last_epoch,
+            (long long)g.st.iterations, (long long)g.st.persist_launches, (long long)g.st.persist_aborts, ok ? "" : "(unreadable) ", f[0], f[1], f[2],
+            (unsigned)st);
+    }
+    if (have_side) (void)hipStreamDestroy(side);
+#undef add
+    const size_t n = std::min(o.size(), (size_t)cap - 1);
+    memcpy(buf, o.data(), n);
+    buf[n] = 0;
+    return (int)n;
+}
 
 int dppr_init_solve(dppr_engine *e, int32_t slot, double eps, float *out_ms) { return dppr_init_solve_at(e, slot, -1, eps, out_ms); }
 
@@ -2891,7 +3002,7 @@ int dppr_reset_stats(dppr_engine *e, int32_t slot) {
     GET_SLOT(e, slot);
     HIP_TRY(hipSetDevice(e->device));
     s.st = dppr_stats_t{};
-    HIP_TRY(hipMemsetAsync(s.dstats, 0, sizeof(IterStats), e->stream));
+    HIP_TRY(hipMemsetAsync(s.dstats, 0, 2 * sizeof(IterStats), e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return DPPR_OK;
 }
@@ -3051,13 +3162,13 @@ int dppr_add_source_group(dppr_engine *e, const int32_t *sources, int32_t n, int
     GRP_TRY(hipMalloc((void **)&g.act[1], g.act_bytes));
     GRP_TRY(hipMalloc((void **)&g.cnt, sizeof(int) * (5 * GS_MAX + MAX_CHUNK * GS_MAX))); // rows 3, 4: scratch of multi-sweep launches
     GRP_TRY(hipMalloc((void **)&g.mlog, sizeof(int) * (size_t)(GMULTI_MAX + 2) * GS_MAX));
-    GRP_TRY(hipMalloc((void **)&g.dstats, sizeof(IterStats)));
+    GRP_TRY(hipMalloc((void **)&g.dstats, 2 * sizeof(IterStats)));
     GRP_TRY(hipMalloc((void **)&g.gq, sizeof(int) * 3 * GQ_PAD));
     GRP_TRY(hipMemsetAsync(g.gq, 0, sizeof(int) * 3 * GQ_PAD, e->stream));
     GRP_TRY(hipMemsetAsync(g.act[0], 0, g.act_bytes, e->stream));
     GRP_TRY(hipMemsetAsync(g.act[1], 0, g.act_bytes, e->stream));
     GRP_TRY(hipMemsetAsync(g.cnt, 0, sizeof(int) * (5 * GS_MAX + MAX_CHUNK * GS_MAX), e->stream));
-    GRP_TRY(hipMemsetAsync(g.dstats, 0, sizeof(IterStats), e->stream));
+    GRP_TRY(hipMemsetAsync(g.dstats, 0, 2 * sizeof(IterStats), e->stream));
     // the memory is there: now the ids (a source outside the window receives one; a parked one is revived)
     for (int s = 0; s < n; ++s) (void)to_int(e, sources[s]);
     for (int s = 0; s < n; ++s) g.src.s[s] = e->ext2int[(size_t)sources[s]]; // (after ALL revivals: one may move another)
@@ -3164,7 +3275,7 @@ int dppr_group_reset_stats(dppr_engine *e, int32_t group) {
     GET_GROUP(e, group);
     HIP_TRY(hipSetDevice(e->device));
     g.st = dppr_stats_t{};
-    HIP_TRY(hipMemsetAsync(g.dstats, 0, sizeof(IterStats), e->stream));
+    HIP_TRY(hipMemsetAsync(g.dstats, 0, 2 * sizeof(IterStats), e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return DPPR_OK;
 }
@@ -3173,12 +3284,16 @@ int dppr_group_stats(dppr_engine *e, int32_t group, dppr_stats_t *out) {
     GET_GROUP(e, group);
     if (!out) return DPPR_ERR_INVALID;
     HIP_TRY(hipSetDevice(e->device));
-    static thread_local IterStats h;
-    HIP_TRY(hipMemcpyAsync(&h, g.dstats, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+    static thread_local IterStats h[2];
+    HIP_TRY(hipMemcpyAsync(h, g.dstats, sizeof(h), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    unsigned long long t = 0;
-    for (int i = 0; i < STAT_SLOTS; ++i) t += h.blk_E[i];
-    g.st.sum_E = (int64_t)t;
+    unsigned long long t = 0, ts = 0;
+    for (int i = 0; i < STAT_SLOTS; ++i) {
+        t += h[0].blk_E[i];
+        ts += h[1].blk_E[i];
+    }
+    g.st.sum_E = (int64_t)(t + ts);
+    g.st.sweep_E = (int64_t)ts;
     g.st.sum_N = g.st.sum_F;
     g.st.algorithmic_bytes = 8ll * g.st.inspected + 45ll * g.st.records + 72ll * g.st.sum_F + 24ll * g.st.sum_E +
                              4ll * g.st.sum_N;

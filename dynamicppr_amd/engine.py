@@ -30,7 +30,8 @@ class Stats(C.Structure):
                 ("pull_iterations", C.c_int64),
                 ("algorithmic_bytes", C.c_int64), ("gpu_ms", C.c_double), ("push_ms", C.c_double),
                 ("push_launches", C.c_int64), ("persist_launches", C.c_int64), ("persist_aborts", C.c_int64),
-                ("binned_sweeps", C.c_int64)]
+                ("binned_sweeps", C.c_int64), ("sweep_F", C.c_int64), ("sweep_E", C.c_int64), ("sweep_ms", C.c_double),
+                ("sweep_launches", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -57,6 +58,7 @@ EXPORTS = [
     "dppr_add_source_group", "dppr_group_init_solve", "dppr_group_update", "dppr_group_read", "dppr_group_stats",
     "dppr_group_reset_stats", "dppr_set_group_seeding", "dppr_seed_lists", "dppr_set_sweep_bitmap", "dppr_set_group_resident", "dppr_set_resident_slots", "dppr_set_resident_update",
     "dppr_set_renumbering", "dppr_id_space", "dppr_set_group_push", "dppr_set_binned_sweep", "dppr_device_count", "dppr_set_phase_merge", "dppr_init_solve_at", "dppr_group_init_solve_at", "dppr_set_variant", "dppr_set_batch_grouping",
+    "dppr_time_batch_grouping", "dppr_debug_dump",
 ]
 
 
@@ -125,6 +127,8 @@ def lib():
     L.dppr_group_reset_stats.argtypes = [vp, C.c_int32]
     L.dppr_set_group_seeding.argtypes = [vp, C.c_int]
     L.dppr_bench_atomics.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, fp]
+    L.dppr_time_batch_grouping.argtypes = [vp, C.c_int32, C.c_int32, fp]
+    L.dppr_debug_dump.argtypes = [vp, C.c_char_p, C.c_int32]
     for name in EXPORTS:
         if name not in ("dppr_strerror", "dppr_last_error", "dppr_destroy"):
             getattr(L, name).restype = C.c_int
@@ -376,6 +380,18 @@ class Engine:
 
     def synchronize(self):
         self._ck(self._L.dppr_synchronize(self._h), "synchronize")
+
+    def time_batch_grouping(self, epoch=-1, reps=5):
+        """ms per batch of what grouping-at-slide keeps out of the timed region (out-degree gather + sort of the records by tail)."""
+        ms = C.c_float(0)
+        self._ck(self._L.dppr_time_batch_grouping(self._h, int(epoch), int(reps), C.byref(ms)), "time_batch_grouping")
+        return ms.value
+
+    def debug_dump(self):
+        """Post-mortem text of the engine (dppr_debug_dump): callable from another thread than the one stuck in a call."""
+        buf = C.create_string_buffer(1 << 16)
+        n = self._L.dppr_debug_dump(self._h, buf, len(buf))
+        return buf.raw[:max(n, 0)].decode(errors="replace")
 
 
 def bench_atomics(table_elems, n, scope=0, reps=5, device=0):

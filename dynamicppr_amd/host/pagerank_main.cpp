@@ -2,7 +2,9 @@
 // engine. `./pagerank -d g.bin -a 0 -i 0 -y 1 -w 0.1 -n 0 -r 0.01 -b 100 -s 1` behaves like the
 // reference binary; `-g N` spreads the sources of `--sources <file>` round-robin over N GPUs
 // (one host thread and one full window-graph replica per device, no collective).
+#include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <memory>
@@ -59,6 +61,40 @@ int main(int argc, char *argv[]) {
         graphs[(size_t)d].reset(new SlidingGraphVec(gDataFileName, gIsDirected != 0));
         drivers[(size_t)d].reset(new PPRRevPushGPU(graphs[(size_t)d].get(), present ? d % present : d, mine, /*quiet=*/d != 0 && ngpu > 1));
     }
+    // DPPR_WATCHDOG_S=<seconds>: a thread that ends the process -- after printing dppr_debug_dump of every engine -- when no
+    // driver has made progress (a from-scratch solve, a slide, a batch) for that long. The engine waits on device-side
+    // barriers with their own time limits (dppr_resident.hpp), so this should never fire; the test-suite sets it so that a
+    // hang, should one happen again (one unexplained 300-second guard in round 3), leaves a post-mortem instead
+    // of a silent time-out. Exit code 124.
+    std::atomic<bool> finished{false};
+    std::thread watchdog;
+    if (const char *w = std::getenv("DPPR_WATCHDOG_S")) {
+        const double limit = std::atof(w);
+        if (limit > 0)
+            watchdog = std::thread([&, limit] {
+                unsigned long long last = ~0ull;
+                auto since = std::chrono::steady_clock::now();
+                while (!finished.load()) {
+                    std::this_thread::sleep_for(std::chrono::milliseconds(50));
+                    unsigned long long now = 0;
+                    for (auto &d : drivers) now += d->progress.load();
+                    if (now != last) {
+                        last = now;
+                        since = std::chrono::steady_clock::now();
+                    } else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - since).count() > limit) {
+                        std::cerr << "[watchdog] no progress for " << limit << " s -- engine state:" << std::endl;
+                        std::vector<char> buf(1 << 16);
+                        for (auto &d : drivers) {
+                            dppr_debug_dump(d->engine, buf.data(), (int32_t)buf.size());
+                            std::cerr << buf.data();
+                        }
+                        std::cerr.flush();
+                        std::cout.flush();
+                        std::_Exit(124);
+                    }
+                }
+            });
+    }
     const auto t0 = std::chrono::steady_clock::now();
     if (ngpu == 1) {
         drivers[0]->DynamicExecute();
@@ -68,6 +104,8 @@ int main(int argc, char *argv[]) {
         for (auto &t : th) t.join();
     }
     const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    finished.store(true);
+    if (watchdog.joinable()) watchdog.join();
 
     if (ngpu > 1 || sources.size() > 1) {
         // aggregate: sum over sources of c * batches / slowest device's timed total

@@ -11,6 +11,9 @@
 //     (gpu/GPUUtil.cuh:7-19).
 #pragma once
 
+#include <atomic>
+#include <thread>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -105,6 +108,7 @@ public:
             for (size_t k = 0; k < groups.size(); ++k) {
                 float ms = 0;
                 DPPR_CHECK(engine, dppr_group_init_solve(engine, groups[k], gTolerance, &ms));
+                progress++;
                 if (!quiet_) std::cout << "elapsed time=" << ms << "ms" << std::endl;
             }
             if (gValidate)
@@ -117,6 +121,7 @@ public:
                 float ms = 0;
                 if (gProfile) DPPR_CHECK(engine, dppr_trace_enable(engine, slots[i], 1));
                 DPPR_CHECK(engine, dppr_init_solve(engine, slots[i], gTolerance, &ms));
+                progress++;
                 if (gProfile) PrintIterations(i, 0);
                 if (!quiet_) std::cout << "elapsed time=" << ms << "ms" << std::endl;
                 if (gValidate) ValidateResult(i);
@@ -166,15 +171,19 @@ public:
     // gpu/PPRGPU.cuh:109-177
     virtual void SlidingWindowExecuteMainLoop() {
         size_t stream_batch_count = 0;
+        if (std::getenv("DPPR_TEST_STALL")) // (test hook: a driver that stops making progress -- the watchdog's post-mortem path)
+            for (;;) std::this_thread::sleep_for(std::chrono::seconds(1));
         while (stream_batch_count++ < gStreamBatchCount) {
             if (!quiet_ && (gStreamUpdateCountPerBatch > 100 || stream_batch_count % 100 == 0))
                 Report(stream_batch_count);
+            progress++;
             prof.Start(HostProfile::EXCLUDE_GRAPH_UPDATE);
             if (graph->StreamUpdates(gStreamUpdateCountPerBatch)) break; // partial batch: dropped
             // ---- untimed: batch upload + device graph rebuild ----
             DPPR_CHECK(engine, dppr_set_batch(engine, graph->edge_batch->edge1, graph->edge_batch->edge2,
                                               graph->edge_batch->is_insert, graph->edge_batch->length));
             GPUBuildSlidingGraph();
+            progress++;
             prof.End(HostProfile::EXCLUDE_GRAPH_UPDATE);
             prof.Start(HostProfile::PPR);
             // ---- timed: IncrementalBatchUpdate + ExecuteMainLoop(0) + (1), per source or per group ----
@@ -311,6 +320,7 @@ public:
     std::vector<float> ppr_time; // ms per source (single mode) or per group, timed region only
     HostProfile prof;
     size_t batches_done = 0;
+    std::atomic<unsigned long long> progress{0}; // bumped after every engine call that can take long (the watchdog of pagerank_main.cpp looks at it)
 
 protected:
     // the progress / summary lines scripts/extract_gpu.py scrapes (gpu/PPRGPU.cuh:116-124,170-176);

@@ -64,3 +64,13 @@ def aggregate_units(units_local: int, dist=None) -> int:
     t = torch.tensor([units_local], dtype=torch.int64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
+
+
+def line_blocks(rank: int, world: int, no_cpu_baseline: bool = False, no_merged: bool = False, schedule: str = "eager") -> dict:
+    """Which blocks the ONE JSON line of bench.py carries, decided in one place so that the N > 1 line is not thinner than
+    the N = 1 line: rank 0 prints the line at every N, with `parity` (every source of rank 0, CPU comparison
+    included) and `cpu_baseline` (timed on rank 0's host cores while the other ranks wait at the closing barrier);
+    `roofline` is rank 0's device; only the merged-loop side metric stays an N = 1 extra (a second pass over the run)."""
+    head = rank == 0
+    return {"line": head, "parity": head, "roofline": head, "cpu_baseline": head and not no_cpu_baseline,
+            "merged_loop": head and world == 1 and not no_merged and schedule == "eager"}

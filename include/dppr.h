@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DPPR_ABI_VERSION 2
+#define DPPR_ABI_VERSION 3
 
 typedef struct dppr_engine dppr_engine; /* opaque */
 
@@ -70,6 +70,12 @@ typedef struct dppr_stats_t {
     int64_t persist_launches; /* launches of the resident multi-iteration sweep (k_pull_resident) */
     int64_t persist_aborts;   /* of those, launches that stopped at a grid-barrier time-out */
     int64_t binned_sweeps;    /* pull iterations evaluated as a binned sweep (k_bin_scatter + k_bin_reduce; subset of pull_iterations) */
+    /* ABI 3: the dense sweeps on their own (one launch per sweep: k_pull_iter, k_bin_scatter + k_bin_reduce, k_gsweep), so that
+     * the roofline of the sweep kernel is its own bytes over its own time, reproducible from a rocprofv3 kernel-stats file */
+    int64_t sweep_F;          /* sum of the frontier sizes the sweeps pushed (subset of sum_F) */
+    int64_t sweep_E;          /* in-edges the sweeps traversed (subset of sum_E) */
+    double sweep_ms;          /* sum of the sweeps' event times (profiling on only; subset of push_ms) */
+    int64_t sweep_launches;   /* sweeps timed into sweep_ms */
 } dppr_stats_t;
 
 /* ---- lifetime ----------------------------------------------------------- */
@@ -346,6 +352,23 @@ int dppr_trace_get(dppr_engine *e, int32_t slot, int64_t *n_iters, int64_t *n_id
 
 /* Stream-wide sync (hipStreamSynchronize on the engine's stream). */
 int dppr_synchronize(dppr_engine *e);
+
+/* What dppr_set_batch_grouping(at_slide = 1) and the batch upload move out of the reference's timed region
+ * (gpu/PPRGPU.cuh:138-164 times CopyOutDegree + the whole IncrementalBatchUpdate): the post-batch out-degree gather and the
+ * grouping of epoch `epoch`'s L records by tail (device radix sort), run `reps` times on the engine's stream between two
+ * events; *out_ms = milliseconds per repetition. bench.py adds it to the measured batch time and reports both accountings
+ * (config.timed_region). Touches scratch only. */
+int dppr_time_batch_grouping(dppr_engine *e, int32_t epoch, int32_t reps, float *out_ms);
+
+/* Diagnostics for a call that does not come back (one unexplained 300-second guard in 13 suite runs). Writes a
+ * text report into buf (at most cap bytes, NUL-terminated; returns the length written): last error, epoch / id-space
+ * state, resident-launch settings, per slot and group the host-side loop state and statistics, and -- read through a
+ * SEPARATE stream with a bounded wait, so that it works while the engine's own stream is stuck in a kernel -- the
+ * GridBar words (roll-call outcome, check-ins, per-sweep arrivals) and the status words of resident / multi-sweep
+ * launches. Callable from another host thread than the one inside the engine (it takes no lock: the host-side fields
+ * are read racily, which is what a post-mortem wants). No reference counterpart (its loop is host-driven,
+ * gpu/PPRRevPushGPU.cuh:106-130, and cannot wait on a device-side barrier). */
+int dppr_debug_dump(dppr_engine *e, char *buf, int32_t cap);
 
 /* Microbenchmark used to calibrate the roofline ceiling of the push kernel
  * (SURVEY.md 8d): n returning f64 atomic adds per launch at pseudo-random

@@ -32,7 +32,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} declared in include/dppr.h but not exported"
     assert sorted(eng.EXPORTS) == declared_symbols()
-    assert lib.dppr_abi_version() == 2   # 2: dppr_stats_t grew binned_sweeps, dppr_set_binned_sweep
+    assert lib.dppr_abi_version() == 3   # 3: dppr_time_batch_grouping, dppr_debug_dump (round 4)
 
 
 def test_strerror_and_argument_validation_without_gpu():

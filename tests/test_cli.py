@@ -27,8 +27,21 @@ def small_bin(tmp_path_factory):
     return path, V, e1, e2
 
 
-def run(args, **kw):
-    return subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, **kw)
+WATCHDOG_S = "60"   # ./pagerank ends itself with a post-mortem (dppr_debug_dump of every engine, exit code 124) after this long without progress
+
+
+def run(args, env_extra=None, **kw):
+    """./pagerank as a child process under its own watchdog (DPPR_WATCHDOG_S) and a harder limit here: whatever the child
+    printed goes into the pytest log if either fires (round 3 lost the output of its one unexplained 300-second guard)."""
+    env = dict(os.environ, DPPR_WATCHDOG_S=WATCHDOG_S, **(env_extra or {}))
+    try:
+        r = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=150, env=env, **kw)
+    except subprocess.TimeoutExpired as ex:   # (subprocess.run has killed the child -- the CHILD, never this process)
+        out = ex.stdout.decode(errors="replace") if isinstance(ex.stdout, bytes) else (ex.stdout or "")
+        pytest.fail(f"{' '.join(args)} did not finish within 150 s (its own watchdog should have fired at {WATCHDOG_S} s); output so far:\n{out}")
+    if r.returncode == 124:
+        pytest.fail(f"{' '.join(args)}: the watchdog fired -- no progress for {WATCHDOG_S} s:\n{r.stdout}")
+    return r
 
 
 def test_invalid_arguments_print_usage_and_exit(pagerank, small_bin):
@@ -269,3 +282,18 @@ def test_cli_profile_output_matches_the_reference_profile_build(pagerank, small_
     assert t["ppr_time"] >= t["inc_update_time"] + t["push_time"] - 1e-3 and t["push_time"] > 0 and t["expand_time"] > 0
     cnt = {k: int(v) for k, v in re.findall(r"\[(\w+)\]=(\d+) ", m.group(2))}
     assert cnt["expand_count"] == sum(f for _, _, f in want) and cnt["traverse_count"] == s.stats()["E"]
+
+
+@pytest.mark.gpu
+def test_cli_watchdog_writes_a_post_mortem(pagerank, small_bin):
+    """The diagnostic path itself: a driver that stops making progress (test hook DPPR_TEST_STALL) is ended by the
+    watchdog after the limit, with the engine's state (dppr_debug_dump: last error, epoch, GridBar words read through a
+    side stream, per-slot counters) on stderr and exit code 124."""
+    path, V, e1, e2 = small_bin
+    src = int(datagen.top_sources(V, e1, e2, 600, 0, 1)[0])
+    env = dict(os.environ, DPPR_WATCHDOG_S="2", DPPR_TEST_STALL="1")
+    r = subprocess.run([pagerank, "-d", path, "-a", "0", "-i", "0", "-y", "1", "-w", "0.1", "-n", "0", "-r", "0.01", "-b", "5", "-s", str(src)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120, env=env)
+    assert r.returncode == 124, r.stdout
+    assert "[watchdog] no progress" in r.stdout and "GridBar: gen" in r.stdout and "slot 0: source" in r.stdout, r.stdout
+    assert "engine stream: idle" in r.stdout

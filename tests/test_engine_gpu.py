@@ -9,6 +9,9 @@ Bars (DESIGN.md "Parity"):
     within the north-star tolerance 1e-9 of cpu/PPRCPUMTCilkRev (-t 1 restatement),
     plus the reference's own Validate() criteria (|r| < eps, |p - p_pow| < 100 eps).
 """
+import sys
+import time
+
 import numpy as np
 import pytest
 
@@ -302,6 +305,86 @@ def test_eager_schedule_parity_with_cilk_oracle(directed, eps, tuning):
         assert np.max(np.abs(r - sc.s.r)) < 2 * eps                      # both lie in (-eps, eps)
         src, dst = window_directed_edges(sc.g)
         assert invariant_max_err_np(p, r, src, dst, sc.V, sc.source) < INVARIANT_TOL
+
+
+@pytest.mark.parametrize("schedule", ["sync", "eager"])
+@pytest.mark.parametrize("c", [1, 2])
+@pytest.mark.parametrize("directed", [1, 0])
+def test_single_edge_batches(directed, c, schedule):
+    """The reference's smallest experiment point, scripts/gpu.sh:13 (batch size c = 1: one deleted and one inserted
+    edge per batch, L = 2 records directed / 4 undirected): 25 batches in a row, device CSR every slide, synchronous
+    schedule with the oracle's frontier sets / statistics, production schedule within the north-star tolerance."""
+    sync = schedule == "sync"
+    sc = make(directed, schedule=eng.SCHEDULE_SYNC if sync else eng.SCHEDULE_EAGER, c=c, W=600)
+    if sync:
+        sc.s.sync_execute(sc.g)
+    else:
+        sc.s.cilk_execute(sc.g)
+    sc.e.init_solve(sc.slot, sc.eps)
+    for k in range(25):
+        assert sc.advance_graphs()
+        if sync:
+            sc.s.sync_inc_execute(sc.g)
+        else:
+            sc.s.cilk_inc_execute(sc.g)
+        sc.e.update(sc.slot, sc.eps)
+        if k % 6 == 0:
+            check_csr(sc)
+        p, r = sc.e.read(sc.slot)
+        assert np.max(np.abs(r)) < sc.eps
+        if sync:
+            assert np.max(np.abs(p - sc.s.p)) < SYNC_TOL and np.max(np.abs(r - sc.s.r)) < SYNC_TOL, k
+        else:
+            assert np.max(np.abs(p - sc.s.p)) < NORTH_STAR_TOL, k
+    if sync:
+        st, want = sc.e.stats(sc.slot), sc.s.stats()
+        assert (st["iterations"], st["sum_F"], st["sum_E"]) == (want["iters"], want["F"], want["E"])
+
+
+@pytest.mark.parametrize("eps", [1e-5, 1e-10])
+@pytest.mark.parametrize("directed", [1, 0])
+def test_epsilon_sweep_corners(directed, eps):
+    """The ends of the reference's epsilon sweep, scripts/gpu.sh:83 (1e-5 .. 1e-10): the synchronous schedule does the
+    oracle's work exactly (iterations, sum F, sum E), the production schedule stays within the tolerance scaled as
+    test_eager_schedule_parity_with_cilk_oracle scales it, |r| < eps and the reference's Validate() bound hold."""
+    for sync in (True, False):
+        sc = make(directed, schedule=eng.SCHEDULE_SYNC if sync else eng.SCHEDULE_EAGER, c=30, eps=eps)
+        if sync:
+            sc.s.sync_execute(sc.g)
+        else:
+            sc.s.cilk_execute(sc.g)
+        sc.e.init_solve(sc.slot, eps)
+        for k in range(5):
+            if k:
+                assert sc.advance_graphs()
+                if sync:
+                    sc.s.sync_inc_execute(sc.g)
+                else:
+                    sc.s.cilk_inc_execute(sc.g)
+                sc.e.update(sc.slot, eps)
+            p, r = sc.e.read(sc.slot)
+            assert np.max(np.abs(r)) < eps
+            pw, _ = orc.pow_rev(sc.g, sc.source)
+            assert np.max(np.abs(p - pw)) < 100 * eps
+            if sync:
+                assert np.max(np.abs(p - sc.s.p)) < SYNC_TOL and np.max(np.abs(r - sc.s.r)) < SYNC_TOL
+            else:
+                assert np.max(np.abs(p - sc.s.p)) < max(NORTH_STAR_TOL * (eps / 1e-9), 1e-12)
+        if sync:
+            st, want = sc.e.stats(sc.slot), sc.s.stats()
+            assert (st["iterations"], st["sum_F"], st["sum_E"]) == (want["iters"], want["F"], want["E"])
+        sc.e.close()
+
+
+@pytest.mark.parametrize("eps", [1e-5, 1e-10])
+@pytest.mark.parametrize("c", [1, 40])
+def test_source_group_batch_size_and_epsilon_corners(c, eps):
+    """The same corners for a source group (10 sources, 80-byte rows): single-edge batches and both ends of the epsilon
+    sweep, per-source p / r of the oracle's synchronous schedule and its summed statistics."""
+    V, e1, e2 = datagen.rmat_stream(10, 9000, 5)
+    W, directed = 1500, 1
+    sources = [int(x) for x in datagen.top_sources(V, e1, e2, W, directed, 10)]
+    run_source_group(V, e1, e2, W, c, eps, directed, sources, 8 if c == 1 else 4, "tails")
 
 
 def test_split_interface_matches_reference_driver_flow():
@@ -1189,6 +1272,21 @@ def test_source_group_sources_outside_the_window_and_duplicates():
     run_source_group(V, e1, e2, W, c, 1e-9, directed, lonely + top + [top[0]], 4, "tails")
 
 
+def test_debug_dump_reads_the_engine_from_another_thread():
+    """dppr_debug_dump (the hang post-mortem): host-side loop state plus the device words, read through a side stream;
+    also after a launch whose roll-call cannot succeed (persist_timeout_us = -1: the launch gives up untouched)."""
+    sc = make(0, c=20, tuning=dict(persist_timeout_us=-1))
+    sc.e.init_solve(sc.slot, sc.eps)
+    for _ in range(2):
+        assert sc.advance_graphs()
+        sc.e.update(sc.slot, sc.eps)
+    text = sc.e.debug_dump()
+    assert "last error: (none)" in text and "engine stream: idle" in text
+    assert "GridBar: gen" in text and "slot 0: source" in text
+    assert sc.e.stats(sc.slot)["persist_aborts"] >= 1 and "ok 0" in text   # the failed roll-call switched resident launches off
+    assert sc.e.time_batch_grouping(reps=3) > 0.0
+
+
 def test_two_engines_on_one_device_from_two_threads():
     """Two engines share device 0 and are driven from two host threads at once: their resident
     launches compete for the same CUs (each wants all of them). Whatever the interleaving -- one
@@ -1214,12 +1312,16 @@ def test_two_engines_on_one_device_from_two_threads():
         except BaseException as ex:  # noqa: BLE001 - reported by the main thread
             errors.append(repr(ex))
 
-    threads = [threading.Thread(target=drive, args=(sc,)) for sc in scs]
+    threads = [threading.Thread(target=drive, args=(sc,), daemon=True) for sc in scs]
     for t in threads:
         t.start()
+    deadline = time.monotonic() + 90
     for t in threads:
-        t.join(timeout=300)
-    assert not any(t.is_alive() for t in threads), "a driver thread hangs"
+        t.join(timeout=max(0.0, deadline - time.monotonic()))
+    if any(t.is_alive() for t in threads):   # post-mortem into the pytest log: Python stacks + both engines' device-side state
+        import faulthandler
+        faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+        pytest.fail("a driver thread hangs; engine state:\n" + "\n".join(sc.e.debug_dump() for sc in scs))
     assert not errors, errors
     assert sum(sc.e.stats(sc.slot)["persist_launches"] for sc in scs) > 0
 

@@ -62,7 +62,8 @@ WORKER = textwrap.dedent("""
         time.sleep(0.05 * (rank + 1))          # rank 1 is the slow one
     dt, w = shard.timed_region(run, lambda: None, dist)
     units = shard.aggregate_units(wl.per_batch * steps * len(mine), dist)
-    json.dump(dict(rank=rank, world=w, sources=mine, pool=pool, dt=dt, units=units, psum=float(sum(s.p.sum() for s in states)), checksum=checksum),
+    blocks = shard.line_blocks(rank, w)   # what bench.py's line carries at this rank / world size
+    json.dump(dict(rank=rank, world=w, sources=mine, pool=pool, dt=dt, units=units, psum=float(sum(s.p.sum() for s in states)), checksum=checksum, blocks=blocks),
               open(os.path.join({out!r}, "rank%d.json" % rank), "w"))
     dist.barrier()
     dist.destroy_process_group()
@@ -90,3 +91,8 @@ def test_two_rank_gloo_run(tmp_path):
     assert a["units"] == b["units"] == 10 * 6 * 3           # SUM over ranks of sources * c * steps
     assert a["psum"] != b["psum"]
     assert a["checksum"] == b["checksum"]                   # one stream file, written once
+    # the N = 2 line is rank 0's and is as complete as the N = 1 line: parity, roofline and the CPU baseline (only the
+    # merged-loop side metric is an N = 1 extra); rank 1 prints nothing
+    assert a["blocks"] == {"line": True, "parity": True, "roofline": True, "cpu_baseline": True, "merged_loop": False}
+    assert not any(b["blocks"].values())
+    assert shard.line_blocks(0, 1)["merged_loop"] and not shard.line_blocks(0, 1, no_cpu_baseline=True)["cpu_baseline"]

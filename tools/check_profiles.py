@@ -120,7 +120,43 @@ def check(directory):
         if tl["busy_us"] > tl["span_us"] * 1.001:
             print(f"FAIL {tag}: busy {tl['busy_us']} us exceeds the span {tl['span_us']} us")
             bad += 1
-    print(f"{pairs} timeline / stats pair(s) checked, {bad} disagreement(s)")
+    # Round 4 on: a committed bench line's roofline must be reproducible from the kernel-stats file of the same command --
+    # frac = algorithmic bytes per launch / (average launch time of the dominant kernel(s) in the CSV) / peak, within 10 %
+    # (friendster's 0.32 came from another box's run than the committed CSV, which gives 0.27).
+    lines = 0
+    for b_path in sorted(glob.glob(os.path.join(directory, "r*_bench_*_1gpu.json"))):
+        rnd = os.path.basename(b_path).split("_")[0]
+        if int(rnd[1:]) < 4:
+            continue
+        tag = re.sub(r"^r\d+_bench_", "", os.path.basename(b_path))[:-len("_1gpu.json")]
+        st_path = os.path.join(directory, f"{rnd}_kernel_stats_{tag}.csv")
+        if not os.path.exists(st_path):
+            continue   # (a line without a profile of its own makes no claim the profile could contradict)
+        line = json.loads(open(b_path).read().strip().splitlines()[-1])
+        roof = line.get("roofline") or {}
+        heads = [h.strip().split(" ")[0] for h in roof.get("kernel", "").split("(")[0].split("+")]
+        stats = list(csv.DictReader(open(st_path)))
+        avg_ns = 0.0
+        for h in heads:
+            rows = [r for r in stats if r["Name"].startswith(h)]
+            calls = sum(int(r["Calls"]) for r in rows)
+            if not calls:
+                print(f"FAIL {tag}: the line's dominant kernel {h} is not in {os.path.basename(st_path)}")
+                bad += 1
+                avg_ns = 0.0
+                break
+            avg_ns += sum(float(r["TotalDurationNs"]) for r in rows) / calls
+        if avg_ns <= 0:
+            continue
+        lines += 1
+        per = roof.get("iterations_per_launch", 1.0) if heads[0].startswith("k_pull_resident") else 1.0
+        frac_csv = roof["algorithmic_bytes_per_launch"] / (avg_ns * 1e-9) / (roof["peak"] * 1e9)
+        if abs(frac_csv - roof["frac"]) > 0.10 * max(frac_csv, roof["frac"]):
+            print(f"FAIL {tag}: roofline.frac {roof['frac']:.3f} in {os.path.basename(b_path)}, {frac_csv:.3f} from {os.path.basename(st_path)} "
+                  f"({roof['algorithmic_bytes_per_launch'] / 1e6:.1f} MB per launch / {avg_ns / 1e3:.1f} us)")
+            bad += 1
+        del per
+    print(f"{pairs} timeline / stats pair(s) and {lines} bench line(s) checked, {bad} disagreement(s)")
     return 1 if bad else 0
 
 

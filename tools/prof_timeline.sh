@@ -12,5 +12,6 @@ mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -- python3 $ROOT/bench.py --no-cpu-baseline "$@" > $OUT/bench.log 2>&1 || true
 cp "$(find $OUT/raw -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats_full.csv
 python3 $ROOT/tools/check_profiles.py --cut "$(find $OUT/raw -name '*kernel_trace.csv' | head -1)" $OUT/kernel_stats_full.csv $OUT
+grep "^{" $OUT/bench.log | tail -1 > $OUT/bench.json   # the line of THIS run: profiles/rNN_bench_<tag>_1gpu.json next to the stats file it must agree with
 cat $OUT/timeline.txt
 rm -rf $OUT/raw $OUT/kernel_stats_full.csv
