@@ -293,7 +293,7 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_reduce(int NV, int NV_bin, int n
         if (lg) {
             p[v] += ALPHA * rn;
             n_legal++;
-            deg += in_row_ptr ? in_row_ptr[v + 1] - in_row_ptr[v] : s_den[i] - 1; // (undirected: the in-edges are the out-edges)
+            if (deg_out) deg += in_row_ptr ? in_row_ptr[v + 1] - in_row_ptr[v] : s_den[i] - 1; // (undirected: the in-edges are the out-edges)
         }
     }
     const int cw = wave_inclusive_scan(n_legal);
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_reduce(int NV, int NV_bin, int n
             td += s_deg[k];
         }
         if (tot) atomicAdd(cnt_out, tot);
-        if (td) atomicAdd(deg_out, td);
+        if (td && deg_out) atomicAdd(deg_out, td);
         if (te) atomicAdd(&stats->blk_E[blockIdx.x & (STAT_SLOTS - 1)], te); // (more workgroups than slots: slots are shared)
     }
     BSTAMP(1, 3, wall_clock64());

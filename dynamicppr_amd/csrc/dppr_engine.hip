@@ -311,10 +311,10 @@ inline int grid_for(int64_t n, int per_block = BLOCK, int cap = 2048) {
 // Wait for the engine's stream from inside a frontier loop (the read-back at the end of a chunk of iterations): polling the
 // stream's completion instead of a blocking hipStreamSynchronize, whose wake-up is part of every chunk boundary's gap
 // (DPPR_SYNC_SPIN=0: the blocking call, for A/B runs).
-// The poll is bounded: a chunk of sweeps is over within a few hundred microseconds; after LOOP_SPIN_US the
+// The poll is bounded: a chunk of sweeps is over within a millisecond or two; after LOOP_SPIN_US the
 // thread gives its core back and blocks -- N engines driven by N host threads (./pagerank -g N, two engines on one
 // device) must not hold N cores at 100 % for a wait that has turned long.
-constexpr long LOOP_SPIN_US = 200;
+constexpr long LOOP_SPIN_US = 2000; // (covers a resident launch of a configs[1]-size batch, ~0.4 ms: at 200 the blocking call's wake-up cost that path 6 %)
 inline hipError_t loop_sync(hipStream_t st) {
     static const bool spin = !(getenv("DPPR_SYNC_SPIN") && atoi(getenv("DPPR_SYNC_SPIN")) == 0);
     if (!spin) return hipStreamSynchronize(st);
@@ -1335,7 +1335,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                                    extracted ? 1 : 0);
                 dense_valid = true;
             }
-            if (binned) HIP_TRY(hipMemsetAsync(dsum + nxt, 0, sizeof(unsigned long long), e->stream));
+            if (costly) HIP_TRY(hipMemsetAsync(dsum + nxt, 0, sizeof(unsigned long long), e->stream));
             const bool timed = e->profiling || (costly && n == 1); // (the push / sweep decision prices both by what the last ones took)
             if (timed) HIP_TRY(hipEventRecord(e->evpool[2 * k], e->stream));
             if (pull && binned) {
@@ -1347,7 +1347,8 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 hipLaunchKernelGGL(k_bin_reduce, dim3(ep.n_b + (ep.grp_n_int - ep.bin_n_int + rows_cap - 1) / rows_cap), dim3(BIN_NT),
                                    (size_t)rows_cap * 20, e->stream, ep.grp_n_int, ep.bin_n_int, ep.n_b, s.cnt + cur, ep.bcut, rows_cap,
                                    ep.out_row_ptr, ep.dl, e->bin_vals, s.x,
-                                   s.x2, s.r, s.p, s.cnt + nxt, s.cnt + zer, phase, eps, s.dstats + 1, log_slot, e->directed ? ep.row_ptr : (const int *)nullptr, dsum + nxt);
+                                   s.x2, s.r, s.p, s.cnt + nxt, s.cnt + zer, phase, eps, s.dstats + 1, log_slot, e->directed ? ep.row_ptr : (const int *)nullptr,
+                                   costly ? dsum + nxt : (unsigned long long *)nullptr);
                 std::swap(s.x, s.x2);
                 dense_valid = true;
                 extracted = false;
