@@ -612,10 +612,12 @@ def cpu_baseline(V, e1, e2, directed, W, c, sources, eps, batches, p_end, stream
 
 
 def reference_fifo_baseline(bin_path, directed, flags, source, eps, c, batches=4):
-    """The REAL reference code that can be built here: cpu/PPRCPURev.h, the reference's (deprecated)
-    single-thread FIFO reverse push, compiled from /root/reference by oracle/Makefile into
-    oracle/_ref/ref_driver (the binary travels to the GPU box, the sources do not). Timed scope:
-    IncExecuteImpl only. None when the binary or the .bin file is not there."""
+    """The REAL reference code that can be built in the dev container: cpu/PPRCPURev.h, the reference's (deprecated)
+    single-thread FIFO reverse push, compiled from /root/reference by oracle/Makefile into oracle/_ref/ref_driver.
+    Timed scope: IncExecuteImpl only. The binary exists only where it was built: a box reached through gpurun from the
+    dev container has it (oracle/_ref travels with the snapshot), a fresh checkout built by __graft_entry__.build() without
+    /root/reference -- the driver's round-end box -- does not, and the key is then absent from the line (None here): this
+    leg is an extra of development runs on small streams (< 10 M edges), never part of `cpu_baseline.value`."""
     import subprocess
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
     if not bin_path or not os.path.exists(exe) or not os.path.exists(bin_path):

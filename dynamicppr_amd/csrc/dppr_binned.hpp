@@ -164,7 +164,7 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_scatter(int NV, const int *__res
 }
 
 // In-edges of the vertices of a frontier list (what pushing it costs in returning atomics): one thread per vertex.
-__global__ __launch_bounds__(BLOCK) void k_degsum(const int *__restrict__ list, const int *__restrict__ cnt, const int *__restrict__ in_row_ptr,
+__global__ __launch_bounds__(BLOCK) void k_front_degree(const int *__restrict__ list, const int *__restrict__ cnt, const int *__restrict__ in_row_ptr,
                                                   unsigned long long *__restrict__ out) {
     const int n = *cnt;
     unsigned long long d = 0;

@@ -1212,12 +1212,12 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             // Push or sweep by what each would cost. A push is one returning atomic per in-edge of the
             // frontier, executed at the memory side at ~23.5 G/s chip-wide whatever the locality (profiles/r03_atomics_probe.json);
             // a sweep of this window costs what the last ones did. The frontier's in-edges are counted by the sweep that left it
-            // (k_bin_reduce) or, for a list, by k_degsum. (Round 3 switched on the vertex count: a late frontier of 1.7 M
+            // (k_bin_reduce) or, for a list, by k_front_degree. (Round 3 switched on the vertex count: a late frontier of 1.7 M
             // low-degree vertices is pushed in 0.23 ms and was swept for 2.6, the 156 K batch tails -- hubs -- cost a sweep's time.)
             if (D < 0 && F >= 1024) {
                 if (!list_valid && (rc = make_list())) return rc;
                 HIP_TRY(hipMemsetAsync(dsum + cur, 0, sizeof(unsigned long long), e->stream));
-                hipLaunchKernelGGL(k_degsum, dim3(grid_for(F)), dim3(BLOCK), 0, e->stream, s.ft[buf], s.cnt + cur, ep.row_ptr, dsum + cur);
+                hipLaunchKernelGGL(k_front_degree, dim3(grid_for(F)), dim3(BLOCK), 0, e->stream, s.ft[buf], s.cnt + cur, ep.row_ptr, dsum + cur);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(e->pinned, dsum + cur, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
                 HIP_TRY(loop_sync(e->stream));

@@ -339,7 +339,10 @@ protected:
     bool quiet_;
 };
 
-// The one variant built: OPTIMIZED (-o 0), the reference's PPRRevPushGPU (gpu/PPRRevPushGPU.cuh).
+// The reference has one driver class per variant (gpu/PPRRevPushGPU.cuh, gpu/PPRRevPushGPUVariants.cuh); here all four variants
+// (-o 0 OPTIMIZED, 1 FAST_FRONTIER, 2 EAGER, 3 VANILLA) are mechanisms of one engine, selected by dppr_set_variant in the base
+// class's constructor (gVariant): the duplicate filter (threshold crossing | status array) and the residual read (eager | pre-extracted)
+// of the push kernels. One class therefore serves every -o.
 class PPRRevPushGPU : public PPRGPU {
 public:
     using PPRGPU::PPRGPU;
