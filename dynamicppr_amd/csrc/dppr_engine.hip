@@ -242,7 +242,8 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     long long bin_target = 0;       // edges a B-block is cut for (one workgroup of k_bin_reduce); 0: from the window, clamp(Ed / 256, 16 K, 192 K)
                                     // (measured: LiveJournal stand-in best at 16-32 K, twitter / friendster at 192 K)
     long long bin_target_a = 4ll << 20; // ... an A-block (its edges are dealt to workgroups of k_bin_scatter in chunks: large, so that tiles are long runs)
-    long long bin_min_ids = 1ll << 20; // (smaller windows run resident, or are too small to fill the chip with blocks)
+    long long bin_min_ids = 1ll << 19; // (smaller windows run resident or gather: R-MAT window of 2 M edges, ~0.65 M ids, single source: binned 2.66 ms per batch
+                                       // against 3.26 gathering; window of 1 M edges, ~0.38 M ids: 2.45 against 1.47 -- tools/r04/midsize_probe.sh)
     uint32_t *bin_k[2] = {nullptr, nullptr}; // sort keys (Ed each)
     int *bin_vblk_a = nullptr, *bin_vblk_b = nullptr; // vertex -> block (V each)
     int *bin_small = nullptr;       // quantile vertices | big rows | counter (bin_cut)
@@ -1721,8 +1722,8 @@ int group_multi_capacity(dppr_engine *e, int spl) {
     int &cap = e->gmulti_cap[spl - 1];
     if (cap < 0) {
         int per_cu = 0, cus = 0; // (the widest row of each lane split: narrower ones need no more)
-        hipError_t rc = spl == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gsweep<1, 8, 1024, true>, GNT, 0)
-                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gsweep<2, 16, 512, true>, GNT, 0);
+        hipError_t rc = spl == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gsweep<1, 8, 1024, true, 2>, GNT, 0)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gsweep<2, 16, 512, true, 2>, GNT, 0);
         if (rc != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess)
             per_cu = 0;
         cap = std::min(per_cu * cus, STAT_SLOTS);
@@ -1905,7 +1906,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
             int *status = g.mlog, *rows = g.mlog + GWM;
 #define DPPR_LAUNCH_GMULTI(SPL, GW, NVX)                                                                                 \
-    hipLaunchKernelGGL((k_gsweep<SPL, GW, NVX, true>), dim3(ep.n_ggroups), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.gtab,   \
+    hipLaunchKernelGGL((k_gsweep<SPL, GW, NVX, true, 2>), dim3(ep.n_ggroups), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.gtab,   \
                        ep.n_ggroups, g.cnt + cur * GWM, e->gsweep_hot_rows, ep.out_col, g.x, g.x2, g.act[0], g.act[1], g.r, g.p, \
                        g.cnt + 3 * GWM, g.cnt + 4 * GWM, phase, eps, g.dstats + 1, rows, n, e->bar, status, e->persist_ticks,    \
                        e->persist_rollcall_extra, owed ? 1 : 0, (int *)nullptr, (int *)nullptr)
@@ -1984,8 +1985,9 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
         for (int k = 0; k < n; ++k) {
             const int nxt = (cur + 1) % 3, zer = (cur + 2) % 3;
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k], e->stream));
-#define DPPR_LAUNCH_GSWEEP(SPL, GW, NVX)                                                                                  \
-    hipLaunchKernelGGL((k_gsweep<SPL, GW, NVX, false>), dim3(sweep_grid), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.gtab,      \
+#define DPPR_LAUNCH_GSWEEP(SPL, GW, NVX) do { if (owed) DPPR_LAUNCH_GSWEEP_CM(SPL, GW, NVX, 1); else DPPR_LAUNCH_GSWEEP_CM(SPL, GW, NVX, 0); } while (0)
+#define DPPR_LAUNCH_GSWEEP_CM(SPL, GW, NVX, CM)                                                                          \
+    hipLaunchKernelGGL((k_gsweep<SPL, GW, NVX, false, CM>), dim3(sweep_grid), dim3(GNT), 0, e->stream, ep.grp_n_int, ep.gtab,  \
                        ep.n_ggroups, g.cnt + cur * GWM, e->gsweep_hot_rows, ep.out_col, g.x, g.x2, g.act[0], g.act[1], g.r, g.p,  \
                        g.cnt + nxt * GWM, g.cnt + zer * GWM, phase, eps, g.dstats + 1, log + k * GWM, 1, (GridBar *)nullptr,      \
                        (int *)nullptr, 0ull, 0, owed ? 1 : 0, g.gq + (g.gq_seq % 3) * GQ_PAD, g.gq + ((g.gq_seq + 1) % 3) * GQ_PAD)
@@ -1996,6 +1998,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
                 else DPPR_LAUNCH_GSWEEP(1, GW, 1024);
             });
 #undef DPPR_LAUNCH_GSWEEP
+#undef DPPR_LAUNCH_GSWEEP_CM
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[2 * k + 1], e->stream));
             std::swap(g.x, g.x2);
             std::swap(g.act[0], g.act[1]);

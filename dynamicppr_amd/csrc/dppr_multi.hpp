@@ -353,7 +353,10 @@ constexpr int GSM_SWEEPS = (1 << 16) - 1;
 // frontier sizes of all sources are row g of `mlog` (row 0 = cnt_in): the loop ends when a row is
 // all zero. Co-residency is verified by the same roll-call as k_pull_resident's before anything is
 // changed; a failed roll-call leaves everything untouched and the host goes on with one-sweep launches.
-template <int SPL, int GW, int NVX, bool MULTI>
+// CM: how pagerank is credited -- 0 a deferring sweep, 1 a crediting one (one-sweep launches: the host alternates the two
+// instantiations; a deferring sweep loads one row per vertex instead of two, so it finishes ALL of an octet's vertices in one
+// step -- one memory round trip in its vertex phase instead of two), 2 decided per sweep inside the launch (multi-sweep form).
+template <int SPL, int GW, int NVX, bool MULTI, int CM>
 __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int *__restrict__ gtab, int n_groups,
                                                    const int *cnt_in, int hot_rows,
                                                    const int *__restrict__ out_col, double *x_a, double *x_b,
@@ -374,7 +377,9 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
 #ifndef DPPR_GS_FU
 #define DPPR_GS_FU (4 / SPL)
 #endif
-    constexpr int FU = MULTI ? NVX / NOCT : (DPPR_GS_FU) <= NVX / NOCT ? (DPPR_GS_FU) : NVX / NOCT;
+    constexpr int FU_WANT = CM == 0 && SPL == 2 ? 2 * (DPPR_GS_FU) : (DPPR_GS_FU); // (8-wide rows finish 4 vertices per step in either mode: 8 at once spill)
+    constexpr int FU = MULTI ? NVX / NOCT : FU_WANT <= NVX / NOCT ? FU_WANT : NVX / NOCT;
+    static_assert(MULTI == (CM == 2), "the multi-sweep form decides per sweep, a one-sweep launch is compiled for its mode");
     static_assert(NVX % NOCT == 0 && (NVX / NOCT) % FU == 0, "vertex phase covers the group in whole steps");
     __shared__ double s_acc[NVX * GW];   // per vertex and source: sum of this sweep's adds (zero between groups)
     __shared__ int s_cstart[NVX + 1];    // non-empty rows of the group, compacted: first edge (relative)
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
             double *x_new = (it & 1) ? x_a : x_b;
             const uint32_t *act_in = (it & 1) ? act_b : act_a;
             uint32_t *act_out = (it & 1) ? act_a : act_b;
-            const bool credit = ((credit0 ^ it) & 1) != 0; // this sweep settles pagerank for the value it pushes and the one it creates
+            const bool credit = CM == 2 ? ((credit0 ^ it) & 1) != 0 : CM == 1; // this sweep settles pagerank for the value it pushes and the one it creates
             if constexpr (MULTI) {
                 // frontier sizes of iteration `it`: row `it` of the log (row 0 = what the seeding left in cnt_in)
                 const int *row = it == 0 ? cnt_in : log_slot + (size_t)it * GS_MAX;

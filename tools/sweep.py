@@ -24,8 +24,12 @@ EPSILONS = ["0.00001", "0.000001", "0.0000001", "0.00000001", "0.000000001", "0.
 
 def scrape(text, key):
     """Last occurrence wins, as scripts/extract_gpu.py:18-32 does."""
-    vals = re.findall(rf"^{key} ([-+.e\d]+)", text, flags=re.M)
-    return float(vals[-1]) if vals else None
+    vals = re.findall(rf"^{key} (\S+)", text, flags=re.M)
+    try:   # (a run without a complete batch prints nan: no value)
+        v = float(vals[-1]) if vals else None
+    except ValueError:
+        return None
+    return v if v is not None and v == v and abs(v) != float("inf") else None
 
 
 def run(args, log_path):
