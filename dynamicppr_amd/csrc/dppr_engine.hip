@@ -870,6 +870,10 @@ static_assert(BIN_MAX_HB_TILES * WAVE * 20 + 4096 <= 160 * 1024, "k_bin_reduce: 
 // partial allocations are released, the sticky HIP error is cleared and the epoch sweeps with k_pull_iter.
 static bool bin_alloc(void **p, size_t bytes) {
     if (*p) return true;
+    if (getenv("DPPR_TEST_BIN_OOM")) { // (test hook: these allocations fail as if the device were out of memory)
+        *p = nullptr;
+        return false;
+    }
     if (hipMalloc(p, bytes) == hipSuccess) return true;
     *p = nullptr;
     (void)hipGetLastError();

@@ -1272,6 +1272,29 @@ def test_source_group_sources_outside_the_window_and_duplicates():
     run_source_group(V, e1, e2, W, c, 1e-9, directed, lonely + top + [top[0]], 4, "tails")
 
 
+def test_binned_tables_that_cannot_be_allocated_fall_back_to_gather_sweeps(monkeypatch):
+    """the binned-sweep tables are an optimisation. When their allocations fail (test hook
+    DPPR_TEST_BIN_OOM: every one of them reports out-of-memory) dppr_load_window / dppr_slide / dppr_add_source still
+    succeed, the sweeps gather (k_pull_iter) and the results are the oracle's; once memory is there again the next epoch gets
+    its tables."""
+    monkeypatch.setenv("DPPR_TEST_BIN_OOM", "1")
+    sc = make(1, schedule=eng.SCHEDULE_SYNC, scale=12, edges=60000, seed=5, W=20000, c=200,
+              tuning=dict(binned=(2, 0, 0, 0, 0), pull_min_frontier=1, persistent=0))
+    sc.s.sync_execute(sc.g)
+    sc.e.init_solve(sc.slot, sc.eps)
+    for k in range(3):
+        if k == 2:
+            monkeypatch.delenv("DPPR_TEST_BIN_OOM")   # (the slide of this batch can allocate again)
+        assert sc.advance_graphs()
+        sc.s.sync_inc_execute(sc.g)
+        sc.e.update(sc.slot, sc.eps)
+        p, r = sc.e.read(sc.slot)
+        assert np.max(np.abs(p - sc.s.p)) < SYNC_TOL and np.max(np.abs(r - sc.s.r)) < SYNC_TOL
+        st = sc.e.stats(sc.slot)
+        assert st["pull_iterations"] > 0
+        assert (st["binned_sweeps"] == 0) if k < 2 else (st["binned_sweeps"] > 0), (k, st["binned_sweeps"])
+
+
 def test_debug_dump_reads_the_engine_from_another_thread():
     """dppr_debug_dump (the hang post-mortem): host-side loop state plus the device words, read through a side stream;
     also after a launch whose roll-call cannot succeed (persist_timeout_us = -1: the launch gives up untouched)."""
