@@ -33,6 +33,10 @@ def test_bench_line_contract(extra, sources):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and 0 < rf["frac"] < 1
     assert 0 < rf["frac_group_adjusted"] <= rf["frac"] and "frac_traffic" in rf     # (a group reads a column entry once for its S sources)
     assert (rf["frac_group_adjusted"] == rf["frac"]) == (sources == 1)
+    assert rf["hbm_achievable"] == 6300.0 and "fabric" in rf["traffic_kind"] and rf["all_iteration_launches"]["launches"] >= rf["launches"] > 0
+    tr = d["config"]["timed_region"]    # which accounting produced `value`, and the batch time under the reference's own
+    assert tr["grouping"] == "at_slide" and tr["grouping_ms_per_step"] > 0
+    assert abs(tr["ms_per_step_grouping_in_region"] - (d["ms_per_step"] + tr["grouping_ms_per_step"])) < 2e-4
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     pr = d["parity"]
