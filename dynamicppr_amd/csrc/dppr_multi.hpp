@@ -415,7 +415,12 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
         if (blockIdx.x == 0 && tid0 == 0) *q_zero = 0; // the NEXT launch's group counter (before the early return: a no-op launch keeps the rotation intact)
         if (__ballot(my_cnt != 0) == 0) return;
 #ifdef DPPR_STAMPS
-#ifdef DPPR_STAMP_SPARSE
+#if defined(DPPR_STAMP_MID) // (a "hovering" sweep: between V / 16 and V / 2 frontier pairs -- few pairs on hub heads that still reach most rows)
+        {
+            const long long tot = __builtin_amdgcn_readlane(wave_inclusive_scan(my_cnt), WAVE - 1);
+            stamp_dense = tot * 16 > (long long)V && tot * 2 < (long long)V;
+        }
+#elif defined(DPPR_STAMP_SPARSE)
         stamp_dense = (long long)__builtin_amdgcn_readlane(wave_inclusive_scan(my_cnt), WAVE - 1) * 64 < (long long)V;
 #else
         stamp_dense = (long long)__builtin_amdgcn_readlane(wave_inclusive_scan(my_cnt), WAVE - 1) > 4ll * V;
@@ -501,7 +506,10 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
     bool converged = false, fault = false;
     // One-sweep launches: a workgroup's first group is its block index, every further one a ticket from a device counter
     // (the groups are cut for equal edge weight, not equal time: with a fixed stride the slots of the last round idle for
-    // a fifth of a sweep; the counter's round trip hides behind the edge phase).
+    // a fifth of a sweep; the counter's round trip hides behind the edge phase). ONE counter on purpose: returning atomics on
+    // one word serialise at ~11 ns, which is 34 us for 3 075 tickets and most of a near-empty sweep's 47-52 us -- but eight
+    // counters, one per XCD (with and without taking from the others' once dry), made those sweeps 42-44 us and every larger
+    // one 3-7 % slower (groups handed out in global order keep the chip on neighbouring rows): 12.07 -> 12.21-12.37 ms per batch.
     for (int g = blockIdx.x; g < n_groups;) { // workgroup-uniform loop (MULTI: one group per workgroup)
         __syncthreads(); // the previous group's tables are no longer read; the initial fills are in place
         int ticket = 0, g_next = n_groups;
