@@ -212,6 +212,7 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     uint64_t *bk[4] = {nullptr, nullptr, nullptr, nullptr}; // del-in, ins-in, del-out, ins-out (unsorted)
     uint64_t *bks[4] = {nullptr, nullptr, nullptr, nullptr}; // the same, sorted
     uint8_t *keep = nullptr;
+    int *cmp_tiles = nullptr; // kept keys per tile of the sorted keys / their starts (key merge of a slide)
     void *inc_tmp = nullptr;
     size_t inc_tmp_bytes = 0;
     bool incremental = true; // dppr_slide merges the batch into the sorted keys (false: full re-sort)
@@ -723,9 +724,12 @@ int merge_batch_keys(dppr_engine *e, uint64_t *&sorted, uint64_t *del_unsorted, 
     HIP_TRY(hipMemsetAsync(e->keep, 1, (size_t)Ed, e->stream));
     hipLaunchKernelGGL(k_mark_deleted, dim3(grid_for(nd)), dim3(BLOCK), 0, e->stream, sorted, Ed, del_sorted, nd, e->keep);
     HIP_TRY(hipGetLastError());
-    int *d_count = e->hub_hist + 40; // scratch word
-    tmp = e->inc_tmp_bytes;
-    HIP_TRY(rocprim::select(e->inc_tmp, tmp, sorted, e->keep, e->keys_a, d_count, (size_t)Ed, e->stream));
+    // the kept keys, in order (dppr_builder.hpp: count per tile, scan, compact -- in place of rocprim::select)
+    const int n_tiles = (Ed + CMP_TILE - 1) / CMP_TILE;
+    hipLaunchKernelGGL(k_keep_count, dim3(n_tiles), dim3(BLOCK), 0, e->stream, e->keep, Ed, e->cmp_tiles);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, e->stream, e->cmp_tiles, n_tiles);
+    hipLaunchKernelGGL(k_compact_keys, dim3(n_tiles), dim3(BLOCK), 0, e->stream, sorted, e->keep, Ed, e->cmp_tiles, e->keys_a);
+    HIP_TRY(hipGetLastError());
     tmp = e->inc_tmp_bytes;
     HIP_TRY(rocprim::merge(e->inc_tmp, tmp, e->keys_a, ins_sorted, e->keys_b, (size_t)(Ed - nd), (size_t)ni,
                            rocprim::less<uint64_t>(), e->stream));
@@ -2188,6 +2192,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     HIP_TRY_C(hipMalloc((void **)&e->in_sorted, sizeof(uint64_t) * Edn));
     if (e->directed) HIP_TRY_C(hipMalloc((void **)&e->out_sorted, sizeof(uint64_t) * Edn));
     HIP_TRY_C(hipMalloc((void **)&e->keep, Edn));
+    HIP_TRY_C(hipMalloc((void **)&e->cmp_tiles, sizeof(int) * (Edn / CMP_TILE + 2)));
     {
         const size_t bn = (size_t)std::max(2 * c, 1);
         for (int k = 0; k < 4; ++k) {
@@ -2195,7 +2200,6 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
             HIP_TRY_C(hipMalloc((void **)&e->bks[k], sizeof(uint64_t) * bn));
         }
         size_t a = 0, b = 0;
-        HIP_TRY_C(rocprim::select(nullptr, a, e->in_sorted, e->keep, e->keys_a, e->hub_hist, Edn, e->stream));
         HIP_TRY_C(rocprim::merge(nullptr, b, e->keys_a, e->bks[1], e->keys_b, Edn, bn, rocprim::less<uint64_t>(),
                                  e->stream));
         e->inc_tmp_bytes = std::max(a, b);
@@ -2263,7 +2267,7 @@ void dppr_destroy(dppr_engine *e) {
     (void)hipFree(e->hub_slot_of); (void)hipFree(e->hub_hist); (void)hipFree(e->d_ext2int); (void)hipFree(e->d_xfer);
     (void)hipFree(e->mv_idx); (void)hipFree(e->mv_tmp);
     (void)hipFree(e->keys_a); (void)hipFree(e->keys_b); (void)hipFree(e->sort_tmp);
-    (void)hipFree(e->in_sorted); (void)hipFree(e->out_sorted); (void)hipFree(e->keep); (void)hipFree(e->inc_tmp);
+    (void)hipFree(e->in_sorted); (void)hipFree(e->out_sorted); (void)hipFree(e->keep); (void)hipFree(e->inc_tmp); (void)hipFree(e->cmp_tiles);
     for (int k = 0; k < 4; ++k) { (void)hipFree(e->bk[k]); (void)hipFree(e->bks[k]); }
     for (int k = 0; k < 2; ++k) { (void)hipFree(e->su_k[k]); (void)hipFree(e->su_v[k]); }
     (void)hipFree(e->su_term); (void)hipFree(e->su_ins); (void)hipFree(e->su_tmp);
