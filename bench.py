@@ -293,7 +293,9 @@ def main():
             "launches_from": ("a replay of the timed batches from the saved state" if S == 1 or pair_as_singles else
                               f"the {n_prof} batches that follow the timed region on the same stream"),
             "note": "achieved / frac = SURVEY.md 8(d) bytes (72 F + 24 E + 4 N, summed over the sources) of the hipEvent-"
-                    "bracketed launches / their time: a WORK rate in the survey's unit. frac_group_adjusted prices a traversed "
+                    "bracketed launches / their time: a WORK rate in the survey's unit -- for a source group it can exceed 1, because the "
+                    "unit prices every traversed edge at 24 bytes PER SOURCE while a group reads the column entry once and one state row "
+                    "for all its sources; what the memory system moved is frac_traffic. frac_group_adjusted prices a traversed "
                     "edge at 16 + 8 / S bytes (a group reads the column entry once for its S sources); frac_traffic = the fabric bytes "
                     "the counters saw per launch (traffic, from the committed rocprofv3 --pmc passes of this workload) / the "
                     "launch time measured here / peak: what the memory system actually moved (DESIGN.md section 6)",
