@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <ctime>
 #include <string>
 #include <type_traits>
@@ -212,6 +213,16 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     uint64_t *bk[4] = {nullptr, nullptr, nullptr, nullptr}; // del-in, ins-in, del-out, ins-out (unsorted)
     uint64_t *bks[4] = {nullptr, nullptr, nullptr, nullptr}; // the same, sorted
     uint8_t *keep = nullptr;
+    struct Pre { // dppr_hint_next_batch
+        std::future<bool> task;
+        const int32_t *src[4] = {nullptr, nullptr, nullptr, nullptr};
+        int n[4] = {0, 0, 0, 0};
+        std::vector<int32_t> out[4];
+        std::vector<uint32_t> miss[4]; // positions the lookup left at -1 (no id yet / parked), in array order
+        unsigned long long epoch = 0;
+        bool armed = false, ok = false;
+    } pre;
+    long long pre_hits = 0, pre_misses = 0; // id arrays that dppr_set_batch / dppr_slide took from the lookahead; entries resolved at the call
     int *cmp_tiles = nullptr; // kept keys per tile of the sorted keys / their starts (key merge of a slide)
     void *inc_tmp = nullptr;
     size_t inc_tmp_bytes = 0;
@@ -340,10 +351,29 @@ int fail(dppr_engine *e, int code, const char *msg) {
     return code;
 }
 
-inline int to_int(dppr_engine *e, int ext) { return e->to_int(ext); } // (IdSpace: assigns, or revives a parked vertex)
+// dppr_hint_next_batch: the lookups of the NEXT batch's ids run on helper threads while dppr_update waits for the device. They
+// only read the id maps; every path that changes the maps waits for them first (pre_join).
+inline void pre_join(dppr_engine *e) {
+    if (e->pre.task.valid()) e->pre.ok = e->pre.task.get();
+}
+
+inline int to_int(dppr_engine *e, int ext) { // (IdSpace: assigns, or revives a parked vertex)
+    pre_join(e);
+    return e->to_int(ext);
+}
+
+// a finished, still valid lookahead for exactly this array? (its index in e->pre, or -1)
+int pre_find(dppr_engine *e, const int32_t *src, int n) {
+    pre_join(e);
+    if (!e->pre.armed || !e->pre.ok || e->pre.epoch != e->renumber_epoch || n <= 0) return -1;
+    for (int k = 0; k < 4; ++k)
+        if (e->pre.src[k] == src && e->pre.n[k] == n) return k;
+    return -1;
+}
 
 // ids inside [0, V)? (no side effect: a rejected call must not assign ids, revive parked vertices or queue row moves)
-bool ids_in_range(const dppr_engine *e, const int32_t *src, int n) {
+bool ids_in_range(dppr_engine *e, const int32_t *src, int n) {
+    if (pre_find(e, src, n) >= 0) return true; // (the lookahead checked every id)
     for (int i = 0; i < n; ++i)
         if (src[i] < 0 || src[i] >= e->V) return false;
     return true;
@@ -351,6 +381,17 @@ bool ids_in_range(const dppr_engine *e, const int32_t *src, int n) {
 
 // translate an id array; returns false (nothing changed) if any id is outside [0, V)
 bool translate(dppr_engine *e, const int32_t *src, int n, std::vector<int32_t> &dst) {
+    // looked up ahead of time (dppr_hint_next_batch) and still valid: no renumbering since (ids assigned or revived in between only
+    // concern entries the lookup left at -1: those are resolved now, in array order, exactly as IdSpace::translate does)
+    const int k = pre_find(e, src, n);
+    if (k >= 0) {
+        e->pre.src[k] = nullptr; // (consumed)
+        dst.swap(e->pre.out[k]);
+        for (const uint32_t i : e->pre.miss[k]) dst[i] = e->to_int(src[i]);
+        e->pre_hits++;
+        e->pre_misses += (long long)e->pre.miss[k].size();
+        return true;
+    }
     dst.resize((size_t)std::max(n, 1));
     return e->translate(src, (size_t)std::max(n, 0), dst.data());
 }
@@ -535,6 +576,7 @@ int device_numbering_order(dppr_engine *e, const std::vector<uint8_t> &live, int
 // numbering, and *did tells the caller to sort the whole window for the epoch it is about to build.
 int compact_ids(dppr_engine *e, bool *did) {
     *did = false;
+    pre_join(e);
     if (!e->renumber_on || e->W == 0 || e->n_int < e->renumber_next) return DPPR_OK;
     if (e->slots.empty() && e->groups.empty()) return DPPR_OK;
     for (const auto &s : e->slots)
@@ -2241,6 +2283,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
 
 void dppr_destroy(dppr_engine *e) {
     if (!e) return;
+    if (e->pre.task.valid()) e->pre.task.wait();
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto &s : e->slots) {
@@ -2495,6 +2538,30 @@ int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32
     return DPPR_OK;
 }
 
+int dppr_hint_next_batch(dppr_engine *e, const int32_t *b1, const int32_t *b2, int32_t L, const int32_t *n1, const int32_t *n2, int32_t c) {
+    if (!e || e->broken || L < 0 || L > 4 * e->c || c < 0 || c > e->c || (L > 0 && (!b1 || !b2)) || (c > 0 && (!n1 || !n2)))
+        return fail(e, DPPR_ERR_INVALID, "hint_next_batch: lengths exceed max_batch");
+    pre_join(e);
+    dppr_engine::Pre &pr = e->pre;
+    const int32_t *src[4] = {b1, b2, n1, n2};
+    const int n[4] = {L, L, c, c};
+    for (int k = 0; k < 4; ++k) {
+        pr.src[k] = src[k];
+        pr.n[k] = n[k];
+        pr.out[k].resize((size_t)std::max(n[k], 1));
+    }
+    pr.epoch = e->renumber_epoch;
+    pr.armed = true;
+    pr.ok = false;
+    pr.task = std::async(std::launch::async, [e] {
+        bool ok = true;
+        for (int k = 0; k < 4; ++k)
+            if (e->pre.n[k] > 0) ok = e->lookup_only(e->pre.src[k], (size_t)e->pre.n[k], e->pre.out[k].data(), e->pre.miss[k]) && ok;
+        return ok;
+    });
+    return DPPR_OK;
+}
+
 int dppr_set_batch(dppr_engine *e, const int32_t *b1, const int32_t *b2, const uint8_t *ins, int32_t L) {
     if (!e || e->broken || L < 0 || L > 4 * e->c || (L > 0 && (!b1 || !b2 || !ins)))
         return fail(e, DPPR_ERR_INVALID, "set_batch: length exceeds 4*max_batch");
@@ -2694,6 +2761,7 @@ int dppr_debug_dump(dppr_engine *e, char *buf, int32_t cap) {
     add("dppr engine %p device %d: V %d W %d c %d directed %d n_int %d newest epoch %d broken %d\n", (void *)e, e->device, e->V, e->W, e->c,
         e->directed, e->n_int, e->newest, (int)e->broken);
     add("last error: %s\n", e->err.empty() ? "(none)" : e->err.c_str());
+    add("id lookahead (dppr_hint_next_batch): %lld id arrays taken from it so far (%lld entries resolved at the call), renumberings %llu\n", e->pre_hits, e->pre_misses, e->renumber_epoch);
     add("resident launches: mode %d ok %d retry %d time limit %llu ticks (100 MHz) rollcall_extra %d; schedule %d merge %d\n", e->persist_mode,
         (int)e->persist_ok, e->persist_retry, e->persist_ticks, e->persist_rollcall_extra, e->schedule, (int)e->merge_phases);
     // device words through a stream of their own, waited for at most ~2 s

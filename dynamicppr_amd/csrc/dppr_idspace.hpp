@@ -15,6 +15,7 @@
 #include <functional>
 #include <cstdint>
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <utility>
@@ -50,6 +51,7 @@ struct IdSpace {
     int n_int = 0, n_parked = 0;
     long long revivals = 0;
     bool map_dirty = true; // a device copy of ext2int is stale
+    unsigned long long renumber_epoch = 0; // bumped by renumber(): the only operation that changes the internal id of a LIVE vertex
     // pending row moves: position -> position whose rows it will receive (-1: zero rows). Composed on the host while
     // ids are assigned, applied to every state array in one gather + scatter + zero pass (take_moves).
     std::unordered_map<int32_t, int32_t> mv_origin;
@@ -69,11 +71,18 @@ struct IdSpace {
     // External ids -> internal ids for a whole array. False (and NOTHING changed) if an id lies outside [0, cap).
     // The lookups run in parallel and only read; ids that are new or parked -- rare -- then go through to_int one by one
     // in array order (a revival may move another parked vertex: parked entries are all resolved in that serial pass).
-    bool translate(const int32_t *src, size_t n, int32_t *dst) {
+    // The read-only half of translate(): internal id of every live vertex, -1 for ids without one and for parked ones (whose id
+    // changes when they are revived), and the positions of those -1 entries in array order. Touches nothing: may run on other
+    // threads while no call that assigns, revives or renumbers is in progress (dppr_hint_next_batch). False if an id is outside
+    // [0, cap).
+    bool lookup_only(const int32_t *src, size_t n, int32_t *dst, std::vector<uint32_t> &miss) const {
         const int32_t lo_parked = cap - n_parked;
-        std::atomic<int> bad{0}, slow{0};
+        std::atomic<int> bad{0};
+        std::mutex mu;
+        std::vector<std::pair<size_t, std::vector<uint32_t>>> parts; // (first index of a piece, its misses)
         parallel_pieces(n, 1 << 16, [&](size_t a, size_t b) {
-            bool any_bad = false, any_slow = false;
+            bool any_bad = false;
+            std::vector<uint32_t> mine;
             for (size_t i = a; i < b; ++i) {
                 const int32_t v = src[i];
                 if (v < 0 || v >= cap) {
@@ -82,17 +91,28 @@ struct IdSpace {
                 }
                 const int32_t m = ext2int[(size_t)v];
                 dst[i] = (m >= 0 && m < lo_parked) ? m : -1;
-                any_slow |= dst[i] < 0;
+                if (dst[i] < 0) mine.push_back((uint32_t)i);
             }
             if (any_bad) bad.store(1, std::memory_order_relaxed);
-            if (any_slow) slow.store(1, std::memory_order_relaxed);
+            if (!mine.empty()) {
+                std::lock_guard<std::mutex> lk(mu);
+                parts.emplace_back(a, std::move(mine));
+            }
         });
-        if (bad.load()) return false;
-        if (slow.load())
-            for (size_t i = 0; i < n; ++i)
-                if (dst[i] < 0) dst[i] = to_int(src[i]);
+        miss.clear();
+        std::sort(parts.begin(), parts.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+        for (const auto &pt : parts) miss.insert(miss.end(), pt.second.begin(), pt.second.end());
+        return !bad.load();
+    }
+
+    // The lookups run in parallel and only read; ids that are new or parked -- rare -- then go through to_int one by one in
+    // array order (a revival may move another parked vertex: parked entries are all resolved in that serial pass).
+    bool translate(const int32_t *src, size_t n, int32_t *dst) {
+        if (!lookup_only(src, n, dst, miss_scratch)) return false;
+        for (const uint32_t i : miss_scratch) dst[i] = to_int(src[i]);
         return true;
     }
+    std::vector<uint32_t> miss_scratch;
 
     // external -> internal id, assigning a new one on first sight, bringing a parked vertex back to the live zone
     int to_int(int ext) {
@@ -195,6 +215,7 @@ struct IdSpace {
         n_int = n_live;
         n_parked = R_new;
         map_dirty = true;
+        renumber_epoch++;
     }
 };
 

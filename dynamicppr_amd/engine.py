@@ -58,7 +58,7 @@ EXPORTS = [
     "dppr_add_source_group", "dppr_group_init_solve", "dppr_group_update", "dppr_group_read", "dppr_group_stats",
     "dppr_group_reset_stats", "dppr_set_group_seeding", "dppr_seed_lists", "dppr_set_sweep_bitmap", "dppr_set_group_resident", "dppr_set_resident_slots", "dppr_set_resident_update",
     "dppr_set_renumbering", "dppr_id_space", "dppr_set_group_push", "dppr_set_binned_sweep", "dppr_device_count", "dppr_set_phase_merge", "dppr_init_solve_at", "dppr_group_init_solve_at", "dppr_set_variant", "dppr_set_batch_grouping",
-    "dppr_time_batch_grouping", "dppr_debug_dump",
+    "dppr_time_batch_grouping", "dppr_debug_dump", "dppr_hint_next_batch",
 ]
 
 
@@ -129,6 +129,7 @@ def lib():
     L.dppr_bench_atomics.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, fp]
     L.dppr_time_batch_grouping.argtypes = [vp, C.c_int32, C.c_int32, fp]
     L.dppr_debug_dump.argtypes = [vp, C.c_char_p, C.c_int32]
+    L.dppr_hint_next_batch.argtypes = [vp, ip, ip, C.c_int32, ip, ip, C.c_int32]
     for name in EXPORTS:
         if name not in ("dppr_strerror", "dppr_last_error", "dppr_destroy"):
             getattr(L, name).restype = C.c_int
@@ -238,6 +239,16 @@ class Engine:
         b, pb = _i32(b2)
         i = np.ascontiguousarray(ins, dtype=np.uint8)
         self._ck(self._L.dppr_set_batch(self._h, pa, pb, i.ctypes.data_as(C.POINTER(C.c_uint8)), len(a)), "set_batch")
+
+    def hint_next_batch(self, b1, b2, n1, n2):
+        """Lookahead (dppr_hint_next_batch): the id lookups of the next set_batch(b1, b2, ..) / slide(n1, n2) run on helper
+        threads from now on. Returns the four arrays as contiguous int32 -- pass THESE objects to set_batch / slide (the
+        engine matches the hint by pointer and length) and leave them untouched until then."""
+        arrs = [_i32(x) for x in (b1, b2, n1, n2)]
+        self._hint_keep = [a for a, _ in arrs]   # (keeps the memory alive until the next hint)
+        self._ck(self._L.dppr_hint_next_batch(self._h, arrs[0][1], arrs[1][1], len(arrs[0][0]), arrs[2][1], arrs[3][1], len(arrs[2][0])),
+                 "hint_next_batch")
+        return tuple(self._hint_keep)
 
     def slide(self, n1, n2):
         a, pa = _i32(n1)

@@ -12,6 +12,7 @@
 #pragma once
 
 #include <atomic>
+#include <future>
 #include <thread>
 #include <chrono>
 #include <cmath>
@@ -133,6 +134,9 @@ public:
         prof.End(HostProfile::DYNA_GRAPH_CALC);
         prof.End(HostProfile::TOTAL);
         if (!quiet_) std::cout << "finish!" << std::endl;
+        if (std::getenv("DPPR_HOST_TIMES")) // (stderr, not a line of the reference: the loop's wall time beside the ppr_time it reports)
+            std::cerr << "host_times batches=" << batches_done << " dynamic_ms=" << prof.ms[HostProfile::DYNA_GRAPH_CALC]
+                      << " graph_update_ms=" << prof.ms[HostProfile::EXCLUDE_GRAPH_UPDATE] << " ppr_ms=" << prof.ms[HostProfile::PPR] << std::endl;
         if (gProfile && !quiet_) ReportProfile();
     }
 
@@ -173,18 +177,35 @@ public:
         size_t stream_batch_count = 0;
         if (std::getenv("DPPR_TEST_STALL")) // (test hook: a driver that stops making progress -- the watchdog's post-mortem path)
             for (;;) std::this_thread::sleep_for(std::chrono::seconds(1));
+        // Lookahead (include/dppr.h dppr_hint_next_batch): once batch k's graph is built, a helper thread advances the host stream to
+        // batch k+1 and tells the engine which id arrays it will get next -- the stream advance and the id lookups then run while
+        // this thread waits for batch k's update (the reference's untimed region, gpu/PPRGPU.cuh:114-135, is serial). Not with
+        // --validate (its power iteration reads the host graph at batch k); DPPR_NO_LOOKAHEAD=1 for A/B runs. Results are identical.
+        const bool lookahead = !gValidate && std::getenv("DPPR_NO_LOOKAHEAD") == nullptr;
+        bool ahead = false, ahead_end = false; // the next batch is staged in graph->edge_batch / new_stream already | the stream ended there
+        std::future<int> ahead_task;
         while (stream_batch_count++ < gStreamBatchCount) {
             if (!quiet_ && (gStreamUpdateCountPerBatch > 100 || stream_batch_count % 100 == 0))
                 Report(stream_batch_count);
             progress++;
             prof.Start(HostProfile::EXCLUDE_GRAPH_UPDATE);
-            if (graph->StreamUpdates(gStreamUpdateCountPerBatch)) break; // partial batch: dropped
+            if (ahead ? ahead_end : graph->StreamUpdates(gStreamUpdateCountPerBatch)) break; // partial batch: dropped
+            ahead = false;
             // ---- untimed: batch upload + device graph rebuild ----
             DPPR_CHECK(engine, dppr_set_batch(engine, graph->edge_batch->edge1, graph->edge_batch->edge2,
                                               graph->edge_batch->is_insert, graph->edge_batch->length));
             GPUBuildSlidingGraph();
             progress++;
             prof.End(HostProfile::EXCLUDE_GRAPH_UPDATE);
+            if (lookahead && stream_batch_count < gStreamBatchCount) { // (both calls above have consumed the host arrays of batch k)
+                ahead = true;
+                ahead_task = std::async(std::launch::async, [this, &ahead_end] {
+                    ahead_end = graph->StreamUpdates(gStreamUpdateCountPerBatch);
+                    if (ahead_end) return (int)DPPR_OK;
+                    return dppr_hint_next_batch(engine, graph->edge_batch->edge1, graph->edge_batch->edge2, graph->edge_batch->length,
+                                                graph->new_stream->edge1, graph->new_stream->edge2, graph->new_stream->length);
+                });
+            }
             prof.Start(HostProfile::PPR);
             // ---- timed: IncrementalBatchUpdate + ExecuteMainLoop(0) + (1), per source or per group ----
             for (size_t k = 0; k < groups.size(); ++k) {
@@ -218,6 +239,10 @@ public:
                 if (gValidate) ValidateResult(i);
             }
             prof.End(HostProfile::PPR);
+            if (ahead_task.valid()) {
+                const int ahead_rc = ahead_task.get();
+                DPPR_CHECK(engine, ahead_rc);
+            }
         }
         batches_done = stream_batch_count - 1;
         if (!quiet_) Report(stream_batch_count);

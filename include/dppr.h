@@ -353,6 +353,20 @@ int dppr_trace_get(dppr_engine *e, int32_t slot, int64_t *n_iters, int64_t *n_id
 /* Stream-wide sync (hipStreamSynchronize on the engine's stream). */
 int dppr_synchronize(dppr_engine *e);
 
+/* Lookahead for the untimed region (no reference counterpart: its graph update is serial,
+ * gpu/PPRGPU.cuh:114-135). Tells the engine which id arrays the NEXT dppr_set_batch (b1, b2: L records) and dppr_slide
+ * (n1, n2: c new edges) will be called with -- the SAME pointers and lengths, contents final and untouched until those
+ * calls. Their external -> internal lookups (the dominant host cost of a large batch: 18 + 5 ms of a twitter-size
+ * slide) then run on helper threads while the caller is inside dppr_update / dppr_group_update, and the two calls only
+ * resolve what the lookups could not (ids without an internal id yet, parked vertices). Read-only on the engine: every
+ * call that changes the id maps waits for the lookups first; after a renumbering, or when the pointers / lengths differ,
+ * the hint is ignored. Results are identical with and without it.
+ * Threads: this is the ONE call that may also come from another host thread than the engine's while that one is inside
+ * dppr_update / dppr_group_update / dppr_incremental_batch_update / dppr_execute_main_loop (none of which touches the id maps) --
+ * so a host can advance its own stream and hint from a helper while the update runs (./pagerank does) -- provided the helper
+ * has returned from it before the engine's thread makes its next call. */
+int dppr_hint_next_batch(dppr_engine *e, const int32_t *b1, const int32_t *b2, int32_t L, const int32_t *n1, const int32_t *n2, int32_t c);
+
 /* What dppr_set_batch_grouping(at_slide = 1) and the batch upload move out of the reference's timed region
  * (gpu/PPRGPU.cuh:138-164 times CopyOutDegree + the whole IncrementalBatchUpdate): the post-batch out-degree gather and the
  * grouping of epoch `epoch`'s L records by tail (device radix sort), run `reps` times on the engine's stream between two

@@ -12,6 +12,8 @@ Bars (DESIGN.md "Parity"):
 import sys
 import time
 
+import threading
+
 import numpy as np
 import pytest
 
@@ -1293,6 +1295,52 @@ def test_binned_tables_that_cannot_be_allocated_fall_back_to_gather_sweeps(monke
         st = sc.e.stats(sc.slot)
         assert st["pull_iterations"] > 0
         assert (st["binned_sweeps"] == 0) if k < 2 else (st["binned_sweeps"] > 0), (k, st["binned_sweeps"])
+
+
+@pytest.mark.parametrize("directed", [1, 0])
+def test_lookahead_id_lookups_change_nothing(directed):
+    """dppr_hint_next_batch: the next batch's id arrays announced before the update, looked up on helper
+    threads while it runs, consumed by set_batch / slide -- with ids that have no internal id yet (fresh vertices arrive with most
+    batches of this stream) and, with renumbering forced at every slide, with hints that a renumbering invalidates. The device
+    CSR stays the oracle's every slide, p / r the synchronous oracle's, and the hint is actually used (dppr_debug_dump counts it)."""
+    for forced in (False, True):
+        sc = make(directed, schedule=eng.SCHEDULE_SYNC, scale=11, edges=30000, seed=17, W=3000, c=60)
+        if forced:
+            sc.e.set_renumbering(1, growth_pct=1, min_parked=1)
+        sc.s.sync_execute(sc.g)
+        sc.e.init_solve(sc.slot, sc.eps)
+        assert not sc.g.stream_updates()
+        sc.g.inc_construct(1)
+        nxt = (*sc.g.batch()[:2], *sc.g.new_stream())          # batch 1: no hint (nothing ran before it)
+        ins = sc.g.batch()[2]
+        for k in range(8):
+            sc.e.set_batch(nxt[0], nxt[1], ins)
+            sc.e.slide(nxt[2], nxt[3])
+            check_csr(sc)
+            sc.s.sync_inc_execute(sc.g)
+            more = not sc.g.stream_updates()                   # the host stream moves on to batch k + 2 BEFORE the update ...
+            if more:
+                sc.g.inc_construct(1)
+                b1, b2, ins = sc.g.batch()
+                n1, n2 = sc.g.new_stream()
+                if k % 2:                                      # ... whose id lookups run while it does
+                    nxt = sc.e.hint_next_batch(b1, b2, n1, n2)
+                else:                                          # (hinted from a helper thread DURING the update, as ./pagerank does)
+                    box = []
+                    th = threading.Thread(target=lambda: box.append(sc.e.hint_next_batch(b1, b2, n1, n2)))
+                    th.start()
+            sc.e.update(sc.slot, sc.eps)
+            if more and not k % 2:
+                th.join()
+                nxt = box[0]
+            p, r = sc.e.read(sc.slot)
+            assert np.max(np.abs(p - sc.s.p)) < SYNC_TOL and np.max(np.abs(r - sc.s.r)) < SYNC_TOL, (forced, k)
+            if not more:
+                break
+        text = sc.e.debug_dump()
+        hits = int(text.split("id lookahead (dppr_hint_next_batch): ")[1].split(" ")[0])
+        assert hits >= (4 if not forced else 2), text   # (a renumbering slide drops the hint for its own two arrays, never the batch's)
+        sc.e.close()
 
 
 def test_debug_dump_reads_the_engine_from_another_thread():
