@@ -318,6 +318,10 @@ __device__ __forceinline__ void gs_stu(uint32_t *p, uint32_t v) {
 // falling in-degree (dppr_idspace.hpp): rows below `hot_rows` take a third to a half of all gathers. They are loaded with
 // the default policy, everything that is touched once per sweep is marked non-temporal so that it does not push them out:
 //   bit 0: gathers of rows >= hot_rows;  bit 1: the vertex phase's row loads;  bit 2: the vertex phase's row stores
+// Measured twice (before and after the spill fix) and off by default: bits 1 + 2 cost 12.5-12.7 against 11.6-11.8 ms per batch; bit 0
+// gains 7-11 % in a pure gather loop (tools/r04/policy_probe.hip: only `nt` does anything, sc0 / sc1 do not) and nothing in the sweep
+// (11.65 / 11.83 against 11.64 / 11.85): with every gather redirected to 4 096 rows (all L2 hits, -DDPPR_WHATIF=16) a launch still
+// costs 137 us against 157 -- the sweep is bound by its chain of dependent round trips per group, not by the fills.
 #ifndef DPPR_GS_NT
 #define DPPR_GS_NT 0
 #endif
@@ -510,6 +514,8 @@ __global__ __launch_bounds__(GNT, MULTI ? 4 : 8) void k_gsweep(int V, const int 
     // one word serialise at ~11 ns, which is 34 us for 3 075 tickets and most of a near-empty sweep's 47-52 us -- but eight
     // counters, one per XCD (with and without taking from the others' once dry), made those sweeps 42-44 us and every larger
     // one 3-7 % slower (groups handed out in global order keep the chip on neighbouring rows): 12.07 -> 12.21-12.37 ms per batch.
+    // Nor does it pay to deal the groups of a SPARSE sweep (fewer than ids / 16 frontier pairs; the count is known at launch) by a
+    // fixed stride without any ticket: 11.90 against 11.68 ms, and worse the higher the threshold (12.04 / 12.26 / 12.60).
     for (int g = blockIdx.x; g < n_groups;) { // workgroup-uniform loop (MULTI: one group per workgroup)
         __syncthreads(); // the previous group's tables are no longer read; the initial fills are in place
         int ticket = 0, g_next = n_groups;
