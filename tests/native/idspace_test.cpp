@@ -106,6 +106,35 @@ int main(int argc, char **argv) {
                 CHECK(!ids.translate(bad.data(), bad.size(), o2.data()), "translate accepted an id out of range");
                 CHECK(ids.ext2int == snap.ext2int && ids.n_int == snap.n_int && ids.n_parked == snap.n_parked && ids.revivals == snap.revivals, "a refused translate changed the maps");
             }
+            if (rng() % 3 == 0) { // the lookahead form (dppr_hint_next_batch): read-only lookups of an array, OTHER ids named in between
+                                  // (the batch before it), then only the entries the lookup left open are resolved, in array order
+                std::vector<int32_t> in, between, out;
+                std::vector<uint32_t> miss;
+                for (int i = 0; i < n + 8; ++i) in.push_back((int32_t)(rng() % (unsigned)cap));
+                for (int i = 0; i < n; ++i) between.push_back((int32_t)(rng() % (unsigned)cap));
+                out.assign(in.size(), -7);
+                const dppr::IdSpace before_lookup = ids;
+                const unsigned long long epoch = ids.renumber_epoch;
+                CHECK(static_cast<const dppr::IdSpace &>(ids).lookup_only(in.data(), in.size(), out.data(), miss), "lookup_only refused ids in range");
+                CHECK(ids.ext2int == before_lookup.ext2int && ids.int2ext == before_lookup.int2ext && ids.n_int == before_lookup.n_int &&
+                      ids.n_parked == before_lookup.n_parked && ids.mv_origin == before_lookup.mv_origin, "lookup_only changed the maps");
+                size_t n_open = 0;
+                for (size_t i = 0; i < in.size(); ++i) n_open += out[i] < 0 ? 1 : 0;
+                CHECK(n_open == miss.size(), "lookup_only: %zu open entries, %zu listed", n_open, miss.size());
+                for (size_t i = 0; i + 1 < miss.size(); ++i) CHECK(miss[i] < miss[i + 1], "lookup_only: the open entries are not in array order");
+                dppr::IdSpace ref = ids;
+                for (int32_t x : between) (void)ref.to_int(x);
+                for (int32_t x : in) (void)ref.to_int(x);
+                for (int32_t x : between) (void)ids.to_int(x);
+                CHECK(ids.renumber_epoch == epoch, "naming ids bumped the renumbering epoch");
+                for (const uint32_t i : miss) out[i] = ids.to_int(in[i]);
+                CHECK(ids.ext2int == ref.ext2int && ids.int2ext == ref.int2ext && ids.n_int == ref.n_int && ids.n_parked == ref.n_parked &&
+                      ids.mv_origin == ref.mv_origin, "lookahead + resolve and to_int one by one leave different maps");
+                for (size_t i = 0; i < in.size(); ++i) // (a LIVE vertex never moves outside a renumbering: every entry is final)
+                    CHECK(out[i] == ids.ext2int[(size_t)in[i]] && out[i] < ids.n_int, "lookahead: ext %d -> %d, the map says %d", in[i], out[i], ids.ext2int[(size_t)in[i]]);
+                for (int32_t x : in) named.push_back(x);
+                for (int32_t x : between) named.push_back(x);
+            }
             for (int i = 0; i < n; ++i) {
                 const int x = (int)(rng() % (unsigned)cap);
                 const int m = ids.to_int(x);
