@@ -75,42 +75,63 @@ __global__ __launch_bounds__(BLOCK) void k_bin_vertex_block(const int *__restric
     for (int k = blockIdx.x * BLOCK + threadIdx.x; k <= n_blocks; k += gridDim.x * BLOCK) start[k] = row_ptr[cut[k]];
 }
 
-// out-orientation keys (row v << bits | head u, sorted) -> sort key (B-block of v, A-block of u); the value carried
-// through the sort is the edge itself
+// The two orders of the tables come out of two KEY-ONLY radix sorts of 64-bit words that carry everything the tables need (a
+// pair sort moves a 32-bit key and a 64-bit value: 12 bytes per entry and pass instead of 8, and the fill kernels looked the
+// blocks' first vertices up again):
+//   word 1 = B-block | A-block | row inside its B-block (BIN_RL bits) | head inside its A-block (BIN_HL bits)
+//            sorted by the two block fields, stable: the (row, head) order of the input survives inside a (B, A) cell -> B-major
+//   word 2 = A-block | B-major position (31 bits) | head inside its A-block
+//            sorted by the A-block field, stable -> A-major
+constexpr int BIN_RL = 13, BIN_HL = 15; // rows of a B-block <= 64 x BIN_MAX_HB_TILES = 7 680, heads of an A-block <= 64 x BIN_MAX_HA_TILES = 17 408
+constexpr int BIN_W2_POS = BIN_HL, BIN_W2_A = BIN_HL + 31;
+
+// The keys come in (row, head) order: consecutive entries share their row or its neighbours (vblk_b[v] is a cached, coalesced
+// read), the heads are random -- their A-block is found by bisection of the block cuts (a few thousand entries, staged in LDS when
+// they fit `cuts_in_lds` ints) instead of a random 4-byte gather per edge out of a V-sized table (361 M of them on the friendster
+// stand-in: 4.0 ms of a 40-ms slide).
 __global__ __launch_bounds__(BLOCK) void k_bin_keys(const uint64_t *__restrict__ out_keys, int Ed, int bits,
-                                                    const int *__restrict__ vblk_a, const int *__restrict__ vblk_b,
-                                                    int abits, uint32_t *__restrict__ k1) {
+                                                    const int *__restrict__ acut, int n_a, int cuts_in_lds,
+                                                    const int *__restrict__ vblk_b, const int *__restrict__ bcut, int abits,
+                                                    uint64_t *__restrict__ w1) {
+    extern __shared__ int s_acut[];
+    const int *cut = acut;
+    if (cuts_in_lds) {
+        for (int k = threadIdx.x; k <= n_a; k += BLOCK) s_acut[k] = acut[k];
+        __syncthreads();
+        cut = s_acut;
+    }
     const uint64_t mask = (1ull << bits) - 1;
     for (int o = blockIdx.x * BLOCK + threadIdx.x; o < Ed; o += gridDim.x * BLOCK) {
         const uint64_t k = out_keys[o];
         const int v = (int)(k >> bits), u = (int)(k & mask);
-        k1[o] = ((uint32_t)vblk_b[v] << abits) | (uint32_t)vblk_a[u];
+        int lo = 0, hi = n_a; // last block whose first vertex is <= u (k_bin_vertex_block's rule)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (cut[mid] <= u) lo = mid; else hi = mid;
+        }
+        const int b = vblk_b[v];
+        w1[o] = ((((uint64_t)(uint32_t)b << abits) | (uint64_t)(uint32_t)lo) << (BIN_RL + BIN_HL)) |
+                ((uint64_t)(uint32_t)(v - bcut[b]) << BIN_HL) | (uint64_t)(uint32_t)(u - cut[lo]);
     }
 }
 
-// B-major order reached: row index of every position, and the keys / values of the second (A-major) sort
-__global__ __launch_bounds__(BLOCK) void k_bin_fill_b(const uint64_t *__restrict__ edges_b, int Ed, int bits,
-                                                      const int *__restrict__ vblk_a, const int *__restrict__ vblk_b,
-                                                      const int *__restrict__ bcut, uint16_t *__restrict__ dl,
-                                                      uint32_t *__restrict__ k2, uint64_t *__restrict__ v2) {
-    const uint64_t mask = (1ull << bits) - 1;
+// B-major order reached: row index of every position, and the words of the second (A-major) sort
+__global__ __launch_bounds__(BLOCK) void k_bin_fill_b(const uint64_t *__restrict__ w1s, int Ed, int abits, uint16_t *__restrict__ dl,
+                                                      uint64_t *__restrict__ w2) {
+    const uint64_t amask = (1ull << abits) - 1ull;
     for (int q = blockIdx.x * BLOCK + threadIdx.x; q < Ed; q += gridDim.x * BLOCK) {
-        const uint64_t k = edges_b[q];
-        const int v = (int)(k >> bits), u = (int)(k & mask);
-        dl[q] = (uint16_t)(v - bcut[vblk_b[v]]);
-        k2[q] = (uint32_t)vblk_a[u];
-        v2[q] = ((uint64_t)(uint32_t)q << 32) | (uint32_t)u;
+        const uint64_t w = w1s[q];
+        dl[q] = (uint16_t)((w >> BIN_HL) & ((1u << BIN_RL) - 1u));
+        w2[q] = (((w >> (BIN_RL + BIN_HL)) & amask) << BIN_W2_A) | ((uint64_t)(uint32_t)q << BIN_W2_POS) | (w & ((1ull << BIN_HL) - 1ull));
     }
 }
 
 // A-major order reached: head index inside its block and B-major position of every entry
-__global__ __launch_bounds__(BLOCK) void k_bin_fill_a(const uint32_t *__restrict__ k2s, const uint64_t *__restrict__ v2s, int Ed,
-                                                      const int *__restrict__ acut, uint16_t *__restrict__ hl,
-                                                      int *__restrict__ apos) {
+__global__ __launch_bounds__(BLOCK) void k_bin_fill_a(const uint64_t *__restrict__ w2s, int Ed, uint16_t *__restrict__ hl, int *__restrict__ apos) {
     for (int j = blockIdx.x * BLOCK + threadIdx.x; j < Ed; j += gridDim.x * BLOCK) {
-        const uint64_t qu = v2s[j];
-        apos[j] = (int)(qu >> 32);
-        hl[j] = (uint16_t)((int)(qu & 0xffffffffu) - acut[k2s[j]]);
+        const uint64_t w = w2s[j];
+        apos[j] = (int)((w >> BIN_W2_POS) & 0x7fffffffull);
+        hl[j] = (uint16_t)(w & ((1ull << BIN_HL) - 1ull));
     }
 }
 

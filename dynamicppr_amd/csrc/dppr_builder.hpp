@@ -164,14 +164,21 @@ __global__ __launch_bounds__(BLOCK) void k_compact_keys(const uint64_t *__restri
 constexpr int HUB_MIN_DEGREE_DEFAULT = 256;
 __global__ __launch_bounds__(BLOCK) void k_deg_hist(const int *__restrict__ outdeg, int V, int min_deg,
                                                     int *__restrict__ hist) {
+    __shared__ int s_hist[32]; // (per-workgroup counts first: a vertex above min_deg is no rarity on a large window)
+    if (threadIdx.x < 32) s_hist[threadIdx.x] = 0;
+    __syncthreads();
     for (int v = blockIdx.x * BLOCK + threadIdx.x; v < V; v += gridDim.x * BLOCK) {
         const int d = outdeg[v];
-        if (d >= min_deg) atomicAdd(&hist[31 - __clz(d / min_deg)], 1);
+        if (d >= min_deg) atomicAdd(&s_hist[31 - __clz(d / min_deg)], 1);
     }
+    __syncthreads();
+    if (threadIdx.x < 32 && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
 }
-// hub_slot_of[v] = slot for vertices with outdeg >= thresh (first HUB_CAP takers), else -1
+// degp1_enc[v] = ~slot for vertices with outdeg >= thresh (first HUB_CAP takers), else outdeg + 1: what an Adj entry carries for
+// its tail, so that the CSR build gathers ONE word per edge (two -- slot, then degree -- were 361 M + 361 M random reads on the
+// friendster stand-in)
 __global__ __launch_bounds__(BLOCK) void k_assign_hubs(const int *__restrict__ outdeg, int V, int thresh,
-                                                       int *__restrict__ hub_slot_of, int *__restrict__ hub_v,
+                                                       int *__restrict__ degp1_enc, int *__restrict__ hub_v,
                                                        int *__restrict__ hub_degp1, int *__restrict__ n_hubs) {
     for (int v = blockIdx.x * BLOCK + threadIdx.x; v < V; v += gridDim.x * BLOCK) {
         int slot = -1;
@@ -185,14 +192,13 @@ __global__ __launch_bounds__(BLOCK) void k_assign_hubs(const int *__restrict__ o
                 slot = -1;
             }
         }
-        hub_slot_of[v] = slot;
+        degp1_enc[v] = slot >= 0 ? ~slot : d + 1;
     }
 }
 
 // sorted keys -> row_ptr + Adj entries (cusparseXcoo2csr + EdgePairGather, :214-220)
 __global__ __launch_bounds__(BLOCK) void k_build_csr(const uint64_t *__restrict__ skeys, int Ed, int V, int bits,
-                                                     const int *__restrict__ outdeg,
-                                                     const int *__restrict__ hub_slot_of, int *__restrict__ row_ptr,
+                                                     const int *__restrict__ degp1_enc, int *__restrict__ row_ptr,
                                                      Adj *__restrict__ adj) {
     const uint64_t mask = (1ull << bits) - 1;
     for (int j = blockIdx.x * BLOCK + threadIdx.x; j < Ed; j += gridDim.x * BLOCK) {
@@ -200,8 +206,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_csr(const uint64_t *__restrict_
         const int dst = (int)(k >> bits), src = (int)(k & mask);
         Adj a;
         a.v = src;
-        const int slot = hub_slot_of[src];
-        a.degp1 = slot >= 0 ? ~slot : outdeg[src] + 1; // negative: hub slot (see k_push_iter)
+        a.degp1 = degp1_enc[src]; // negative: hub slot (see k_push_iter)
         adj[j] = a;
         const int prev = (j == 0) ? -1 : (int)(skeys[j - 1] >> bits);
         for (int x = prev + 1; x <= dst; ++x) row_ptr[x] = j;

@@ -198,7 +198,7 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     bool loaded = false;
     bool broken = false; // a renumbering failed half way (HIP error after the host maps changed): every call but dppr_destroy is refused
     int *outdeg = nullptr;
-    int *hub_slot_of = nullptr; // V, scratch of the CSR build
+    int *hub_slot_of = nullptr; // V, scratch of the CSR build (k_assign_hubs: ~hub slot, or out-degree + 1)
     int *hub_hist = nullptr;    // 32 + 1 ints (histogram, hub counter)
     int hub_min_degree = HUB_MIN_DEGREE_DEFAULT;
     int big_row = BIG_ROW_DEFAULT;
@@ -256,7 +256,6 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     long long bin_target_a = 4ll << 20; // ... an A-block (its edges are dealt to workgroups of k_bin_scatter in chunks: large, so that tiles are long runs)
     long long bin_min_ids = 1ll << 19; // (smaller windows run resident or gather: R-MAT window of 2 M edges, ~0.65 M ids, single source: binned 2.66 ms per batch
                                        // against 3.26 gathering; window of 1 M edges, ~0.38 M ids: 2.45 against 1.47 -- tools/r04/midsize_probe.sh)
-    uint32_t *bin_k[2] = {nullptr, nullptr}; // sort keys (Ed each)
     int *bin_vblk_a = nullptr, *bin_vblk_b = nullptr; // vertex -> block (V each)
     int *bin_small = nullptr;       // quantile vertices | big rows | counter (bin_cut)
     long long bin_chunk = 32768;    // edges per workgroup of k_bin_scatter
@@ -911,6 +910,8 @@ bool bin_wanted(const dppr_engine *e) {
 constexpr int BIN_MAX_HA_TILES = 272, BIN_MAX_HB_TILES = 120;
 static_assert(BIN_MAX_HA_TILES * WAVE * (int)sizeof(double) + 4096 <= 160 * 1024, "k_bin_scatter: the largest A-block's slice of x + static LDS fits a gfx950 CU");
 static_assert(BIN_MAX_HB_TILES * WAVE * 20 + 4096 <= 160 * 1024, "k_bin_reduce: the largest B-block's rows + static LDS fit a gfx950 CU");
+static_assert(BIN_MAX_HB_TILES * WAVE <= (1 << BIN_RL) && BIN_MAX_HA_TILES * WAVE <= (1 << BIN_HL), "a row / head index inside its block fits its field of the sort words");
+static_assert(BIN_RL + BIN_HL + 32 <= 64 && BIN_W2_A + 16 <= 64, "sort words: two block numbers of <= 32 bits together, an A-block number of <= 16 bits (BIN_MAX_BLOCKS)");
 
 // An allocation of the (optional) binned-sweep tables that fails is not an error of the call that wanted them: the
 // partial allocations are released, the sticky HIP error is cleared and the epoch sweeps with k_pull_iter.
@@ -934,17 +935,15 @@ int bin_prepare(dppr_engine *e, bool *have) { // engine-level scratch, once (ide
     }
     const size_t Edn = (size_t)std::max(e->Ed, 1);
     bool ok = true;
-    for (int k = 0; k < 2; ++k) ok = ok && bin_alloc((void **)&e->bin_k[k], sizeof(uint32_t) * Edn);
     ok = ok && bin_alloc((void **)&e->bin_vblk_a, sizeof(int) * (size_t)e->V);
     ok = ok && bin_alloc((void **)&e->bin_vblk_b, sizeof(int) * (size_t)e->V);
     ok = ok && bin_alloc((void **)&e->bin_small, sizeof(int) * BIN_SMALL_INTS);
     ok = ok && bin_alloc((void **)&e->bin_vals, sizeof(double) * (Edn + 64));
     if (ok && !e->bin_tmp) {
-        HIP_TRY(rocprim::radix_sort_pairs(nullptr, e->bin_tmp_bytes, e->bin_k[0], e->bin_k[1], e->keys_a, e->keys_b, Edn, 0u, 32u, e->stream));
+        HIP_TRY(rocprim::radix_sort_keys(nullptr, e->bin_tmp_bytes, e->keys_a, e->keys_b, Edn, 0u, 64u, e->stream));
         ok = bin_alloc(&e->bin_tmp, std::max<size_t>(e->bin_tmp_bytes, 16));
     }
     if (!ok) { // out of memory: nothing half-built stays behind, the sweeps of this engine gather (k_pull_iter)
-        for (int k = 0; k < 2; ++k) { (void)hipFree(e->bin_k[k]); e->bin_k[k] = nullptr; }
         (void)hipFree(e->bin_vblk_a); (void)hipFree(e->bin_vblk_b); (void)hipFree(e->bin_small); (void)hipFree(e->bin_vals); (void)hipFree(e->bin_tmp);
         e->bin_vblk_a = e->bin_vblk_b = e->bin_small = nullptr;
         e->bin_vals = nullptr;
@@ -1040,22 +1039,21 @@ int build_bins(dppr_engine *e, Epoch &ep) {
     int *d_bstart = e->bin_small; // (not kept: a B-block's edges are out_row_ptr[bcut[b]] .. out_row_ptr[bcut[b + 1]])
     hipLaunchKernelGGL(k_bin_vertex_block, dim3(grid_for(NV)), dim3(BLOCK), 0, e->stream, ep.bcut, ep.n_b, NV, ep.out_row_ptr, e->bin_vblk_b, d_bstart);
     const uint64_t *out_keys = e->directed ? e->out_sorted : e->in_sorted;
-    hipLaunchKernelGGL(k_bin_keys, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->stream, out_keys, Ed, e->bits, e->bin_vblk_a, e->bin_vblk_b,
-                       abits, e->bin_k[0]);
+    const bool cuts_in_lds = (size_t)(ep.n_a + 1) * sizeof(int) <= 48 * 1024;
+    hipLaunchKernelGGL(k_bin_keys, dim3(grid_for(Ed)), dim3(BLOCK), cuts_in_lds ? (size_t)(ep.n_a + 1) * sizeof(int) : 0, e->stream, out_keys, Ed,
+                       e->bits, ep.acut, ep.n_a, cuts_in_lds ? 1 : 0, e->bin_vblk_b, ep.bcut, abits, e->keys_b);
     HIP_TRY(hipGetLastError());
     // chunks of the A-major runs (a block of many edges is dealt to several workgroups of k_bin_scatter)
     std::vector<int32_t> astart((size_t)ep.n_a + 1);
     HIP_TRY(hipMemcpyAsync(astart.data(), d_astart, sizeof(int) * astart.size(), hipMemcpyDeviceToHost, e->stream));
-    size_t tmp = e->bin_tmp_bytes; // B-major: stable by (B-block, A-block); the keys are in (row, head) order
-    HIP_TRY(rocprim::radix_sort_pairs(e->bin_tmp, tmp, e->bin_k[0], e->bin_k[1], out_keys, e->keys_a, (size_t)Ed, 0u,
-                                      (unsigned)(abits + bbits), e->stream));
-    hipLaunchKernelGGL(k_bin_fill_b, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->stream, e->keys_a, Ed, e->bits, e->bin_vblk_a,
-                       e->bin_vblk_b, ep.bcut, ep.dl, e->bin_k[0], e->keys_b);
+    size_t tmp = e->bin_tmp_bytes; // B-major: stable by (B-block, A-block); the words are in (row, head) order
+    HIP_TRY(rocprim::radix_sort_keys(e->bin_tmp, tmp, e->keys_b, e->keys_a, (size_t)Ed, (unsigned)(BIN_RL + BIN_HL),
+                                     (unsigned)(BIN_RL + BIN_HL + abits + bbits), e->stream));
+    hipLaunchKernelGGL(k_bin_fill_b, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->stream, e->keys_a, Ed, abits, ep.dl, e->keys_b);
     HIP_TRY(hipGetLastError());
     tmp = e->bin_tmp_bytes;        // A-major: the B-major sequence, stable by A-block
-    HIP_TRY(rocprim::radix_sort_pairs(e->bin_tmp, tmp, e->bin_k[0], e->bin_k[1], e->keys_b, e->keys_a, (size_t)Ed, 0u,
-                                      (unsigned)abits, e->stream));
-    hipLaunchKernelGGL(k_bin_fill_a, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->stream, e->bin_k[1], e->keys_a, Ed, ep.acut, ep.hl, ep.apos);
+    HIP_TRY(rocprim::radix_sort_keys(e->bin_tmp, tmp, e->keys_b, e->keys_a, (size_t)Ed, (unsigned)BIN_W2_A, (unsigned)(BIN_W2_A + abits), e->stream));
+    hipLaunchKernelGGL(k_bin_fill_a, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->stream, e->keys_a, Ed, ep.hl, ep.apos);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream)); // astart has arrived; the cuts are locals
     std::vector<BinChunk> chunks;
@@ -1110,7 +1108,7 @@ int build_epoch(dppr_engine *e, Epoch &ep) {
     }
     // row pointers are filled for the whole id capacity: ids assigned later read as empty rows
     hipLaunchKernelGGL(k_build_csr, dim3(grid_for(std::max(Ed, e->V + 1))), dim3(BLOCK), 0, e->stream, e->in_sorted, Ed,
-                       e->V, e->bits, e->outdeg, e->hub_slot_of, ep.row_ptr, ep.adj);
+                       e->V, e->bits, e->hub_slot_of, ep.row_ptr, ep.adj);
     hipLaunchKernelGGL(k_build_out_csr, dim3(grid_for(std::max(Ed, e->V + 1))), dim3(BLOCK), 0, e->stream,
                        e->directed ? e->out_sorted : e->in_sorted, Ed, e->V, e->bits, ep.out_row_ptr, ep.out_col);
     HIP_TRY(hipGetLastError());
@@ -2302,7 +2300,6 @@ void dppr_destroy(dppr_engine *e) {
         (void)hipFree(ep.acut); (void)hipFree(ep.chunks); (void)hipFree(ep.hl); (void)hipFree(ep.dl); (void)hipFree(ep.apos);
         (void)hipFree(ep.res_pk); (void)hipFree(ep.su_rng);
     }
-    for (int k = 0; k < 2; ++k) (void)hipFree(e->bin_k[k]);
     (void)hipFree(e->bin_vblk_a); (void)hipFree(e->bin_vblk_b); (void)hipFree(e->bin_small); (void)hipFree(e->bin_vals); (void)hipFree(e->bin_tmp);
     (void)hipFree(e->w1); (void)hipFree(e->w2); (void)hipFree(e->outdeg);
     (void)hipFree(e->bar);
