@@ -138,6 +138,31 @@ def test_cli_multiple_sources_one_gpu(pagerank, small_bin, tmp_path, extra, nsrc
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("directed", [1, 0])
+def test_cli_lookahead_on_and_off_give_the_same_run(pagerank, small_bin, tmp_path, directed):
+    """The id lookahead of the batch loop (dppr_hint_next_batch from a helper thread during the update; default without --validate)
+    against DPPR_NO_LOOKAHEAD=1: the same lines on stdout apart from the timings, the same vectors; with a stream long enough
+    that batches keep bringing vertices without an id (which the lookahead leaves to the call)."""
+    path, V, e1, e2 = small_bin
+    srcs = [int(x) for x in datagen.top_sources(V, e1, e2, 600, directed, 3)]
+    sf = tmp_path / "sources.txt"
+    sf.write_text("\n".join(map(str, srcs)) + "\n")
+    outs, dumps = [], []
+    for k, env in enumerate(({}, {"DPPR_NO_LOOKAHEAD": "1"})):
+        dump = str(tmp_path / f"out{k}.dump")
+        r = run([pagerank, "-d", path, "-a", "0", "-i", str(directed), "-y", "1", "-n", "1", "-c", "40", "-l", "1200",
+                 "--sources", str(sf), "--dump", dump, "-o", "1"], env_extra=env)
+        assert r.returncode == 0, r.stdout
+        timing = ("elapsed time=", "ppr_time", "ppr_latency", "ppr_throughput", "aggregate_ppr", "wall_ms")
+        outs.append([l for l in r.stdout.splitlines() if not l.startswith(timing)])
+        dumps.append(read_dump(dump))
+    assert outs[0] == outs[1]
+    assert "coming stream_batch_count=31" in "\n".join(outs[0])
+    for sv in srcs:      # (-o 1: the synchronous schedule -- only the arrival order of float atomics differs between two runs)
+        assert np.max(np.abs(dumps[0][sv][0] - dumps[1][sv][0])) < 1e-14 and np.max(np.abs(dumps[0][sv][1] - dumps[1][sv][1])) < 1e-14
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ngpu,nsrc", [(2, 5), (3, 10)])
 def test_cli_device_threads_share_the_device(pagerank, small_bin, tmp_path, ngpu, nsrc):
     """`./pagerank -g N --sources f --share-device`: the thread-per-device flow of pagerank_main.cpp (N host threads, each with
