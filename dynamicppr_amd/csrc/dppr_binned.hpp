@@ -115,6 +115,78 @@ __global__ __launch_bounds__(BLOCK) void k_bin_keys(const uint64_t *__restrict__
     }
 }
 
+// B-major order without a radix sort. The words arrive in (row, head) order, i.e. B-block-major already: what the first sort does is
+// group every B-block's segment by A-block, stably -- four radix passes over the whole window for a key of which the upper half is
+// sorted. Here one workgroup owns a B-block: a histogram of its segment over the A-blocks (LDS, all waves), an exclusive scan, and
+// then ONE wave walks the segment in order and places every word at (start of its A-block inside the segment + number of earlier
+// words of that A-block): the rank inside a 64-word step from ballots (one per bit of the A-block number: the lanes that agree in
+// every bit hold the same block; no memory access), the running starts in LDS (gathered once per step, advanced by the last lane of each A-block). Deterministic and equal to
+// the stable sort. A block that is ONE row (a hub alone in its block) is sorted already -- heads ascend -- and is copied by all waves.
+// Needs n_a <= BIN_CS_MAX_A counters; beyond, the radix sort stays.
+constexpr int BIN_CS_NT = 256, BIN_CS_MAX_A = 8192, BIN_CS_AHEAD = 8;
+__global__ __launch_bounds__(BIN_CS_NT) void k_bin_bmajor(const uint64_t *__restrict__ w1, const int *__restrict__ bstart,
+                                                          const int *__restrict__ bcut, int n_a, int n_pad, int abits,
+                                                          uint64_t *__restrict__ out) {
+    extern __shared__ int s_cnt[]; // n_pad (a power of two >= max(n_a, 64))
+    const int b = blockIdx.x, tid = threadIdx.x, lane = lane_id();
+    const int s0 = bstart[b], s1 = bstart[b + 1];
+    if (s1 <= s0) return;
+    if (bcut[b + 1] - bcut[b] == 1) { // one row: in order already
+        for (int i = s0 + tid; i < s1; i += BIN_CS_NT) out[i] = w1[i];
+        return;
+    }
+    const uint32_t amask = (1u << abits) - 1u;
+    for (int k = tid; k < n_pad; k += BIN_CS_NT) s_cnt[k] = 0;
+    __syncthreads();
+    for (int i = s0 + tid; i < s1; i += BIN_CS_NT) atomicAdd(&s_cnt[(uint32_t)(w1[i] >> (BIN_RL + BIN_HL)) & amask], 1);
+    __syncthreads();
+    if (tid >= WAVE) return; // the walk is one wave's (nothing below needs a workgroup barrier)
+    { // exclusive scan over the A-blocks: a lane sums its n_pad / 64 consecutive counters, the wave scans the lane sums
+        const int per = n_pad / WAVE;
+        int sum = 0;
+        for (int k = 0; k < per; ++k) sum += s_cnt[lane * per + k];
+        int run = s0 + wave_inclusive_scan(sum) - sum;
+        for (int k = 0; k < per; ++k) {
+            const int c = s_cnt[lane * per + k];
+            s_cnt[lane * per + k] = run;
+            run += c;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the starts are in LDS before the first step gathers them
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t gt = lane == WAVE - 1 ? 0ull : (~0ull << (lane + 1)); // the lanes above this one
+    for (int base = s0; base < s1; base += WAVE * BIN_CS_AHEAD) {
+        uint64_t w[BIN_CS_AHEAD];
+#pragma unroll
+        for (int h = 0; h < BIN_CS_AHEAD; ++h) { // the steps' words are requested together
+            const int i = base + h * WAVE + lane;
+            w[h] = i < s1 ? w1[i] : 0ull;
+        }
+#pragma unroll
+        for (int h = 0; h < BIN_CS_AHEAD; ++h) {
+            const int i = base + h * WAVE + lane;
+            const bool valid = i < s1;
+            const int a = (int)((uint32_t)(w[h] >> (BIN_RL + BIN_HL)) & amask);
+            uint64_t m = __ballot(valid); // -> the valid lanes of this step that hold the same A-block as this lane: one ballot per key bit
+            if (!m) break;
+            for (int bit = 0; bit < abits; ++bit) {
+                const bool set = (a >> bit) & 1;
+                const uint64_t bm = __ballot(valid && set);
+                m &= set ? bm : ~bm;
+            }
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            const bool last = (m & gt) == 0ull;
+            int pos = 0;
+            if (valid) pos = s_cnt[a] + rank;
+            __builtin_amdgcn_wave_barrier();
+            if (valid && last) s_cnt[a] = pos + 1;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            if (valid) out[pos] = w[h];
+        }
+    }
+}
+
 // B-major order reached: row index of every position, and the words of the second (A-major) sort
 __global__ __launch_bounds__(BLOCK) void k_bin_fill_b(const uint64_t *__restrict__ w1s, int Ed, int abits, uint16_t *__restrict__ dl,
                                                       uint64_t *__restrict__ w2) {

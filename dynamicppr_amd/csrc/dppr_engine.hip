@@ -1047,8 +1047,20 @@ int build_bins(dppr_engine *e, Epoch &ep) {
     std::vector<int32_t> astart((size_t)ep.n_a + 1);
     HIP_TRY(hipMemcpyAsync(astart.data(), d_astart, sizeof(int) * astart.size(), hipMemcpyDeviceToHost, e->stream));
     size_t tmp = e->bin_tmp_bytes; // B-major: stable by (B-block, A-block); the words are in (row, head) order
-    HIP_TRY(rocprim::radix_sort_keys(e->bin_tmp, tmp, e->keys_b, e->keys_a, (size_t)Ed, (unsigned)(BIN_RL + BIN_HL),
-                                     (unsigned)(BIN_RL + BIN_HL + abits + bbits), e->stream));
+    const char *placement = getenv("DPPR_BIN_PLACEMENT"); // (tests / A-B runs: "counting" wherever it can run -- small windows never qualify by themselves --, "radix" never)
+    const bool cs_force = placement && !strcmp(placement, "counting"), cs_never = placement && !strcmp(placement, "radix");
+    // every B-block's segment grouped by A-block in one pass (k_bin_bmajor) where the radix sort would need FOUR passes over its
+    // 8-bit digits (friendster stand-in, 26 bits: 6.0 ms against 8.9; with three -- twitter, 23 bits -- the sort wins, 3.0 against 3.8:
+    // the single pass scatters 8-byte words over thousands of runs, a radix pass over 256)
+    if (ep.n_a <= BIN_CS_MAX_A && (abits + bbits > 24 || cs_force) && !cs_never) {
+        int n_pad = WAVE;
+        while (n_pad < ep.n_a) n_pad *= 2;
+        hipLaunchKernelGGL(k_bin_bmajor, dim3(ep.n_b), dim3(BIN_CS_NT), sizeof(int) * (size_t)n_pad, e->stream, e->keys_b, d_bstart, ep.bcut, ep.n_a,
+                           n_pad, abits, e->keys_a);
+    } else {
+        HIP_TRY(rocprim::radix_sort_keys(e->bin_tmp, tmp, e->keys_b, e->keys_a, (size_t)Ed, (unsigned)(BIN_RL + BIN_HL),
+                                         (unsigned)(BIN_RL + BIN_HL + abits + bbits), e->stream));
+    }
     hipLaunchKernelGGL(k_bin_fill_b, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->stream, e->keys_a, Ed, abits, ep.dl, e->keys_b);
     HIP_TRY(hipGetLastError());
     tmp = e->bin_tmp_bytes;        // A-major: the B-major sequence, stable by A-block

@@ -1297,6 +1297,29 @@ def test_binned_tables_that_cannot_be_allocated_fall_back_to_gather_sweeps(monke
         assert (st["binned_sweeps"] == 0) if k < 2 else (st["binned_sweeps"] > 0), (k, st["binned_sweeps"])
 
 
+@pytest.mark.parametrize("shape", [(2, 1, 1, 64, 0, 64, 64), (2, 2, 3, 200, 0, 100, 500), (2, 0, 0, 0, 0)])
+@pytest.mark.parametrize("directed", [1, 0])
+def test_binned_tables_placed_by_counting_equal_the_sorted_ones(monkeypatch, directed, shape):
+    """The B-major order of the binned tables by k_bin_bmajor (a histogram + one ordered walk per B-block; chosen by itself only
+    where the radix sort would need four passes: friendster-size windows) forced on small windows (DPPR_BIN_PLACEMENT=counting):
+    dozens of tiny blocks, blocks of a few tiles -- hub rows alone in their block, which are copied --, and one block for
+    everything. The same stable order as the sort, so the sweeps do the oracle's work exactly and give its p / r to rounding."""
+    monkeypatch.setenv("DPPR_BIN_PLACEMENT", "counting")
+    sc = make(directed, schedule=eng.SCHEDULE_SYNC, scale=12, edges=60000, seed=5, W=20000, c=200,
+              tuning=dict(binned=shape, pull_min_frontier=1, persistent=0))
+    sc.s.sync_execute(sc.g)
+    sc.e.init_solve(sc.slot, sc.eps)
+    for k in range(4):
+        assert sc.advance_graphs()
+        sc.s.sync_inc_execute(sc.g)
+        sc.e.update(sc.slot, sc.eps)
+        p, r = sc.e.read(sc.slot)
+        assert np.max(np.abs(p - sc.s.p)) < SYNC_TOL and np.max(np.abs(r - sc.s.r)) < SYNC_TOL, k
+    st, w = sc.e.stats(sc.slot), sc.s.stats()
+    assert (st["iterations"], st["sum_F"], st["sum_E"]) == (w["iters"], w["F"], w["E"]) and st["binned_sweeps"] == st["pull_iterations"] > 0
+    sc.e.close()
+
+
 @pytest.mark.parametrize("directed", [1, 0])
 def test_lookahead_id_lookups_change_nothing(directed):
     """dppr_hint_next_batch: the next batch's id arrays announced before the update, looked up on helper
