@@ -386,7 +386,7 @@ bool translate(dppr_engine *e, const int32_t *src, int n, std::vector<int32_t> &
     if (k >= 0) {
         e->pre.src[k] = nullptr; // (consumed)
         dst.swap(e->pre.out[k]);
-        for (const uint32_t i : e->pre.miss[k]) dst[i] = e->to_int(src[i]);
+        e->resolve(src, dst.data(), e->pre.miss[k]);
         e->pre_hits++;
         e->pre_misses += (long long)e->pre.miss[k].size();
         return true;

@@ -109,8 +109,16 @@ struct IdSpace {
     // array order (a revival may move another parked vertex: parked entries are all resolved in that serial pass).
     bool translate(const int32_t *src, size_t n, int32_t *dst) {
         if (!lookup_only(src, n, dst, miss_scratch)) return false;
-        for (const uint32_t i : miss_scratch) dst[i] = to_int(src[i]);
+        resolve(src, dst, miss_scratch);
         return true;
+    }
+    // the entries a lookup left open, in array order (their map entries are cache misses on a large id range: asked for a few ahead)
+    void resolve(const int32_t *src, int32_t *dst, const std::vector<uint32_t> &miss) {
+        const size_t n = miss.size();
+        for (size_t k = 0; k < n; ++k) {
+            if (k + 8 < n) __builtin_prefetch(&ext2int[(size_t)src[miss[k + 8]]], 1);
+            dst[miss[k]] = to_int(src[miss[k]]);
+        }
     }
     std::vector<uint32_t> miss_scratch;
 
