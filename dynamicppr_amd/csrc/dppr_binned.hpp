@@ -64,7 +64,7 @@ __global__ __launch_bounds__(BLOCK) void k_bin_big_rows(const int *__restrict__ 
 __global__ __launch_bounds__(BLOCK) void k_bin_vertex_block(const int *__restrict__ cut, int n_blocks, int NV,
                                                             const int *__restrict__ row_ptr, int *__restrict__ vblk,
                                                             int *__restrict__ start) {
-    for (int v = blockIdx.x * BLOCK + threadIdx.x; v < NV; v += gridDim.x * BLOCK) {
+    for (int v = blockIdx.x * BLOCK + threadIdx.x; v < NV && vblk != nullptr; v += gridDim.x * BLOCK) { // (no table wanted: only the blocks' first entries)
         int lo = 0, hi = n_blocks; // last block whose first vertex is <= v
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;

@@ -256,7 +256,7 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     long long bin_target_a = 4ll << 20; // ... an A-block (its edges are dealt to workgroups of k_bin_scatter in chunks: large, so that tiles are long runs)
     long long bin_min_ids = 1ll << 19; // (smaller windows run resident or gather: R-MAT window of 2 M edges, ~0.65 M ids, single source: binned 2.66 ms per batch
                                        // against 3.26 gathering; window of 1 M edges, ~0.38 M ids: 2.45 against 1.47 -- tools/r04/midsize_probe.sh)
-    int *bin_vblk_a = nullptr, *bin_vblk_b = nullptr; // vertex -> block (V each)
+    int *bin_vblk_b = nullptr;      // vertex -> B-block (V ints; the A-block of a head is found by bisection, k_bin_keys)
     int *bin_small = nullptr;       // quantile vertices | big rows | counter (bin_cut)
     long long bin_chunk = 32768;    // edges per workgroup of k_bin_scatter
     double *bin_vals = nullptr;     // the values in B-major order: what pass 1 hands to pass 2 (one loop runs at a time)
@@ -935,7 +935,6 @@ int bin_prepare(dppr_engine *e, bool *have) { // engine-level scratch, once (ide
     }
     const size_t Edn = (size_t)std::max(e->Ed, 1);
     bool ok = true;
-    ok = ok && bin_alloc((void **)&e->bin_vblk_a, sizeof(int) * (size_t)e->V);
     ok = ok && bin_alloc((void **)&e->bin_vblk_b, sizeof(int) * (size_t)e->V);
     ok = ok && bin_alloc((void **)&e->bin_small, sizeof(int) * BIN_SMALL_INTS);
     ok = ok && bin_alloc((void **)&e->bin_vals, sizeof(double) * (Edn + 64));
@@ -944,8 +943,8 @@ int bin_prepare(dppr_engine *e, bool *have) { // engine-level scratch, once (ide
         ok = bin_alloc(&e->bin_tmp, std::max<size_t>(e->bin_tmp_bytes, 16));
     }
     if (!ok) { // out of memory: nothing half-built stays behind, the sweeps of this engine gather (k_pull_iter)
-        (void)hipFree(e->bin_vblk_a); (void)hipFree(e->bin_vblk_b); (void)hipFree(e->bin_small); (void)hipFree(e->bin_vals); (void)hipFree(e->bin_tmp);
-        e->bin_vblk_a = e->bin_vblk_b = e->bin_small = nullptr;
+        (void)hipFree(e->bin_vblk_b); (void)hipFree(e->bin_small); (void)hipFree(e->bin_vals); (void)hipFree(e->bin_tmp);
+        e->bin_vblk_b = e->bin_small = nullptr;
         e->bin_vals = nullptr;
         e->bin_tmp = nullptr;
         return DPPR_OK;
@@ -1035,7 +1034,7 @@ int build_bins(dppr_engine *e, Epoch &ep) {
     ep.bcut = d_astart + (ep.n_a + 1);
     HIP_TRY(hipMemcpyAsync(ep.acut, cut_a.data(), sizeof(int) * cut_a.size(), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(ep.bcut, cut_b.data(), sizeof(int) * cut_b.size(), hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(k_bin_vertex_block, dim3(grid_for(NV)), dim3(BLOCK), 0, e->stream, ep.acut, ep.n_a, NV, ep.row_ptr, e->bin_vblk_a, d_astart);
+    hipLaunchKernelGGL(k_bin_vertex_block, dim3(grid_for(NV)), dim3(BLOCK), 0, e->stream, ep.acut, ep.n_a, NV, ep.row_ptr, (int *)nullptr, d_astart);
     int *d_bstart = e->bin_small; // (not kept: a B-block's edges are out_row_ptr[bcut[b]] .. out_row_ptr[bcut[b + 1]])
     hipLaunchKernelGGL(k_bin_vertex_block, dim3(grid_for(NV)), dim3(BLOCK), 0, e->stream, ep.bcut, ep.n_b, NV, ep.out_row_ptr, e->bin_vblk_b, d_bstart);
     const uint64_t *out_keys = e->directed ? e->out_sorted : e->in_sorted;
@@ -2312,7 +2311,7 @@ void dppr_destroy(dppr_engine *e) {
         (void)hipFree(ep.acut); (void)hipFree(ep.chunks); (void)hipFree(ep.hl); (void)hipFree(ep.dl); (void)hipFree(ep.apos);
         (void)hipFree(ep.res_pk); (void)hipFree(ep.su_rng);
     }
-    (void)hipFree(e->bin_vblk_a); (void)hipFree(e->bin_vblk_b); (void)hipFree(e->bin_small); (void)hipFree(e->bin_vals); (void)hipFree(e->bin_tmp);
+    (void)hipFree(e->bin_vblk_b); (void)hipFree(e->bin_small); (void)hipFree(e->bin_vals); (void)hipFree(e->bin_tmp);
     (void)hipFree(e->w1); (void)hipFree(e->w2); (void)hipFree(e->outdeg);
     (void)hipFree(e->bar);
     (void)hipFree(e->res_arena);
