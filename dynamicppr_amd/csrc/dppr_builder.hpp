@@ -65,84 +65,72 @@ __device__ __forceinline__ int lower_bound_u64(const uint64_t *__restrict__ a, i
     return lo;
 }
 
-// keep[] is all ones on entry; the rank-th deletion of a key clears the rank-th instance
-__global__ __launch_bounds__(BLOCK) void k_mark_deleted(const uint64_t *__restrict__ sorted, int n,
-                                                        const uint64_t *__restrict__ del_sorted, int nd,
-                                                        uint8_t *__restrict__ keep) {
+// position in the persistent sorted keys of every key a slide retires: the rank-th deletion of a key takes its rank-th
+// instance. Ascending, because del_sorted is (a key that is not there -- never, on a consistent window -- gets n)
+__global__ __launch_bounds__(BLOCK) void k_del_positions(const uint64_t *__restrict__ sorted, int n,
+                                                         const uint64_t *__restrict__ del_sorted, int nd, int *__restrict__ delpos) {
     for (int j = blockIdx.x * BLOCK + threadIdx.x; j < nd; j += gridDim.x * BLOCK) {
         const uint64_t key = del_sorted[j];
         const int rank = j - lower_bound_u64(del_sorted, nd, key);
         const int pos = lower_bound_u64(sorted, n, key) + rank;
-        if (pos < n && sorted[pos] == key) keep[pos] = 0;
+        delpos[j] = (pos < n && sorted[pos] == key) ? pos : n;
     }
+}
+__device__ __forceinline__ int lower_bound_i32(const int *__restrict__ a, int n, int key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
 }
 
-// Compaction of the persistent sorted keys by the keep flags (f1: the kept keys, in order), in three small kernels:
-// kept entries per tile, exclusive scan of the tile counts (one workgroup), and the tiles' kept keys staged in LDS and written
-// out in whole lines. What it replaces is rocprim::select, which took 4.45 ms per 147 M 64-bit keys on the twitter stand-in
-// (0.5 TB/s; 11.7 ms on friendster's 361 M) -- three quarters of a slide's key merge; this moves the same 2.4 GB at the
-// machine's streaming rate.
-constexpr int CMP_TILE = 4096;                 // keys per workgroup
+// The key merge of a slide (f1) in ONE pass over the persistent sorted keys: a workgroup takes a tile of CMP_TILE old keys, drops
+// the retired ones (their positions: delpos), and merges what is left with the inserted keys that fall into the tile's key range
+// -- every key goes straight to its final place: tile start - retired before it + inserted before it, then the rank inside the
+// tile's merge (kept keys: binary search of the tile's inserted keys; inserted keys: of the kept ones in LDS; equal keys: old
+// before new). Round 4 first replaced rocprim::select (4.45 ms per 147 M keys) by a count / scan / compact triple followed by
+// rocprim::merge: 35 bytes per key in five kernels; this is 16.
+constexpr int CMP_TILE = 2048;                 // keys per workgroup (16 KB of LDS; 4 096: 1.30 / 1.92 ms per twitter / friendster array, 2 048: 0.98 / 1.36, 1 024: 1.24 / 1.85)
 constexpr int CMP_PER = CMP_TILE / BLOCK;      // ... per thread, strided (coalesced): element k * BLOCK + tid of the tile
-__global__ __launch_bounds__(BLOCK) void k_keep_count(const uint8_t *__restrict__ keep, int n, int *__restrict__ tile_cnt) {
-    __shared__ int s_w[WAVES_PER_BLOCK];
-    const int t0 = blockIdx.x * CMP_TILE;
-    int c = 0;
-#pragma unroll
-    for (int k = 0; k < CMP_PER; ++k) {
-        const int i = t0 + k * BLOCK + (int)threadIdx.x;
-        c += i < n && keep[i] ? 1 : 0;
-    }
-    const int ws = wave_inclusive_scan(c);
-    if (lane_id() == WAVE - 1) s_w[wave_id()] = ws;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int tot = 0;
-#pragma unroll
-        for (int w = 0; w < WAVES_PER_BLOCK; ++w) tot += s_w[w];
-        tile_cnt[blockIdx.x] = tot;
-    }
-}
-// exclusive scan of n_tiles counts in place (one workgroup of 1024 threads)
-__global__ __launch_bounds__(1024) void k_tile_scan(int *__restrict__ tile_cnt, int n_tiles) {
-    __shared__ int s_w[16];
-    __shared__ int s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n_tiles; base += 1024) {
-        const int i = base + (int)threadIdx.x;
-        const int c = i < n_tiles ? tile_cnt[i] : 0;
-        const int inc = wave_inclusive_scan(c);
-        if (lane_id() == WAVE - 1) s_w[wave_id()] = inc;
-        __syncthreads();
-        int woff = 0;
-        for (int k = 0; k < wave_id(); ++k) woff += s_w[k];
-        const int carry = s_carry;
-        if (i < n_tiles) tile_cnt[i] = carry + woff + inc - c;
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + woff + inc;
-        __syncthreads();
-    }
-}
-__global__ __launch_bounds__(BLOCK) void k_compact_keys(const uint64_t *__restrict__ keys, const uint8_t *__restrict__ keep, int n,
-                                                         const int *__restrict__ tile_off, uint64_t *__restrict__ out) {
-    __shared__ uint64_t s_out[CMP_TILE];
+constexpr int CMP_INS_LDS = 256;               // inserted keys of a tile searched in LDS when they are at most this many
+__global__ __launch_bounds__(BLOCK) void k_merge_tiles(const uint64_t *__restrict__ keys, int n, const int *__restrict__ delpos, int nd,
+                                                       const uint64_t *__restrict__ ins, int ni, uint64_t *__restrict__ out) {
+    __shared__ uint64_t s_key[CMP_TILE];
+    __shared__ uint64_t s_ins[CMP_INS_LDS];
+    __shared__ uint32_t s_del[CMP_TILE / 32];
     __shared__ int s_cnt[CMP_PER * WAVES_PER_BLOCK + 1];
-    const int t0 = blockIdx.x * CMP_TILE, lane = lane_id(), w = wave_id();
+    __shared__ int s_b[4];
+    const int tid = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+    const int t0 = blockIdx.x * CMP_TILE, t1 = min(n, t0 + CMP_TILE);
+    if (tid < CMP_TILE / 32) s_del[tid] = 0u;
+    if (tid == 0) s_b[0] = lower_bound_i32(delpos, nd, t0);
+    if (tid == 1) s_b[1] = lower_bound_i32(delpos, nd, t1);
+    if (tid == 2) s_b[2] = blockIdx.x == 0 ? 0 : lower_bound_u64(ins, ni, keys[t0]); // (keys below the first old key: the first tile's)
+    if (tid == 3) s_b[3] = t1 < n ? lower_bound_u64(ins, ni, keys[t1]) : ni;
+    __syncthreads();
+    const int d0 = s_b[0], d1 = s_b[1], k0 = s_b[2], k1 = s_b[3], nk = k1 - k0;
+    for (int d = d0 + tid; d < d1; d += BLOCK) {
+        const int o = delpos[d] - t0;
+        atomicOr(&s_del[o >> 5], 1u << (o & 31));
+    }
+    if (nk <= CMP_INS_LDS)
+        for (int k = tid; k < nk; k += BLOCK) s_ins[k] = ins[k0 + k];
+    __syncthreads();
     uint64_t key[CMP_PER];
     bool kp[CMP_PER];
     int rank[CMP_PER];
 #pragma unroll
     for (int k = 0; k < CMP_PER; ++k) { // coalesced: consecutive lanes, consecutive keys
-        const int i = t0 + k * BLOCK + (int)threadIdx.x;
-        kp[k] = i < n && keep[i];
-        key[k] = i < n ? keys[i] : 0ull;
+        const int o = k * BLOCK + tid, i = t0 + o;
+        kp[k] = i < t1 && !((s_del[o >> 5] >> (o & 31)) & 1u);
+        key[k] = i < t1 ? keys[i] : 0ull;
         const uint64_t bal = __ballot(kp[k]);
         rank[k] = mbcnt(bal);
         if (lane == 0) s_cnt[k * WAVES_PER_BLOCK + w] = __popcll(bal);
     }
     __syncthreads();
-    if (threadIdx.x == 0) { // the (k, wave) pieces are consecutive runs of the tile: their kept counts -> starts
+    if (tid == 0) { // the (k, wave) pieces are consecutive runs of the tile: their kept counts -> starts
         int run = 0;
         for (int q = 0; q < CMP_PER * WAVES_PER_BLOCK; ++q) {
             const int c = s_cnt[q];
@@ -154,10 +142,29 @@ __global__ __launch_bounds__(BLOCK) void k_compact_keys(const uint64_t *__restri
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < CMP_PER; ++k)
-        if (kp[k]) s_out[s_cnt[k * WAVES_PER_BLOCK + w] + rank[k]] = key[k];
+        if (kp[k]) s_key[s_cnt[k * WAVES_PER_BLOCK + w] + rank[k]] = key[k];
     __syncthreads();
-    const int kept = s_cnt[CMP_PER * WAVES_PER_BLOCK], base = tile_off[blockIdx.x];
-    for (int i = threadIdx.x; i < kept; i += BLOCK) out[(size_t)base + i] = s_out[i];
+    const int kept = s_cnt[CMP_PER * WAVES_PER_BLOCK];
+    const size_t base = (size_t)(t0 - d0) + (size_t)k0;
+    const uint64_t *tin = nk <= CMP_INS_LDS ? s_ins : ins + k0; // (generic address space: LDS or global)
+    for (int j = tid; j < kept; j += BLOCK) { // an old key: after the inserted keys below it
+        const uint64_t kk = s_key[j];
+        int lo = 0, hi = nk;
+        while (lo < hi) {
+            const int mid = lo + ((hi - lo) >> 1);
+            if (tin[mid] < kk) lo = mid + 1; else hi = mid;
+        }
+        out[base + (size_t)j + (size_t)lo] = kk;
+    }
+    for (int k = tid; k < nk; k += BLOCK) { // an inserted key: after the old keys up to and including it
+        const uint64_t kk = tin[k];
+        int lo = 0, hi = kept;
+        while (lo < hi) {
+            const int mid = lo + ((hi - lo) >> 1);
+            if (s_key[mid] <= kk) lo = mid + 1; else hi = mid;
+        }
+        out[base + (size_t)k + (size_t)lo] = kk;
+    }
 }
 
 // hub selection: hist[b] = #vertices with min_deg * 2^b <= outdeg < min_deg * 2^(b+1)

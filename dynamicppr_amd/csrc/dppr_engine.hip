@@ -209,10 +209,10 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     uint64_t *keys_a = nullptr, *keys_b = nullptr;
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
-    // incremental maintenance (f1): batch keys, keep flags, select/merge scratch
+    // incremental maintenance (f1): batch keys, positions of the retired keys
     uint64_t *bk[4] = {nullptr, nullptr, nullptr, nullptr}; // del-in, ins-in, del-out, ins-out (unsorted)
     uint64_t *bks[4] = {nullptr, nullptr, nullptr, nullptr}; // the same, sorted
-    uint8_t *keep = nullptr;
+    int *delpos = nullptr; // positions of a slide's retired keys in the persistent sorted keys (2 * max_batch)
     struct Pre { // dppr_hint_next_batch
         std::future<bool> task;
         const int32_t *src[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -223,9 +223,6 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
         bool armed = false, ok = false;
     } pre;
     long long pre_hits = 0, pre_misses = 0; // id arrays that dppr_set_batch / dppr_slide took from the lookahead; entries resolved at the call
-    int *cmp_tiles = nullptr; // kept keys per tile of the sorted keys / their starts (key merge of a slide)
-    void *inc_tmp = nullptr;
-    size_t inc_tmp_bytes = 0;
     bool incremental = true; // dppr_slide merges the batch into the sorted keys (false: full re-sort)
     bool sweep_bits = false;        // per-iteration single-source sweeps test an activity bitmap before each gather (dppr_set_sweep_bitmap;
                                     // measured slower on every stand-in, DESIGN.md section 6: off unless asked for)
@@ -762,18 +759,11 @@ int merge_batch_keys(dppr_engine *e, uint64_t *&sorted, uint64_t *del_unsorted, 
     tmp = e->sort_tmp_bytes;
     HIP_TRY(rocprim::radix_sort_keys(e->sort_tmp, tmp, ins_unsorted, ins_sorted, (size_t)ni, 0u, (unsigned)(2 * e->bits),
                                      e->stream));
-    HIP_TRY(hipMemsetAsync(e->keep, 1, (size_t)Ed, e->stream));
-    hipLaunchKernelGGL(k_mark_deleted, dim3(grid_for(nd)), dim3(BLOCK), 0, e->stream, sorted, Ed, del_sorted, nd, e->keep);
-    HIP_TRY(hipGetLastError());
-    // the kept keys, in order (dppr_builder.hpp: count per tile, scan, compact -- in place of rocprim::select)
+    // retired positions, then one pass: every kept and every inserted key straight to its place (dppr_builder.hpp k_merge_tiles)
+    hipLaunchKernelGGL(k_del_positions, dim3(grid_for(nd)), dim3(BLOCK), 0, e->stream, sorted, Ed, del_sorted, nd, e->delpos);
     const int n_tiles = (Ed + CMP_TILE - 1) / CMP_TILE;
-    hipLaunchKernelGGL(k_keep_count, dim3(n_tiles), dim3(BLOCK), 0, e->stream, e->keep, Ed, e->cmp_tiles);
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, e->stream, e->cmp_tiles, n_tiles);
-    hipLaunchKernelGGL(k_compact_keys, dim3(n_tiles), dim3(BLOCK), 0, e->stream, sorted, e->keep, Ed, e->cmp_tiles, e->keys_a);
+    hipLaunchKernelGGL(k_merge_tiles, dim3(n_tiles), dim3(BLOCK), 0, e->stream, sorted, Ed, e->delpos, nd, ins_sorted, ni, e->keys_b);
     HIP_TRY(hipGetLastError());
-    tmp = e->inc_tmp_bytes;
-    HIP_TRY(rocprim::merge(e->inc_tmp, tmp, e->keys_a, ins_sorted, e->keys_b, (size_t)(Ed - nd), (size_t)ni,
-                           rocprim::less<uint64_t>(), e->stream));
     std::swap(sorted, e->keys_b); // the merged array is the new persistent one; the old becomes scratch
     return DPPR_OK;
 }
@@ -2242,19 +2232,13 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     HIP_TRY_C(hipMalloc((void **)&e->keys_b, sizeof(uint64_t) * Edn));
     HIP_TRY_C(hipMalloc((void **)&e->in_sorted, sizeof(uint64_t) * Edn));
     if (e->directed) HIP_TRY_C(hipMalloc((void **)&e->out_sorted, sizeof(uint64_t) * Edn));
-    HIP_TRY_C(hipMalloc((void **)&e->keep, Edn));
-    HIP_TRY_C(hipMalloc((void **)&e->cmp_tiles, sizeof(int) * (Edn / CMP_TILE + 2)));
+    HIP_TRY_C(hipMalloc((void **)&e->delpos, sizeof(int) * ((size_t)2 * (size_t)std::max(c, 1) + 16)));
     {
         const size_t bn = (size_t)std::max(2 * c, 1);
         for (int k = 0; k < 4; ++k) {
             HIP_TRY_C(hipMalloc((void **)&e->bk[k], sizeof(uint64_t) * bn));
             HIP_TRY_C(hipMalloc((void **)&e->bks[k], sizeof(uint64_t) * bn));
         }
-        size_t a = 0, b = 0;
-        HIP_TRY_C(rocprim::merge(nullptr, b, e->keys_a, e->bks[1], e->keys_b, Edn, bn, rocprim::less<uint64_t>(),
-                                 e->stream));
-        e->inc_tmp_bytes = std::max(a, b);
-        HIP_TRY_C(hipMalloc(&e->inc_tmp, std::max<size_t>(e->inc_tmp_bytes, 16)));
     }
     HIP_TRY_C(rocprim::radix_sort_keys(nullptr, e->sort_tmp_bytes, e->keys_a, e->keys_b, Edn, 0u,
                                        (unsigned)(2 * e->bits), e->stream));
@@ -2318,7 +2302,7 @@ void dppr_destroy(dppr_engine *e) {
     (void)hipFree(e->hub_slot_of); (void)hipFree(e->hub_hist); (void)hipFree(e->d_ext2int); (void)hipFree(e->d_xfer);
     (void)hipFree(e->mv_idx); (void)hipFree(e->mv_tmp);
     (void)hipFree(e->keys_a); (void)hipFree(e->keys_b); (void)hipFree(e->sort_tmp);
-    (void)hipFree(e->in_sorted); (void)hipFree(e->out_sorted); (void)hipFree(e->keep); (void)hipFree(e->inc_tmp); (void)hipFree(e->cmp_tiles);
+    (void)hipFree(e->in_sorted); (void)hipFree(e->out_sorted); (void)hipFree(e->delpos);
     for (int k = 0; k < 4; ++k) { (void)hipFree(e->bk[k]); (void)hipFree(e->bks[k]); }
     for (int k = 0; k < 2; ++k) { (void)hipFree(e->su_k[k]); (void)hipFree(e->su_v[k]); }
     (void)hipFree(e->su_term); (void)hipFree(e->su_ins); (void)hipFree(e->su_tmp);

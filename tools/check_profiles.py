@@ -56,7 +56,7 @@ def cut(trace_csv, stats_csv, outdir):
         marks.append(j if j >= 0 and ev[j][0] == "k_su_keys" else i)
     batches = [(marks[i], marks[i + 1]) for i in range(len(marks) - 1)]
     spans = []
-    slide_kernels = ("k_make", "k_deg", "k_mark", "k_build", "k_assign", "k_tile", "k_gather_deg", "k_gtables", "k_bin_keys", "k_bin_fill", "k_bin_vertex",
+    slide_kernels = ("k_make", "k_deg", "k_mark", "k_del_pos", "k_merge_tiles", "k_build", "k_assign", "k_tile", "k_gather_deg", "k_gtables", "k_bin_keys", "k_bin_fill", "k_bin_vertex",
                      "k_bin_quant", "k_bin_big", "k_in_degree", "k_number", "k_live", "k_remap", "k_permute", "k_rows", "k_res_")
     for lo, hi in batches:                                                       # a batch ends where the next slide's kernels begin
         seg = []
