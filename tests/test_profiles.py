@@ -58,3 +58,25 @@ def test_the_cut_finds_a_batch_in_each_of_its_forms(tmp_path):
         assert tl["batches_in_run"] == 3, (form, tl["batches_in_run"])       # four marks delimit three complete batches
         assert len(tl["iteration_kernel_durations_us"]) == sum(n.startswith(("k_gsweep", "k_pull")) for n in batch), form
         assert not any(n.startswith(("k_make", "k_build", "rocprim::radix_sort_onesweep")) for n in tl["kernels"]), (form, tl["kernels"])
+
+
+def test_the_gap_report_reads_a_kernel_trace(tmp_path):
+    """tools/r04/gaps.py on a synthetic trace: batches from one IncrementalBatchUpdate kernel to the next (the slide's kernels at
+    a batch's tail are not part of it), idle time = span - busy, every gap above 5 us listed with the kernels around it."""
+    rows, t = [], 1000
+    for b in range(5):
+        for n, dur, gap in [("k_su_terms", 30000, 0), ("k_su_apply", 80000, 500), ("k_gsweep<2, 10, 512, false, 0>", 150000, 500),
+                            ("__amd_rocclr_copyBuffer", 4000, 500), ("k_gsweep<2, 10, 512, false, 1>", 160000, 22000),
+                            ("k_make_keys_seg", 9000, 40000), ("k_build_csr", 500000, 500)]:
+            t += gap
+            rows.append((n, t, t + dur))
+            t += dur
+    with open(tmp_path / "trace.csv", "w") as f:
+        f.write('"Kernel_Name","Start_Timestamp","End_Timestamp"\n')
+        for n, a, b in rows:
+            f.write(f'"{n}",{a},{b}\n')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "r04", "gaps.py"), str(tmp_path / "trace.csv")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "4 batches; median span 447.5 us, 5 dispatches" in r.stdout, r.stdout
+    assert "busy 424.0 us, idle 23.5 us" in r.stdout and "gap   22.0 us  after __amd_rocclr_copyBuffer" in r.stdout and "gaps > 5 us: 22.0 us" in r.stdout, r.stdout
+
