@@ -95,7 +95,7 @@ constexpr int CMP_TILE = 2048;                 // keys per workgroup (16 KB of L
 constexpr int CMP_PER = CMP_TILE / BLOCK;      // ... per thread, strided (coalesced): element k * BLOCK + tid of the tile
 constexpr int CMP_INS_LDS = 256;               // inserted keys of a tile searched in LDS when they are at most this many
 __global__ __launch_bounds__(BLOCK) void k_merge_tiles(const uint64_t *__restrict__ keys, int n, const int *__restrict__ delpos, int nd,
-                                                       const uint64_t *__restrict__ ins, int ni, uint64_t *__restrict__ out) {
+                                                       const uint64_t *__restrict__ ins, int ni, uint64_t *__restrict__ out, size_t n_out) {
     __shared__ uint64_t s_key[CMP_TILE];
     __shared__ uint64_t s_ins[CMP_INS_LDS];
     __shared__ uint32_t s_del[CMP_TILE / 32];
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(BLOCK) void k_merge_tiles(const uint64_t *__restric
             const int mid = lo + ((hi - lo) >> 1);
             if (tin[mid] < kk) lo = mid + 1; else hi = mid;
         }
-        out[base + (size_t)j + (size_t)lo] = kk;
+        if (base + (size_t)j + (size_t)lo < n_out) out[base + (size_t)j + (size_t)lo] = kk; // (n_out: a retired key that was not there must not push the tail past the array)
     }
     for (int k = tid; k < nk; k += BLOCK) { // an inserted key: after the old keys up to and including it
         const uint64_t kk = tin[k];
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(BLOCK) void k_merge_tiles(const uint64_t *__restric
             const int mid = lo + ((hi - lo) >> 1);
             if (s_key[mid] <= kk) lo = mid + 1; else hi = mid;
         }
-        out[base + (size_t)k + (size_t)lo] = kk;
+        if (base + (size_t)k + (size_t)lo < n_out) out[base + (size_t)k + (size_t)lo] = kk;
     }
 }
 

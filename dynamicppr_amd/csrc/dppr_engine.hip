@@ -762,7 +762,8 @@ int merge_batch_keys(dppr_engine *e, uint64_t *&sorted, uint64_t *del_unsorted, 
     // retired positions, then one pass: every kept and every inserted key straight to its place (dppr_builder.hpp k_merge_tiles)
     hipLaunchKernelGGL(k_del_positions, dim3(grid_for(nd)), dim3(BLOCK), 0, e->stream, sorted, Ed, del_sorted, nd, e->delpos);
     const int n_tiles = (Ed + CMP_TILE - 1) / CMP_TILE;
-    hipLaunchKernelGGL(k_merge_tiles, dim3(n_tiles), dim3(BLOCK), 0, e->stream, sorted, Ed, e->delpos, nd, ins_sorted, ni, e->keys_b);
+    hipLaunchKernelGGL(k_merge_tiles, dim3(n_tiles), dim3(BLOCK), 0, e->stream, sorted, Ed, e->delpos, nd, ins_sorted, ni, e->keys_b,
+                       (size_t)Ed - (size_t)nd + (size_t)ni);
     HIP_TRY(hipGetLastError());
     std::swap(sorted, e->keys_b); // the merged array is the new persistent one; the old becomes scratch
     return DPPR_OK;
