@@ -112,7 +112,7 @@ __global__ __launch_bounds__(BLOCK) void k_merge_tiles(const uint64_t *__restric
     const int d0 = s_b[0], d1 = s_b[1], k0 = s_b[2], k1 = s_b[3], nk = k1 - k0;
     for (int d = d0 + tid; d < d1; d += BLOCK) {
         const int o = delpos[d] - t0;
-        atomicOr(&s_del[o >> 5], 1u << (o & 31));
+        if ((unsigned)o < (unsigned)CMP_TILE) atomicOr(&s_del[o >> 5], 1u << (o & 31)); // (always, while delpos ascends)
     }
     if (nk <= CMP_INS_LDS)
         for (int k = tid; k < nk; k += BLOCK) s_ins[k] = ins[k0 + k];
