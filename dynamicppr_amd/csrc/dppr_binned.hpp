@@ -132,13 +132,31 @@ __global__ __launch_bounds__(BIN_CS_NT) void k_bin_bmajor(const uint64_t *__rest
     const int s0 = bstart[b], s1 = bstart[b + 1];
     if (s1 <= s0) return;
     if (bcut[b + 1] - bcut[b] == 1) { // one row: in order already
-        for (int i = s0 + tid; i < s1; i += BIN_CS_NT) out[i] = w1[i];
+        int i = s0 + tid;
+        for (; i + 7 * BIN_CS_NT < s1; i += 8 * BIN_CS_NT) { // (a hub's row can hold a million words: eight loads in flight per thread)
+            uint64_t w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[k] = w1[i + k * BIN_CS_NT];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) out[i + k * BIN_CS_NT] = w[k];
+        }
+        for (; i < s1; i += BIN_CS_NT) out[i] = w1[i];
         return;
     }
     const uint32_t amask = (1u << abits) - 1u;
     for (int k = tid; k < n_pad; k += BIN_CS_NT) s_cnt[k] = 0;
     __syncthreads();
-    for (int i = s0 + tid; i < s1; i += BIN_CS_NT) atomicAdd(&s_cnt[(uint32_t)(w1[i] >> (BIN_RL + BIN_HL)) & amask], 1);
+    {
+        int i = s0 + tid;
+        for (; i + 3 * BIN_CS_NT < s1; i += 4 * BIN_CS_NT) { // (four loads in flight per thread)
+            uint64_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = w1[i + k * BIN_CS_NT];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) atomicAdd(&s_cnt[(uint32_t)(w[k] >> (BIN_RL + BIN_HL)) & amask], 1);
+        }
+        for (; i < s1; i += BIN_CS_NT) atomicAdd(&s_cnt[(uint32_t)(w1[i] >> (BIN_RL + BIN_HL)) & amask], 1);
+    }
     __syncthreads();
     if (tid >= WAVE) return; // the walk is one wave's (nothing below needs a workgroup barrier)
     { // exclusive scan over the A-blocks: a lane sums its n_pad / 64 consecutive counters, the wave scans the lane sums
@@ -155,12 +173,19 @@ __global__ __launch_bounds__(BIN_CS_NT) void k_bin_bmajor(const uint64_t *__rest
     __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the starts are in LDS before the first step gathers them
     __builtin_amdgcn_wave_barrier();
     const uint64_t gt = lane == WAVE - 1 ? 0ull : (~0ull << (lane + 1)); // the lanes above this one
+    uint64_t nxt[BIN_CS_AHEAD]; // the words of the NEXT run of steps are requested before this run's are placed
+#pragma unroll
+    for (int h = 0; h < BIN_CS_AHEAD; ++h) {
+        const int i = s0 + h * WAVE + lane;
+        nxt[h] = i < s1 ? w1[i] : 0ull;
+    }
     for (int base = s0; base < s1; base += WAVE * BIN_CS_AHEAD) {
         uint64_t w[BIN_CS_AHEAD];
 #pragma unroll
-        for (int h = 0; h < BIN_CS_AHEAD; ++h) { // the steps' words are requested together
-            const int i = base + h * WAVE + lane;
-            w[h] = i < s1 ? w1[i] : 0ull;
+        for (int h = 0; h < BIN_CS_AHEAD; ++h) {
+            w[h] = nxt[h];
+            const int i = base + WAVE * BIN_CS_AHEAD + h * WAVE + lane;
+            nxt[h] = i < s1 ? w1[i] : 0ull;
         }
 #pragma unroll
         for (int h = 0; h < BIN_CS_AHEAD; ++h) {
