@@ -53,15 +53,18 @@ PLANS = {
     "twitter": (0, "top10"), "friendster": (0, "top1000"),
 }
 
-# committed rocprofv3 --pmc summaries (tools/r04/pmc_fabric.sh: requests by size) of the dominant kernel per workload
+# committed rocprofv3 --pmc summaries (tools/r05/pmc_fabric.sh: requests by size) of the dominant kernel per workload. Each carries
+# the build id of the library that ran under the counters ("_stamp"); a file from another build is REFUSED (traffic: null + reason)
+PMC_ROUND = "r05"
 PMC_FILES = {
-    ("youtube", 1): ("profiles/r04_pmc_fabric_youtube_1src.json", ("k_pull_resident",)),
-    ("livejournal", 10): ("profiles/r04_pmc_fabric_livejournal_group10.json", ("k_gsweep",)),
-    ("livejournal", 1): ("profiles/r04_pmc_fabric_livejournal_1src.json", ("k_bin_scatter", "k_bin_reduce")),
-    ("twitter", 8): ("profiles/r04_pmc_fabric_twitter_group8.json", ("k_gsweep",)),
-    ("twitter", 1): ("profiles/r04_pmc_fabric_twitter_1src.json", ("k_bin_scatter", "k_bin_reduce")),
-    ("friendster", 1): ("profiles/r04_pmc_fabric_friendster_1src.json", ("k_bin_scatter", "k_bin_reduce")),
-    ("friendster", 10): ("profiles/r04_pmc_fabric_friendster_group10.json", ("k_gsweep",)),
+    ("youtube", 1): ("pmc_fabric_youtube_1src.json", ("k_pull_resident",)),
+    ("dblp", 1): ("pmc_fabric_dblp_1src.json", ("k_pull_resident",)),
+    ("livejournal", 10): ("pmc_fabric_livejournal_group10.json", ("k_gsweep",)),
+    ("livejournal", 1): ("pmc_fabric_livejournal_1src.json", ("k_bin_scatter", "k_bin_reduce")),
+    ("twitter", 8): ("pmc_fabric_twitter_group8.json", ("k_gsweep",)),
+    ("twitter", 1): ("pmc_fabric_twitter_1src.json", ("k_bin_scatter", "k_bin_reduce")),
+    ("friendster", 1): ("pmc_fabric_friendster_1src.json", ("k_bin_scatter", "k_bin_reduce")),
+    ("friendster", 10): ("pmc_fabric_friendster_group10.json", ("k_gsweep",)),
 }
 
 
@@ -85,6 +88,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-group", action="store_true", help="two sources per GPU on a large window as a source group (default there: one after the other)")
     ap.add_argument("--no-merged", action="store_true", help="skip the extra pass with the merged loop (N = 1 only)")
+    ap.add_argument("--no-ceilings", action="store_true", help="skip the calibration probes (line fills, atomics, streaming copy)")
+    ap.add_argument("--no-extra-passes", action="store_true", help="skip the at-slide-accounting pass (N = 1 only)")
     ap.add_argument("--no-extra", action="store_true",
                     help="default workload at N = 1 only: do not append the configs[1] (single source, resident path) line")
     ap.add_argument("--group", type=int, default=None, help=argparse.SUPPRESS)  # old spelling of --sources
@@ -99,9 +104,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # `python bench.py --gpus N` typed as such: become the launcher. Nothing in this process has touched HIP (torch is not
+        # even imported yet), and the ranks are CHILD processes -- never an exec of a process that holds the GPU.
+        sys.exit(self_launch(a.gpus))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
         a.gpus = world
 
     # torch first: its bundled HIP runtime and ours share one SONAME, the first one loaded wins
@@ -118,16 +125,20 @@ def main():
         local_rank %= ndev
     torch.cuda.set_device(local_rank)
     if world > 1:
-        # RCCL (backend "nccl") carries only the barrier and two scalar reductions; if it cannot come up
-        # on this node the same three calls work over gloo -- the data path has no collective either way
-        try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            dist.barrier()
-        except Exception as exc:  # noqa: BLE001
-            print(f"[rank {rank}] RCCL init failed ({exc}); falling back to gloo", file=sys.stderr, flush=True)
-            if dist.is_initialized():
-                dist.destroy_process_group()
+        # RCCL (backend "nccl") carries only the barrier and a few scalar reductions; where ranks share a device (more ranks
+        # than GPUs: RCCL refuses two ranks on one device) or it cannot come up on this node, the same calls work over gloo --
+        # the data path has no collective either way
+        if world > ndev:
             dist.init_process_group("gloo")
+        else:
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                dist.barrier()
+            except Exception as exc:  # noqa: BLE001
+                print(f"[rank {rank}] RCCL init failed ({exc}); falling back to gloo", file=sys.stderr, flush=True)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group("gloo")
     D = dist if world > 1 else None
 
     # ---------------- workload (untimed) ----------------
@@ -236,9 +247,11 @@ def main():
     stats = solver.stats()
     units = shard.aggregate_units(S * c * a.steps, D)
     total_sources = shard.aggregate_units(S, D)
+    ranks_seen, rank_dts, backend = shard.rank_census(shard.timed_region.last_local, D)
 
-    # what the default accounting keeps out of the bracket (the reference times it: gpu/PPRGPU.cuh:138-164): the out-degree
-    # gather and the grouping of the batch's records by tail, done at slide time (dppr_set_batch_grouping) -- measured on its own
+    # `value` is measured under the reference's bracket (gpu/PPRGPU.cuh:138-164, gpu/StreamUpdate.cuh:7-33): CopyOutDegree and the
+    # grouping of the batch's records by tail run INSIDE the timed region (the engine's default since ABI 4). What they cost, run on
+    # their own (a whole-batch resident launch does both inside the launch: the figure is then what the separate kernels would cost):
     grouping_ms = e.time_batch_grouping(epoch=n_steps, reps=5) * (1 if S > 1 and not pair_as_singles else S)
 
     # ---------------- parity at the end of the timed region: every source of this rank ----------------
@@ -253,6 +266,7 @@ def main():
               "max_abs_dp_vs_cpu_t1": None, "tolerance": NORTH_STAR_TOL,
               "ok": bool(max_r < a.eps and max_inv < 1e-12)}
     p_end = [solver.read(i)[0] for i in range(min(2, len(sources)))] if want_cpu else []   # p at the END of the timed region
+    p_head = p_end if p_end else [solver.read(0)[0]]   # (what the at-slide-accounting pass must arrive at too)
 
     # ---------------- roofline of the dominant kernel ----------------
     roof = cpu = p_cpu = None
@@ -266,39 +280,48 @@ def main():
             # so that frac can be recomputed from a rocprofv3 kernel-stats file of the same command (tools/check_profiles.py)
             ps = dict(ps, sum_F=ps["sweep_F"], sum_E=ps["sweep_E"], sum_N=ps["sweep_F"], push_ms=ps["sweep_ms"], push_launches=ps["sweep_launches"],
                       iterations=ps["sweep_launches"])
-        push_bytes = 72 * ps["sum_F"] + 24 * ps["sum_E"] + 4 * ps["sum_N"]
-        achieved = push_bytes / (ps["push_ms"] * 1e-3) / 1e9 if ps["push_ms"] > 0 else 0.0
-        traffic, traffic_src, traffic_detail = pmc_traffic_per_launch(a.config if not a.bin and not a.batch_edges else None, S)
-        launch_s = 1e-3 * ps["push_ms"] / max(ps["push_launches"], 1)
-        # SURVEY.md 8(d)'s 24 bytes per traversed edge were written for ONE source (4 out_col + 4 degree + 16 residual); a
-        # group of S sources reads the column entry and the degree once for all of them: 16 + 8 / S per edge and source
-        adj_bytes = 72 * ps["sum_F"] + (16 + 8 / (1 if pair_as_singles else S)) * ps["sum_E"] + 4 * ps["sum_N"]
+        # Bytes per launch, priced for the design that ran. SURVEY.md 8(d) prices a traversed edge at 24 bytes PER SOURCE (4 column
+        # entry + 4 degree + 16 residual read-modify-write); a group of S sources reads the column entry and the degree once for all
+        # of them: 72 F + (16 + 8 / S) E + 4 N (F, E, N summed over the sources). For one source the two are the same number.
+        S_eff = 1 if (S == 1 or pair_as_singles) else S
+        survey_bytes = 72 * ps["sum_F"] + 24 * ps["sum_E"] + 4 * ps["sum_N"]
+        design_bytes = 72 * ps["sum_F"] + (16 + 8 / S_eff) * ps["sum_E"] + 4 * ps["sum_N"]
+        t_s = ps["push_ms"] * 1e-3
+        achieved = design_bytes / t_s / 1e9 if t_s > 0 else 0.0
+        traffic, traffic_src, traffic_detail = pmc_traffic_per_launch(a.config if not a.bin and not a.batch_edges else None, S, eng.build_id())
+        launch_s = t_s / max(ps["push_launches"], 1)
+        ceilings = measure_ceilings(eng, local_rank) if not a.no_ceilings else None
         roof = {
             "bound": "hbm", "kernel": solver.kernel_name(ps),
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 5),
-            "frac_group_adjusted": round(adj_bytes / (ps["push_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if ps["push_ms"] > 0 else None,
+            "bytes_model": ("72 F + 24 E + 4 N (SURVEY.md 8(d), one source)" if S_eff == 1 else
+                            f"72 F + (16 + 8 / {S_eff}) E + 4 N: SURVEY.md 8(d) with the column entry and the degree of a traversed edge read once for the "
+                            f"group's {S_eff} sources (F, E, N summed over the sources)"),
+            "work_rate_survey_unit": {"GBps": round(survey_bytes / t_s / 1e9, 2) if t_s > 0 else None,
+                                      "over_peak": round(survey_bytes / t_s / 1e9 / HBM_PEAK_GBPS, 5) if t_s > 0 else None,
+                                      "bytes_per_launch": round(survey_bytes / max(ps["push_launches"], 1), 1),
+                                      "note": "72 F + 24 E + 4 N per source: a WORK rate (a group does not move these bytes), kept for comparison with rounds 1-4"},
             "frac_traffic": round(traffic / launch_s / 1e9 / HBM_PEAK_GBPS, 5) if traffic and launch_s > 0 else None,
             "traffic": traffic, "traffic_source": traffic_src,
             "traffic_kind": "L2 <-> fabric bytes per launch (read requests counted by size 32 / 64 / 128 B + write requests 64 / 32 B; "
                             "Infinity-Cache hits are in them: fabric traffic, an upper bound of HBM traffic)",
             "traffic_fetch_size_method": traffic_detail,
-            "hbm_achievable": HBM_ACHIEVABLE_GBPS,
-            "frac_traffic_of_achievable": round(traffic / launch_s / 1e9 / HBM_ACHIEVABLE_GBPS, 5) if traffic and launch_s > 0 else None,
+            "ceilings_measured_in_this_run": ceilings,
+            "frac_traffic_of_stream_copy": (round(traffic / launch_s / 1e9 / ceilings["stream_copy_GBps"], 5)
+                                            if traffic and launch_s > 0 and ceilings and ceilings.get("stream_copy_GBps") else None),
             "iterations_per_launch": round(ps["iterations"] / max(ps["push_launches"], 1), 2),
             "launches": ps["push_launches"], "avg_launch_us": round(1e3 * ps["push_ms"] / max(ps["push_launches"], 1), 3),
-            "algorithmic_bytes_per_launch": round(push_bytes / max(ps["push_launches"], 1), 1),
+            "algorithmic_bytes_per_launch": round(design_bytes / max(ps["push_launches"], 1), 1),
             "all_iteration_launches": all_iters,
-            "whole_batch_algorithmic_GBps": round(stats["algorithmic_bytes"] / (ev_ms * 1e-3) / 1e9, 2),
+            "whole_batch_algorithmic_GBps": round((stats["algorithmic_bytes"] - (24 - (16 + 8 / S_eff)) * stats["sum_E"]) / (ev_ms * 1e-3) / 1e9, 2),
             "launches_from": ("a replay of the timed batches from the saved state" if S == 1 or pair_as_singles else
                               f"the {n_prof} batches that follow the timed region on the same stream"),
-            "note": "achieved / frac = SURVEY.md 8(d) bytes (72 F + 24 E + 4 N, summed over the sources) of the hipEvent-"
-                    "bracketed launches / their time: a WORK rate in the survey's unit -- for a source group it can exceed 1, because the "
-                    "unit prices every traversed edge at 24 bytes PER SOURCE while a group reads the column entry once and one state row "
-                    "for all its sources; what the memory system moved is frac_traffic. frac_group_adjusted prices a traversed "
-                    "edge at 16 + 8 / S bytes (a group reads the column entry once for its S sources); frac_traffic = the fabric bytes "
-                    "the counters saw per launch (traffic, from the committed rocprofv3 --pmc passes of this workload) / the "
-                    "launch time measured here / peak: what the memory system actually moved (DESIGN.md section 6)",
+            "build_id": eng.build_id(),
+            "note": "achieved = bytes_model of the hipEvent-bracketed launches of the dominant kernel / their time; frac = achieved / peak. "
+                    "traffic = what the counters saw per launch (a committed rocprofv3 --pmc pass of THIS build of the library, refused "
+                    "otherwise); frac_traffic = traffic / the launch time measured here / peak. ceilings_measured_in_this_run: random "
+                    "128-byte line fills, returning f64 atomics and a streaming copy on this device, this run (DESIGN.md section 6)",
         }
         if want_cpu:
             cpu = cpu_baseline(V, e1, e2, directed, W, c, sources[:len(p_end)], a.eps, cpu_batches, p_end if cpu_batches == n_steps else [], stream_len)
@@ -343,12 +366,32 @@ def main():
                   "iterations_per_step": round(st2["iterations"] / a.steps, 2), "speedup_vs_value": round(dt / dt2, 3),
                   "parity": {"max_abs_residual": mr, "invariant_max_err": mi, "max_abs_dp_vs_cpu_t1": md, "tolerance": NORTH_STAR_TOL,
                              "ok": bool(mr <= a.eps / 4 and mi < 1e-12 and (md is None or md < NORTH_STAR_TOL))}}
+    # ---------------- the other accounting beside it: grouping + CopyOutDegree at slide time (rounds 3-4) ----------------
+    # The same K steps from the same start with dppr_set_batch_grouping(1): the epochs' records are grouped on entry to each update,
+    # BEFORE its event bracket opens, so the event-timed batch time is the at-slide accounting's. (Last pass of the run: the epochs stay grouped.) N = 1 on streams whose from-scratch
+    # solve is cheap; elsewhere the figure is the subtraction (batch time - the grouping kernels on their own).
+    at_slide = {"event_ms_per_step": round(ev_ms / a.steps - grouping_ms, 4), "how": "estimated: event_ms_per_step - grouping_ms_per_step"}
+    if rank == 0 and world == 1 and stream_len < 100_000_000 and not a.no_extra_passes:
+        # (the headline's own solver state is restarted -- no new device allocations, the same buffers at the same addresses)
+        e.set_batch_grouping(1)
+        solver.init_solve(a.eps, epoch=0)
+        for k in range(1, a.warmup + 1):
+            solver.update(a.eps, k)
+        ev3 = sum(solver.update(a.eps, k) for k in range(a.warmup + 1, n_steps + 1))
+        e.set_batch_grouping(0)
+        worst3 = max(float(np.max(np.abs(solver.read(i)[0] - p_head[i]))) for i in range(len(p_head)))
+        at_slide = {"event_ms_per_step": round(ev3 / a.steps, 4), "how": "measured: the same K steps from the same start under dppr_set_batch_grouping(1)",
+                    "max_abs_dp_vs_headline_state": worst3, "sources_compared": len(p_head)}
+
     if rank == 0:
         value = units / dt
         line = {
             "metric": "edge-updates/sec (ppr_throughput, summed over sources); ms_per_step = mean per-batch PPR update time",
             "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True, "scaling": scaling,
+            "ranks_seen": ranks_seen, "backend": backend, "per_rank_ms_per_step": [round(1e3 * t / a.steps, 4) for t in rank_dts],
+            "launcher": os.environ.get("DPPR_BENCH_LAUNCHER", "torchrun" if world > 1 else "single process"),
+            "devices_visible": ndev, "build_id": eng.build_id(),
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{name}, {'directed' if directed else 'undirected'}, -a 0 -y 1 -w 0.1 {flags} "
                                    f"-e {a.eps:g}, "
@@ -362,12 +405,13 @@ def main():
                        "timed_region": {
                            "what": "IncrementalBatchUpdate replay + ExecuteMainLoop(0) + ExecuteMainLoop(1) per batch (gpu/PPRGPU.cuh:138-164), "
                                    "event-bracketed inside dppr_update / dppr_group_update; batch upload and graph rebuild outside, as in the reference",
-                           "grouping": "at_slide", "copy_out_degree": "at_slide",
+                           "grouping": "in_region", "copy_out_degree": "in_region",
                            "grouping_ms_per_step": round(grouping_ms, 4),
-                           "ms_per_step_grouping_in_region": round(1e3 * dt / a.steps + grouping_ms, 4),
-                           "note": "`value` / `ms_per_step` use the default accounting (the records' grouping by tail and the out-degree gather run "
-                                   "when the batch is uploaded: functions of the batch alone); the reference times both, so the line also carries "
-                                   "the batch time with them put back (measured on the same epoch, 5 repetitions)"},
+                           "at_slide_accounting": at_slide,
+                           "note": "`value` / `ms_per_step` are measured under the reference's bracket: CopyOutDegree and the grouping of the batch's "
+                                   "records by tail run inside the timed region (one ranking launch up to 16 Ki records, a device radix sort beyond; a "
+                                   "whole-batch resident launch does both itself). grouping_ms_per_step = those kernels run on their own; "
+                                   "at_slide_accounting = the batch time when both are done at slide time instead (the accounting of rounds 3-4)"},
                        "parallelism": (f"{total_sources} sources dealt round-robin over {world} GPU(s) (rank 0: {S}), replicated graph, no collective"
                                        if scaling == "strong" else f"{S} source(s) per GPU x {world} GPU(s), replicated graph, no collective"),
                        "stream_file": provenance},
@@ -381,9 +425,8 @@ def main():
         if scaling == "strong":
             # what the multi-GPU value has to be read against: ALL of the configuration's sources as one source group on ONE GPU
             # (this very script at --gpus 1; the committed line of that run is quoted when this is an N > 1 run)
-            alt = os.path.join(ROOT, "profiles", f"r04_bench_{a.config}_group_1gpu.json")
-            if not os.path.exists(alt):
-                alt = os.path.join(ROOT, "profiles", f"r03_bench_{a.config}_group_1gpu.json")
+            alt = next((pth for pth in (os.path.join(ROOT, "profiles", f"r0{rnd}_bench_{a.config}_group_1gpu.json") for rnd in (5, 4, 3))
+                        if os.path.exists(pth)), "")
             line["single_gpu_group_alternative"] = (
                 {"this_run": True, "ms_per_step": line["ms_per_step"], "value": line["value"]} if world == 1 else
                 ({k: json.load(open(alt)).get(k) for k in ("ms_per_step", "value", "unit", "steps")} | {"source": os.path.relpath(alt, ROOT)})
@@ -400,6 +443,37 @@ def main():
     if rank == 0 and not parity["ok"]:
         print(f"PARITY FAILED: {parity}", file=sys.stderr, flush=True)
         sys.exit(3)
+    if ranks_seen != world:
+        print(f"RANK CENSUS FAILED: {ranks_seen} of {world} ranks answered", file=sys.stderr, flush=True)
+        sys.exit(5)
+
+
+def launch_command(n, argv, port):
+    """The torchrun command line of an N-rank run of this script (one process per GPU, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without torchrun: run `python -m torch.distributed.run --nproc-per-node N bench.py <same args>`
+    as a child, pass its stderr through, print the ONE JSON line of its rank 0 and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:   # a free rendezvous port (the driver passes its own when it launches torchrun itself)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, DPPR_BENCH_LAUNCHER="self")
+    r = subprocess.run(launch_command(n, sys.argv[1:], port), stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    for ln in r.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    elif r.returncode == 0:
+        print("bench.py: the ranks exited 0 but printed no line", file=sys.stderr)
+        return 4
+    return r.returncode
 
 
 def extra_line(args):
@@ -539,16 +613,43 @@ def invariant_max_err(p, r, src, dst, V, source, alpha=0.15):
     return float(np.max(np.abs(p + alpha * r - rhs)))
 
 
-def pmc_traffic_per_launch(config, S):
+def measure_ceilings(eng, device):
+    """SURVEY.md 8(d)'s calibrated ceilings, measured on this device in this run (dppr_bench_*): random 128-byte line fills out of a
+    1 GiB table (what a gather-bound sweep is held against), returning f64 atomics into a V-sized table (a push iteration), and a
+    streaming copy (what HBM sustains for a kernel that only streams)."""
+    out = {}
+    try:
+        lines = 1 << 26
+        ms = eng.bench_line_fills(1 << 30, lines, reps=3, device=device)
+        out["line_fills_per_s"] = round(lines / (ms * 1e-3), 1)
+        out["line_fill_GBps"] = round(lines * 128 / (ms * 1e-3) / 1e9, 1)
+        n = 1 << 26
+        ms = eng.bench_atomics(1 << 23, n, scope=0, reps=3, device=device)
+        out["returning_f64_atomics_per_s"] = round(n / (ms * 1e-3), 1)
+        out["atomics_algorithmic_GBps"] = round(n * 24 / (ms * 1e-3) / 1e9, 1)   # (24 B of SURVEY 8(d) per traversed edge = per atomic)
+        nbytes = 1 << 30
+        ms = eng.bench_stream_copy(nbytes, reps=5, device=device)
+        out["stream_copy_GBps"] = round(2 * nbytes / (ms * 1e-3) / 1e9, 1)
+    except Exception as ex:  # noqa: BLE001 -- a calibration probe never takes the line down
+        out["error"] = f"{type(ex).__name__}: {ex}"
+    return out
+
+
+def pmc_traffic_per_launch(config, S, build_id):
     """Fabric bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this
     same workload (tools/r04/pmc_fabric.sh: read requests by size, write requests, FETCH_SIZE / WRITE_SIZE,
     each in its own pass). bench.py cannot run the profiler on itself, so the figure is read back from
     profiles/ and labelled with its file; (None, None, None) when there is none for this workload."""
-    rel, heads = PMC_FILES.get((config, S), (None, ()))
+    name, heads = PMC_FILES.get((config, S), (None, ()))
+    rel = f"profiles/{PMC_ROUND}_{name}" if name else None
     path = os.path.join(ROOT, rel) if rel else None
     if not path or not os.path.exists(path):
-        return None, None, None
+        return None, (f"no counter profile of this round for this workload ({rel})" if rel else None), None
     d = json.load(open(path))
+    stamp = d.get("_stamp") or {}
+    if stamp.get("build_id") != build_id:   # (kernels changed since the capture: the bytes are another build's)
+        return None, f"REFUSED: {rel} was captured on build {stamp.get('build_id')}, this library is build {build_id}", None
+    d = {k: v for k, v in d.items() if not k.startswith("_")}
     per_launch = raw = corrected = 0.0   # (several heads = the stages of ONE iteration, e.g. k_bin_scatter + k_bin_reduce: their bytes add up)
     for head in heads:
         rows = [v for k, v in d.items() if k.startswith(head)]
@@ -561,7 +662,7 @@ def pmc_traffic_per_launch(config, S):
     detail = {"FETCH_SIZE_plus_WRITE_SIZE_raw": round(raw, 1), "two_x_FETCH_SIZE_plus_WRITE_SIZE": round(corrected, 1),
               "note": "rounds 1-3 reported 2 x FETCH_SIZE + WRITE_SIZE; FETCH_SIZE tallies 128-byte requests at 64, so the factor is right only "
                       "where every read request is a 128-byte one -- `traffic` counts the requests by size instead"}
-    return round(per_launch, 1), f"committed profile {rel}", detail
+    return round(per_launch, 1), f"committed profile {rel} (build {build_id}, commit {stamp.get('git_commit')})", detail
 
 
 def cpu_baseline(V, e1, e2, directed, W, c, sources, eps, batches, p_end, stream_len):

@@ -28,6 +28,7 @@
 #include "dppr_multi.hpp"
 #include "dppr_gpush.hpp"
 #include "dppr_binned.hpp"
+#include "dppr_calib.hpp"
 
 using namespace dppr;
 
@@ -170,7 +171,10 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     // the reference's variants (-o, gpu/PPRRevPushGPUVariants.cuh) as mechanisms of the push iterations: dppr_set_variant
     bool status_dedup = false; // duplicate filter of a push iteration: status array (EAGER 2, VANILLA 3) instead of the threshold crossing
     bool pre_extract = false;  // synchronous push iterations zero residual[u] at the snapshot (InspectExtra: FAST_FRONTIER 1, VANILLA 3) instead of repairing
-    bool group_at_slide = true; // the batch's records are grouped by tail when the batch is uploaded (dppr_slide), not inside dppr_update (dppr_set_batch_grouping)
+    bool group_at_slide = false; // dppr_set_batch_grouping(1): the batch's records are grouped by tail (and CopyOutDegree done) when the batch is uploaded
+                                 // (dppr_slide); default since round 5: inside dppr_update, where the reference times them (gpu/PPRGPU.cuh:138-164)
+    bool launch_called_off = false; // batch_ahead: the last whole-batch launch changed nothing (roll-call failed, or a group had too many records)
+    int raw_backoff = 0;         // batches for which a resident launch does not take the records raw (after one called itself off: a group with more records than threads)
     bool merge_phases = false; // dppr_set_phase_merge: one loop for residuals of both signs (eager schedule only)
     int merge_div = 4;         // ... run to eps / merge_div
     hipStream_t stream = nullptr;
@@ -236,6 +240,7 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     bool any_groups = false;        // a source group exists: epochs carry the second group table
     int ggroups_min = 256;          // ... of at least this many groups (DPPR_GGROUPS_MIN: tuning runs; 512 / 1008 measured slower on
                                     // the configs[1] stand-in, equal on the LiveJournal one)
+    bool force_radix_grouping = false; // (A/B, tests: DPPR_GROUPING_RADIX=1 -- the in-region grouping always as key kernel + device radix sort)
     bool cost_model = true;         // binned windows: push or sweep by estimated cost (DPPR_COST_MODEL=0: by the vertex-count threshold)
     bool group_full_rows = false;   // (A/B, DPPR_GROUP_FULL_ROWS=1: rows of 64 / 128 bytes whatever the source count, as until round 3)
     bool wide_groups = false;       // ... one of more than 8 sources: its groups hold at most 512 vertices
@@ -1559,7 +1564,9 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
     if (e->chunk_explicit) n = std::min(n, e->chunk_iters); // (tests: launches that stop mid-phase and are resumed)
     n = std::min(n, RES_MAX_SWEEPS);
     int *status = s.cnt + 7; // (the GridBar was zeroed by the batch's first kernel, k_su_keys)
-    const ResUpdate upd = inline_update ? ResUpdate{ep.su_rng, ep.sk, ep.sv, ep.b2, ep.ins, ep.deg_after, s.source} : ResUpdate{};
+    const ResUpdate upd = !inline_update ? ResUpdate{}
+                          : ep.grouped   ? ResUpdate{ep.su_rng, ep.sk, ep.sv, ep.b2, ep.ins, ep.deg_after, s.source, nullptr, 0}
+                                         : ResUpdate{nullptr, nullptr, nullptr, ep.b2, ep.ins, nullptr, s.source, ep.b1, ep.L}; // raw records
     const int plan = (merged ? PLAN_SEED : (PLAN_SEED | PLAN_BOTH)) | (inline_update ? PLAN_UPDATE : 0);
     if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[0], e->stream));
 #define DPPR_LAUNCH_PERSIST(PB)                                                                                        \
@@ -1586,8 +1593,17 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
     *en1 = LoopEntry();
     s.st.persist_launches++;
     if (st & PERSIST_FAULT) return fail(e, DPPR_ERR_HIP, "a wait inside the resident sweep timed out");
+    e->launch_called_off = false;
+    if ((st & PERSIST_ABORTED) && inline_update && !ep.grouped && e->pinned[4] == 1) {
+        // a sweep group owns more of the batch's records than it has threads: the launch called itself off before anything was
+        // changed -- not a residency problem. The caller applies the update with its own kernels; the next batches do so at once.
+        e->launch_called_off = true;
+        e->raw_backoff = 16;
+        return DPPR_OK;
+    }
     if (st & PERSIST_ABORTED) { // roll-call failed: nothing was changed, the lists of the stream update stand
         s.st.persist_aborts++;
+        e->launch_called_off = true;
         e->persist_ok = false;
         e->persist_retry = PERSIST_RETRY_BATCHES;
         return DPPR_OK;
@@ -1680,6 +1696,10 @@ int epoch_group_records(dppr_engine *e, Epoch &ep) {
     ep.grouped = false;
     ep.su_inline = false;
     if (!e->group_at_slide || ep.L <= 0) return DPPR_OK;
+    if (ep.id >= 0) { // an epoch built while the default accounting was on, grouped outside the bracket after all (prepare_epoch): its degrees too
+        hipLaunchKernelGGL(k_copy_out_degree, dim3(grid_for(ep.L)), dim3(BLOCK), 0, e->stream, ep.b1, ep.L, ep.out_row_ptr, ep.deg_after);
+        HIP_TRY(hipGetLastError());
+    }
     hipLaunchKernelGGL(k_su_keys, dim3(grid_for(ep.L)), dim3(BLOCK), 0, e->stream, ep.b1, ep.L, e->su_k[0], e->su_v[0],
                        (unsigned long long *)nullptr, 0, (int *)nullptr, 0);
     size_t tmp = e->su_tmp_bytes;
@@ -1696,11 +1716,26 @@ int group_records_by_tail(dppr_engine *e, const Epoch &ep, unsigned long long *z
         HIP_TRY(hipGetLastError());
         return DPPR_OK;
     }
+    // inside the timed region (default): CopyOutDegree (gpu/StreamUpdate.cuh:7-17; a tail's post-batch out-degree = the length of
+    // its row in this epoch's out-CSR) and the grouping by tail -- ranked in one launch up to SU_RANK_MAX records, radix-sorted beyond
+    if (L <= SU_RANK_MAX && !e->force_radix_grouping) {
+        hipLaunchKernelGGL(k_su_group_rank, dim3((L + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, ep.b1, L, ep.out_row_ptr, e->su_k[1],
+                           e->su_v[1], ep.deg_after, zero, nz, zero_ints, nzi);
+        HIP_TRY(hipGetLastError());
+        return DPPR_OK;
+    }
+    hipLaunchKernelGGL(k_copy_out_degree, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, ep.out_row_ptr, ep.deg_after);
     hipLaunchKernelGGL(k_su_keys, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->su_k[0], e->su_v[0], zero, nz,
                        zero_ints, nzi);
     size_t tmp = e->su_tmp_bytes;
     HIP_TRY(rocprim::radix_sort_pairs(e->su_tmp, tmp, e->su_k[0], e->su_k[1], e->su_v[0], e->su_v[1], (size_t)L, 0u,
                                       (unsigned)e->bits, e->stream));
+    return DPPR_OK;
+}
+
+// dppr_set_batch_grouping(1) after epochs were built: their records are grouped now, BEFORE the caller's event bracket opens
+inline int prepare_epoch(dppr_engine *e, Epoch &ep) {
+    if (e->group_at_slide && !ep.grouped && ep.L > 0) return epoch_group_records(e, ep);
     return DPPR_OK;
 }
 
@@ -2200,6 +2235,8 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     if (const char *v = getenv("DPPR_GROUP_PUSH_FACTOR")) e->gpush_auto_factor = std::max(1, atoi(v));
     if (const char *v = getenv("DPPR_GGROUPS_MIN")) e->ggroups_min = std::max(1, atoi(v));
     if (const char *v = getenv("DPPR_COST_MODEL")) e->cost_model = atoi(v) != 0;
+    if (const char *v = getenv("DPPR_GROUPING_RADIX")) e->force_radix_grouping = atoi(v) != 0;
+    if (const char *v = getenv("DPPR_GROUP_AT_SLIDE")) e->group_at_slide = atoi(v) != 0;
     if (const char *v = getenv("DPPR_GROUP_FULL_ROWS")) e->group_full_rows = atoi(v) != 0;
     e->device = device;
     e->V = V;
@@ -2649,11 +2686,13 @@ int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, 
             HIP_TRY(hipMemcpyAsync(ep.b1, e->st_b1.data(), sizeof(int) * (size_t)L, hipMemcpyHostToDevice, e->stream));
             HIP_TRY(hipMemcpyAsync(ep.b2, e->st_b2.data(), sizeof(int) * (size_t)L, hipMemcpyHostToDevice, e->stream));
             HIP_TRY(hipMemcpyAsync(ep.ins, e->st_ins.data(), (size_t)L, hipMemcpyHostToDevice, e->stream));
-            // CopyOutDegree (gpu/StreamUpdate.cuh:7-17): post-batch out-degree of every tail
-            hipLaunchKernelGGL(k_gather_deg, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->outdeg,
-                               ep.deg_after);
-            HIP_TRY(hipGetLastError());
-            if (int grc = epoch_group_records(e, ep)) return grc; // the records grouped by tail, for IncrementalBatchUpdate
+            if (e->group_at_slide) {
+                // CopyOutDegree (gpu/StreamUpdate.cuh:7-17): post-batch out-degree of every tail
+                hipLaunchKernelGGL(k_gather_deg, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->outdeg,
+                                   ep.deg_after);
+                HIP_TRY(hipGetLastError());
+                if (int grc = epoch_group_records(e, ep)) return grc; // the records grouped by tail, for IncrementalBatchUpdate
+            } // (default: both are part of the timed region -- group_records_by_tail, or the resident launch itself)
         }
     }
     HIP_TRY(hipStreamSynchronize(e->stream)); // staged host vectors may be reused now
@@ -2725,9 +2764,16 @@ int dppr_time_batch_grouping(dppr_engine *e, int32_t epoch, int32_t reps, float 
     const int L = ep.L;
     if (L <= 0) return DPPR_OK;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    int *deg_scratch = reinterpret_cast<int *>(e->su_term);
     for (int k = 0; k < reps; ++k) {
-        // CopyOutDegree (gpu/StreamUpdate.cuh:7-17) into scratch, then (tail, index) keys and their stable sort, as epoch_group_records does
-        hipLaunchKernelGGL(k_gather_deg, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->outdeg, (int *)e->su_v[1]);
+        // CopyOutDegree (gpu/StreamUpdate.cuh:7-17) + the stable grouping by tail, into scratch, as group_records_by_tail runs them
+        // inside the timed region (one ranking launch up to SU_RANK_MAX records; degree gather + keys + radix sort beyond)
+        if (L <= SU_RANK_MAX && !e->force_radix_grouping) {
+            hipLaunchKernelGGL(k_su_group_rank, dim3((L + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, ep.b1, L, ep.out_row_ptr, e->su_k[1],
+                               e->su_v[1], deg_scratch, (unsigned long long *)nullptr, 0, (int *)nullptr, 0);
+            continue;
+        }
+        hipLaunchKernelGGL(k_copy_out_degree, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, ep.out_row_ptr, deg_scratch);
         hipLaunchKernelGGL(k_su_keys, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->su_k[0], e->su_v[0],
                            (unsigned long long *)nullptr, 0, (int *)nullptr, 0);
         size_t tmp = e->su_tmp_bytes;
@@ -2847,7 +2893,9 @@ int dppr_incremental_batch_update(dppr_engine *e, int32_t slot, int32_t epoch) {
     HIP_TRY(hipSetDevice(e->device));
     // after a converged solve the update also lists the tails that left [-eps, eps] (dppr_seed_lists)
     const bool seeded = s.converged;
-    int rc = stream_update(e, s, ep, s.conv_eps, seeded);
+    int rc = prepare_epoch(e, ep);
+    if (rc) return rc;
+    rc = stream_update(e, s, ep, s.conv_eps, seeded);
     if (rc) return rc;
     s.seed_lists_valid = seeded;
     s.last_epoch = ep.id;
@@ -2894,22 +2942,28 @@ int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *
     const bool ahead = seeded && can_batch_ahead(e, s, ep) && resident_arena(e, ep);
     int rc = settle_parked(e, s.p, s.r, 1, eps, &s.park_eps, &s.st);
     if (rc) return rc;
+    rc = prepare_epoch(e, ep);
+    if (rc) return rc;
+    if (e->raw_backoff > 0) --e->raw_backoff;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    // A whole-batch resident launch applies the records itself (PLAN_UPDATE): only the counters and the GridBar are cleared
-    // here. Should its roll-call fail, nothing was changed and the update runs as its own kernel after all.
-    bool inline_su = ahead && e->res_update && ep.su_inline && ep.grouped;
+    // A whole-batch resident launch applies the records itself (PLAN_UPDATE) -- grouped at slide time and cut into the sweep groups'
+    // ranges, or (default accounting) RAW: the launch finds, orders and applies every group's records itself. Only the counters
+    // and the GridBar are cleared here. Should the launch call itself off, nothing was changed and the update runs as its own
+    // kernels after all.
+    const bool raw_ok = !ep.grouped && ep.L > 0 && ep.L <= RES_RAW_STEPS * sweep_block(e) && e->raw_backoff == 0;
+    bool inline_su = ahead && e->res_update && ((ep.su_inline && ep.grouped) || raw_ok);
     if (inline_su) {
-        rc = group_records_by_tail(e, ep, reinterpret_cast<unsigned long long *>(e->bar), (int)(sizeof(GridBar) / sizeof(unsigned long long)),
-                                   s.cnt, 5);
+        hipLaunchKernelGGL(k_su_keys, dim3(1), dim3(BLOCK), 0, e->stream, ep.b1, 0, e->su_k[0], e->su_v[0],
+                           reinterpret_cast<unsigned long long *>(e->bar), (int)(sizeof(GridBar) / sizeof(unsigned long long)), s.cnt, 5);
+        HIP_TRY(hipGetLastError());
     } else {
         rc = stream_update(e, s, ep, eps, seeded, ahead);
     }
     if (rc) return rc;
     s.converged = false;
-    const int64_t aborts_before = s.st.persist_aborts;
-    auto update_after_abort = [&]() -> int { // (inline_su only) the launch gave up at its roll-call
+    auto update_after_abort = [&]() -> int { // (inline_su only) the launch called itself off
         if (!inline_su) return DPPR_OK;
-        if (s.st.persist_aborts != aborts_before) {
+        if (e->launch_called_off) {
             inline_su = false;
             return stream_update(e, s, ep, eps, seeded, false);
         }
@@ -3300,6 +3354,8 @@ int dppr_group_update(dppr_engine *e, int32_t group, int32_t epoch, double eps, 
     const bool tails = g.converged && g.conv_eps <= eps && e->group_tail_seeding;
     int rc = settle_parked(e, g.p, g.r, g.gw, eps, &g.park_eps, &g.st);
     if (rc) return rc;
+    rc = prepare_epoch(e, ep);
+    if (rc) return rc;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
     rc = group_stream_update(e, g, ep);
     if (rc) return rc;
@@ -3425,5 +3481,76 @@ int dppr_bench_atomics(int device, int64_t table_elems, int64_t n, int scope, in
     (void)hipFree(sink);
     return err == hipSuccess ? DPPR_OK : DPPR_ERR_HIP;
 }
+
+int dppr_bench_line_fills(int device, int64_t table_bytes, int64_t lines, int reps, float *out_ms) {
+    if (table_bytes < 128 || (table_bytes & (table_bytes - 1)) || lines <= 0 || reps <= 0 || !out_ms) return DPPR_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return DPPR_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return DPPR_ERR_HIP;
+    double2 *table = nullptr;
+    double *sink = nullptr;
+    if (hipMalloc((void **)&table, (size_t)table_bytes) != hipSuccess) return DPPR_ERR_NOMEM;
+    (void)hipMalloc((void **)&sink, sizeof(double));
+    (void)hipMemset(table, 0, (size_t)table_bytes);
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    const int grid = 2048; // 2048 x 128 octets
+    const int per = (int)std::max<int64_t>(8, (lines + (int64_t)grid * 128 - 1) / ((int64_t)grid * 128) / 8 * 8);
+    auto launch = [&]() {
+        hipLaunchKernelGGL(k_bench_lines<8>, dim3(grid), dim3(1024), 0, 0, table, (uint64_t)(table_bytes / 128) - 1, per, sink);
+    };
+    launch(); // warm-up
+    (void)hipEventRecord(a, 0);
+    for (int i = 0; i < reps; ++i) launch();
+    (void)hipEventRecord(b, 0);
+    hipError_t err = hipEventSynchronize(b);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    // per launch, scaled to the number of lines asked for (the launch fetches grid * 128 * per of them)
+    *out_ms = ms / reps * (float)((double)lines / ((double)grid * 128.0 * per));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    (void)hipFree(table);
+    (void)hipFree(sink);
+    return err == hipSuccess ? DPPR_OK : DPPR_ERR_HIP;
+}
+
+int dppr_bench_stream_copy(int device, int64_t bytes, int reps, float *out_ms) {
+    if (bytes < 16 || reps <= 0 || !out_ms) return DPPR_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return DPPR_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return DPPR_ERR_HIP;
+    double2 *src = nullptr, *dst = nullptr;
+    if (hipMalloc((void **)&src, (size_t)bytes) != hipSuccess) return DPPR_ERR_NOMEM;
+    if (hipMalloc((void **)&dst, (size_t)bytes) != hipSuccess) {
+        (void)hipFree(src);
+        return DPPR_ERR_NOMEM;
+    }
+    (void)hipMemset(src, 0, (size_t)bytes);
+    (void)hipMemset(dst, 0, (size_t)bytes);
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    auto launch = [&]() { hipLaunchKernelGGL(k_bench_copy, dim3(4096), dim3(1024), 0, 0, src, dst, bytes / 16); };
+    launch();
+    (void)hipEventRecord(a, 0);
+    for (int i = 0; i < reps; ++i) launch();
+    (void)hipEventRecord(b, 0);
+    hipError_t err = hipEventSynchronize(b);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    *out_ms = ms / reps;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    return err == hipSuccess ? DPPR_OK : DPPR_ERR_HIP;
+}
+
+#ifndef DPPR_BUILD_ID
+#define DPPR_BUILD_ID "unstamped"
+#endif
+const char *dppr_build_id(void) { return DPPR_BUILD_ID; }
 
 } // extern "C"

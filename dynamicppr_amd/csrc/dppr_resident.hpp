@@ -140,14 +140,26 @@ constexpr int PLAN_UPDATE = 4; // apply the batch's records to the residuals fir
 // has just loaded, before it seeds the frontier from them. Same terms, same order per tail, same expressions as k_su_apply_fused
 // (dppr_update.hpp; gpu/StreamUpdate.cuh:34-76, cpu/PPRCPUMTCilkRev.h:108-124): bit-identical residuals. What it saves is a
 // kernel of ~20 us and the gap in front of it -- 6 % of a configs[1] batch, 9 % of a configs[0] one.
+//
+// Round 5 -- the records taken RAW (b1 != nullptr; the default accounting, in which nothing of IncrementalBatchUpdate is
+// prepared at slide time): every workgroup reads the batch's L tails once (coalesced, 16 independent loads per lane, served
+// by the L2s after the first workgroup), keeps the records whose tail is one of ITS rows -- found in batch order by ballots,
+// ranked by (row, batch index) in LDS -- and proceeds as above. CopyOutDegree (gpu/StreamUpdate.cuh:7-17) is the length of
+// the tail's row in the epoch's out-CSR, which the row's thread holds anyway. No radix sort, no range table, no degree
+// array: the whole of gpu/StreamUpdate.cuh:7-76 runs inside the launch. A group that owns more than PB records (a hub's
+// tail in a large batch) or a tail beyond the last group calls the launch off before anything is changed (cnt[4] = 1;
+// the host applies the update with its own kernels and launches again).
+constexpr int RES_RAW_STEPS = 16; // 64-record steps per wave: L <= RES_RAW_STEPS * PB
 struct ResUpdate {
-    const int *rng;          // per sweep group: first record (n_groups + 1 entries); nullptr: no update
+    const int *rng;          // per sweep group: first record (n_groups + 1 entries); nullptr: no update, or raw records
     const uint32_t *tails;   // the records' tails, ascending
     const uint32_t *order;   // ... and their indices in the batch (stable)
     const int *b2;           // heads
     const uint8_t *ins;      // 1 = insertion
     const int *deg_after;    // out-degree of the tail after the batch
     int source;              // the slot's source vertex
+    const int *b1;           // raw form: the tails in batch order (rng / tails / order / deg_after unused)
+    int L;                   // ... and their number
 };
 // first record of every sweep group's range (tails[] is sorted); rng[n_groups] = first record whose tail lies beyond the last
 // group; stat[0] = the largest range (atomicMax), stat[1] = rng[n_groups]
@@ -236,12 +248,90 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
         pv = p[v];
         if (!(plan & PLAN_SEED)) xv = b0[v];
     }
+    bool overflow = false; // (PLAN_UPDATE, raw records) this group cannot apply its records inside the launch
     if (plan & PLAN_UPDATE) {
         // the group's records: terms in parallel, then one lane per tail applies its records in batch order
-        const int lo = upd.rng[blockIdx.x], nrec = upd.rng[blockIdx.x + 1] - lo; // <= PB (the host checked)
-        int row = -1, rdeg = 0, u = 0;
+        int nrec, row = -1, rdeg = 0, u = 0;
         double term = 0.0;
         bool rin = false;
+        if (upd.b1) {
+            // ---- raw records: this group's, in batch order (wave w looks at records [w * span, (w + 1) * span))
+            const int L = upd.L;
+            const int span = ((L + NW - 1) / NW + WAVE - 1) / WAVE * WAVE;
+            const int vlo = t0 * WAVE, vhi = blockIdx.x + 1 == gridDim.x ? 0x7fffffff : t1 * WAVE; // (the last group also sees tails beyond it)
+            uint64_t mine[RES_RAW_STEPS];
+            int tl[RES_RAW_STEPS];
+#pragma unroll
+            for (int k = 0; k < RES_RAW_STEPS; ++k) {
+                const int i = w * span + k * WAVE + lane;
+                tl[k] = (k * WAVE < span && i < L) ? upd.b1[i] : -1;
+            }
+            int wn = 0;
+#pragma unroll
+            for (int k = 0; k < RES_RAW_STEPS; ++k) {
+                mine[k] = __ballot(tl[k] >= vlo && tl[k] < vhi);
+                wn += __popcll(mine[k]);
+            }
+            if (lane == 0) s_cnt[w] = wn;
+            __syncthreads();
+            int base = 0;
+            nrec = 0;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                const int c = s_cnt[k];
+                base += k < w ? c : 0;
+                nrec += c;
+            }
+            overflow = nrec > PB;
+#pragma unroll
+            for (int k = 0; k < RES_RAW_STEPS; ++k) {
+                if ((mine[k] >> lane) & 1ull) {
+                    const int pos = base + mbcnt(mine[k]);
+                    if (pos < PB) {
+                        s_scan[pos] = w * span + k * WAVE + lane; // record index
+                        s_rs[pos] = tl[k] - vlo;                  // its tail as a row of the group
+                    }
+                }
+                base += __popcll(mine[k]);
+            }
+            __syncthreads();
+            if (overflow) nrec = 0;
+            int rec = 0, key_row = 0x7fffffff;
+            if (tid < nrec) {
+                rec = s_scan[tid];
+                key_row = s_rs[tid];
+                overflow = key_row >= PB || vlo + key_row >= V; // (a tail beyond the groups: an id the cut does not cover)
+            }
+            overflow = __syncthreads_or(overflow ? 1 : 0) != 0;
+            if (overflow) nrec = 0;
+            // stable order by row: position = #{j : row_j < row or (row_j == row and j < tid)}
+            int rank = 0;
+            if (tid < nrec)
+                for (int j = 0; j < nrec; ++j) {
+                    const int rj = s_rs[j];
+                    rank += (rj < key_row || (rj == key_row && j < tid)) ? 1 : 0;
+                }
+            __syncthreads(); // (s_scan / s_rs are read; s_scan now carries the rows' lengths = post-batch out-degrees)
+            s_scan[tid] = d;
+            s_rtail[tid] = -1;
+            s_rins[tid] = 0;
+            __syncthreads();
+            if (tid < nrec) {
+                const int uu = vlo + key_row;
+                s_rtail[rank] = key_row;
+                s_rins[rank] = upd.ins[rec] != 0 ? 1 : 0;
+                s_acc[1][rank] = ONE_MINUS_ALPHA * p[upd.b2[rec]] - p[uu];
+            }
+            s_acc[0][tid] = rv;
+            __syncthreads();
+            if (tid < nrec) {
+                row = s_rtail[tid];
+                u = vlo + row;
+                rdeg = s_scan[row];
+            }
+        } else {
+        const int lo = upd.rng[blockIdx.x];
+        nrec = upd.rng[blockIdx.x + 1] - lo; // <= PB (the host checked)
         if (tid < nrec) {
             u = (int)upd.tails[lo + tid];
             const int rec = (int)upd.order[lo + tid];
@@ -255,6 +345,7 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
         s_acc[1][tid] = term;
         s_acc[0][tid] = rv;
         __syncthreads();
+        }
         if (tid < nrec && (tid == 0 || s_rtail[tid - 1] != row)) {
             int end = tid, delta = 0; // extent of the tail's records and its net degree change (post-batch minus pre-batch)
             while (end < nrec && s_rtail[end] == row) {
@@ -297,6 +388,11 @@ __global__ __launch_bounds__(PB) void k_pull_resident(int V, const int *__restri
     if (lane == WAVE - 1) s_wtot[w] = incl;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the EMPTY marks (and seeds) are in place before this workgroup checks in
     __syncthreads();
+    if (tid == 0 && overflow) { // the launch is called off before anybody is told to go: workgroup 0 publishes READY only after EVERY check-in
+        cnt[4] = 1;
+        (void)bar_cas(&bar->gen.w, 0ull, BAR_ABORT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the swap has been performed before this workgroup checks in)
+    }
     if (tid == 0) { // roll-call: this workgroup is running and has initialised its entries
         unsigned long long seeds = 0;
         if (plan & PLAN_SEED)

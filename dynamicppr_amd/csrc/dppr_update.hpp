@@ -47,6 +47,71 @@ __global__ __launch_bounds__(BLOCK) void k_su_keys(const int *__restrict__ e1, i
     }
 }
 
+// The grouping INSIDE the timed region (round 5; the reference times all of IncrementalBatchUpdate, gpu/PPRGPU.cuh:138-164,
+// gpu/StreamUpdate.cuh:7-33, so the default accounting keeps it there). For batches of up to SU_RANK_MAX records the stable
+// order by tail needs no sort passes: record i goes to position  #{j : (tail_j, j) < (tail_i, i)}. One thread per record,
+// 256 records per workgroup; the batch's tails pass through LDS in tiles of SU_RANK_TILE, every thread compares its own
+// 64-bit key with four broadcast keys per LDS read. L^2 / 256 comparisons per workgroup, L / 256 workgroups side by side:
+// a few microseconds for the 1 380 records of the configs[2] stand-in, where the device radix sort is five dispatches and
+// ~80 us with their gaps. (First form of this kernel: the inner loop over b1 through the scalar cache -- one s_load_dwordx8
+// per 8 pairs, waited for every time: 60 us for 1 380 records, 400 us for 12 K.) The same launch does CopyOutDegree
+// (gpu/StreamUpdate.cuh:7-17) -- the post-batch out-degree of a tail is the length of its row in the epoch's out-CSR, built
+// from the post-batch window -- and clears the loop's counters.
+constexpr int SU_RANK_MAX = 4096;
+constexpr int SU_RANK_TILE = 2048;
+__global__ __launch_bounds__(BLOCK) void k_su_group_rank(const int *__restrict__ e1, int L, const int *__restrict__ out_row_ptr,
+                                                        uint32_t *__restrict__ skeys, uint32_t *__restrict__ svals,
+                                                        int *__restrict__ deg_after, unsigned long long *__restrict__ zero, int nz,
+                                                        int *__restrict__ zero_ints, int nzi) {
+    __shared__ int4 s_t[SU_RANK_TILE / 4];
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < nz; i += BLOCK) zero[i] = 0ull;
+        for (int i = threadIdx.x; i < nzi; i += BLOCK) zero_ints[i] = 0;
+    }
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    const int t = i < L ? e1[i] : 0x7ffffffe; // (threads beyond the batch rank nothing)
+    if (i < L && out_row_ptr) deg_after[i] = out_row_ptr[t + 1] - out_row_ptr[t];
+    int *s_flat = reinterpret_cast<int *>(s_t);
+    int rank = 0;
+    for (int j0 = 0; j0 < L; j0 += SU_RANK_TILE) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < SU_RANK_TILE; k += BLOCK) s_flat[k] = j0 + k < L ? e1[j0 + k] : 0x7fffffff; // (padding ranks behind every record)
+        __syncthreads();
+        const int n4 = (min(SU_RANK_TILE, L - j0) + 3) / 4;
+        // records that precede i in batch order count on equality, the others only when smaller: tail_j < t + [j < i].
+        // Quads entirely before i, the one that straddles it, quads behind it: one comparison and one add per pair.
+        const int nb = min(max((i - j0) >> 2, 0), n4);
+        const int t1 = t + 1;
+        for (int k4 = 0; k4 < nb; ++k4) {
+            const int4 q = s_t[k4];
+            rank += (q.x < t1 ? 1 : 0) + (q.y < t1 ? 1 : 0) + (q.z < t1 ? 1 : 0) + (q.w < t1 ? 1 : 0);
+        }
+        if (nb < n4) {
+            const int4 q = s_t[nb];
+            const int j = j0 + 4 * nb;
+            rank += (q.x < t + (j < i ? 1 : 0) ? 1 : 0) + (q.y < t + (j + 1 < i ? 1 : 0) ? 1 : 0) + (q.z < t + (j + 2 < i ? 1 : 0) ? 1 : 0) +
+                    (q.w < t + (j + 3 < i ? 1 : 0) ? 1 : 0);
+        }
+        for (int k4 = nb + 1; k4 < n4; ++k4) {
+            const int4 q = s_t[k4];
+            rank += (q.x < t ? 1 : 0) + (q.y < t ? 1 : 0) + (q.z < t ? 1 : 0) + (q.w < t ? 1 : 0);
+        }
+    }
+    if (i < L) {
+        skeys[rank] = (uint32_t)t;
+        svals[rank] = (uint32_t)i;
+    }
+}
+
+// CopyOutDegree for the larger batches (the radix-sort path): post-batch out-degree of every record's tail from the epoch's out-CSR
+__global__ __launch_bounds__(BLOCK) void k_copy_out_degree(const int *__restrict__ e1, int L, const int *__restrict__ out_row_ptr,
+                                                          int *__restrict__ deg_after) {
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < L; i += gridDim.x * BLOCK) {
+        const int t = e1[i];
+        deg_after[i] = out_row_ptr[t + 1] - out_row_ptr[t];
+    }
+}
+
 // blockIdx.y = source lane of a group (0 for a single source); state element (v, lane) sits at
 // base[v * stride + lane]
 __global__ __launch_bounds__(BLOCK) void k_su_terms(const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ svals,

@@ -59,6 +59,7 @@ EXPORTS = [
     "dppr_group_reset_stats", "dppr_set_group_seeding", "dppr_seed_lists", "dppr_set_sweep_bitmap", "dppr_set_group_resident", "dppr_set_resident_slots", "dppr_set_resident_update",
     "dppr_set_renumbering", "dppr_id_space", "dppr_set_group_push", "dppr_set_binned_sweep", "dppr_device_count", "dppr_set_phase_merge", "dppr_init_solve_at", "dppr_group_init_solve_at", "dppr_set_variant", "dppr_set_batch_grouping",
     "dppr_time_batch_grouping", "dppr_debug_dump", "dppr_hint_next_batch",
+    "dppr_bench_line_fills", "dppr_bench_stream_copy", "dppr_build_id",
 ]
 
 
@@ -130,8 +131,11 @@ def lib():
     L.dppr_time_batch_grouping.argtypes = [vp, C.c_int32, C.c_int32, fp]
     L.dppr_debug_dump.argtypes = [vp, C.c_char_p, C.c_int32]
     L.dppr_hint_next_batch.argtypes = [vp, ip, ip, C.c_int32, ip, ip, C.c_int32]
+    L.dppr_bench_line_fills.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int, fp]
+    L.dppr_bench_stream_copy.argtypes = [C.c_int, C.c_int64, C.c_int, fp]
+    L.dppr_build_id.restype = C.c_char_p
     for name in EXPORTS:
-        if name not in ("dppr_strerror", "dppr_last_error", "dppr_destroy"):
+        if name not in ("dppr_strerror", "dppr_last_error", "dppr_destroy", "dppr_build_id"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -208,6 +212,11 @@ class Engine:
     def set_phase_merge(self, on, eps_divisor=0):
         """One loop for residuals of both signs, run to eps / eps_divisor (include/dppr.h); eager schedule only."""
         self._ck(self._L.dppr_set_phase_merge(self._h, int(on), int(eps_divisor)), "set_phase_merge")
+
+    def set_batch_grouping(self, at_slide):
+        """0 (default): CopyOutDegree + the grouping of a batch's records run inside the timed region, as the reference times them;
+        1: at slide time (for epochs already built: on entry to the next update, before its event bracket opens)."""
+        self._ck(self._L.dppr_set_batch_grouping(self._h, int(at_slide)), "set_batch_grouping")
 
     def set_incremental_graph(self, on):
         self._ck(self._L.dppr_set_incremental_graph(self._h, int(on)), "set_incremental_graph")
@@ -393,7 +402,7 @@ class Engine:
         self._ck(self._L.dppr_synchronize(self._h), "synchronize")
 
     def time_batch_grouping(self, epoch=-1, reps=5):
-        """ms per batch of what grouping-at-slide keeps out of the timed region (out-degree gather + sort of the records by tail)."""
+        """ms per batch of CopyOutDegree + the grouping of the records by tail, run on their own as the timed region runs them."""
         ms = C.c_float(0)
         self._ck(self._L.dppr_time_batch_grouping(self._h, int(epoch), int(reps), C.byref(ms)), "time_batch_grouping")
         return ms.value
@@ -411,3 +420,26 @@ def bench_atomics(table_elems, n, scope=0, reps=5, device=0):
     if rc:
         raise DpprError(f"bench_atomics: {lib().dppr_strerror(rc).decode()}")
     return ms.value
+
+
+def bench_line_fills(table_bytes=1 << 30, lines=1 << 26, reps=3, device=0):
+    """ms for `lines` random 128-byte line fetches out of a table of table_bytes (dppr_bench_line_fills)."""
+    ms = C.c_float(0)
+    rc = lib().dppr_bench_line_fills(int(device), int(table_bytes), int(lines), int(reps), C.byref(ms))
+    if rc:
+        raise DpprError(f"bench_line_fills: {lib().dppr_strerror(rc).decode()}")
+    return ms.value
+
+
+def bench_stream_copy(nbytes=1 << 30, reps=5, device=0):
+    """ms per streaming copy of nbytes (read + write)."""
+    ms = C.c_float(0)
+    rc = lib().dppr_bench_stream_copy(int(device), int(nbytes), int(reps), C.byref(ms))
+    if rc:
+        raise DpprError(f"bench_stream_copy: {lib().dppr_strerror(rc).decode()}")
+    return ms.value
+
+
+def build_id():
+    """Identity of the loaded library's sources (dppr_build_id; tools/build_id.py computes the tree's)."""
+    return lib().dppr_build_id().decode()

@@ -46,6 +46,7 @@ def timed_region(run_steps: Callable[[], None], device_sync: Callable[[], None],
     run_steps()
     fence()
     dt = time.perf_counter() - t0
+    timed_region.last_local = dt   # this rank's own bracket (rank_census reports every rank's beside the MAX)
     if world > 1:
         import torch
         dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
@@ -53,6 +54,25 @@ def timed_region(run_steps: Callable[[], None], device_sync: Callable[[], None],
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt, world
+
+
+timed_region.last_local = 0.0
+
+
+def rank_census(value_local: float, dist=None):
+    """Proof that N ranks ran: every rank contributes a 1 (all-reduce SUM -> ranks_seen) and its own value
+    (all-gather, rank order), over whatever backend carries the barrier. Returns (ranks_seen, [values], backend)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return 1, [float(value_local)], None
+    import torch
+    backend = dist.get_backend()
+    dev = "cuda" if backend == "nccl" else "cpu"
+    one = torch.ones(1, dtype=torch.int64, device=dev)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    mine = torch.tensor([value_local], dtype=torch.float64, device=dev)
+    every = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, mine)
+    return int(one.item()), [float(t.item()) for t in every], backend
 
 
 def aggregate_units(units_local: int, dist=None) -> int:

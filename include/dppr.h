@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DPPR_ABI_VERSION 3
+#define DPPR_ABI_VERSION 4
 
 typedef struct dppr_engine dppr_engine; /* opaque */
 
@@ -85,10 +85,13 @@ typedef struct dppr_stats_t {
 int dppr_device_count(void);
 
 /* IncrementalBatchUpdate replays a batch's records tail by tail, each tail's records in batch order (lock-free; the
- * reference serialises them with a spin lock per tail, gpu/StreamUpdate.cuh:50-72). The grouping by tail is a function of the
- * batch alone. at_slide = 1 (default): dppr_slide does it when it uploads the batch -- untimed, like the reference's own batch
- * upload (GPUEdgeBatch::CudaMemcpy, gpu/PPRGPU.cuh:131-135) -- and the timed region holds only the replay; at_slide = 0: the
- * grouping (a device radix sort of the L records) runs inside dppr_update / dppr_group_update, as in rounds 1-2. Same results. */
+ * reference serialises them with a spin lock per tail, gpu/StreamUpdate.cuh:50-72), after CopyOutDegree (gpu/StreamUpdate.cuh:7-17).
+ * at_slide = 0 (DEFAULT since ABI 4): both run inside dppr_update / dppr_group_update / dppr_incremental_batch_update -- the
+ * reference's bracket (gpu/PPRGPU.cuh:138-164 times all of IncrementalBatchUpdate). Up to 16 Ki records the grouping is one
+ * ranking launch (k_su_group_rank), beyond that a device radix sort; a whole-batch resident launch takes the records raw and
+ * groups them itself (dppr_resident.hpp). at_slide = 1 (rounds 3-4): the grouping and the degree gather, functions of the batch
+ * alone, are done when the batch is uploaded (dppr_slide; for epochs that already exist: on entry to the next call, BEFORE its
+ * event bracket opens) and the timed region holds only the replay. Same results bit for bit. */
 int dppr_set_batch_grouping(dppr_engine *e, int at_slide);
 
 /* The reference's four variants (-o, Meta.h; gpu/PPRRevPushGPUVariants.cuh:6-150) as MECHANISMS of the push iterations:
@@ -389,6 +392,17 @@ int dppr_debug_dump(dppr_engine *e, char *buf, int32_t cap);
  * addresses of a table of table_elems doubles; scope 0 = agent, 1 = workgroup.
  * Returns the average kernel time in ms over reps launches. */
 int dppr_bench_atomics(int device, int64_t table_elems, int64_t n, int scope, int reps, float *out_ms);
+/* The other two calibrated ceilings of SURVEY.md 8(d), measured by bench.py in the run that prints the line (ABI 4):
+ * dppr_bench_line_fills -- `lines` random 128-byte line fetches (one request per 8 lanes, the access shape of the group
+ * sweep's row gathers) out of a table of table_bytes (a power of two; 1 GiB = beyond every cache); *out_ms = time for
+ * `lines` fetches. dppr_bench_stream_copy -- a streaming copy of `bytes` (read + write): *out_ms per copy. */
+int dppr_bench_line_fills(int device, int64_t table_bytes, int64_t lines, int reps, float *out_ms);
+int dppr_bench_stream_copy(int device, int64_t bytes, int reps, float *out_ms);
+
+/* Identity of the build: the first 16 hex digits of the SHA-256 over the kernel / engine sources the library was compiled
+ * from (the .hpp files of csrc in name order, csrc/dppr_engine.hip, include/dppr.h; see csrc/Makefile). Profiles under profiles/ carry the id of
+ * the library that produced them; bench.py refuses counter traffic measured on another build. */
+const char *dppr_build_id(void);
 
 #ifdef __cplusplus
 }

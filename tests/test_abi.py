@@ -32,7 +32,13 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} declared in include/dppr.h but not exported"
     assert sorted(eng.EXPORTS) == declared_symbols()
-    assert lib.dppr_abi_version() == 3   # 3: dppr_time_batch_grouping, dppr_debug_dump (round 4)
+    assert lib.dppr_abi_version() == 4   # 4: grouping inside the timed region by default, dppr_bench_line_fills / _stream_copy, dppr_build_id (round 5)
+    # the library knows which sources it was built from, and says the same as the tree (profiles are stamped with it)
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import build_id
+    lib.dppr_build_id.restype = ctypes.c_char_p
+    assert lib.dppr_build_id().decode() == build_id.tree_build_id() == eng.build_id()
 
 
 def test_strerror_and_argument_validation_without_gpu():

@@ -30,13 +30,26 @@ def test_bench_line_contract(extra, sources):
     assert abs(d["value"] - sources * c / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and 0 < rf["frac"] < 1
-    assert 0 < rf["frac_group_adjusted"] <= rf["frac"] and "frac_traffic" in rf     # (a group reads a column entry once for its S sources)
-    assert (rf["frac_group_adjusted"] == rf["frac"]) == (sources == 1)
-    assert rf["hbm_achievable"] == 6300.0 and "fabric" in rf["traffic_kind"] and rf["all_iteration_launches"]["launches"] >= rf["launches"] > 0
-    tr = d["config"]["timed_region"]    # which accounting produced `value`, and the batch time under the reference's own
-    assert tr["grouping"] == "at_slide" and tr["grouping_ms_per_step"] > 0
-    assert abs(tr["ms_per_step_grouping_in_region"] - (d["ms_per_step"] + tr["grouping_ms_per_step"])) < 2e-4
+    # frac is a roofline fraction: bytes priced for the design that ran (a group reads a column entry once for its S sources) / time / peak
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and 0 < rf["frac"] <= 1
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e9) <= 2e-3 * rf["achieved"]
+    wr = rf["work_rate_survey_unit"]      # SURVEY 8(d)'s per-source unit beside it: equal for one source, larger for a group
+    assert (abs(wr["over_peak"] - rf["frac"]) < 1e-4) == (sources == 1) and wr["over_peak"] >= rf["frac"] - 1e-4
+    assert (f"(16 + 8 / {sources})" in rf["bytes_model"]) == (sources > 1)
+    assert "fabric" in rf["traffic_kind"] and rf["all_iteration_launches"]["launches"] >= rf["launches"] > 0
+    ce = rf["ceilings_measured_in_this_run"]   # SURVEY 8(d)'s calibrated ceilings, measured by this very run
+    assert 1e10 < ce["line_fills_per_s"] < 2e11 and 5e9 < ce["returning_f64_atomics_per_s"] < 1e11 and 2000 < ce["stream_copy_GBps"] < 8000
+    # counter traffic is taken only from a profile of THIS build of the library; anything else is refused with a reason
+    from dynamicppr_amd import engine as eng
+    assert rf["build_id"] == d["build_id"] == eng.build_id()
+    assert rf["traffic"] is None or eng.build_id() in rf["traffic_source"]
+    assert rf["traffic"] is not None or rf["frac_traffic"] is None
+    tr = d["config"]["timed_region"]    # `value` is measured under the reference's bracket; the other accounting is carried beside it
+    assert tr["grouping"] == "in_region" and tr["copy_out_degree"] == "in_region" and tr["grouping_ms_per_step"] > 0
+    asl = tr["at_slide_accounting"]
+    assert asl["how"].startswith("measured") and 0 < asl["event_ms_per_step"] < 1.25 * d["event_ms_per_step"]
+    assert asl["max_abs_dp_vs_headline_state"] < 1e-12   # (same batches, same schedule: the two accountings end in the same state)
+    assert d["ranks_seen"] == 1 and d["backend"] is None and len(d["per_rank_ms_per_step"]) == 1 and d["launcher"] == "single process"
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     pr = d["parity"]
@@ -46,3 +59,20 @@ def test_bench_line_contract(extra, sources):
     assert ml["parity"]["ok"] is True and ml["parity"]["max_abs_residual"] <= pr["eps"] / 4 and ml["parity"]["max_abs_dp_vs_cpu_t1"] < pr["tolerance"]
     assert ml["ms_per_step"] > 0 and abs(ml["speedup_vs_value"] - d["ms_per_step"] / ml["ms_per_step"]) < 0.02 * ml["speedup_vs_value"]
     assert "end of the timed region" in pr["cpu_compared"] and f"{min(sources, 2)} source(s)" in pr["cpu_compared"]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` typed as such (no torchrun in front): the script starts torch.distributed.run itself as a CHILD
+    process before anything has touched HIP, forwards the one line of rank 0 and its exit code. On a one-GPU box the two ranks
+    share the device (gloo carries the barrier: RCCL refuses two ranks on one device); the line proves both ranks ran."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "dblp", "--steps", "4", "--warmup", "2",
+                        "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["backend"] in ("nccl", "gloo") and d["launcher"] == "self"
+    assert len(d["per_rank_ms_per_step"]) == 2 and abs(max(d["per_rank_ms_per_step"]) - d["ms_per_step"]) < 1e-3
+    assert d["scaling"] == "weak" and d["parity"]["ok"] is True
+    c = d["config"]["batch_c"]
+    assert abs(d["value"] - 2 * c / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]      # both ranks' units over the slowest rank's time

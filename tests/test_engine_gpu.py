@@ -52,8 +52,9 @@ TUNINGS = [dict(pull_min_frontier=-1), dict(hub_min_degree=3, big_row_edges=8, p
            # block shape (one block each), and mixed with push iterations in chunks of 3
            dict(pull_min_frontier=1, persistent=0, binned=(2, 1, 1, 64, 0, 64, 64)), dict(pull_min_frontier=1, persistent=0, binned=2),
            dict(pull_min_frontier=40, persistent=0, binned=(2, 2, 3, 200, 0, 100, 500), chunk_iters=3),
-           # the batch's records grouped by tail inside the timed region (rounds 1-2) instead of at slide time
-           dict(group_at_slide=0), dict(pull_min_frontier=1, group_at_slide=0),
+           # the batch's records grouped by tail (and CopyOutDegree done) at slide time, outside the timed region (rounds 3-4; the
+           # default since round 5 keeps both inside, where the reference times them)
+           dict(group_at_slide=1), dict(pull_min_frontier=1, group_at_slide=1),
            # edge slots of the resident sweep in CSR order (rounds 1-2; the default is the table sorted by gather position), also
            # on several small groups
            dict(pull_min_frontier=1, resident_slots=0), dict(resident_slots=0, pull_block=256),
@@ -63,7 +64,7 @@ TUNINGS = [dict(pull_min_frontier=-1), dict(hub_min_degree=3, big_row_edges=8, p
 TUNING_IDS = ["push-only", "push-hubs+bigrows", "push-all-hub-all-big", "pull-only", "mixed-pull>=40", "default",
               "mixed-chunk1", "mixed-chunk3", "pull-wg512", "mixed-wg1024", "pull-no-persist", "pull-wg256",
               "pull-rollcall-fails", "pull-resident-3-sweeps", "pull-bitmap-wg256", "mixed-bitmap", "pull-bitmap-wg640",
-              "binned-tiny-blocks", "binned-one-block", "mixed-binned-chunk3", "grouping-in-update", "pull-grouping-in-update",
+              "binned-tiny-blocks", "binned-one-block", "mixed-binned-chunk3", "grouping-at-slide", "pull-grouping-at-slide",
               "resident-csr-slots", "resident-csr-slots-wg256", "resident-update-own-kernel", "resident-update-own-kernel-wg256"]
 
 
@@ -709,8 +710,9 @@ def test_update_inside_the_resident_launch_equals_the_update_kernel():
     W, c, _, _ = orc.workload_config(len(e1), 0.1, 0, 0.01, 100, 0, 0)
     src = int(datagen.top_sources(V, e1, e2, W, cfg.directed, 1)[0])
     eps = 1e-9
-    engines = [eng.Engine(V, W, cfg.directed, c, resident_update=m) for m in (0, 1)]
+    engines = [eng.Engine(V, W, cfg.directed, c, resident_update=m) for m in (0, 1)]   # (1: the default -- the launch takes the records RAW)
     engines.append(eng.Engine(V, W, cfg.directed, c, persist_timeout_us=-1))   # every roll-call fails
+    engines.append(eng.Engine(V, W, cfg.directed, c, group_at_slide=1))        # records grouped at slide time, ranges per sweep group
     slots = []
     for e in engines:
         e.load_window(e1[:W], e2[:W])
@@ -726,16 +728,50 @@ def test_update_inside_the_resident_launch_equals_the_update_kernel():
             e.slide(e1[pos:pos + c], e2[pos:pos + c])
             e.update(sl, eps)
         pos += c
-        (p0, r0), (p1, r1), (p2, r2) = (e.read(sl) for e, sl in zip(engines, slots))
+        (p0, r0), (p1, r1), (p2, r2), (p3, r3) = (e.read(sl) for e, sl in zip(engines, slots))
         assert np.max(np.abs(p0 - p1)) < 1e-13 and np.max(np.abs(r0 - r1)) < 1e-13, k
         assert np.max(np.abs(p0 - p2)) < 1e-13 and np.max(np.abs(r0 - r2)) < 1e-13, k
-    st0, st1, st2 = (e.stats(sl) for e, sl in zip(engines, slots))
-    for st in (st1, st2):
+        assert np.max(np.abs(p0 - p3)) < 1e-13 and np.max(np.abs(r0 - r3)) < 1e-13, k   # (raw and pre-grouped records: same terms, same order per tail)
+    st0, st1, st2, st3 = (e.stats(sl) for e, sl in zip(engines, slots))
+    for st in (st1, st2, st3):
         assert (st0["iterations"], st0["sum_F"], st0["sum_E"], st0["records"]) == (st["iterations"], st["sum_F"], st["sum_E"], st["records"])
     assert st1["persist_launches"] >= 8 and st1["persist_aborts"] == 0   # (the from-scratch solve's launches count too)
+    assert st3["persist_launches"] == st1["persist_launches"] and st3["persist_aborts"] == 0
     assert st2["persist_aborts"] == 1
     for e in engines:
         e.close()
+
+
+@pytest.mark.parametrize("directed", [1, 0])
+def test_resident_launch_calls_itself_off_when_a_group_owns_too_many_records(directed):
+    """Default accounting: the whole-batch resident launch takes the batch's records raw and every sweep group applies its own.
+    Here every inserted edge has the same tail, so one 256-thread sweep group owns 300 records of a batch: the launch calls
+    itself off before anything is changed (NOT a residency failure: no abort is counted, resident launches stay on), the update
+    runs as its own kernels, the next batches do so at once -- and every state equals that of an engine whose update is always a
+    kernel of its own, and the -t 1 oracle's within the north-star tolerance."""
+    V, W, c, eps = 512, 600, 300, 1e-9
+    rng = np.random.default_rng(3)
+    e1, e2 = rng.integers(0, V, 6000).astype(np.int32), rng.integers(0, V, 6000).astype(np.int32)
+    e1[W:] = 5
+    e2[e2 == e1] = (e1[e2 == e1] + 1) % V
+    scs = [Scenario(V, e1, e2, directed, W, c, 5, eps, pull_min_frontier=1, pull_block=256, **kw) for kw in (dict(), dict(resident_update=0))]
+    sc, ref = scs
+    for x in scs:
+        x.e.init_solve(x.slot, eps)
+    sc.s.cilk_execute(sc.g)
+    for k in range(6):
+        for x in scs:
+            assert x.advance_graphs()
+            x.e.update(x.slot, eps)
+        (p0, r0), (p1, r1) = sc.e.read(sc.slot), ref.e.read(ref.slot)
+        assert np.max(np.abs(p0 - p1)) < 1e-13 and np.max(np.abs(r0 - r1)) < 1e-13, k
+        sc.s.cilk_inc_execute(sc.g)
+        assert np.max(np.abs(p0 - sc.s.p)) < NORTH_STAR_TOL and np.max(np.abs(r0)) < eps, k
+    st, st_ref = sc.e.stats(sc.slot), ref.e.stats(ref.slot)
+    assert st["persist_aborts"] == 0 and st["records"] == st_ref["records"]
+    assert st["persist_launches"] > st_ref["persist_launches"]   # (the launch that called itself off is counted as a launch)
+    for x in scs:
+        x.e.close()
 
 
 def test_full_size_livejournal_standin_two_sources():

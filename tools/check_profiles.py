@@ -43,6 +43,8 @@ def cut(trace_csv, stats_csv, outdir):
     # two-kernel form), or the k_su_keys just before it (counter clear; with dppr_set_batch_grouping(0) k_su_keys + the
     # device sort). The k_su_keys of a slide-time grouping belongs to the SLIDE and is not a mark.
     # With the update applied inside the resident launch (PLAN_UPDATE) a batch is k_su_keys (counter clear) -> k_pull_resident.
+    # Round 5 (grouping and CopyOutDegree inside the timed region by default): a batch starts at k_su_group_rank (one launch: degrees,
+    # grouping, counter clear) or, beyond 16 K records, at k_copy_out_degree -> k_su_keys -> device sort.
     marks = []
     for i, (n, _, _) in enumerate(ev):
         if n == "k_su_keys" and i + 1 < len(ev) and ev[i + 1][0].startswith("k_pull_resident"):
@@ -53,7 +55,13 @@ def cut(trace_csv, stats_csv, outdir):
         j = i - 1
         while j >= 0 and ev[j][0].startswith("rocprim::radix"):
             j -= 1
-        marks.append(j if j >= 0 and ev[j][0] == "k_su_keys" else i)
+        if j >= 0 and ev[j][0] == "k_su_group_rank":
+            marks.append(j)
+            continue
+        if j >= 0 and ev[j][0] == "k_su_keys":
+            marks.append(j - 1 if j >= 1 and ev[j - 1][0] == "k_copy_out_degree" else j)
+            continue
+        marks.append(i)
     batches = [(marks[i], marks[i + 1]) for i in range(len(marks) - 1)]
     spans = []
     slide_kernels = ("k_make", "k_deg", "k_mark", "k_del_pos", "k_merge_tiles", "k_build", "k_assign", "k_tile", "k_gather_deg", "k_gtables", "k_bin_keys", "k_bin_fill", "k_bin_vertex",
