@@ -43,12 +43,12 @@ __global__ __launch_bounds__(1024) void k_bench_copy(const double2 *__restrict__
     const int64_t stride = (int64_t)gridDim.x * 1024;
     int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
     for (; i + 3 * stride < n16; i += 4 * stride) { // four independent 16-byte loads in flight per lane
-        const v2d a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
-        const v2d c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-        __builtin_nontemporal_store(a, dst + i);
-        __builtin_nontemporal_store(b, dst + i + stride);
-        __builtin_nontemporal_store(c, dst + i + 2 * stride);
-        __builtin_nontemporal_store(d, dst + i + 3 * stride);
+        const v2d a = src[i], b = src[i + stride];
+        const v2d c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a;
+        dst[i + stride] = b;
+        dst[i + 2 * stride] = c;
+        dst[i + 3 * stride] = d;
     }
     for (; i < n16; i += stride) dst[i] = src[i];
 }

@@ -8,6 +8,7 @@
 // There is NO CPU fallback: without a HIP device dppr_create fails with
 // DPPR_ERR_NO_DEVICE.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -282,6 +283,9 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     std::vector<Slot> slots;
     std::vector<Group> groups;
     int *pinned = nullptr; // host-pinned readback words
+    std::atomic<unsigned long long> heartbeat{0}; // bumped at every read-back of a frontier loop and every stage of a graph build (dppr_heartbeat)
+    char *dump_pin = nullptr;     // host-pinned landing area of dppr_debug_dump's device reads, owned by the engine for its whole life
+    static constexpr size_t DUMP_PIN_BYTES = sizeof(GridBar) + 4096;
     // vertex compaction: external id <-> internal id (assigned on first appearance), live zone [0, n_int) and parked
     // zone [V - n_parked, V): IdSpace. Renumbering (dppr_builder.hpp) is decided here:
     bool renumber_on = true;       // dppr_set_renumbering
@@ -345,6 +349,11 @@ inline hipError_t loop_sync(hipStream_t st) {
         __builtin_ia32_pause();
     }
     return r;
+}
+
+inline hipError_t loop_wait(dppr_engine *e) { // a read-back of a frontier loop: a sign of life for a watchdog (dppr_heartbeat)
+    e->heartbeat.fetch_add(1, std::memory_order_relaxed);
+    return loop_sync(e->stream);
 }
 
 int fail(dppr_engine *e, int code, const char *msg) {
@@ -1089,6 +1098,7 @@ int build_bins(dppr_engine *e, Epoch &ep) {
 
 // Hub directory + in-CSR + out-CSR of `ep` from the persistent sorted keys and outdeg.
 int build_epoch(dppr_engine *e, Epoch &ep) {
+    e->heartbeat.fetch_add(1, std::memory_order_relaxed);
     const int Ed = e->Ed;
     const int NV = e->n_int; // only vertices that ever had an edge (or are a source) exist internally
     // hub directory: the (at most HUB_CAP) vertices of largest out-degree, at least hub_min_degree
@@ -1120,13 +1130,17 @@ int build_epoch(dppr_engine *e, Epoch &ep) {
                        e->directed ? e->out_sorted : e->in_sorted, Ed, e->V, e->bits, ep.out_row_ptr, ep.out_col);
     HIP_TRY(hipGetLastError());
     ep.Ed = Ed;
+    e->heartbeat.fetch_add(1, std::memory_order_relaxed);
     if (int rc = cut_sweep_groups(e, ep)) return rc;
-    return build_bins(e, ep);
+    e->heartbeat.fetch_add(1, std::memory_order_relaxed);
+    const int brc = build_bins(e, ep);
+    e->heartbeat.fetch_add(1, std::memory_order_relaxed);
+    return brc;
 }
 
 int read_count(dppr_engine *e, const int *dptr, int *out) {
     HIP_TRY(hipMemcpyAsync(e->pinned, dptr, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(loop_sync(e->stream));
+    HIP_TRY(loop_wait(e));
     *out = e->pinned[0];
     return DPPR_OK;
 }
@@ -1257,7 +1271,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             s.trace_ids.resize(old + (size_t)F);
             HIP_TRY(hipMemcpyAsync(s.trace_ids.data() + old, s.ft[buf], sizeof(int) * (size_t)F,
                                    hipMemcpyDeviceToHost, e->stream));
-            HIP_TRY(loop_sync(e->stream));
+            HIP_TRY(loop_wait(e));
             for (size_t i = old; i < s.trace_ids.size(); ++i) s.trace_ids[i] = e->int2ext[(size_t)s.trace_ids[i]];
             s.trace_off.push_back((int64_t)s.trace_ids.size());
         }
@@ -1276,7 +1290,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 hipLaunchKernelGGL(k_front_degree, dim3(grid_for(F)), dim3(BLOCK), 0, e->stream, s.ft[buf], s.cnt + cur, ep.row_ptr, dsum + cur);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(e->pinned, dsum + cur, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
-                HIP_TRY(loop_sync(e->stream));
+                HIP_TRY(loop_wait(e));
                 unsigned long long d;
                 memcpy(&d, e->pinned, sizeof(d));
                 D = (long long)d;
@@ -1341,7 +1355,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[1], e->stream));
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(e->pinned, s.cnt, sizeof(int) * (size_t)(CNT_HDR + n), hipMemcpyDeviceToHost, e->stream));
-            HIP_TRY(loop_sync(e->stream));
+            HIP_TRY(loop_wait(e));
             const int status = e->pinned[7];
             s.st.persist_launches++;
             if (status & PERSIST_FAULT) return fail(e, DPPR_ERR_HIP, "grid barrier of the resident sweep timed out");
@@ -1468,7 +1482,7 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
         HIP_TRY(hipGetLastError());
         // one read-back per chunk: the new frontier size and the F of each iteration just run
         HIP_TRY(hipMemcpyAsync(e->pinned, s.cnt, sizeof(int) * (size_t)(CNT_HDR + n), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(loop_sync(e->stream));
+        HIP_TRY(loop_wait(e));
         for (int k = 0; k < n; ++k) {
             const int f = e->pinned[CNT_HDR + k];
             if (f <= 0) continue; // the frontier emptied inside the chunk: the rest were no-ops
@@ -1584,7 +1598,7 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
     if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[1], e->stream));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e->pinned, s.cnt, sizeof(int) * (size_t)(CNT_HDR + n), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(loop_sync(e->stream));
+    HIP_TRY(loop_wait(e));
 
     const int st = e->pinned[7];
     *stage = 0;
@@ -1832,7 +1846,7 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
     const int GWM = GS_MAX;
     const int cap = std::max(1024, std::min(e->gpush_list_cap, e->V));
     if (g.plist_cap != cap) {
-        HIP_TRY(loop_sync(e->stream));
+        HIP_TRY(loop_wait(e));
         (void)hipFree(g.plist[0]); (void)hipFree(g.plist[1]); (void)hipFree(g.ppre); (void)hipFree(g.pctl);
         g.plist[0] = g.plist[1] = g.ppre = nullptr;
         g.pctl = nullptr;
@@ -1893,7 +1907,7 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(&h, g.pctl, sizeof(GPushCtl), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(loop_sync(e->stream));
+        HIP_TRY(loop_wait(e));
         for (int i = it_done; i < h.it; ++i) {
             long long F = 0;
             for (int s = 0; s < GWM; ++s) F += h.F[i & (GPUSH_LOG - 1)][s];
@@ -1960,7 +1974,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
         return false;
     };
     HIP_TRY(hipMemcpyAsync(e->pinned, g.cnt + cur * GWM, sizeof(int) * GWM, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(loop_sync(e->stream));
+    HIP_TRY(loop_wait(e));
     bool more = any_left(e->pinned);
     int active_iters = 0;
     if (e->gsweep_grid_cap <= 0) {
@@ -2005,7 +2019,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
             if (e->profiling) HIP_TRY(hipEventRecord(e->evpool[1], e->stream));
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(e->pinned, g.mlog, sizeof(int) * (size_t)(n + 2) * GWM, hipMemcpyDeviceToHost, e->stream));
-            HIP_TRY(loop_sync(e->stream));
+            HIP_TRY(loop_wait(e));
             const int st = e->pinned[0];
             g.st.persist_launches++;
             if (st & GSM_FAULT) return fail(e, DPPR_ERR_HIP, "a grid barrier of the multi-sweep group launch timed out");
@@ -2094,7 +2108,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(e->pinned, g.cnt, sizeof(int) * (size_t)(5 * GWM + n * GWM), hipMemcpyDeviceToHost,
                                e->stream));
-        HIP_TRY(loop_sync(e->stream));
+        HIP_TRY(loop_wait(e));
         for (int k = 0; k < n; ++k) {
             const int *f = e->pinned + 5 * GWM + k * GWM;
             if (!any_left(f)) continue;
@@ -2141,7 +2155,7 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
                     else { // back in sweep form: frontier sizes in row 0; the next try waits for a much smaller frontier
                         cur = 0;
                         HIP_TRY(hipMemcpyAsync(e->pinned, g.cnt, sizeof(int) * GWM, hipMemcpyDeviceToHost, e->stream));
-                        HIP_TRY(loop_sync(e->stream));
+                        HIP_TRY(loop_wait(e));
                         more = any_left(e->pinned);
                         push_thr = std::max<long long>(F / 8, 1);
                         dense_len = -1;
@@ -2252,6 +2266,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     HIP_TRY_C(hipEventCreate(&e->ev0));
     HIP_TRY_C(hipEventCreate(&e->ev1));
     for (auto &ev : e->evpool) HIP_TRY_C(hipEventCreate(&ev));
+    HIP_TRY_C(hipHostMalloc((void **)&e->dump_pin, dppr_engine::DUMP_PIN_BYTES, hipHostMallocDefault));
     HIP_TRY_C(hipHostMalloc((void **)&e->pinned, sizeof(int) * ((GMULTI_MAX + 2) * GS_MAX + 3 * GS_MAX + MAX_CHUNK * GS_MAX + 16), hipHostMallocDefault));
     const size_t Wn = (size_t)std::max(W, 1), Edn = (size_t)std::max(e->Ed, 1), Ln = (size_t)std::max(4 * c, 1);
     HIP_TRY_C(hipMalloc((void **)&e->w1, sizeof(int) * Wn));
@@ -2345,6 +2360,7 @@ void dppr_destroy(dppr_engine *e) {
     for (int k = 0; k < 2; ++k) { (void)hipFree(e->su_k[k]); (void)hipFree(e->su_v[k]); }
     (void)hipFree(e->su_term); (void)hipFree(e->su_ins); (void)hipFree(e->su_tmp);
     if (e->pinned) (void)hipHostFree(e->pinned);
+    if (e->dump_pin) (void)hipHostFree(e->dump_pin);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     for (auto &ev : e->evpool)
@@ -2803,19 +2819,28 @@ int dppr_debug_dump(dppr_engine *e, char *buf, int32_t cap) {
     add("id lookahead (dppr_hint_next_batch): %lld id arrays taken from it so far (%lld entries resolved at the call), renumberings %llu\n", e->pre_hits, e->pre_misses, e->renumber_epoch);
     add("resident launches: mode %d ok %d retry %d time limit %llu ticks (100 MHz) rollcall_extra %d; schedule %d merge %d\n", e->persist_mode,
         (int)e->persist_ok, e->persist_retry, e->persist_ticks, e->persist_rollcall_extra, e->schedule, (int)e->merge_phases);
-    // device words through a stream of their own, waited for at most ~2 s
+    // Device words through a stream of their own, waited for at most ~2 s in total. The copies land in a PINNED buffer the engine
+    // owns for its whole life (a copy into pageable memory is staged and may block inside the call on a wedged device,
+    // and one that completes after its stack destination is gone writes into dead memory); once a copy has not completed in time no
+    // further one is issued and the side stream is abandoned, not destroyed (hipStreamDestroy would wait for it).
     hipStream_t side = nullptr;
-    const bool have_side = hipSetDevice(e->device) == hipSuccess && hipStreamCreateWithFlags(&side, hipStreamNonBlocking) == hipSuccess;
+    const bool have_side = e->dump_pin && hipSetDevice(e->device) == hipSuccess && hipStreamCreateWithFlags(&side, hipStreamNonBlocking) == hipSuccess;
+    bool side_stuck = false;
+    int polls_left = 2000; // x 1 ms, shared by all fetches of this dump
     auto fetch = [&](void *dst, const void *src, size_t bytes) -> bool {
-        if (!have_side || !src) return false;
-        if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, side) != hipSuccess) return false;
-        for (int k = 0; k < 2000; ++k) {
+        if (!have_side || side_stuck || !src || bytes > dppr_engine::DUMP_PIN_BYTES) return false;
+        if (hipMemcpyAsync(e->dump_pin, src, bytes, hipMemcpyDeviceToHost, side) != hipSuccess) return false;
+        while (polls_left-- > 0) {
             const hipError_t q = hipStreamQuery(side);
-            if (q == hipSuccess) return true;
+            if (q == hipSuccess) {
+                memcpy(dst, e->dump_pin, bytes);
+                return true;
+            }
             if (q != hipErrorNotReady) return false;
             timespec ts{0, 1000000};
             nanosleep(&ts, nullptr);
         }
+        side_stuck = true; // the copy stays queued: its destination outlives it
         return false;
     };
     add("engine stream: %s\n", hipStreamQuery(e->stream) == hipSuccess ? "idle" : "BUSY (work enqueued or running)");
@@ -2853,7 +2878,8 @@ int dppr_debug_dump(dppr_engine *e, char *buf, int32_t cap) {
             (long long)g.st.iterations, (long long)g.st.persist_launches, (long long)g.st.persist_aborts, ok ? "" : "(unreadable) ", f[0], f[1], f[2],
             (unsigned)st);
     }
-    if (have_side) (void)hipStreamDestroy(side);
+    if (side_stuck) add("(a device read did not complete within 2 s: the remaining ones were skipped, the side stream is abandoned)\n");
+    if (have_side && !side_stuck) (void)hipStreamDestroy(side);
 #undef add
     const size_t n = std::min(o.size(), (size_t)cap - 1);
     memcpy(buf, o.data(), n);
@@ -3547,6 +3573,8 @@ int dppr_bench_stream_copy(int device, int64_t bytes, int reps, float *out_ms) {
     (void)hipFree(dst);
     return err == hipSuccess ? DPPR_OK : DPPR_ERR_HIP;
 }
+
+unsigned long long dppr_heartbeat(const dppr_engine *e) { return e ? e->heartbeat.load(std::memory_order_relaxed) : 0ull; }
 
 #ifndef DPPR_BUILD_ID
 #define DPPR_BUILD_ID "unstamped"

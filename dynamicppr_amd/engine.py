@@ -59,7 +59,7 @@ EXPORTS = [
     "dppr_group_reset_stats", "dppr_set_group_seeding", "dppr_seed_lists", "dppr_set_sweep_bitmap", "dppr_set_group_resident", "dppr_set_resident_slots", "dppr_set_resident_update",
     "dppr_set_renumbering", "dppr_id_space", "dppr_set_group_push", "dppr_set_binned_sweep", "dppr_device_count", "dppr_set_phase_merge", "dppr_init_solve_at", "dppr_group_init_solve_at", "dppr_set_variant", "dppr_set_batch_grouping",
     "dppr_time_batch_grouping", "dppr_debug_dump", "dppr_hint_next_batch",
-    "dppr_bench_line_fills", "dppr_bench_stream_copy", "dppr_build_id",
+    "dppr_bench_line_fills", "dppr_bench_stream_copy", "dppr_build_id", "dppr_heartbeat",
 ]
 
 
@@ -134,8 +134,10 @@ def lib():
     L.dppr_bench_line_fills.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int, fp]
     L.dppr_bench_stream_copy.argtypes = [C.c_int, C.c_int64, C.c_int, fp]
     L.dppr_build_id.restype = C.c_char_p
+    L.dppr_heartbeat.argtypes = [vp]
+    L.dppr_heartbeat.restype = C.c_ulonglong
     for name in EXPORTS:
-        if name not in ("dppr_strerror", "dppr_last_error", "dppr_destroy", "dppr_build_id"):
+        if name not in ("dppr_strerror", "dppr_last_error", "dppr_destroy", "dppr_build_id", "dppr_heartbeat"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -65,7 +65,7 @@ int main(int argc, char *argv[]) {
     // driver has made progress (a from-scratch solve, a slide, a batch) for that long. The engine waits on device-side
     // barriers with their own time limits (dppr_resident.hpp), so this should never fire; the test-suite sets it so that a
     // hang, should one happen again (one unexplained 300-second guard in round 3), leaves a post-mortem instead
-    // of a silent time-out. Exit code 124.
+    // of a silent time-out. Exit code 125.
     std::atomic<bool> finished{false};
     std::thread watchdog;
     if (const char *w = std::getenv("DPPR_WATCHDOG_S")) {
@@ -77,20 +77,28 @@ int main(int argc, char *argv[]) {
                 while (!finished.load()) {
                     std::this_thread::sleep_for(std::chrono::milliseconds(50));
                     unsigned long long now = 0;
-                    for (auto &d : drivers) now += d->progress.load();
+                    for (auto &d : drivers) now += d->progress.load() + dppr_heartbeat(d->engine); // (the engine's own read-backs count: one long call is not a hang)
                     if (now != last) {
                         last = now;
                         since = std::chrono::steady_clock::now();
                     } else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - since).count() > limit) {
-                        std::cerr << "[watchdog] no progress for " << limit << " s -- engine state:" << std::endl;
+                        // what the host knows first, flushed; then the engines' dumps (bounded inside the library) under a hard
+                        // deadline of their own -- a wedged device must not turn the post-mortem into a silent time-out.
+                        // Exit code 125: 124 is what `timeout` returns, and the two causes must be told apart.
+                        std::cerr << "[watchdog] no progress for " << limit << " s (" << last << " progress marks so far) -- engine state:" << std::endl;
+                        std::cout.flush();
+                        std::thread([] {
+                            std::this_thread::sleep_for(std::chrono::seconds(10));
+                            std::cerr << "[watchdog] the dump did not finish within 10 s" << std::endl;
+                            std::_Exit(125);
+                        }).detach();
                         std::vector<char> buf(1 << 16);
                         for (auto &d : drivers) {
                             dppr_debug_dump(d->engine, buf.data(), (int32_t)buf.size());
                             std::cerr << buf.data();
+                            std::cerr.flush();
                         }
-                        std::cerr.flush();
-                        std::cout.flush();
-                        std::_Exit(124);
+                        std::_Exit(125);
                     }
                 }
             });

@@ -386,6 +386,10 @@ int dppr_time_batch_grouping(dppr_engine *e, int32_t epoch, int32_t reps, float 
  * are read racily, which is what a post-mortem wants). No reference counterpart (its loop is host-driven,
  * gpu/PPRRevPushGPU.cuh:106-130, and cannot wait on a device-side barrier). */
 int dppr_debug_dump(dppr_engine *e, char *buf, int32_t cap);
+/* A counter that advances at every host read-back of a frontier loop and every stage of a graph build (ABI 4): a watchdog
+ * samples it so that ONE long call (the first solve on a large window, a group's from-scratch solve) is told from a hang
+ * (ADVICE r04). Callable from any thread. */
+unsigned long long dppr_heartbeat(const dppr_engine *e);
 
 /* Microbenchmark used to calibrate the roofline ceiling of the push kernel
  * (SURVEY.md 8d): n returning f64 atomic adds per launch at pseudo-random

@@ -27,7 +27,7 @@ def small_bin(tmp_path_factory):
     return path, V, e1, e2
 
 
-WATCHDOG_S = "60"   # ./pagerank ends itself with a post-mortem (dppr_debug_dump of every engine, exit code 124) after this long without progress
+WATCHDOG_S = "60"   # ./pagerank ends itself with a post-mortem (dppr_debug_dump of every engine, exit code 125) after this long without progress
 
 
 def run(args, env_extra=None, **kw):
@@ -39,7 +39,7 @@ def run(args, env_extra=None, **kw):
     except subprocess.TimeoutExpired as ex:   # (subprocess.run has killed the child -- the CHILD, never this process)
         out = ex.stdout.decode(errors="replace") if isinstance(ex.stdout, bytes) else (ex.stdout or "")
         pytest.fail(f"{' '.join(args)} did not finish within 150 s (its own watchdog should have fired at {WATCHDOG_S} s); output so far:\n{out}")
-    if r.returncode == 124:
+    if r.returncode in (124, 125):
         pytest.fail(f"{' '.join(args)}: the watchdog fired -- no progress for {WATCHDOG_S} s:\n{r.stdout}")
     return r
 
@@ -225,6 +225,31 @@ def test_sweep_tool_scrapes_the_stdout_contract(pagerank, small_bin, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("what", ["source_feature", "batch_ratio"])
+def test_sweep_tool_source_features_and_batch_ratios(pagerank, small_bin, tmp_path, what):
+    """The other two sweeps of the reference's experiment matrix (scripts/gpu.sh:112-170): sources taken from the workload
+    tool's top10 / top1000 / top1000000 files (written on demand by dynamicppr_amd/tools.py workload; a 512-vertex graph has no
+    vertex of rank >= 1000, so -- like the reference's tool -- no third file), -r 0.01 / 0.001 / 0.0001."""
+    import json
+    path, V, e1, e2 = small_bin
+    r = run(["python3", os.path.join(ROOT, "tools", "sweep.py"), what, "--data", path, "--directed", "1", "--batches", "3",
+             "--log-dir", str(tmp_path / "log")])
+    assert r.returncode == 0, r.stdout
+    rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    feats = ["top10", "top1000"]
+    base = os.path.basename(path)
+    ids = {f: [int(x) for x in open(tmp_path / "log" / f"{base}_{f}.txt").read().split()] for f in feats}
+    assert all(len(v) == 10 for v in ids.values())
+    if what == "source_feature":
+        assert [(x["source_feature"], x["source"]) for x in rows] == [(f, ids[f][3]) for f in feats]     # entry 3 of each file, scripts/gpu.sh:17
+        assert all(x["ppr_latency_ms"] and x["ppr_throughput"] > 0 for x in rows)
+    else:
+        assert [(x["batch_ratio"], x["source_feature"]) for x in rows] == [(r_, f) for r_ in (0.01, 0.001, 0.0001) for f in feats]
+        # (6 000 stream edges: -r 0.0001 is less than one edge per batch -- the run has no complete batch and prints no latency, as the reference would)
+        assert all(x["ppr_latency_ms"] for x in rows if x["batch_ratio"] == 0.01)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nsrc", [1, 3])
 def test_cli_long_churning_stream_renumbers_and_matches_oracle(pagerank, tmp_path, nsrc):
     """The reference driver's flow (slide, update, slide, ...) over a stream that churns through the id range: the
@@ -313,12 +338,12 @@ def test_cli_profile_output_matches_the_reference_profile_build(pagerank, small_
 def test_cli_watchdog_writes_a_post_mortem(pagerank, small_bin):
     """The diagnostic path itself: a driver that stops making progress (test hook DPPR_TEST_STALL) is ended by the
     watchdog after the limit, with the engine's state (dppr_debug_dump: last error, epoch, GridBar words read through a
-    side stream, per-slot counters) on stderr and exit code 124."""
+    side stream, per-slot counters) on stderr and exit code 125 (124 is `timeout`'s)."""
     path, V, e1, e2 = small_bin
     src = int(datagen.top_sources(V, e1, e2, 600, 0, 1)[0])
     env = dict(os.environ, DPPR_WATCHDOG_S="2", DPPR_TEST_STALL="1")
     r = subprocess.run([pagerank, "-d", path, "-a", "0", "-i", "0", "-y", "1", "-w", "0.1", "-n", "0", "-r", "0.01", "-b", "5", "-s", str(src)],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120, env=env)
-    assert r.returncode == 124, r.stdout
+    assert r.returncode == 125, r.stdout
     assert "[watchdog] no progress" in r.stdout and "GridBar: gen" in r.stdout and "slot 0: source" in r.stdout, r.stdout
     assert "engine stream: idle" in r.stdout

@@ -412,22 +412,40 @@ def test_split_interface_matches_reference_driver_flow():
             assert np.array_equal(np.sort(x), np.sort(y))
 
 
+# The reference's own incremental window graph is wrong on this one fixture (quirk Q1, tests/test_oracle_golden.py::
+# test_quirk_q1_inc_construct_undirected_misaligned: undirected stream, W % c != 0 -- IncConstructWindowGraph expires mirrored records by
+# count from the list front and transiently holds another multiset of edges than the window), so the p its FIFO run left in the
+# fixture belongs to a different graph than the stream's; the engine is held to the from-scratch power iteration there.
+REFERENCE_GRAPH_QUIRK = {"und_long_misaligned_e9"}
+
+
 @pytest.mark.parametrize("name", golden_names())
 def test_golden_fixtures_reference_ground_truth(name):
-    """Engine vs vectors computed by the REAL reference (power iteration + FIFO push)."""
+    """Engine vs vectors computed by the REAL reference (power iteration + FIFO push), at the bound the mathematics gives.
+    Any state with the loop invariant p + a r = a e_s + M p (M = (1-a) D^-1 A over outdeg + 1, row sums < 1 - a) satisfies
+    p - p* = -a (I - M)^-1 r, and |(I - M)^-1|_inf <= 1 / a: every state with |r| < eps lies within eps of the fixed point,
+    the engine's and the reference's FIFO state within 2 eps of each other (round 4 asserted 200 eps). Measured on these
+    fixtures: 0.2 - 1.1 eps (printed with -s)."""
     d, m = load_golden(name)
     eps = m["eps"]
     sc = Scenario(m["V"], d["stream.e1"], d["stream.e2"], m["directed"], m["W"], m["c"], m["source"], eps)
     sc.e.init_solve(sc.slot, eps)
+    worst = 0.0
     for k in range(0, min(m["done"], 12) + 1):
         if k:
             assert sc.advance_graphs()
             sc.e.update(sc.slot, eps)
         p, r = sc.e.read(sc.slot)
         assert np.max(np.abs(r)) < eps
-        assert np.max(np.abs(p - d[f"b{k}.pow.p"])) < 100 * eps
-        if not (not m["directed"] and m["W"] % m["c"] != 0 and m["done"] > 12):
-            assert np.max(np.abs(p - d[f"b{k}.fifo.p"])) < 200 * eps
+        assert np.max(np.abs(p - d[f"b{k}.pow.p"])) < 100 * eps      # (the reference's own Validate() bound against its power iteration)
+        if name in REFERENCE_GRAPH_QUIRK and k > 0:
+            continue
+        dev = float(np.max(np.abs(p - d[f"b{k}.fifo.p"])))
+        worst = max(worst, dev)
+        assert dev < 2 * eps, (f"batch {k}: |p_engine - p_reference_fifo| = {dev / eps:.2f} eps; both states have |r| < eps and must lie within "
+                               f"eps of the fixed point each")
+    print(f"{name}: max |p_engine - p_reference_fifo| = {worst / eps:.3f} eps")
+    assert (name in REFERENCE_GRAPH_QUIRK) == (not m["directed"] and m["W"] % m["c"] != 0 and m["done"] > 12)   # the quirk's condition, stated once
 
 
 def test_edge_cases():
