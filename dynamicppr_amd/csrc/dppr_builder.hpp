@@ -66,14 +66,19 @@ __device__ __forceinline__ int lower_bound_u64(const uint64_t *__restrict__ a, i
 }
 
 // position in the persistent sorted keys of every key a slide retires: the rank-th deletion of a key takes its rank-th
-// instance. Ascending, because del_sorted is (a key that is not there -- never, on a consistent window -- gets n)
+// instance. Ascending, because del_sorted is. A key that is not there -- never, on a consistent window -- gets n AND is counted
+// in *miss: k_merge_tiles bisects delpos and would silently drop or duplicate keys behind a hole, so a slide that
+// finds a miss discards the merge and re-sorts the whole window (dppr_engine.hip: dppr_slide).
 __global__ __launch_bounds__(BLOCK) void k_del_positions(const uint64_t *__restrict__ sorted, int n,
-                                                         const uint64_t *__restrict__ del_sorted, int nd, int *__restrict__ delpos) {
+                                                         const uint64_t *__restrict__ del_sorted, int nd, int *__restrict__ delpos,
+                                                         int *__restrict__ miss) {
     for (int j = blockIdx.x * BLOCK + threadIdx.x; j < nd; j += gridDim.x * BLOCK) {
         const uint64_t key = del_sorted[j];
         const int rank = j - lower_bound_u64(del_sorted, nd, key);
         const int pos = lower_bound_u64(sorted, n, key) + rank;
-        delpos[j] = (pos < n && sorted[pos] == key) ? pos : n;
+        const bool found = pos < n && sorted[pos] == key;
+        delpos[j] = found ? pos : n;
+        if (!found) atomicAdd(miss, 1);
     }
 }
 __device__ __forceinline__ int lower_bound_i32(const int *__restrict__ a, int n, int key) {

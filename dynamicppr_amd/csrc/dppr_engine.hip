@@ -43,6 +43,7 @@ static constexpr int GMULTI_MAX = 2 * MAX_CHUNK; // sweeps a multi-sweep launch 
 static constexpr int GQ_PAD = 32;               // ints between the rotating group counters of k_gsweep (own 128-byte line each)
 static constexpr int BIN_MAX_BLOCKS = 1 << 16, BIN_MAX_BIG = 4096, BIN_SMALL_INTS = BIN_MAX_BLOCKS + BIN_MAX_BIG + 1 + 64; // bin_cut scratch
 static constexpr int SU_SPLIT_MIN = 1 << 16;  // batch records from which IncrementalBatchUpdate runs as k_su_terms + k_su_apply (stream_update)
+static constexpr int MERGE_MISS_WORD = 44; // word of hub_hist (64 ints) that counts the retired keys a slide's merge did not find
 static constexpr int RESIDENT_MARGIN = 8; // sweeps a resident launch is given beyond what the last batch needed
 
 namespace {
@@ -174,6 +175,9 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     bool pre_extract = false;  // synchronous push iterations zero residual[u] at the snapshot (InspectExtra: FAST_FRONTIER 1, VANILLA 3) instead of repairing
     bool group_at_slide = false; // dppr_set_batch_grouping(1): the batch's records are grouped by tail (and CopyOutDegree done) when the batch is uploaded
                                  // (dppr_slide); default since round 5: inside dppr_update, where the reference times them (gpu/PPRGPU.cuh:138-164)
+    int merge_miss_host = 0;        // retired keys the last slide's merge did not find (read back with the build's synchronisations)
+    long long merge_fallbacks = 0;  // slides that re-sorted the window because of that
+    bool test_force_merge_miss = false; // (test hook, DPPR_TEST_MERGE_MISS=1: every incremental slide takes the fallback)
     bool launch_called_off = false; // batch_ahead: the last whole-batch launch changed nothing (roll-call failed, or a group had too many records)
     int raw_backoff = 0;         // batches for which a resident launch does not take the records raw (after one called itself off: a group with more records than threads)
     bool merge_phases = false; // dppr_set_phase_merge: one loop for residuals of both signs (eager schedule only)
@@ -377,7 +381,21 @@ int pre_find(dppr_engine *e, const int32_t *src, int n) {
     pre_join(e);
     if (!e->pre.armed || !e->pre.ok || e->pre.epoch != e->renumber_epoch || n <= 0) return -1;
     for (int k = 0; k < 4; ++k)
-        if (e->pre.src[k] == src && e->pre.n[k] == n) return k;
+        if (e->pre.src[k] == src && e->pre.n[k] == n) {
+            // same pointer, same length -- and still the same CONTENTS? (a caller that refilled the buffer without hinting again would get
+            // the ids of the old contents: ADVICE r04.) First, last and strided samples: an id the lookup resolved maps back to src[i].
+            const std::vector<int32_t> &o = e->pre.out[k];
+            const int step = std::max(1, n / 64);
+            for (int i = 0; i < n; i = (i + step < n || i == n - 1) ? i + step : n - 1) {
+                const int m = o[(size_t)i];
+                if (m >= 0 && (m >= (int)e->int2ext.size() || e->int2ext[(size_t)m] != src[i])) {
+                    e->pre.armed = false; // stale: everything the hint holds is dropped
+                    return -1;
+                }
+                if (i == n - 1) break;
+            }
+            return k;
+        }
     return -1;
 }
 
@@ -402,6 +420,9 @@ bool translate(dppr_engine *e, const int32_t *src, int n, std::vector<int32_t> &
         e->pre_misses += (long long)e->pre.miss[k].size();
         return true;
     }
+    // an array the lookahead does not cover: whatever it still holds is for calls that did not come -- drop it rather than let a
+    // later call match a reused buffer by pointer and length alone
+    if (n > 0) e->pre.armed = false;
     dst.resize((size_t)std::max(n, 1));
     return e->translate(src, (size_t)std::max(n, 0), dst.data());
 }
@@ -774,7 +795,8 @@ int merge_batch_keys(dppr_engine *e, uint64_t *&sorted, uint64_t *del_unsorted, 
     HIP_TRY(rocprim::radix_sort_keys(e->sort_tmp, tmp, ins_unsorted, ins_sorted, (size_t)ni, 0u, (unsigned)(2 * e->bits),
                                      e->stream));
     // retired positions, then one pass: every kept and every inserted key straight to its place (dppr_builder.hpp k_merge_tiles)
-    hipLaunchKernelGGL(k_del_positions, dim3(grid_for(nd)), dim3(BLOCK), 0, e->stream, sorted, Ed, del_sorted, nd, e->delpos);
+    hipLaunchKernelGGL(k_del_positions, dim3(grid_for(nd)), dim3(BLOCK), 0, e->stream, sorted, Ed, del_sorted, nd, e->delpos,
+                       e->hub_hist + MERGE_MISS_WORD);
     const int n_tiles = (Ed + CMP_TILE - 1) / CMP_TILE;
     hipLaunchKernelGGL(k_merge_tiles, dim3(n_tiles), dim3(BLOCK), 0, e->stream, sorted, Ed, e->delpos, nd, ins_sorted, ni, e->keys_b,
                        (size_t)Ed - (size_t)nd + (size_t)ni);
@@ -2250,6 +2272,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     if (const char *v = getenv("DPPR_GGROUPS_MIN")) e->ggroups_min = std::max(1, atoi(v));
     if (const char *v = getenv("DPPR_COST_MODEL")) e->cost_model = atoi(v) != 0;
     if (const char *v = getenv("DPPR_GROUPING_RADIX")) e->force_radix_grouping = atoi(v) != 0;
+    if (const char *v = getenv("DPPR_TEST_MERGE_MISS")) e->test_force_merge_miss = atoi(v) != 0;
     if (const char *v = getenv("DPPR_GROUP_AT_SLIDE")) e->group_at_slide = atoi(v) != 0;
     if (const char *v = getenv("DPPR_GROUP_FULL_ROWS")) e->group_full_rows = atoi(v) != 0;
     e->device = device;
@@ -2682,9 +2705,13 @@ int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, 
     ep.grouped = false;  //  the previous occupant's -- possibly in an older numbering)
     ep.su_inline = false;
     int rc;
+    e->merge_miss_host = 0;
     if (inc) { // f1: merge the batch into the previous sorted keys
+        HIP_TRY(hipMemsetAsync(e->hub_hist + MERGE_MISS_WORD, 0, sizeof(int), e->stream));
         rc = merge_batch_keys(e, e->in_sorted, e->bk[0], e->bks[0], c * per, e->bk[1], e->bks[1], c * per);
         if (!rc && e->directed) rc = merge_batch_keys(e, e->out_sorted, e->bk[2], e->bks[2], c, e->bk[3], e->bks[3], c);
+        // (read with the build's own synchronisations below: no extra wait on the path that finds every key)
+        if (!rc) HIP_TRY(hipMemcpyAsync(&e->merge_miss_host, e->hub_hist + MERGE_MISS_WORD, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     } else {
         rc = sort_window_full(e);
     }
@@ -2692,6 +2719,16 @@ int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, 
     mark("sorted keys (merge / full sort)");
     rc = build_epoch(e, ep);
     if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (inc && (e->merge_miss_host != 0 || e->test_force_merge_miss)) {
+        // a retired key was not among the kept sorted keys (an inconsistent window: never seen): the merged arrays
+        // cannot be trusted -- the ring itself is right, so sort it afresh and build the epoch again
+        e->merge_fallbacks++;
+        rc = sort_window_full(e);
+        if (rc) return rc;
+        rc = build_epoch(e, ep);
+        if (rc) return rc;
+    }
     mark("hubs, CSRs, group cut + tables");
     ep.L = 0;
     ep.grouped = false;
@@ -2816,6 +2853,7 @@ int dppr_debug_dump(dppr_engine *e, char *buf, int32_t cap) {
     add("dppr engine %p device %d: V %d W %d c %d directed %d n_int %d newest epoch %d broken %d\n", (void *)e, e->device, e->V, e->W, e->c,
         e->directed, e->n_int, e->newest, (int)e->broken);
     add("last error: %s\n", e->err.empty() ? "(none)" : e->err.c_str());
+    add("slides that discarded their key merge and re-sorted the window (a retired key was missing): %lld\n", e->merge_fallbacks);
     add("id lookahead (dppr_hint_next_batch): %lld id arrays taken from it so far (%lld entries resolved at the call), renumberings %llu\n", e->pre_hits, e->pre_misses, e->renumber_epoch);
     add("resident launches: mode %d ok %d retry %d time limit %llu ticks (100 MHz) rollcall_extra %d; schedule %d merge %d\n", e->persist_mode,
         (int)e->persist_ok, e->persist_retry, e->persist_ticks, e->persist_rollcall_extra, e->schedule, (int)e->merge_phases);

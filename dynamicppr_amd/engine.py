@@ -256,6 +256,8 @@ class Engine:
         threads from now on. Returns the four arrays as contiguous int32 -- pass THESE objects to set_batch / slide (the
         engine matches the hint by pointer and length) and leave them untouched until then."""
         arrs = [_i32(x) for x in (b1, b2, n1, n2)]
+        if len(arrs[0][0]) != len(arrs[1][0]) or len(arrs[2][0]) != len(arrs[3][0]):
+            raise DpprError("hint_next_batch: b1 / b2 and n1 / n2 must have equal lengths")
         self._hint_keep = [a for a, _ in arrs]   # (keeps the memory alive until the next hint)
         self._ck(self._L.dppr_hint_next_batch(self._h, arrs[0][1], arrs[1][1], len(arrs[0][0]), arrs[2][1], arrs[3][1], len(arrs[2][0])),
                  "hint_next_batch")

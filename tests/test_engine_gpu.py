@@ -1420,6 +1420,43 @@ def test_lookahead_id_lookups_change_nothing(directed):
         sc.e.close()
 
 
+def test_a_hint_whose_buffers_were_refilled_is_dropped():
+    """the lookahead is matched by pointer and length; a caller that refills the announced buffers with ANOTHER batch
+    before handing them over must get that batch's edges, not the announced ones (content samples are checked before a hint is
+    trusted). Device CSR == oracle after every slide."""
+    sc = make(1, scale=11, edges=30000, seed=23, W=3000, c=60)
+    sc.e.init_solve(sc.slot, sc.eps)
+    for k in range(4):
+        assert not sc.g.stream_updates()
+        sc.g.inc_construct(1)
+        b1, b2, ins = sc.g.batch()
+        n1, n2 = sc.g.new_stream()
+        # announce buffers of the right shape but with OTHER ids, then overwrite them in place with the real batch
+        h = sc.e.hint_next_batch(np.roll(b1, 1), np.roll(b2, 3), np.roll(n1, 2), np.roll(n2, 5))
+        time.sleep(0.05)                                    # (the helper's lookups of a few hundred ids are long over)
+        for dst, src in zip(h, (b1, b2, n1, n2)):
+            dst[:] = src
+        sc.e.set_batch(h[0], h[1], ins)
+        sc.e.slide(h[2], h[3])
+        check_csr(sc)
+        sc.e.update(sc.slot, sc.eps)
+    sc.e.close()
+
+
+def test_a_slide_whose_key_merge_misses_a_key_resorts_the_window(monkeypatch):
+    """k_del_positions counts the retired keys it cannot find in the kept sorted keys; a slide that finds one discards
+    the merge and re-sorts the whole window (test hook DPPR_TEST_MERGE_MISS: every incremental slide takes that path). The device
+    CSR stays the oracle's."""
+    monkeypatch.setenv("DPPR_TEST_MERGE_MISS", "1")
+    sc = make(0, W=100, c=7, edges=2000)
+    for _ in range(10):
+        assert sc.advance_graphs()
+        check_csr(sc)
+    text = sc.e.debug_dump()
+    assert "re-sorted the window (a retired key was missing): 10" in text, text
+    sc.e.close()
+
+
 def test_debug_dump_reads_the_engine_from_another_thread():
     """dppr_debug_dump (the hang post-mortem): host-side loop state plus the device words, read through a side stream;
     also after a launch whose roll-call cannot succeed (persist_timeout_us = -1: the launch gives up untouched)."""
