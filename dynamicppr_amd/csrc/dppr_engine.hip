@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <future>
+#include <mutex>
 #include <ctime>
 #include <string>
 #include <type_traits>
@@ -182,7 +183,13 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     int raw_backoff = 0;         // batches for which a resident launch does not take the records raw (after one called itself off: a group with more records than threads)
     bool merge_phases = false; // dppr_set_phase_merge: one loop for residuals of both signs (eager schedule only)
     int merge_div = 4;         // ... run to eps / merge_div
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr; // the SOLVER's stream: IncrementalBatchUpdate, the frontier loops, reads and writes of p / r
+    hipStream_t bs = nullptr;     // the graph BUILDER's stream (lowest priority): window ring, key merge, CSRs, group cuts and tables, binned tables,
+                                  // id-space row moves. Every builder entry point ends with a host synchronisation of bs, every solver call with one of
+                                  // `stream`, so calls made one after the other need no cross-stream event; dppr_slide_concurrent runs beside a solver call.
+    bool build_concurrent = false; // (builder thread only) the slide in progress may run beside dppr_update / dppr_group_update on an OLDER epoch
+    std::mutex err_mu;             // `err` is written by whichever of the two threads fails
+    unsigned map_gen_on_device = 0; // IdSpace::map_gen the device copy of ext2int was taken at
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t evpool[2 * 64] = {};
     bool profiling = false;
@@ -312,13 +319,18 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
 
 namespace {
 
+inline void set_err(dppr_engine *e, const char *msg) {
+    std::lock_guard<std::mutex> lk(e->err_mu);
+    e->err = msg;
+}
+
 #define HIP_TRY(call)                                                                                   \
     do {                                                                                                \
         hipError_t _e = (call);                                                                         \
         if (_e != hipSuccess) {                                                                         \
             char _b[512];                                                                               \
             snprintf(_b, sizeof(_b), "%s in %s at line %d", hipGetErrorString(_e), __FILE__, __LINE__); \
-            e->err = _b;                                                                                \
+            set_err(e, _b);                                                                             \
             return _e == hipErrorOutOfMemory ? DPPR_ERR_NOMEM : DPPR_ERR_HIP;                           \
         }                                                                                               \
     } while (0)
@@ -361,7 +373,7 @@ inline hipError_t loop_wait(dppr_engine *e) { // a read-back of a frontier loop:
 }
 
 int fail(dppr_engine *e, int code, const char *msg) {
-    if (e) e->err = msg;
+    if (e) set_err(e, msg);
     return code;
 }
 
@@ -446,10 +458,11 @@ int recut_stale_groups(dppr_engine *e) {
 }
 
 int sync_map(dppr_engine *e) {
-    if (!e->map_dirty) return DPPR_OK;
+    const unsigned gen = e->map_gen.load(std::memory_order_acquire); // (read BEFORE the copy: an id assigned during it leaves the copy stale)
+    if (gen == e->map_gen_on_device) return DPPR_OK;
     HIP_TRY(hipMemcpyAsync(e->d_ext2int, e->ext2int.data(), sizeof(int) * (size_t)e->V, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    e->map_dirty = false;
+    e->map_gen_on_device = gen;
     return DPPR_OK;
 }
 
@@ -463,7 +476,7 @@ int flush_moves(dppr_engine *e) {
     if (e->slots.empty() && e->groups.empty()) return DPPR_OK;
     const size_t need_idx = (size_t)2 * n + nz + 1;
     if (need_idx > e->mv_idx_cap) {
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipStreamSynchronize(e->bs));
         (void)hipFree(e->mv_idx);
         e->mv_idx = nullptr;
         e->mv_idx_cap = 0;
@@ -472,7 +485,7 @@ int flush_moves(dppr_engine *e) {
     }
     const size_t need_tmp = (size_t)std::max(n, 1) * GS_MAX;
     if (need_tmp > e->mv_tmp_cap) {
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipStreamSynchronize(e->bs));
         (void)hipFree(e->mv_tmp);
         e->mv_tmp = nullptr;
         e->mv_tmp_cap = 0;
@@ -481,17 +494,17 @@ int flush_moves(dppr_engine *e) {
     }
     int *d_src = e->mv_idx, *d_dst = e->mv_idx + n, *d_zero = e->mv_idx + 2 * n;
     if (n > 0) {
-        HIP_TRY(hipMemcpyAsync(d_src, e->mv_src.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(hipMemcpyAsync(d_dst, e->mv_dst.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(d_src, e->mv_src.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, e->bs));
+        HIP_TRY(hipMemcpyAsync(d_dst, e->mv_dst.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, e->bs));
     }
-    if (nz > 0) HIP_TRY(hipMemcpyAsync(d_zero, e->mv_zero.data(), sizeof(int) * (size_t)nz, hipMemcpyHostToDevice, e->stream));
+    if (nz > 0) HIP_TRY(hipMemcpyAsync(d_zero, e->mv_zero.data(), sizeof(int) * (size_t)nz, hipMemcpyHostToDevice, e->bs));
     auto move = [&](double *a, int w) -> int {
         if (n > 0) {
-            hipLaunchKernelGGL(k_rows_gather<double>, dim3(grid_for((int64_t)n * w)), dim3(BLOCK), 0, e->stream, e->mv_tmp, a, d_src, n, w);
-            hipLaunchKernelGGL(k_rows_scatter<double>, dim3(grid_for((int64_t)n * w)), dim3(BLOCK), 0, e->stream, a, e->mv_tmp, d_dst, n, w);
+            hipLaunchKernelGGL(k_rows_gather<double>, dim3(grid_for((int64_t)n * w)), dim3(BLOCK), 0, e->bs, e->mv_tmp, a, d_src, n, w);
+            hipLaunchKernelGGL(k_rows_scatter<double>, dim3(grid_for((int64_t)n * w)), dim3(BLOCK), 0, e->bs, a, e->mv_tmp, d_dst, n, w);
         }
         if (nz > 0)
-            hipLaunchKernelGGL(k_rows_zero<double>, dim3(grid_for((int64_t)nz * w)), dim3(BLOCK), 0, e->stream, a, d_zero, nz, w);
+            hipLaunchKernelGGL(k_rows_zero<double>, dim3(grid_for((int64_t)nz * w)), dim3(BLOCK), 0, e->bs, a, d_zero, nz, w);
         HIP_TRY(hipGetLastError());
         return DPPR_OK;
     };
@@ -503,7 +516,7 @@ int flush_moves(dppr_engine *e) {
         if (int rc = move(g.p, g.gw)) return rc;
         if (int rc = move(g.r, g.gw)) return rc;
     }
-    HIP_TRY(hipStreamSynchronize(e->stream)); // the host index vectors are reused
+    HIP_TRY(hipStreamSynchronize(e->bs)); // the host index vectors are reused
     return DPPR_OK;
 }
 
@@ -561,39 +574,39 @@ int device_numbering_order(dppr_engine *e, const std::vector<uint8_t> &live, int
     NO_TRY(hipMalloc((void **)&d_vals2, sizeof(int) * n));
     NO_TRY(hipMalloc((void **)&d_keys, sizeof(uint64_t) * n));
     NO_TRY(hipMalloc((void **)&d_keys2, sizeof(uint64_t) * n));
-    NO_TRY(hipMemcpyAsync(d_live, live.data(), n, hipMemcpyHostToDevice, e->stream));
-    NO_TRY(hipMemcpyAsync(d_i2e, e->int2ext.data(), sizeof(int) * n, hipMemcpyHostToDevice, e->stream));
+    NO_TRY(hipMemcpyAsync(d_live, live.data(), n, hipMemcpyHostToDevice, e->bs));
+    NO_TRY(hipMemcpyAsync(d_i2e, e->int2ext.data(), sizeof(int) * n, hipMemcpyHostToDevice, e->bs));
     HotThresholds ht{};
     int *d_deg = e->hub_slot_of; // (scratch of the CSR build, V ints)
     if ((size_t)n_live > HOT_WINDOW_MIN) {
         NO_TRY(hipMalloc((void **)&d_deg2, sizeof(int) * n));
-        NO_TRY(hipMemsetAsync(d_deg, 0, sizeof(int) * n, e->stream));
-        hipLaunchKernelGGL(k_in_degree, dim3(grid_for(e->W)), dim3(BLOCK), 0, e->stream, e->w1, e->w2, e->W, e->directed, d_deg);
-        hipLaunchKernelGGL(k_live_degree, dim3(grid_for(n_old)), dim3(BLOCK), 0, e->stream, d_live, d_deg, n_old, d_vals);
+        NO_TRY(hipMemsetAsync(d_deg, 0, sizeof(int) * n, e->bs));
+        hipLaunchKernelGGL(k_in_degree, dim3(grid_for(e->W)), dim3(BLOCK), 0, e->bs, e->w1, e->w2, e->W, e->directed, d_deg);
+        hipLaunchKernelGGL(k_live_degree, dim3(grid_for(n_old)), dim3(BLOCK), 0, e->bs, d_live, d_deg, n_old, d_vals);
         size_t tb = 0;
-        NO_TRY(rocprim::radix_sort_keys_desc(nullptr, tb, d_vals, d_deg2, n, 0u, 32u, e->stream));
+        NO_TRY(rocprim::radix_sort_keys_desc(nullptr, tb, d_vals, d_deg2, n, 0u, 32u, e->bs));
         NO_TRY(hipMalloc(&d_tmp, tb));
-        NO_TRY(rocprim::radix_sort_keys_desc(d_tmp, tb, d_vals, d_deg2, n, 0u, 32u, e->stream));
+        NO_TRY(rocprim::radix_sort_keys_desc(d_tmp, tb, d_vals, d_deg2, n, 0u, 32u, e->bs));
         // in-degree of rank k among the live vertices (the non-live ones sorted last as -1)
         for (size_t k = HOT_SET; k >= (e->hot_blocks ? HOT_MIN : HOT_SET); k >>= 1) {
             if (k >= (size_t)n_live) continue;
-            NO_TRY(hipMemcpyAsync(&ht.thr[ht.n], d_deg2 + k, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+            NO_TRY(hipMemcpyAsync(&ht.thr[ht.n], d_deg2 + k, sizeof(int), hipMemcpyDeviceToHost, e->bs));
             ht.n++;
         }
-        NO_TRY(hipStreamSynchronize(e->stream));
+        NO_TRY(hipStreamSynchronize(e->bs));
         (void)hipFree(d_tmp);
         d_tmp = nullptr;
     }
-    hipLaunchKernelGGL(k_number_keys, dim3(grid_for(n_old)), dim3(BLOCK), 0, e->stream, d_live, d_i2e, d_deg, ht, n_old, d_keys, d_vals);
+    hipLaunchKernelGGL(k_number_keys, dim3(grid_for(n_old)), dim3(BLOCK), 0, e->bs, d_live, d_i2e, d_deg, ht, n_old, d_keys, d_vals);
     {
         size_t tb = 0;
-        NO_TRY(rocprim::radix_sort_pairs(nullptr, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0u, 64u, e->stream));
+        NO_TRY(rocprim::radix_sort_pairs(nullptr, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0u, 64u, e->bs));
         NO_TRY(hipMalloc(&d_tmp, tb));
-        NO_TRY(rocprim::radix_sort_pairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0u, 64u, e->stream));
+        NO_TRY(rocprim::radix_sort_pairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0u, 64u, e->bs));
     }
     order.resize((size_t)n_live);
-    NO_TRY(hipMemcpyAsync(order.data(), d_vals2, sizeof(int) * (size_t)n_live, hipMemcpyDeviceToHost, e->stream));
-    NO_TRY(hipStreamSynchronize(e->stream));
+    NO_TRY(hipMemcpyAsync(order.data(), d_vals2, sizeof(int) * (size_t)n_live, hipMemcpyDeviceToHost, e->bs));
+    NO_TRY(hipStreamSynchronize(e->bs));
     NO_TRY(hipGetLastError());
 #undef NO_TRY
     cleanup();
@@ -608,6 +621,7 @@ int device_numbering_order(dppr_engine *e, const std::vector<uint8_t> &live, int
 int compact_ids(dppr_engine *e, bool *did) {
     *did = false;
     pre_join(e);
+    if (e->build_concurrent) return DPPR_OK; // (a renumbering moves every state row: only an exclusive slide may; dppr_renumbering_due tells the host)
     if (!e->renumber_on || e->W == 0 || e->n_int < e->renumber_next) return DPPR_OK;
     if (e->slots.empty() && e->groups.empty()) return DPPR_OK;
     for (const auto &s : e->slots)
@@ -629,11 +643,11 @@ int compact_ids(dppr_engine *e, bool *did) {
     // which ids have an edge in the window
     uint8_t *d_live = nullptr;
     HIP_TRY(hipMalloc((void **)&d_live, (size_t)std::max(n_old, 1)));
-    HIP_TRY(hipMemsetAsync(d_live, 0, (size_t)std::max(n_old, 1), e->stream));
-    hipLaunchKernelGGL(k_mark_live, dim3(grid_for(e->W)), dim3(BLOCK), 0, e->stream, e->w1, e->w2, e->W, d_live);
+    HIP_TRY(hipMemsetAsync(d_live, 0, (size_t)std::max(n_old, 1), e->bs));
+    hipLaunchKernelGGL(k_mark_live, dim3(grid_for(e->W)), dim3(BLOCK), 0, e->bs, e->w1, e->w2, e->W, d_live);
     std::vector<uint8_t> live((size_t)std::max(n_old, 1));
-    hipError_t herr = hipMemcpyAsync(live.data(), d_live, (size_t)n_old, hipMemcpyDeviceToHost, e->stream);
-    if (herr == hipSuccess) herr = hipStreamSynchronize(e->stream);
+    hipError_t herr = hipMemcpyAsync(live.data(), d_live, (size_t)n_old, hipMemcpyDeviceToHost, e->bs);
+    if (herr == hipSuccess) herr = hipStreamSynchronize(e->bs);
     (void)hipFree(d_live);
     HIP_TRY(herr);
     if (e->batch_staged) { // the staged records are in internal ids already: their vertices stay where they are
@@ -697,30 +711,30 @@ int compact_ids(dppr_engine *e, bool *did) {
             return DPPR_ERR_HIP;                                         \
         }                                                                \
     } while (0)
-    RN_TRY(hipMemcpyAsync(d_perm, perm.data(), sizeof(int) * (size_t)V, hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(k_remap_ids, dim3(grid_for(e->W)), dim3(BLOCK), 0, e->stream, e->w1, e->W, d_perm);
-    hipLaunchKernelGGL(k_remap_ids, dim3(grid_for(e->W)), dim3(BLOCK), 0, e->stream, e->w2, e->W, d_perm);
+    RN_TRY(hipMemcpyAsync(d_perm, perm.data(), sizeof(int) * (size_t)V, hipMemcpyHostToDevice, e->bs));
+    hipLaunchKernelGGL(k_remap_ids, dim3(grid_for(e->W)), dim3(BLOCK), 0, e->bs, e->w1, e->W, d_perm);
+    hipLaunchKernelGGL(k_remap_ids, dim3(grid_for(e->W)), dim3(BLOCK), 0, e->bs, e->w2, e->W, d_perm);
     { // out-degrees (ints) through the row scratch
         int *itmp = reinterpret_cast<int *>(tmp);
-        RN_TRY(hipMemsetAsync(itmp, 0, sizeof(int) * (size_t)V, e->stream));
-        hipLaunchKernelGGL(k_permute_rows<int>, dim3(grid_for(V)), dim3(BLOCK), 0, e->stream, itmp, e->outdeg, d_perm, V, 1);
-        RN_TRY(hipMemcpyAsync(e->outdeg, itmp, sizeof(int) * (size_t)V, hipMemcpyDeviceToDevice, e->stream));
+        RN_TRY(hipMemsetAsync(itmp, 0, sizeof(int) * (size_t)V, e->bs));
+        hipLaunchKernelGGL(k_permute_rows<int>, dim3(grid_for(V)), dim3(BLOCK), 0, e->bs, itmp, e->outdeg, d_perm, V, 1);
+        RN_TRY(hipMemcpyAsync(e->outdeg, itmp, sizeof(int) * (size_t)V, hipMemcpyDeviceToDevice, e->bs));
     }
     auto permute = [&](double *&a, int w) -> hipError_t { // a's rows in the new order; the old array becomes the scratch
-        hipError_t r = hipMemsetAsync(tmp, 0, sizeof(double) * (size_t)V * (size_t)w, e->stream);
+        hipError_t r = hipMemsetAsync(tmp, 0, sizeof(double) * (size_t)V * (size_t)w, e->bs);
         if (r != hipSuccess) return r;
-        hipLaunchKernelGGL(k_permute_rows<double>, dim3(grid_for((int64_t)V * w)), dim3(BLOCK), 0, e->stream, tmp, a, d_perm, V, w);
-        r = hipMemcpyAsync(a, tmp, sizeof(double) * (size_t)V * (size_t)w, hipMemcpyDeviceToDevice, e->stream);
+        hipLaunchKernelGGL(k_permute_rows<double>, dim3(grid_for((int64_t)V * w)), dim3(BLOCK), 0, e->bs, tmp, a, d_perm, V, w);
+        r = hipMemcpyAsync(a, tmp, sizeof(double) * (size_t)V * (size_t)w, hipMemcpyDeviceToDevice, e->bs);
         return r != hipSuccess ? r : hipGetLastError();
     };
     for (auto &s : e->slots) {
         RN_TRY(permute(s.p, 1));
         RN_TRY(permute(s.r, 1));
         // between two loops the snapshot vectors are all zero and the lists empty: nothing to carry over
-        RN_TRY(hipMemsetAsync(s.x, 0, sizeof(double) * (size_t)V, e->stream));
-        RN_TRY(hipMemsetAsync(s.x2, 0, sizeof(double) * (size_t)V, e->stream));
-        RN_TRY(hipMemsetAsync(s.act[0], 0, s.act_bytes, e->stream));
-        RN_TRY(hipMemsetAsync(s.act[1], 0, s.act_bytes, e->stream));
+        RN_TRY(hipMemsetAsync(s.x, 0, sizeof(double) * (size_t)V, e->bs));
+        RN_TRY(hipMemsetAsync(s.x2, 0, sizeof(double) * (size_t)V, e->bs));
+        RN_TRY(hipMemsetAsync(s.act[0], 0, s.act_bytes, e->bs));
+        RN_TRY(hipMemsetAsync(s.act[1], 0, s.act_bytes, e->bs));
         s.source = perm[(size_t)s.source];
         s.seed_lists_valid = false;
         s.phase0_done = false;
@@ -730,12 +744,12 @@ int compact_ids(dppr_engine *e, bool *did) {
         RN_TRY(permute(g.p, g.gw));
         RN_TRY(permute(g.r, g.gw));
         // (snapshot rows mean something only where an activity bit is set, and between loops none is)
-        RN_TRY(hipMemsetAsync(g.act[0], 0, g.act_bytes, e->stream));
-        RN_TRY(hipMemsetAsync(g.act[1], 0, g.act_bytes, e->stream));
+        RN_TRY(hipMemsetAsync(g.act[0], 0, g.act_bytes, e->bs));
+        RN_TRY(hipMemsetAsync(g.act[1], 0, g.act_bytes, e->bs));
         for (int k = 0; k < g.n; ++k) g.src.s[k] = perm[(size_t)g.src.s[k]];
         g.park_eps = std::max(g.park_eps, g.conv_eps);
     }
-    RN_TRY(hipStreamSynchronize(e->stream));
+    RN_TRY(hipStreamSynchronize(e->bs));
 #undef RN_TRY
     mark("ring, degrees, state rows");
     cleanup();
@@ -768,18 +782,18 @@ Epoch *find_epoch(dppr_engine *e, int epoch) {
 int sort_window_full(dppr_engine *e) {
     const int W = e->W, Ed = e->Ed;
     if (W == 0) return DPPR_OK;
-    hipLaunchKernelGGL(k_make_keys, dim3(grid_for(W)), dim3(BLOCK), 0, e->stream, e->w1, e->w2, W, e->directed, e->bits,
+    hipLaunchKernelGGL(k_make_keys, dim3(grid_for(W)), dim3(BLOCK), 0, e->bs, e->w1, e->w2, W, e->directed, e->bits,
                        e->keys_a);
     HIP_TRY(hipGetLastError());
     size_t tmp = e->sort_tmp_bytes;
     HIP_TRY(rocprim::radix_sort_keys(e->sort_tmp, tmp, e->keys_a, e->in_sorted, (size_t)Ed, 0u, (unsigned)(2 * e->bits),
-                                     e->stream));
+                                     e->bs));
     if (e->directed) { // undirected: the out-orientation is the same multiset, out_sorted aliases in_sorted
-        hipLaunchKernelGGL(k_make_out_keys, dim3(grid_for(W)), dim3(BLOCK), 0, e->stream, e->w1, e->w2, W, e->directed,
+        hipLaunchKernelGGL(k_make_out_keys, dim3(grid_for(W)), dim3(BLOCK), 0, e->bs, e->w1, e->w2, W, e->directed,
                            e->bits, e->keys_a);
         tmp = e->sort_tmp_bytes;
         HIP_TRY(rocprim::radix_sort_keys(e->sort_tmp, tmp, e->keys_a, e->out_sorted, (size_t)Ed, 0u,
-                                         (unsigned)(2 * e->bits), e->stream));
+                                         (unsigned)(2 * e->bits), e->bs));
     }
     return DPPR_OK;
 }
@@ -790,15 +804,15 @@ int merge_batch_keys(dppr_engine *e, uint64_t *&sorted, uint64_t *del_unsorted, 
     const int Ed = e->Ed;
     size_t tmp = e->sort_tmp_bytes;
     HIP_TRY(rocprim::radix_sort_keys(e->sort_tmp, tmp, del_unsorted, del_sorted, (size_t)nd, 0u, (unsigned)(2 * e->bits),
-                                     e->stream));
+                                     e->bs));
     tmp = e->sort_tmp_bytes;
     HIP_TRY(rocprim::radix_sort_keys(e->sort_tmp, tmp, ins_unsorted, ins_sorted, (size_t)ni, 0u, (unsigned)(2 * e->bits),
-                                     e->stream));
+                                     e->bs));
     // retired positions, then one pass: every kept and every inserted key straight to its place (dppr_builder.hpp k_merge_tiles)
-    hipLaunchKernelGGL(k_del_positions, dim3(grid_for(nd)), dim3(BLOCK), 0, e->stream, sorted, Ed, del_sorted, nd, e->delpos,
+    hipLaunchKernelGGL(k_del_positions, dim3(grid_for(nd)), dim3(BLOCK), 0, e->bs, sorted, Ed, del_sorted, nd, e->delpos,
                        e->hub_hist + MERGE_MISS_WORD);
     const int n_tiles = (Ed + CMP_TILE - 1) / CMP_TILE;
-    hipLaunchKernelGGL(k_merge_tiles, dim3(n_tiles), dim3(BLOCK), 0, e->stream, sorted, Ed, e->delpos, nd, ins_sorted, ni, e->keys_b,
+    hipLaunchKernelGGL(k_merge_tiles, dim3(n_tiles), dim3(BLOCK), 0, e->bs, sorted, Ed, e->delpos, nd, ins_sorted, ni, e->keys_b,
                        (size_t)Ed - (size_t)nd + (size_t)ni);
     HIP_TRY(hipGetLastError());
     std::swap(sorted, e->keys_b); // the merged array is the new persistent one; the old becomes scratch
@@ -845,11 +859,11 @@ int cut_sweep_groups(dppr_engine *e, Epoch &ep) {
         int *scratch = reinterpret_cast<int *>(e->keys_a); // Ed * 8 bytes >= (n_tiles + 1) * 4 unless the graph is tiny
         const bool fits = (size_t)e->Ed * sizeof(uint64_t) >= ((size_t)n_tiles + 1) * sizeof(int);
         if (!fits) scratch = e->hub_slot_of;               // V ints: always large enough
-        hipLaunchKernelGGL(k_tile_prefix, dim3(grid_for(n_tiles + 1)), dim3(BLOCK), 0, e->stream, ep.out_row_ptr, NV,
+        hipLaunchKernelGGL(k_tile_prefix, dim3(grid_for(n_tiles + 1)), dim3(BLOCK), 0, e->bs, ep.out_row_ptr, NV,
                            n_tiles, scratch);
         HIP_TRY(hipMemcpyAsync(e->h_tiles.data(), scratch, sizeof(int) * ((size_t)n_tiles + 1), hipMemcpyDeviceToHost,
-                               e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+                               e->bs));
+        HIP_TRY(hipStreamSynchronize(e->bs));
     }
     std::vector<int32_t> cut;
     const int32_t *prefix = e->h_tiles.data();
@@ -866,28 +880,30 @@ int cut_sweep_groups(dppr_engine *e, Epoch &ep) {
                    std::max<long long>(252, (n_tiles + max_tiles * 3 / 4 - 1) / std::max(1, max_tiles * 3 / 4)), 2 * WAVE, cut);
     ep.n_groups = (int)cut.size() - 1;
     ep.grp_n_int = NV;
-    HIP_TRY(hipMemcpyAsync(ep.grp_tile, cut.data(), sizeof(int) * cut.size(), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(ep.grp_tile, cut.data(), sizeof(int) * cut.size(), hipMemcpyHostToDevice, e->bs));
     // slot tables for resident launches (a window that got the resident cut; every group must fit the table build's sort)
     ep.res_valid = false;
-    if (fitted && !e->slots.empty()) (void)resident_arena(e, ep); // (a single-source slot exists: its launches will want the arena)
+    // (a single-source slot exists: its launches will want the arena -- grown here unless a solver call may be using it right now:
+    // dppr_update grows it itself before its first resident launch)
+    if (fitted && !e->slots.empty() && !e->build_concurrent) (void)resident_arena(e, ep);
     if (fitted && e->res_slots && ep.Ed > 0 && NV <= RES_ID_LIMIT) {
         long long largest = 0;
         for (size_t g = 0; g + 1 < cut.size(); ++g) largest = std::max<long long>(largest, (long long)prefix[cut[g + 1]] - prefix[cut[g]]);
         if (largest <= RES_SORT_MAX) {
             if ((size_t)ep.Ed > ep.res_pk_cap) {
-                HIP_TRY(hipStreamSynchronize(e->stream));
+                HIP_TRY(hipStreamSynchronize(e->bs));
                 (void)hipFree(ep.res_pk);
                 ep.res_pk = nullptr;
                 ep.res_pk_cap = 0;
                 HIP_TRY(hipMalloc((void **)&ep.res_pk, sizeof(uint32_t) * ((size_t)ep.Ed + (size_t)ep.Ed / 8 + 1024)));
                 ep.res_pk_cap = (size_t)ep.Ed + (size_t)ep.Ed / 8 + 1024;
             }
-            hipLaunchKernelGGL(k_res_slots, dim3(ep.n_groups), dim3(1024), 0, e->stream, NV, ep.grp_tile, ep.out_row_ptr, ep.out_col, ep.res_pk);
+            hipLaunchKernelGGL(k_res_slots, dim3(ep.n_groups), dim3(1024), 0, e->bs, NV, ep.grp_tile, ep.out_row_ptr, ep.out_col, ep.res_pk);
             HIP_TRY(hipGetLastError());
             ep.res_valid = true;
         }
     }
-    HIP_TRY(hipStreamSynchronize(e->stream)); // `cut` is a local
+    HIP_TRY(hipStreamSynchronize(e->bs)); // `cut` is a local
     ep.su_inline = false;
     if (fitted)
         if (int rrc = res_record_ranges(e, ep)) return rrc;
@@ -898,12 +914,12 @@ int cut_sweep_groups(dppr_engine *e, Epoch &ep) {
         ep.ggrp_max_tiles = gmax;
         cut_greedy(prefix, n_tiles, gmax, want, 2 * WAVE, cut);
         ep.n_ggroups = (int)cut.size() - 1;
-        HIP_TRY(hipMemcpyAsync(ep.ggrp_tile, cut.data(), sizeof(int) * cut.size(), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(ep.ggrp_tile, cut.data(), sizeof(int) * cut.size(), hipMemcpyHostToDevice, e->bs));
         // the groups' row tables, once per epoch (every sweep of every source group of this epoch loads them)
         const int nvx = gmax * WAVE;
         const size_t need = (size_t)ep.n_ggroups * (size_t)GT_STRIDE(nvx);
         if (need > ep.gtab_cap) {
-            HIP_TRY(hipStreamSynchronize(e->stream));
+            HIP_TRY(hipStreamSynchronize(e->bs));
             (void)hipFree(ep.gtab);
             ep.gtab = nullptr;
             ep.gtab_cap = 0;
@@ -913,13 +929,13 @@ int cut_sweep_groups(dppr_engine *e, Epoch &ep) {
         if (ep.n_ggroups <= 0) {
             // (no vertex has an id yet: nothing to sweep)
         } else if (nvx == 512)
-            hipLaunchKernelGGL(k_gtables<512>, dim3(std::min(ep.n_ggroups, 1024)), dim3(GNT), 0, e->stream, NV, ep.ggrp_tile,
+            hipLaunchKernelGGL(k_gtables<512>, dim3(std::min(ep.n_ggroups, 1024)), dim3(GNT), 0, e->bs, NV, ep.ggrp_tile,
                                ep.n_ggroups, ep.out_row_ptr, ep.gtab);
         else
-            hipLaunchKernelGGL(k_gtables<1024>, dim3(std::min(ep.n_ggroups, 1024)), dim3(GNT), 0, e->stream, NV, ep.ggrp_tile,
+            hipLaunchKernelGGL(k_gtables<1024>, dim3(std::min(ep.n_ggroups, 1024)), dim3(GNT), 0, e->bs, NV, ep.ggrp_tile,
                                ep.n_ggroups, ep.out_row_ptr, ep.gtab);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipStreamSynchronize(e->bs));
     }
     return DPPR_OK;
 }
@@ -966,7 +982,7 @@ int bin_prepare(dppr_engine *e, bool *have) { // engine-level scratch, once (ide
     ok = ok && bin_alloc((void **)&e->bin_small, sizeof(int) * BIN_SMALL_INTS);
     ok = ok && bin_alloc((void **)&e->bin_vals, sizeof(double) * (Edn + 64));
     if (ok && !e->bin_tmp) {
-        HIP_TRY(rocprim::radix_sort_keys(nullptr, e->bin_tmp_bytes, e->keys_a, e->keys_b, Edn, 0u, 64u, e->stream));
+        HIP_TRY(rocprim::radix_sort_keys(nullptr, e->bin_tmp_bytes, e->keys_a, e->keys_b, Edn, 0u, 64u, e->bs));
         ok = bin_alloc(&e->bin_tmp, std::max<size_t>(e->bin_tmp_bytes, 16));
     }
     if (!ok) { // out of memory: nothing half-built stays behind, the sweeps of this engine gather (k_pull_iter)
@@ -994,14 +1010,14 @@ int bin_cut(dppr_engine *e, const int *row_ptr, int NV, int cap, long long targe
     target = std::max<long long>(target, 64);
     const int K = (int)std::min<long long>((Ed + target - 1) / target, BIN_MAX_BLOCKS);
     int *d_q = e->bin_small, *d_big = e->bin_small + BIN_MAX_BLOCKS, *d_cnt = d_big + BIN_MAX_BIG;
-    HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int), e->stream));
-    if (K > 1) hipLaunchKernelGGL(k_bin_quantiles, dim3(grid_for(K)), dim3(BLOCK), 0, e->stream, row_ptr, NV, target, K, d_q);
-    hipLaunchKernelGGL(k_bin_big_rows, dim3(grid_for(NV)), dim3(BLOCK), 0, e->stream, row_ptr, NV, (int)std::max<long long>(target / 4, 1),
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int), e->bs));
+    if (K > 1) hipLaunchKernelGGL(k_bin_quantiles, dim3(grid_for(K)), dim3(BLOCK), 0, e->bs, row_ptr, NV, target, K, d_q);
+    hipLaunchKernelGGL(k_bin_big_rows, dim3(grid_for(NV)), dim3(BLOCK), 0, e->bs, row_ptr, NV, (int)std::max<long long>(target / 4, 1),
                        BIN_MAX_BIG, d_big, d_cnt);
     HIP_TRY(hipGetLastError());
     std::vector<int32_t> h((size_t)BIN_MAX_BLOCKS + BIN_MAX_BIG + 1);
-    HIP_TRY(hipMemcpyAsync(h.data(), e->bin_small, sizeof(int) * h.size(), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpyAsync(h.data(), e->bin_small, sizeof(int) * h.size(), hipMemcpyDeviceToHost, e->bs));
+    HIP_TRY(hipStreamSynchronize(e->bs));
     cut.clear();
     for (long long v = 0; v < NV; v += cap) cut.push_back((int32_t)v);
     for (int k = 0; k + 1 < K; ++k) cut.push_back(h[(size_t)k]);
@@ -1050,7 +1066,7 @@ int build_bins(dppr_engine *e, Epoch &ep) {
     // per epoch: acut | astart | bcut (block tables), then the chunk table
     const size_t tab_ints = (size_t)2 * (ep.n_a + 1) + (ep.n_b + 1);
     if (tab_ints > ep.bin_tab_cap) {
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipStreamSynchronize(e->bs));
         (void)hipFree(ep.acut);
         ep.acut = nullptr;
         ep.bin_tab_cap = 0;
@@ -1059,19 +1075,19 @@ int build_bins(dppr_engine *e, Epoch &ep) {
     }
     int *d_astart = ep.acut + (ep.n_a + 1);
     ep.bcut = d_astart + (ep.n_a + 1);
-    HIP_TRY(hipMemcpyAsync(ep.acut, cut_a.data(), sizeof(int) * cut_a.size(), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(ep.bcut, cut_b.data(), sizeof(int) * cut_b.size(), hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(k_bin_vertex_block, dim3(grid_for(NV)), dim3(BLOCK), 0, e->stream, ep.acut, ep.n_a, NV, ep.row_ptr, (int *)nullptr, d_astart);
+    HIP_TRY(hipMemcpyAsync(ep.acut, cut_a.data(), sizeof(int) * cut_a.size(), hipMemcpyHostToDevice, e->bs));
+    HIP_TRY(hipMemcpyAsync(ep.bcut, cut_b.data(), sizeof(int) * cut_b.size(), hipMemcpyHostToDevice, e->bs));
+    hipLaunchKernelGGL(k_bin_vertex_block, dim3(grid_for(NV)), dim3(BLOCK), 0, e->bs, ep.acut, ep.n_a, NV, ep.row_ptr, (int *)nullptr, d_astart);
     int *d_bstart = e->bin_small; // (not kept: a B-block's edges are out_row_ptr[bcut[b]] .. out_row_ptr[bcut[b + 1]])
-    hipLaunchKernelGGL(k_bin_vertex_block, dim3(grid_for(NV)), dim3(BLOCK), 0, e->stream, ep.bcut, ep.n_b, NV, ep.out_row_ptr, e->bin_vblk_b, d_bstart);
+    hipLaunchKernelGGL(k_bin_vertex_block, dim3(grid_for(NV)), dim3(BLOCK), 0, e->bs, ep.bcut, ep.n_b, NV, ep.out_row_ptr, e->bin_vblk_b, d_bstart);
     const uint64_t *out_keys = e->directed ? e->out_sorted : e->in_sorted;
     const bool cuts_in_lds = (size_t)(ep.n_a + 1) * sizeof(int) <= 48 * 1024;
-    hipLaunchKernelGGL(k_bin_keys, dim3(grid_for(Ed)), dim3(BLOCK), cuts_in_lds ? (size_t)(ep.n_a + 1) * sizeof(int) : 0, e->stream, out_keys, Ed,
+    hipLaunchKernelGGL(k_bin_keys, dim3(grid_for(Ed)), dim3(BLOCK), cuts_in_lds ? (size_t)(ep.n_a + 1) * sizeof(int) : 0, e->bs, out_keys, Ed,
                        e->bits, ep.acut, ep.n_a, cuts_in_lds ? 1 : 0, e->bin_vblk_b, ep.bcut, abits, e->keys_b);
     HIP_TRY(hipGetLastError());
     // chunks of the A-major runs (a block of many edges is dealt to several workgroups of k_bin_scatter)
     std::vector<int32_t> astart((size_t)ep.n_a + 1);
-    HIP_TRY(hipMemcpyAsync(astart.data(), d_astart, sizeof(int) * astart.size(), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(astart.data(), d_astart, sizeof(int) * astart.size(), hipMemcpyDeviceToHost, e->bs));
     size_t tmp = e->bin_tmp_bytes; // B-major: stable by (B-block, A-block); the words are in (row, head) order
     const char *placement = getenv("DPPR_BIN_PLACEMENT"); // (tests / A-B runs: "counting" wherever it can run -- small windows never qualify by themselves --, "radix" never)
     const bool cs_force = placement && !strcmp(placement, "counting"), cs_never = placement && !strcmp(placement, "radix");
@@ -1081,19 +1097,19 @@ int build_bins(dppr_engine *e, Epoch &ep) {
     if (ep.n_a <= BIN_CS_MAX_A && (abits + bbits > 24 || cs_force) && !cs_never) {
         int n_pad = WAVE;
         while (n_pad < ep.n_a) n_pad *= 2;
-        hipLaunchKernelGGL(k_bin_bmajor, dim3(ep.n_b), dim3(BIN_CS_NT), sizeof(int) * (size_t)n_pad, e->stream, e->keys_b, d_bstart, ep.bcut, ep.n_a,
+        hipLaunchKernelGGL(k_bin_bmajor, dim3(ep.n_b), dim3(BIN_CS_NT), sizeof(int) * (size_t)n_pad, e->bs, e->keys_b, d_bstart, ep.bcut, ep.n_a,
                            n_pad, abits, e->keys_a);
     } else {
         HIP_TRY(rocprim::radix_sort_keys(e->bin_tmp, tmp, e->keys_b, e->keys_a, (size_t)Ed, (unsigned)(BIN_RL + BIN_HL),
-                                         (unsigned)(BIN_RL + BIN_HL + abits + bbits), e->stream));
+                                         (unsigned)(BIN_RL + BIN_HL + abits + bbits), e->bs));
     }
-    hipLaunchKernelGGL(k_bin_fill_b, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->stream, e->keys_a, Ed, abits, ep.dl, e->keys_b);
+    hipLaunchKernelGGL(k_bin_fill_b, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->bs, e->keys_a, Ed, abits, ep.dl, e->keys_b);
     HIP_TRY(hipGetLastError());
     tmp = e->bin_tmp_bytes;        // A-major: the B-major sequence, stable by A-block
-    HIP_TRY(rocprim::radix_sort_keys(e->bin_tmp, tmp, e->keys_b, e->keys_a, (size_t)Ed, (unsigned)BIN_W2_A, (unsigned)(BIN_W2_A + abits), e->stream));
-    hipLaunchKernelGGL(k_bin_fill_a, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->stream, e->keys_a, Ed, ep.hl, ep.apos);
+    HIP_TRY(rocprim::radix_sort_keys(e->bin_tmp, tmp, e->keys_b, e->keys_a, (size_t)Ed, (unsigned)BIN_W2_A, (unsigned)(BIN_W2_A + abits), e->bs));
+    hipLaunchKernelGGL(k_bin_fill_a, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->bs, e->keys_a, Ed, ep.hl, ep.apos);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(e->stream)); // astart has arrived; the cuts are locals
+    HIP_TRY(hipStreamSynchronize(e->bs)); // astart has arrived; the cuts are locals
     std::vector<BinChunk> chunks;
     const int csize = (int)std::max<long long>(e->bin_chunk, 64);
     for (int a = 0; a < ep.n_a; ++a) {
@@ -1125,12 +1141,12 @@ int build_epoch(dppr_engine *e, Epoch &ep) {
     const int NV = e->n_int; // only vertices that ever had an edge (or are a source) exist internally
     // hub directory: the (at most HUB_CAP) vertices of largest out-degree, at least hub_min_degree
     {
-        HIP_TRY(hipMemsetAsync(e->hub_hist, 0, sizeof(int) * 33, e->stream));
-        hipLaunchKernelGGL(k_deg_hist, dim3(grid_for(NV)), dim3(BLOCK), 0, e->stream, e->outdeg, NV, e->hub_min_degree,
+        HIP_TRY(hipMemsetAsync(e->hub_hist, 0, sizeof(int) * 33, e->bs));
+        hipLaunchKernelGGL(k_deg_hist, dim3(grid_for(NV)), dim3(BLOCK), 0, e->bs, e->outdeg, NV, e->hub_min_degree,
                            e->hub_hist);
         int hist[32];
-        HIP_TRY(hipMemcpyAsync(hist, e->hub_hist, sizeof(hist), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipMemcpyAsync(hist, e->hub_hist, sizeof(hist), hipMemcpyDeviceToHost, e->bs));
+        HIP_TRY(hipStreamSynchronize(e->bs));
         long long above = 0;
         int k = 31;
         for (; k >= 0; --k) {
@@ -1140,15 +1156,15 @@ int build_epoch(dppr_engine *e, Epoch &ep) {
         // every bucket > k fits; threshold = lower edge of bucket k+1
         const long long thresh = (long long)e->hub_min_degree << (k + 1);
         const int th = (int)std::min<long long>(thresh, 0x7fffffff);
-        hipLaunchKernelGGL(k_assign_hubs, dim3(grid_for(NV)), dim3(BLOCK), 0, e->stream, e->outdeg, NV, th,
+        hipLaunchKernelGGL(k_assign_hubs, dim3(grid_for(NV)), dim3(BLOCK), 0, e->bs, e->outdeg, NV, th,
                            e->hub_slot_of, ep.hub_v, ep.hub_degp1, e->hub_hist + 32);
         HIP_TRY(hipGetLastError());
         ep.n_hubs = (int)above;
     }
     // row pointers are filled for the whole id capacity: ids assigned later read as empty rows
-    hipLaunchKernelGGL(k_build_csr, dim3(grid_for(std::max(Ed, e->V + 1))), dim3(BLOCK), 0, e->stream, e->in_sorted, Ed,
+    hipLaunchKernelGGL(k_build_csr, dim3(grid_for(std::max(Ed, e->V + 1))), dim3(BLOCK), 0, e->bs, e->in_sorted, Ed,
                        e->V, e->bits, e->hub_slot_of, ep.row_ptr, ep.adj);
-    hipLaunchKernelGGL(k_build_out_csr, dim3(grid_for(std::max(Ed, e->V + 1))), dim3(BLOCK), 0, e->stream,
+    hipLaunchKernelGGL(k_build_out_csr, dim3(grid_for(std::max(Ed, e->V + 1))), dim3(BLOCK), 0, e->bs,
                        e->directed ? e->out_sorted : e->in_sorted, Ed, e->V, e->bits, ep.out_row_ptr, ep.out_col);
     HIP_TRY(hipGetLastError());
     ep.Ed = Ed;
@@ -1202,7 +1218,7 @@ int res_record_ranges(dppr_engine *e, Epoch &ep) {
     if (!e->res_update || !ep.grouped || ep.L <= 0 || ep.L >= SU_SPLIT_MIN || ep.n_groups <= 0 || ep.n_groups > persist_capacity(e)) return DPPR_OK;
     const size_t need = (size_t)ep.n_groups + 3;
     if (need > ep.su_rng_cap) {
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipStreamSynchronize(e->bs));
         (void)hipFree(ep.su_rng);
         ep.su_rng = nullptr;
         ep.su_rng_cap = 0;
@@ -1210,13 +1226,13 @@ int res_record_ranges(dppr_engine *e, Epoch &ep) {
         ep.su_rng_cap = need + 1024;
     }
     int *stat = ep.su_rng + ep.n_groups + 1;
-    HIP_TRY(hipMemsetAsync(stat, 0, sizeof(int) * 2, e->stream));
-    hipLaunchKernelGGL(k_res_rec_ranges, dim3((ep.n_groups + 256) / 256), dim3(256), 0, e->stream, ep.sk, ep.L, ep.grp_tile, ep.n_groups,
+    HIP_TRY(hipMemsetAsync(stat, 0, sizeof(int) * 2, e->bs));
+    hipLaunchKernelGGL(k_res_rec_ranges, dim3((ep.n_groups + 256) / 256), dim3(256), 0, e->bs, ep.sk, ep.L, ep.grp_tile, ep.n_groups,
                        ep.su_rng, stat);
     HIP_TRY(hipGetLastError());
     int h[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(h, stat, sizeof(h), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpyAsync(h, stat, sizeof(h), hipMemcpyDeviceToHost, e->bs));
+    HIP_TRY(hipStreamSynchronize(e->bs));
     ep.su_inline = h[0] <= pb && h[1] == ep.L; // (a tail beyond the last group: an id assigned after the cut -- the cut is redone then)
     return DPPR_OK;
 }
@@ -1269,8 +1285,8 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
     bool x_clean = false;           // a resident launch ended the loop and left s.x / s.x2 all zero
     auto make_list = [&]() -> int { // dense snapshot -> sparse list (after a sweep)
         HIP_TRY(hipMemsetAsync(s.cnt + 7, 0, sizeof(int), e->stream));
-        hipLaunchKernelGGL(k_list_from_dense, dim3(grid_for(e->n_int, BLOCK * INSPECT_ITEMS)), dim3(BLOCK), 0, e->stream,
-                           s.x, e->n_int, s.cnt + cur, s.ft[buf], s.cnt + 7);
+        hipLaunchKernelGGL(k_list_from_dense, dim3(grid_for(ep.grp_n_int, BLOCK * INSPECT_ITEMS)), dim3(BLOCK), 0, e->stream,
+                           s.x, ep.grp_n_int, s.cnt + cur, s.ft[buf], s.cnt + 7);
         HIP_TRY(hipGetLastError());
         list_valid = true;
         return DPPR_OK;
@@ -1551,8 +1567,8 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
     s.iter_hist[hp][0] = active_iters;
     if (any_pull && !x_clean) { // leave both dense vectors all-zero for the next loop
         // only internal ids below n_int are ever written
-        HIP_TRY(hipMemsetAsync(s.x, 0, sizeof(double) * (size_t)e->n_int, e->stream));
-        HIP_TRY(hipMemsetAsync(s.x2, 0, sizeof(double) * (size_t)e->n_int, e->stream));
+        HIP_TRY(hipMemsetAsync(s.x, 0, sizeof(double) * (size_t)ep.grp_n_int, e->stream));
+        HIP_TRY(hipMemsetAsync(s.x2, 0, sizeof(double) * (size_t)ep.grp_n_int, e->stream));
     }
     return DPPR_OK;
 }
@@ -1711,10 +1727,10 @@ int batch_ahead(dppr_engine *e, Slot &s, const Epoch &ep, double eps, int *stage
 int main_loop_inspect(dppr_engine *e, Slot &s, const Epoch &ep, int phase, double eps) {
     s.seed_lists_valid = false;
     HIP_TRY(hipMemsetAsync(s.cnt, 0, sizeof(int) * 3, e->stream));
-    hipLaunchKernelGGL(k_inspect, dim3(grid_for(e->n_int, BLOCK * INSPECT_ITEMS)), dim3(BLOCK), 0, e->stream, s.r,
-                       e->n_int, phase, eps, s.ft[0], s.cnt + 0);
+    hipLaunchKernelGGL(k_inspect, dim3(grid_for(ep.grp_n_int, BLOCK * INSPECT_ITEMS)), dim3(BLOCK), 0, e->stream, s.r,
+                       ep.grp_n_int, phase, eps, s.ft[0], s.cnt + 0);
     HIP_TRY(hipGetLastError());
-    s.st.inspected += e->n_int;
+    s.st.inspected += ep.grp_n_int;
     return run_frontier_loop(e, s, ep, phase, eps, 0, 0);
 }
 
@@ -1733,13 +1749,13 @@ int epoch_group_records(dppr_engine *e, Epoch &ep) {
     ep.su_inline = false;
     if (!e->group_at_slide || ep.L <= 0) return DPPR_OK;
     if (ep.id >= 0) { // an epoch built while the default accounting was on, grouped outside the bracket after all (prepare_epoch): its degrees too
-        hipLaunchKernelGGL(k_copy_out_degree, dim3(grid_for(ep.L)), dim3(BLOCK), 0, e->stream, ep.b1, ep.L, ep.out_row_ptr, ep.deg_after);
+        hipLaunchKernelGGL(k_copy_out_degree, dim3(grid_for(ep.L)), dim3(BLOCK), 0, e->bs, ep.b1, ep.L, ep.out_row_ptr, ep.deg_after);
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_su_keys, dim3(grid_for(ep.L)), dim3(BLOCK), 0, e->stream, ep.b1, ep.L, e->su_k[0], e->su_v[0],
+    hipLaunchKernelGGL(k_su_keys, dim3(grid_for(ep.L)), dim3(BLOCK), 0, e->bs, ep.b1, ep.L, e->su_k[0], e->su_v[0],
                        (unsigned long long *)nullptr, 0, (int *)nullptr, 0);
     size_t tmp = e->su_tmp_bytes;
-    HIP_TRY(rocprim::radix_sort_pairs(e->su_tmp, tmp, e->su_k[0], ep.sk, e->su_v[0], ep.sv, (size_t)ep.L, 0u, (unsigned)e->bits, e->stream));
+    HIP_TRY(rocprim::radix_sort_pairs(e->su_tmp, tmp, e->su_k[0], ep.sk, e->su_v[0], ep.sv, (size_t)ep.L, 0u, (unsigned)e->bits, e->bs));
     ep.grouped = true;
     return res_record_ranges(e, ep);
 }
@@ -1883,7 +1899,7 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
     // no host round trip on the way in: a list that does not fit (overflow) moves nothing and makes the first scan call
     // the mode off, which the read-back of the first chunk shows
     HIP_TRY(hipMemsetAsync(g.pctl, 0, sizeof(GPushCtl), e->stream));
-    const int n_words = (e->n_int + 31) / 32;
+    const int n_words = (ep.grp_n_int + 31) / 32;
     hipLaunchKernelGGL(k_gpush_list, dim3(grid_for(n_words)), dim3(BLOCK), 0, e->stream, g.act[0], n_words, g.plist[0], cap, g.pctl);
     // the frontier's rows move from the snapshot back to residual[]; its bits stay set (they queue it for iteration 0)
     const int rows_grid = grid_for(std::min<long long>(pairs_at_entry, cap), BLOCK / OCT);
@@ -1952,8 +1968,8 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
             if (trace) fprintf(stderr, "[gpush ] phase %d: an iteration of %d vertices called itself off after %d iterations\n", phase, h.n[h.it & 1], h.it);
             HIP_TRY(hipMemsetAsync(g.cnt, 0, sizeof(int) * 3 * GWM, e->stream));
             with_row(g.gw, [&](auto spl, auto gw) {
-                hipLaunchKernelGGL((k_gpush_leave<decltype(spl)::value, decltype(gw)::value>), dim3(grid_for(e->n_int, BLOCK / OCT)), dim3(BLOCK), 0,
-                                   e->stream, e->n_int, g.act[0], g.x, g.r, g.p, h.it > 0 ? 1 : 0, phase, eps, g.cnt);
+                hipLaunchKernelGGL((k_gpush_leave<decltype(spl)::value, decltype(gw)::value>), dim3(grid_for(ep.grp_n_int, BLOCK / OCT)), dim3(BLOCK), 0,
+                                   e->stream, ep.grp_n_int, g.act[0], g.x, g.r, g.p, h.it > 0 ? 1 : 0, phase, eps, g.cnt);
             });
             HIP_TRY(hipGetLastError());
             if (h.it > 0) *owed = false; // (iteration 0 settled the hand-over, k_gpush_leave credited what it queued)
@@ -1983,10 +1999,10 @@ int group_loop(dppr_engine *e, Group &g, const Epoch &ep, int phase, double eps,
     } else {
         // dense seeding: every legal vertex of every source enters, snapshot taken
         with_row(g.gw, [&](auto spl, auto gw) {
-            hipLaunchKernelGGL((k_gseed_dense<decltype(spl)::value, decltype(gw)::value>), dim3(grid_for(e->n_int, BLOCK / OCT)), dim3(BLOCK), 0,
-                               e->stream, e->n_int, g.r, g.x, g.p, g.act[0], phase, eps, g.cnt + cur * GWM);
+            hipLaunchKernelGGL((k_gseed_dense<decltype(spl)::value, decltype(gw)::value>), dim3(grid_for(ep.grp_n_int, BLOCK / OCT)), dim3(BLOCK), 0,
+                               e->stream, ep.grp_n_int, g.r, g.x, g.p, g.act[0], phase, eps, g.cnt + cur * GWM);
         });
-        g.st.inspected += (int64_t)e->n_int * g.n;
+        g.st.inspected += (int64_t)ep.grp_n_int * g.n;
     }
     HIP_TRY(hipGetLastError());
     int *log = g.cnt + 5 * GWM;
@@ -2248,6 +2264,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return DPPR_ERR_NO_DEVICE;
     dppr_engine *e = new dppr_engine();
+    dppr::g_live_engines.fetch_add(1, std::memory_order_relaxed);
     auto bail = [&](int code) {
         dppr_destroy(e);
         return code;
@@ -2286,6 +2303,11 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     while ((1ll << e->bits) < (long long)V) e->bits++;
     HIP_TRY_C(hipSetDevice(device));
     HIP_TRY_C(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    {
+        int least = 0, greatest = 0; // (numerically: least priority >= greatest priority)
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+        HIP_TRY_C(hipStreamCreateWithPriority(&e->bs, hipStreamNonBlocking, least));
+    }
     HIP_TRY_C(hipEventCreate(&e->ev0));
     HIP_TRY_C(hipEventCreate(&e->ev1));
     for (auto &ev : e->evpool) HIP_TRY_C(hipEventCreate(&ev));
@@ -2345,6 +2367,7 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
         HIP_TRY_C(hipMalloc((void **)&ep.hub_v, sizeof(int) * HUB_CAP));
         HIP_TRY_C(hipMalloc((void **)&ep.hub_degp1, sizeof(int) * HUB_CAP));
     }
+    HIP_TRY_C(hipStreamSynchronize(e->stream)); // (the builder's stream is another one: nothing of this set-up may still be in flight)
 #undef HIP_TRY_C
     *out = e;
     return DPPR_OK;
@@ -2355,6 +2378,7 @@ void dppr_destroy(dppr_engine *e) {
     if (e->pre.task.valid()) e->pre.task.wait();
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->bs) (void)hipStreamSynchronize(e->bs);
     for (auto &s : e->slots) {
         (void)hipFree(s.p); (void)hipFree(s.r); (void)hipFree(s.x); (void)hipFree(s.x2);
         (void)hipFree(s.ft[0]); (void)hipFree(s.ft[1]); (void)hipFree(s.neg); (void)hipFree(s.status); (void)hipFree(s.act[0]); (void)hipFree(s.act[1]);
@@ -2389,6 +2413,8 @@ void dppr_destroy(dppr_engine *e) {
     for (auto &ev : e->evpool)
         if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->bs) (void)hipStreamDestroy(e->bs);
+    dppr::g_live_engines.fetch_sub(1, std::memory_order_relaxed);
     delete e;
 }
 
@@ -2577,13 +2603,13 @@ int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32
     if (!translate(e, e1, n, e->h_tmp1) || !translate(e, e2, n, e->h_tmp2))
         return fail(e, DPPR_ERR_INVALID, "load_window: vertex id out of range");
     if (n > 0) {
-        HIP_TRY(hipMemcpyAsync(e->w1, e->h_tmp1.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(hipMemcpyAsync(e->w2, e->h_tmp2.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->w1, e->h_tmp1.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, e->bs));
+        HIP_TRY(hipMemcpyAsync(e->w2, e->h_tmp2.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, e->bs));
     }
     e->head = 0;
-    HIP_TRY(hipMemsetAsync(e->outdeg, 0, sizeof(int) * (size_t)e->V, e->stream));
+    HIP_TRY(hipMemsetAsync(e->outdeg, 0, sizeof(int) * (size_t)e->V, e->bs));
     if (n > 0) {
-        hipLaunchKernelGGL(k_deg_update, dim3(grid_for(n)), dim3(BLOCK), 0, e->stream, e->w1, e->w2, n, e->directed, 1,
+        hipLaunchKernelGGL(k_deg_update, dim3(grid_for(n)), dim3(BLOCK), 0, e->bs, e->w1, e->w2, n, e->directed, 1,
                            e->outdeg);
         HIP_TRY(hipGetLastError());
     }
@@ -2603,13 +2629,13 @@ int dppr_load_window(dppr_engine *e, const int32_t *e1, const int32_t *e2, int32
     e->renumber_next = renumber_threshold(e->n_int, e->renumber_growth_pct);
     e->loaded = true;
     e->batch_staged = false;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipStreamSynchronize(e->bs));
     return DPPR_OK;
 }
 
 int dppr_hint_next_batch(dppr_engine *e, const int32_t *b1, const int32_t *b2, int32_t L, const int32_t *n1, const int32_t *n2, int32_t c) {
-    if (!e || e->broken || L < 0 || L > 4 * e->c || c < 0 || c > e->c || (L > 0 && (!b1 || !b2)) || (c > 0 && (!n1 || !n2)))
-        return fail(e, DPPR_ERR_INVALID, "hint_next_batch: lengths exceed max_batch");
+    // (no message through fail(): this call may come from a helper thread while the engine's own thread writes e->err -- ADVICE r04)
+    if (!e || e->broken || L < 0 || L > 4 * e->c || c < 0 || c > e->c || (L > 0 && (!b1 || !b2)) || (c > 0 && (!n1 || !n2))) return DPPR_ERR_INVALID;
     pre_join(e);
     dppr_engine::Pre &pr = e->pre;
     const int32_t *src[4] = {b1, b2, n1, n2};
@@ -2644,7 +2670,26 @@ int dppr_set_batch(dppr_engine *e, const int32_t *b1, const int32_t *b2, const u
     return flush_moves(e); // (a record may have named a parked vertex)
 }
 
+static int slide_impl(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, int32_t *out_epoch);
+
 int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, int32_t *out_epoch) {
+    if (e) e->build_concurrent = false;
+    return slide_impl(e, n1, n2, c, out_epoch);
+}
+
+int dppr_slide_concurrent(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, int32_t *out_epoch) {
+    if (!e || e->n_epochs < 2) return fail(e, DPPR_ERR_INVALID, "slide_concurrent: needs n_epochs >= 2 (the epoch being built must not be the one being solved)");
+    e->build_concurrent = true;
+    const int rc = slide_impl(e, n1, n2, c, out_epoch);
+    e->build_concurrent = false;
+    return rc;
+}
+
+int dppr_renumbering_due(const dppr_engine *e) {
+    return e && e->renumber_on && e->W > 0 && e->n_int >= e->renumber_next ? 1 : 0;
+}
+
+static int slide_impl(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, int32_t *out_epoch) {
     // c is bounded by max_batch of dppr_create: the batch key buffers (2 * max_batch keys each) and the
     // merge scratch are sized for it
     if (!e || e->broken || !e->loaded || c < 0 || c > e->W || c > e->c || (c > 0 && (!n1 || !n2)))
@@ -2658,7 +2703,7 @@ int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, 
     clock_gettime(CLOCK_MONOTONIC, &t_mark);
     auto mark = [&](const char *what) {
         if (!slide_trace) return;
-        (void)hipStreamSynchronize(e->stream);
+        (void)hipStreamSynchronize(e->bs);
         timespec now;
         clock_gettime(CLOCK_MONOTONIC, &now);
         fprintf(stderr, "[slide] %-34s %8.1f us\n", what, (now.tv_sec - t_mark.tv_sec) * 1e6 + (now.tv_nsec - t_mark.tv_nsec) * 1e-3);
@@ -2681,17 +2726,17 @@ int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, 
     while (done < c) {
         const int pos = (e->head + done) % W;
         const int len = std::min(c - done, W - pos);
-        hipLaunchKernelGGL(k_deg_update, dim3(grid_for(len)), dim3(BLOCK), 0, e->stream, e->w1 + pos, e->w2 + pos, len,
+        hipLaunchKernelGGL(k_deg_update, dim3(grid_for(len)), dim3(BLOCK), 0, e->bs, e->w1 + pos, e->w2 + pos, len,
                            e->directed, -1, e->outdeg);
         if (inc)
-            hipLaunchKernelGGL(k_make_keys_seg, dim3(grid_for(len)), dim3(BLOCK), 0, e->stream, e->w1 + pos, e->w2 + pos,
+            hipLaunchKernelGGL(k_make_keys_seg, dim3(grid_for(len)), dim3(BLOCK), 0, e->bs, e->w1 + pos, e->w2 + pos,
                                len, e->directed, e->bits, e->bk[0] + (size_t)done * per, e->bk[2] + done);
-        HIP_TRY(hipMemcpyAsync(e->w1 + pos, n1 + done, sizeof(int) * (size_t)len, hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(hipMemcpyAsync(e->w2 + pos, n2 + done, sizeof(int) * (size_t)len, hipMemcpyHostToDevice, e->stream));
-        hipLaunchKernelGGL(k_deg_update, dim3(grid_for(len)), dim3(BLOCK), 0, e->stream, e->w1 + pos, e->w2 + pos, len,
+        HIP_TRY(hipMemcpyAsync(e->w1 + pos, n1 + done, sizeof(int) * (size_t)len, hipMemcpyHostToDevice, e->bs));
+        HIP_TRY(hipMemcpyAsync(e->w2 + pos, n2 + done, sizeof(int) * (size_t)len, hipMemcpyHostToDevice, e->bs));
+        hipLaunchKernelGGL(k_deg_update, dim3(grid_for(len)), dim3(BLOCK), 0, e->bs, e->w1 + pos, e->w2 + pos, len,
                            e->directed, 1, e->outdeg);
         if (inc)
-            hipLaunchKernelGGL(k_make_keys_seg, dim3(grid_for(len)), dim3(BLOCK), 0, e->stream, e->w1 + pos, e->w2 + pos,
+            hipLaunchKernelGGL(k_make_keys_seg, dim3(grid_for(len)), dim3(BLOCK), 0, e->bs, e->w1 + pos, e->w2 + pos,
                                len, e->directed, e->bits, e->bk[1] + (size_t)done * per, e->bk[3] + done);
         HIP_TRY(hipGetLastError());
         done += len;
@@ -2707,11 +2752,11 @@ int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, 
     int rc;
     e->merge_miss_host = 0;
     if (inc) { // f1: merge the batch into the previous sorted keys
-        HIP_TRY(hipMemsetAsync(e->hub_hist + MERGE_MISS_WORD, 0, sizeof(int), e->stream));
+        HIP_TRY(hipMemsetAsync(e->hub_hist + MERGE_MISS_WORD, 0, sizeof(int), e->bs));
         rc = merge_batch_keys(e, e->in_sorted, e->bk[0], e->bks[0], c * per, e->bk[1], e->bks[1], c * per);
         if (!rc && e->directed) rc = merge_batch_keys(e, e->out_sorted, e->bk[2], e->bks[2], c, e->bk[3], e->bks[3], c);
         // (read with the build's own synchronisations below: no extra wait on the path that finds every key)
-        if (!rc) HIP_TRY(hipMemcpyAsync(&e->merge_miss_host, e->hub_hist + MERGE_MISS_WORD, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        if (!rc) HIP_TRY(hipMemcpyAsync(&e->merge_miss_host, e->hub_hist + MERGE_MISS_WORD, sizeof(int), hipMemcpyDeviceToHost, e->bs));
     } else {
         rc = sort_window_full(e);
     }
@@ -2719,7 +2764,7 @@ int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, 
     mark("sorted keys (merge / full sort)");
     rc = build_epoch(e, ep);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipStreamSynchronize(e->bs));
     if (inc && (e->merge_miss_host != 0 || e->test_force_merge_miss)) {
         // a retired key was not among the kept sorted keys (an inconsistent window: never seen): the merged arrays
         // cannot be trusted -- the ring itself is right, so sort it afresh and build the epoch again
@@ -2736,19 +2781,19 @@ int dppr_slide(dppr_engine *e, const int32_t *n1, const int32_t *n2, int32_t c, 
         const int L = (int)e->st_b1.size();
         ep.L = L;
         if (L > 0) {
-            HIP_TRY(hipMemcpyAsync(ep.b1, e->st_b1.data(), sizeof(int) * (size_t)L, hipMemcpyHostToDevice, e->stream));
-            HIP_TRY(hipMemcpyAsync(ep.b2, e->st_b2.data(), sizeof(int) * (size_t)L, hipMemcpyHostToDevice, e->stream));
-            HIP_TRY(hipMemcpyAsync(ep.ins, e->st_ins.data(), (size_t)L, hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(hipMemcpyAsync(ep.b1, e->st_b1.data(), sizeof(int) * (size_t)L, hipMemcpyHostToDevice, e->bs));
+            HIP_TRY(hipMemcpyAsync(ep.b2, e->st_b2.data(), sizeof(int) * (size_t)L, hipMemcpyHostToDevice, e->bs));
+            HIP_TRY(hipMemcpyAsync(ep.ins, e->st_ins.data(), (size_t)L, hipMemcpyHostToDevice, e->bs));
             if (e->group_at_slide) {
                 // CopyOutDegree (gpu/StreamUpdate.cuh:7-17): post-batch out-degree of every tail
-                hipLaunchKernelGGL(k_gather_deg, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->outdeg,
+                hipLaunchKernelGGL(k_gather_deg, dim3(grid_for(L)), dim3(BLOCK), 0, e->bs, ep.b1, L, e->outdeg,
                                    ep.deg_after);
                 HIP_TRY(hipGetLastError());
                 if (int grc = epoch_group_records(e, ep)) return grc; // the records grouped by tail, for IncrementalBatchUpdate
             } // (default: both are part of the timed region -- group_records_by_tail, or the resident launch itself)
         }
     }
-    HIP_TRY(hipStreamSynchronize(e->stream)); // staged host vectors may be reused now
+    HIP_TRY(hipStreamSynchronize(e->bs)); // staged host vectors may be reused now
     mark("batch records");
     e->batch_staged = false;
     ep.id = id;

@@ -29,11 +29,17 @@ namespace dppr {
 #ifndef DPPR_PAR_MIN_PIECE
 #define DPPR_PAR_MIN_PIECE 0 // (tests: a tiny piece size so that toy arrays take the threaded path too)
 #endif
+// Engines alive in this process (dppr_create / dppr_destroy). Every engine's host thread spins on its stream inside a timed
+// region (loop_sync) and may have a lookahead running beside it: the helper threads of one call are capped at what the cores
+// leave after one per engine (with -g N, N spinners plus 8 N helpers perturb the times they run beside).
+inline std::atomic<int> g_live_engines{0};
 template <class F>
 inline void parallel_pieces(size_t n, size_t min_piece, F &&fn) {
     if (DPPR_PAR_MIN_PIECE) min_piece = DPPR_PAR_MIN_PIECE;
     static const size_t hw = std::thread::hardware_concurrency(); // (asked once: the call reads /sys)
-    size_t nt = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 8), n / std::max<size_t>(min_piece, 1));
+    const size_t busy = (size_t)std::max(g_live_engines.load(std::memory_order_relaxed), 0);
+    const size_t room = hw > busy ? hw - busy : 1;
+    size_t nt = std::min<size_t>(std::min<size_t>(room, 8), n / std::max<size_t>(min_piece, 1));
     if (nt <= 1) {
         fn((size_t)0, n);
         return;
@@ -45,12 +51,26 @@ inline void parallel_pieces(size_t n, size_t min_piece, F &&fn) {
     for (auto &x : th) x.join();
 }
 
+// an atomic counter inside a struct that stays copyable (the native tests snapshot an IdSpace)
+struct CopyableCounter {
+    std::atomic<unsigned> v{1};
+    CopyableCounter() = default;
+    CopyableCounter(const CopyableCounter &o) : v(o.v.load(std::memory_order_relaxed)) {}
+    CopyableCounter &operator=(const CopyableCounter &o) {
+        v.store(o.v.load(std::memory_order_relaxed), std::memory_order_relaxed);
+        return *this;
+    }
+    unsigned load(std::memory_order mo = std::memory_order_seq_cst) const { return v.load(mo); }
+    unsigned fetch_add(unsigned d, std::memory_order mo = std::memory_order_seq_cst) { return v.fetch_add(d, mo); }
+};
+
 struct IdSpace {
     int cap = 0; // id capacity = the external id range V
     std::vector<int32_t> ext2int, int2ext; // both cap long; -1: no id / position holds no vertex
     int n_int = 0, n_parked = 0;
     long long revivals = 0;
-    bool map_dirty = true; // a device copy of ext2int is stale
+    CopyableCounter map_gen; // bumped whenever ext2int changes: a device copy made at an older value is stale (the copy may be
+                                      // taken by another thread than the one that assigns ids: dppr_slide_concurrent)
     unsigned long long renumber_epoch = 0; // bumped by renumber(): the only operation that changes the internal id of a LIVE vertex
     // pending row moves: position -> position whose rows it will receive (-1: zero rows). Composed on the host while
     // ids are assigned, applied to every state array in one gather + scatter + zero pass (take_moves).
@@ -62,7 +82,7 @@ struct IdSpace {
         int2ext.assign((size_t)V, -1);
         n_int = n_parked = 0;
         revivals = 0;
-        map_dirty = true;
+        map_gen.fetch_add(1, std::memory_order_release);
         mv_origin.clear();
     }
 
@@ -128,7 +148,7 @@ struct IdSpace {
         if (m < 0) {
             m = n_int++;
             int2ext[(size_t)m] = ext;
-            map_dirty = true;
+            map_gen.fetch_add(1, std::memory_order_release);
         } else if (is_parked(m)) {
             revive(ext);
         }
@@ -162,7 +182,7 @@ struct IdSpace {
         int2ext[(size_t)fresh] = ext;
         n_parked--;
         revivals++;
-        map_dirty = true;
+        map_gen.fetch_add(1, std::memory_order_release);
     }
 
     // The pending moves as lists: rows[dst[i]] = OLD rows[src[i]] for all i at once (gather everything, then scatter),
@@ -222,7 +242,7 @@ struct IdSpace {
         for (int i = 0; i < R_old; ++i) place(cap - R_old + i, old_parked[(size_t)i]);
         n_int = n_live;
         n_parked = R_new;
-        map_dirty = true;
+        map_gen.fetch_add(1, std::memory_order_release);
         renumber_epoch++;
     }
 };

@@ -59,7 +59,7 @@ EXPORTS = [
     "dppr_group_reset_stats", "dppr_set_group_seeding", "dppr_seed_lists", "dppr_set_sweep_bitmap", "dppr_set_group_resident", "dppr_set_resident_slots", "dppr_set_resident_update",
     "dppr_set_renumbering", "dppr_id_space", "dppr_set_group_push", "dppr_set_binned_sweep", "dppr_device_count", "dppr_set_phase_merge", "dppr_init_solve_at", "dppr_group_init_solve_at", "dppr_set_variant", "dppr_set_batch_grouping",
     "dppr_time_batch_grouping", "dppr_debug_dump", "dppr_hint_next_batch",
-    "dppr_bench_line_fills", "dppr_bench_stream_copy", "dppr_build_id", "dppr_heartbeat",
+    "dppr_bench_line_fills", "dppr_bench_stream_copy", "dppr_build_id", "dppr_heartbeat", "dppr_slide_concurrent", "dppr_renumbering_due",
 ]
 
 
@@ -135,6 +135,8 @@ def lib():
     L.dppr_bench_stream_copy.argtypes = [C.c_int, C.c_int64, C.c_int, fp]
     L.dppr_build_id.restype = C.c_char_p
     L.dppr_heartbeat.argtypes = [vp]
+    L.dppr_slide_concurrent.argtypes = [vp, ip, ip, C.c_int32, ip]
+    L.dppr_renumbering_due.argtypes = [vp]
     L.dppr_heartbeat.restype = C.c_ulonglong
     for name in EXPORTS:
         if name not in ("dppr_strerror", "dppr_last_error", "dppr_destroy", "dppr_build_id", "dppr_heartbeat"):
@@ -215,6 +217,9 @@ class Engine:
         """One loop for residuals of both signs, run to eps / eps_divisor (include/dppr.h); eager schedule only."""
         self._ck(self._L.dppr_set_phase_merge(self._h, int(on), int(eps_divisor)), "set_phase_merge")
 
+    def renumbering_due(self):
+        return bool(self._L.dppr_renumbering_due(self._h))
+
     def set_batch_grouping(self, at_slide):
         """0 (default): CopyOutDegree + the grouping of a batch's records run inside the timed region, as the reference times them;
         1: at slide time (for epochs already built: on entry to the next update, before its event bracket opens)."""
@@ -263,11 +268,14 @@ class Engine:
                  "hint_next_batch")
         return tuple(self._hint_keep)
 
-    def slide(self, n1, n2):
+    def slide(self, n1, n2, concurrent=False):
+        """GPUBuildSlidingGraph. concurrent=True: dppr_slide_concurrent -- may run (from another thread) beside an update on an older,
+        explicitly named epoch; needs n_epochs >= 2."""
         a, pa = _i32(n1)
         b, pb = _i32(n2)
         ep = C.c_int32(-1)
-        self._ck(self._L.dppr_slide(self._h, pa, pb, len(a), C.byref(ep)), "slide")
+        fn = self._L.dppr_slide_concurrent if concurrent else self._L.dppr_slide
+        self._ck(fn(self._h, pa, pb, len(a), C.byref(ep)), "slide")
         return ep.value
 
     def add_source(self, s):

@@ -67,8 +67,10 @@ public:
         : graph(g), device_id(device), source_vertex_ids(sources), quiet_(quiet) {
         if (!quiet_)
             for (IndexType s : sources) std::cout << "choose " << s << " as source vertex id" << std::endl;
+        // two resident epochs: the graph of batch k + 1 is built (dppr_slide_concurrent) while batch k is being solved
+        overlap_ = !gValidate && !gSplitInterface && std::getenv("DPPR_NO_OVERLAP") == nullptr;
         int rc = dppr_create(&engine, device, g->vertex_count, g->sliding_window_size, g->directed ? 1 : 0,
-                             (int32_t)gStreamUpdateCountPerBatch, 1);
+                             (int32_t)gStreamUpdateCountPerBatch, overlap_ ? 2 : 1);
         if (rc != DPPR_OK) {
             std::cout << "dppr_create: " << dppr_strerror(rc) << std::endl;
             std::exit(-1);
@@ -130,13 +132,15 @@ public:
         }
         prof.End(HostProfile::INIT_GRAPH_CALC);
         prof.Start(HostProfile::DYNA_GRAPH_CALC);
-        SlidingWindowExecuteMainLoop();
+        if (overlap_) SlidingWindowExecuteOverlapped();
+        else SlidingWindowExecuteMainLoop();
         prof.End(HostProfile::DYNA_GRAPH_CALC);
         prof.End(HostProfile::TOTAL);
         if (!quiet_) std::cout << "finish!" << std::endl;
         if (std::getenv("DPPR_HOST_TIMES")) // (stderr, not a line of the reference: the loop's wall time beside the ppr_time it reports)
             std::cerr << "host_times batches=" << batches_done << " dynamic_ms=" << prof.ms[HostProfile::DYNA_GRAPH_CALC]
-                      << " graph_update_ms=" << prof.ms[HostProfile::EXCLUDE_GRAPH_UPDATE] << " ppr_ms=" << prof.ms[HostProfile::PPR] << std::endl;
+                      << " graph_update_ms=" << prof.ms[HostProfile::EXCLUDE_GRAPH_UPDATE] << " ppr_ms=" << prof.ms[HostProfile::PPR]
+                      << " graph_update_beside_ppr_ms=" << build_beside_ms << " overlap=" << (overlap_ ? 1 : 0) << std::endl;
         if (gProfile && !quiet_) ReportProfile();
     }
 
@@ -255,6 +259,97 @@ public:
         }
     }
 
+    // The same loop with the untimed region of batch k + 1 (host stream advance, batch upload, device graph build: gpu/PPRGPU.cuh:114-135)
+    // running on a helper thread WHILE batch k is solved. The engine keeps two epochs; the helper builds epoch
+    // k + 1 through dppr_set_batch + dppr_slide_concurrent (own HIP stream and scratch inside the engine), this thread solves the
+    // explicitly named epoch k. What this thread still waits for -- the first batch's graph, the remainder of a build that outlasts
+    // its solve, and any slide that has to be exclusive (a renumbering of the id space moves every state row: dppr_renumbering_due)
+    // -- is what exclude_graph_update_time reports; the helper's own time is reported beside it. Same stdout lines, same results
+    // (DPPR_NO_OVERLAP=1: the serial loop above with its id lookahead; --validate and --split use that one too).
+    struct Built {
+        bool end = false;      // the stream ended: no such batch (a partial last batch is dropped, like the reference's)
+        bool deferred = false; // host stream advanced, but batch upload + slide wait for the solver (exclusive slide)
+        int32_t epoch = -1;
+        double ms = 0;
+    };
+    Built BuildNext(bool concurrent) {
+        Built b;
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        b.end = graph->StreamUpdates(gStreamUpdateCountPerBatch);
+        if (!b.end) {
+            if (concurrent && dppr_renumbering_due(engine)) {
+                b.deferred = true;
+            } else {
+                DPPR_CHECK(engine, dppr_set_batch(engine, graph->edge_batch->edge1, graph->edge_batch->edge2, graph->edge_batch->is_insert,
+                                                  graph->edge_batch->length));
+                if (concurrent)
+                    DPPR_CHECK(engine, dppr_slide_concurrent(engine, graph->new_stream->edge1, graph->new_stream->edge2, graph->new_stream->length, &b.epoch));
+                else
+                    DPPR_CHECK(engine, dppr_slide(engine, graph->new_stream->edge1, graph->new_stream->edge2, graph->new_stream->length, &b.epoch));
+            }
+        }
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        b.ms = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+        progress++;
+        return b;
+    }
+
+    virtual void SlidingWindowExecuteOverlapped() {
+        size_t stream_batch_count = 0;
+        if (std::getenv("DPPR_TEST_STALL")) // (test hook, as in the serial loop)
+            for (;;) std::this_thread::sleep_for(std::chrono::seconds(1));
+        prof.Start(HostProfile::EXCLUDE_GRAPH_UPDATE);
+        Built nxt = gStreamBatchCount > 0 ? BuildNext(false) : Built(); // batch 1's graph: nothing to run beside
+        prof.End(HostProfile::EXCLUDE_GRAPH_UPDATE);
+        if (gStreamBatchCount == 0) nxt.end = true;
+        while (stream_batch_count++ < gStreamBatchCount) {
+            if (!quiet_ && (gStreamUpdateCountPerBatch > 100 || stream_batch_count % 100 == 0))
+                Report(stream_batch_count);
+            progress++;
+            if (nxt.end) break;
+            if (nxt.deferred) { // the host arrays hold this batch; the solver is idle now
+                prof.Start(HostProfile::EXCLUDE_GRAPH_UPDATE);
+                DPPR_CHECK(engine, dppr_set_batch(engine, graph->edge_batch->edge1, graph->edge_batch->edge2, graph->edge_batch->is_insert,
+                                                  graph->edge_batch->length));
+                DPPR_CHECK(engine, dppr_slide(engine, graph->new_stream->edge1, graph->new_stream->edge2, graph->new_stream->length, &nxt.epoch));
+                prof.End(HostProfile::EXCLUDE_GRAPH_UPDATE);
+                progress++;
+            }
+            const int32_t epoch = nxt.epoch;
+            const bool more = stream_batch_count < gStreamBatchCount;
+            std::future<Built> task;
+            if (more) task = std::async(std::launch::async, [this] { return BuildNext(true); });
+            prof.Start(HostProfile::PPR);
+            for (size_t k = 0; k < groups.size(); ++k) {
+                float ms = 0;
+                DPPR_CHECK(engine, dppr_group_update(engine, groups[k], epoch, gTolerance, &ms));
+                ppr_time[k] += ms;
+            }
+            for (size_t i = 0; i < slots.size(); ++i) {
+                float ms = 0;
+                DPPR_CHECK(engine, dppr_update(engine, slots[i], epoch, gTolerance, &ms));
+                ppr_time[i] += ms;
+            }
+            prof.End(HostProfile::PPR);
+            if (more) {
+                prof.Start(HostProfile::EXCLUDE_GRAPH_UPDATE); // (what is left of the build once the solve is over)
+                nxt = task.get();
+                prof.End(HostProfile::EXCLUDE_GRAPH_UPDATE);
+                build_beside_ms += nxt.ms;
+            }
+        }
+        batches_done = stream_batch_count - 1;
+        if (!quiet_) Report(stream_batch_count);
+        if (!quiet_) {
+            int32_t ids = 0, parked = 0, renumberings = 0;
+            int64_t revivals = 0;
+            DPPR_CHECK(engine, dppr_id_space(engine, &ids, &parked, &renumberings, &revivals));
+            std::cout << "id_space ids=" << ids << " parked=" << parked << " renumberings=" << renumberings
+                      << " revivals=" << revivals << std::endl;
+        }
+    }
+
     // the reference's four virtuals (gpu/PPRGPU.cuh:179-182), per source slot
     virtual void GPUBuildSlidingGraph() {
         DPPR_CHECK(engine, dppr_slide(engine, graph->new_stream->edge1, graph->new_stream->edge2,
@@ -345,6 +440,8 @@ public:
     std::vector<float> ppr_time; // ms per source (single mode) or per group, timed region only
     HostProfile prof;
     size_t batches_done = 0;
+    bool overlap_ = false;       // the graph of batch k + 1 is built while batch k is solved (SlidingWindowExecuteOverlapped)
+    double build_beside_ms = 0;  // ... time the helper thread spent on those builds
     std::atomic<unsigned long long> progress{0}; // bumped after every engine call that can take long (the watchdog of pagerank_main.cpp looks at it)
 
 protected:

@@ -12,7 +12,8 @@
  * Conventions: plain pointers and sizes, no C++ or torch types. Every function
  * returns 0 (DPPR_OK) or a negative dppr_status; nothing exits the process (the
  * reference prints and exit(-1)s, gpu/GPUUtil.cuh:7-19). An engine is confined to
- * one host thread; engines on different devices are independent. Host buffers are
+ * one host thread -- except for the builder / solver pair of dppr_slide_concurrent and the
+ * helper of dppr_hint_next_batch --; engines on different devices are independent. Host buffers are
  * borrowed for the duration of the call only (as EdgeBatch arrays are,
  * SlidingGraphVec.h:17-26). All device memory is owned by the engine
  * (DeviceMemory / SlidingGraphBuilder ownership, gpu/DeviceMemory.cuh:31-50).
@@ -215,6 +216,18 @@ int dppr_set_batch(dppr_engine *e, const int32_t *edge1, const int32_t *edge2,
  * NULL) receives the new epoch id. */
 int dppr_slide(dppr_engine *e, const int32_t *new_e1, const int32_t *new_e2, int32_t c,
                int32_t *out_epoch);
+
+/* The same graph update, allowed to run CONCURRENTLY with one solver call on an OLDER epoch (ABI 4; the overlap of the reference's
+ * untimed region, gpu/PPRGPU.cuh:114-135, with its timed one). Contract: ONE builder thread (dppr_set_batch +
+ * dppr_slide_concurrent for batch k + 1) beside ONE solver thread (dppr_update / dppr_group_update / dppr_incremental_batch_update /
+ * dppr_execute_main_loop / dppr_read / dppr_stats with an EXPLICIT epoch id <= k; never -1 = "newest", which the builder is
+ * changing); the solver must not be given epoch k + 1 before this call has returned; n_epochs >= 2 (epoch k + 1 takes the ring
+ * entry of epoch k + 1 - n_epochs, which nothing may still be solving on). The builder works on its own HIP stream and scratch;
+ * what it shares with the solver are the state rows of vertices that are NEW or REVIVED in batch k + 1, which no older epoch
+ * touches. Such a slide never renumbers the id space and never grows the resident-launch arena: when dppr_renumbering_due(e)
+ * says so, make the next graph update an exclusive dppr_slide (after the solver call has returned). Same results. */
+int dppr_slide_concurrent(dppr_engine *e, const int32_t *new_e1, const int32_t *new_e2, int32_t c, int32_t *out_epoch);
+int dppr_renumbering_due(const dppr_engine *e);
 
 /* How dppr_slide maintains the device CSR. on (default): the previous epoch's sorted edge keys
  * are kept and the batch is merged in (sort of the 2c batch keys + mark + select + merge, O(Ed)

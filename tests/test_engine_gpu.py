@@ -425,7 +425,7 @@ def test_golden_fixtures_reference_ground_truth(name):
     Any state with the loop invariant p + a r = a e_s + M p (M = (1-a) D^-1 A over outdeg + 1, row sums < 1 - a) satisfies
     p - p* = -a (I - M)^-1 r, and |(I - M)^-1|_inf <= 1 / a: every state with |r| < eps lies within eps of the fixed point,
     the engine's and the reference's FIFO state within 2 eps of each other (round 4 asserted 200 eps). Measured on these
-    fixtures: 0.2 - 1.1 eps (printed with -s)."""
+    fixtures: 0.18 - 0.28 eps (printed with -s)."""
     d, m = load_golden(name)
     eps = m["eps"]
     sc = Scenario(m["V"], d["stream.e1"], d["stream.e2"], m["directed"], m["W"], m["c"], m["source"], eps)

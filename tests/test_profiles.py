@@ -14,6 +14,26 @@ def test_batch_timelines_agree_with_their_kernel_stats():
     assert "checked, 0 disagreement(s)" in r.stdout and not r.stdout.startswith("0 timeline")
 
 
+def test_the_checker_catches_artefacts_of_another_build(tmp_path):
+    """Round 5: profiles are stamped with the build id of the library that produced them. A counter summary or a bench line from
+    another build than the manifest's, and an artefact the manifest does not list, each fail the check."""
+    import json
+    man = {"build_id": "aaaaaaaaaaaaaaaa", "git_commit": "0000000", "files": ["r09_pmc_fabric_x.json", "r09_bench_x_1gpu.json"]}
+    json.dump(man, open(tmp_path / "r09_manifest.json", "w"))
+    json.dump({"_stamp": {"build_id": "aaaaaaaaaaaaaaaa"}, "k_gsweep": {}}, open(tmp_path / "r09_pmc_fabric_x.json", "w"))
+    open(tmp_path / "r09_bench_x_1gpu.json", "w").write(json.dumps({"build_id": "aaaaaaaaaaaaaaaa", "roofline": {}}) + "\n")
+    run = lambda: subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_profiles.py"), str(tmp_path)], stdout=subprocess.PIPE, text=True)
+    r = run()
+    assert r.returncode == 0 and "2 stamped artefact(s) checked, 0 disagreement(s)" in r.stdout, r.stdout
+    json.dump({"_stamp": {"build_id": "bbbbbbbbbbbbbbbb"}, "k_gsweep": {}}, open(tmp_path / "r09_pmc_fabric_x.json", "w"))
+    r = run()
+    assert r.returncode == 1 and "r09_pmc_fabric_x.json: build id bbbbbbbbbbbbbbbb" in r.stdout, r.stdout
+    json.dump({"_stamp": {"build_id": "aaaaaaaaaaaaaaaa"}, "k_gsweep": {}}, open(tmp_path / "r09_pmc_fabric_x.json", "w"))
+    open(tmp_path / "r09_kernel_stats_y.csv", "w").write("Name,Calls,TotalDurationNs,AverageNs,MinNs,MaxNs\n")
+    r = run()
+    assert r.returncode == 1 and "r09_kernel_stats_y.csv: not listed" in r.stdout, r.stdout
+
+
 def test_the_checker_catches_a_timeline_from_another_run(tmp_path):
     import json
     import shutil
@@ -37,7 +57,10 @@ def test_the_cut_finds_a_batch_in_each_of_its_forms(tmp_path):
     forms = {"group": ["k_su_terms", "k_su_apply", "k_gsweep<2, 512, false>", "k_gsweep<2, 512, false>", "k_gpush_scan"],
              "fused": ["k_su_keys", "k_su_apply_fused", "k_pull_resident<1024>", "__amd_rocclr_copyBuffer"],
              "in-launch": ["k_su_keys", "k_pull_resident<1024>", "__amd_rocclr_copyBuffer"],
-             "grouping-in-update": ["k_su_keys", "rocprim::radix_sort_block_sort", "k_su_apply_fused", "k_pull_iter<1024, false>"]}
+             "grouping-in-update": ["k_su_keys", "rocprim::radix_sort_block_sort", "k_su_apply_fused", "k_pull_iter<1024, false>"],
+             # round 5 (grouping + CopyOutDegree inside the timed region by default): one ranking launch, or degrees + keys + device sort
+             "ranked-in-update": ["k_su_group_rank", "k_su_terms", "k_su_apply", "k_gsweep<2, 512, false>", "k_gsweep<2, 512, false>"],
+             "sorted-in-update": ["k_copy_out_degree", "k_su_keys", "rocprim::radix_sort_block_sort", "k_su_terms", "k_su_apply", "k_pull_iter<1024, false>"]}
     for form, batch in forms.items():
         d = tmp_path / form.replace(" ", "_")
         d.mkdir()

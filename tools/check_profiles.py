@@ -164,7 +164,38 @@ def check(directory):
                   f"({roof['algorithmic_bytes_per_launch'] / 1e6:.1f} MB per launch / {avg_ns / 1e3:.1f} us)")
             bad += 1
         del per
-    print(f"{pairs} timeline / stats pair(s) and {lines} bench line(s) checked, {bad} disagreement(s)")
+    # Round 5 on: the artefacts say which build of the library produced them (profiles/rNN_manifest.json, tools/r05/manifest.py).
+    # A kernel change without a re-capture must not go unnoticed: the tree's build id (tools/build_id.py) has to be the manifest's,
+    # every bench line and counter summary has to carry it, and every stamped kind of artefact has to be listed.
+    stamped = 0
+    for m_path in sorted(glob.glob(os.path.join(directory, "r*_manifest.json"))):
+        rnd = os.path.basename(m_path).split("_")[0]
+        man = json.load(open(m_path))
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import build_id as _bid
+        real_profiles = os.path.abspath(directory) == os.path.join(_bid.ROOT, "profiles")
+        if real_profiles and man.get("build_id") != _bid.tree_build_id():
+            print(f"FAIL {os.path.basename(m_path)}: captured on build {man.get('build_id')}, the tree is build {_bid.tree_build_id()} -- "
+                  f"kernel / engine sources changed after the capture: re-capture (tools/{rnd}/capture.sh) or revert")
+            bad += 1
+        listed = set(man.get("files", []))
+        for kind in ("bench", "kernel_stats", "batch_timeline", "pmc_fabric"):
+            for f_path in sorted(glob.glob(os.path.join(directory, f"{rnd}_{kind}_*"))):
+                f = os.path.basename(f_path)
+                stamped += 1
+                if f not in listed:
+                    print(f"FAIL {f}: not listed in {os.path.basename(m_path)}")
+                    bad += 1
+                    continue
+                got = None
+                if kind == "bench":
+                    got = json.loads(open(f_path).read().strip().splitlines()[-1]).get("build_id")
+                elif kind == "pmc_fabric":
+                    got = (json.load(open(f_path)).get("_stamp") or {}).get("build_id")
+                if kind in ("bench", "pmc_fabric") and got != man.get("build_id"):
+                    print(f"FAIL {f}: build id {got}, the manifest says {man.get('build_id')}")
+                    bad += 1
+    print(f"{pairs} timeline / stats pair(s), {lines} bench line(s) and {stamped} stamped artefact(s) checked, {bad} disagreement(s)")
     return 1 if bad else 0
 
 
