@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of several builds of the library on one box: tools/ab_libs.sh "<bench args>" lib1.so lib2.so ... ("" = default build)
+# A/B of several builds of the library on one box: tools/r02/ab_libs.sh "<bench args>" lib1.so lib2.so ... ("" = default build)
 ARGS=$1; shift
 for lib in "" "$@"; do
   export DPPR_LIB=$lib

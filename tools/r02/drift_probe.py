@@ -2,7 +2,7 @@
 """In-step run (slide -> update per batch) of one stand-in: per block of batches the mean update time, the swept id
 space, iterations and pushed edges per batch -- separates workload drift from id-space growth -- and what the slides
 cost on the host clock (a renumbering shows up as the block's slowest slide).
-    python tools/drift_probe.py [config] [batches] [block] [sources]          (env DPPR_RENUMBER=0|1)"""
+    python tools/r02/drift_probe.py [config] [batches] [block] [sources]          (env DPPR_RENUMBER=0|1)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 // Gap between two DEPENDENT kernel dispatches: plain stream launches (all enqueued ahead, as the engine's chunks do)
-// against the same launches captured into a hipGraph.   hipcc --offload-arch=gfx950 -O2 tools/graph_gap_probe.hip -o /tmp/gap && /tmp/gap
+// against the same launches captured into a hipGraph.   hipcc --offload-arch=gfx950 -O2 tools/r02/graph_gap_probe.hip -o /tmp/gap && /tmp/gap
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

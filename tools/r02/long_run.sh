@@ -1,6 +1,6 @@
 #!/bin/bash
 # Long in-step runs of ./pagerank (slide -> update every batch, the reference driver's flow) with and without the
-# renumbering of internal ids: mean per-batch latency over -b batches.   tools/long_run.sh [config] [batches] [nsrc]
+# renumbering of internal ids: mean per-batch latency over -b batches.   tools/r02/long_run.sh [config] [batches] [nsrc]
 set -e
 cd $GRAFT_REPO_ROOT
 CFG=${1:-youtube}; B=${2:-150}; NS=${3:-1}

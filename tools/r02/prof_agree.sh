@@ -2,7 +2,7 @@
 # rocprofv3 --kernel-trace --stats of the default bench command, plus -- from the per-dispatch trace of the same run --
 # the dominant kernel's average over the launches that found a frontier (bench.py's roofline.avg_launch_us brackets
 # exactly those with hipEvents; the plain --stats average also counts the empty launches at the end of a chunk).
-# usage: tools/prof_agree.sh <tag> [bench args...]  -> gpurun_out/agree_<tag>/{kernel_stats.csv,agreement.txt,bench.log}
+# usage: tools/r02/prof_agree.sh <tag> [bench args...]  -> gpurun_out/agree_<tag>/{kernel_stats.csv,agreement.txt,bench.log}
 set -e
 TAG=${1:-run}; shift || true
 cd /tmp && export TMPDIR=/tmp

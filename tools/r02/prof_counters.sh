@@ -2,7 +2,7 @@
 # Per-dispatch PMC counters of one kernel over a short bench run, one rocprofv3 pass per counter
 # group (TCC slots: FETCH_SIZE and WRITE_SIZE cannot share a pass, MI355X_MICROARCH.md); only
 # --kernel-trace beside --pmc.
-# usage: tools/prof_counters.sh <tag> <kernel-substring> "<grp1 counters>;<grp2 counters>;..." [bench args...]
+# usage: tools/r02/prof_counters.sh <tag> <kernel-substring> "<grp1 counters>;<grp2 counters>;..." [bench args...]
 #   -> gpurun_out/ctr_<tag>/<group>.csv + table.txt (per dispatch of the LAST batch, launch order)
 set -e
 TAG=$1; KERN=$2; GROUPS_=$3; shift 3

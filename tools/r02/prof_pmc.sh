@@ -2,7 +2,7 @@
 # HBM traffic of the iteration kernels from PMC counters, collected as
 # /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE
 # rocprofv3 passes (TCC slots), no trace domains besides --kernel-trace.
-# usage: tools/prof_pmc.sh <tag> [bench args...]   -> gpurun_out/pmc_<tag>/summary.json
+# usage: tools/r02/prof_pmc.sh <tag> [bench args...]   -> gpurun_out/pmc_<tag>/summary.json
 set -e
 TAG=${1:-run}; shift || true
 cd /tmp && export TMPDIR=/tmp
@@ -14,4 +14,4 @@ for C in FETCH_SIZE WRITE_SIZE; do
   cp "$F" $OUT/$C.csv
   rm -rf $OUT/raw_$C
 done
-python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT
+python3 $GRAFT_REPO_ROOT/tools/r02/pmc_summary.py $OUT

@@ -2,7 +2,7 @@
 # Diagnostic: stage times of ONE sweep of k_gsweep per workgroup: the 13th of a multi-sweep launch on resident-size
 # windows, the last dense one-sweep launch otherwise (there the last two stages are not stamped).
 # Builds a SEPARATE library with -DDPPR_STAMPS (never the product build).
-# usage: tools/stamps_group.sh [config] [sources]
+# usage: tools/r02/stamps_group.sh [config] [sources]
 set -e
 cd $GRAFT_REPO_ROOT
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -ffp-contract=off -munsafe-fp-atomics \

@@ -20,6 +20,6 @@ b friendster_1src_1gpu --config friendster --sources 1 --steps 6 --warmup 2 --no
 bash tools/prof_timeline.sh livejournal_group10 --steps 12 --warmup 3 --no-extra --no-merged > /dev/null 2>&1
 bash tools/prof_timeline.sh twitter_1src --config twitter --sources 1 --steps 4 --warmup 2 --no-merged > /dev/null 2>&1
 bash tools/prof_timeline.sh youtube_1src --config youtube --steps 40 --warmup 5 --no-merged > /dev/null 2>&1
-bash tools/prof_pmc.sh r03_youtube_1src --config youtube --steps 20 --warmup 3 --no-merged | grep "k_pull_resident"
+bash tools/r02/prof_pmc.sh r03_youtube_1src --config youtube --steps 20 --warmup 3 --no-merged | grep "k_pull_resident"
 ls gpurun_out/timeline_livejournal_group10 gpurun_out/timeline_twitter_1src gpurun_out/timeline_youtube_1src
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1

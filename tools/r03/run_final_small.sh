@@ -4,7 +4,7 @@ b() { tag=$1; shift; timeout 900 python bench.py "$@" > gpurun_out/final/r03_ben
 b youtube_1src_1gpu --config youtube --steps 40 --warmup 5
 b dblp_1src_1gpu --config dblp --steps 40 --warmup 5
 bash tools/prof_timeline.sh youtube_1src --config youtube --steps 40 --warmup 5 --no-merged > /dev/null 2>&1
-bash tools/prof_pmc.sh r03_youtube_1src --config youtube --steps 20 --warmup 3 --no-merged | grep "k_pull_resident"
+bash tools/r02/prof_pmc.sh r03_youtube_1src --config youtube --steps 20 --warmup 3 --no-merged | grep "k_pull_resident"
 python - <<'PY'
 import json
 for t in ('youtube_1src_1gpu','dblp_1src_1gpu'):

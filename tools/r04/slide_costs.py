@@ -5,7 +5,7 @@ with the incremental merge of the sorted keys (f1) against the full re-sort, wit
 the phases of a slide (DPPR_SLIDE_TRACE: each mark synchronises, so the phase sum is an upper bound of the wall time)
 and the split of a renumbering slide (DPPR_RENUMBER_TRACE).
 
-    python tools/slide_costs.py <stand-in> [out.jsonl]      # one JSON line per variant
+    python tools/r04/slide_costs.py <stand-in> [out.jsonl]      # one JSON line per variant
 """
 import json
 import os

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Per-kernel cost of the slides of a twitter / friendster-size stand-in: one rocprofv3 --kernel-trace --stats run of the in-step probe
-# (tools/slide_costs.py --child <key> incremental binned renumber lookahead), kernels by total time. usage: tools/r04/slide_kernels.sh <key>
+# (tools/r04/slide_costs.py --child <key> incremental binned renumber lookahead), kernels by total time. usage: tools/r04/slide_kernels.sh <key>
 KEY=${1:-friendster}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/st
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st -- python3 $ROOT/tools/slide_costs.py --child $KEY 1 1 0 1 > /tmp/c.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st -- python3 $ROOT/tools/r04/slide_costs.py --child $KEY 1 1 0 1 > /tmp/c.log 2>&1
 python3 - "$ROOT" <<'PY'
 import csv, glob, sys
 sys.path.insert(0, sys.argv[1] + "/tools")
