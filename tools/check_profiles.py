@@ -156,6 +156,11 @@ def check(directory):
             avg_ns += sum(float(r["TotalDurationNs"]) for r in rows) / calls
         if avg_ns <= 0:
             continue
+        # a "launch" of a two-kernel sweep (k_bin_scatter + k_bin_reduce) is the PAIR as the event bracket of bench.py sees it: the
+        # dispatch gap between the two kernels is inside the bracket and in no kernel's duration -- taken from the timeline of the same run
+        tl_path = os.path.join(directory, f"{rnd}_batch_timeline_{tag}.json")
+        if len(heads) > 1 and os.path.exists(tl_path):
+            avg_ns += (len(heads) - 1) * 1e3 * float(json.load(open(tl_path)).get("median_gap_us") or 0.0)
         lines += 1
         per = roof.get("iterations_per_launch", 1.0) if heads[0].startswith("k_pull_resident") else 1.0
         frac_csv = roof["algorithmic_bytes_per_launch"] / (avg_ns * 1e-9) / (roof["peak"] * 1e9)
