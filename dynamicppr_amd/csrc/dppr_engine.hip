@@ -374,6 +374,7 @@ int dppr_synchronize(dppr_engine *e) {
     if (!e) return DPPR_ERR_INVALID;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipStreamSynchronize(e->bs));
     return DPPR_OK;
 }
 

@@ -569,7 +569,10 @@ int group_records_by_tail(dppr_engine *e, const Epoch &ep, unsigned long long *z
 
 // dppr_set_batch_grouping(1) after epochs were built: their records are grouped now, BEFORE the caller's event bracket opens
 inline int prepare_epoch(dppr_engine *e, Epoch &ep) {
-    if (e->group_at_slide && !ep.grouped && ep.L > 0) return epoch_group_records(e, ep);
+    if (e->group_at_slide && !ep.grouped && ep.L > 0) {
+        if (int rc = epoch_group_records(e, ep)) return rc;
+        HIP_TRY(hipStreamSynchronize(e->bs)); // (the grouping ran on the builder's stream; what follows reads it on the solver's)
+    }
     return DPPR_OK;
 }
 

@@ -51,10 +51,11 @@ __global__ __launch_bounds__(BLOCK) void k_su_keys(const int *__restrict__ e1, i
 // gpu/StreamUpdate.cuh:7-33, so the default accounting keeps it there). For batches of up to SU_RANK_MAX records the stable
 // order by tail needs no sort passes: record i goes to position  #{j : (tail_j, j) < (tail_i, i)}. One thread per record,
 // 256 records per workgroup; the batch's tails pass through LDS in tiles of SU_RANK_TILE, every thread compares its own
-// 64-bit key with four broadcast keys per LDS read. L^2 / 256 comparisons per workgroup, L / 256 workgroups side by side:
-// a few microseconds for the 1 380 records of the configs[2] stand-in, where the device radix sort is five dispatches and
-// ~80 us with their gaps. (First form of this kernel: the inner loop over b1 through the scalar cache -- one s_load_dwordx8
-// per 8 pairs, waited for every time: 60 us for 1 380 records, 400 us for 12 K.) The same launch does CopyOutDegree
+// key with four broadcast keys per LDS read. L^2 / 256 comparisons per workgroup, L / 256 workgroups side by side: a few
+// microseconds for a thousand records, where the device radix sort is five dispatches and 60-80 us with their gaps; beyond
+// SU_RANK_MAX the quadratic work catches up with the sort (12 K records: ~40 us either way) and the sort is used. (First form
+// of this kernel: the inner loop over b1 through the scalar cache -- one s_load_dwordx8 per 8 pairs, waited for every time:
+// 400 us for 12 K records.) The same launch does CopyOutDegree
 // (gpu/StreamUpdate.cuh:7-17) -- the post-batch out-degree of a tail is the length of its row in the epoch's out-CSR, built
 // from the post-batch window -- and clears the loop's counters.
 constexpr int SU_RANK_MAX = 4096;

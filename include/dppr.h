@@ -366,7 +366,7 @@ int dppr_trace_enable(dppr_engine *e, int32_t slot, int on);
 int dppr_trace_get(dppr_engine *e, int32_t slot, int64_t *n_iters, int64_t *n_ids,
                    int64_t *offsets, int32_t *ids);
 
-/* Stream-wide sync (hipStreamSynchronize on the engine's stream). */
+/* Waits for everything the engine has enqueued (the solver's and the builder's HIP streams). */
 int dppr_synchronize(dppr_engine *e);
 
 /* Lookahead for the untimed region (no reference counterpart: its graph update is serial,

@@ -110,6 +110,36 @@ def test_cli_end_to_end_matches_oracle(pagerank, small_bin, tmp_path, directed, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("directed", [1, 0])
+def test_cli_three_loops_agree(pagerank, small_bin, tmp_path, directed):
+    """./pagerank's batch loop in its three forms -- overlapped (default: the graph of batch k + 1 built by a helper thread through
+    dppr_slide_concurrent while batch k is solved), serial with the id lookahead of round 4 (DPPR_NO_OVERLAP=1), plain serial
+    (+ DPPR_NO_LOOKAHEAD=1) -- on the synchronous schedule: the same stdout contract, the same p / r to rounding, the oracle's."""
+    path, V, e1, e2 = small_bin
+    W, c, nb = 600, 24, 12
+    src = int(datagen.top_sources(V, e1, e2, W, directed, 1)[0])
+    outs = {}
+    for name, env in (("overlap", {}), ("lookahead", {"DPPR_NO_OVERLAP": "1"}), ("serial", {"DPPR_NO_OVERLAP": "1", "DPPR_NO_LOOKAHEAD": "1"})):
+        dump = str(tmp_path / f"{name}.dump")
+        r = run([pagerank, "-d", path, "-a", "0", "-i", str(directed), "-y", "1", "-w", "0.1", "-n", "1", "-c", str(c), "-l", str(c * nb),
+                 "-s", str(src), "--sync", "--dump", dump], env_extra=dict(env, DPPR_HOST_TIMES="1"))
+        assert r.returncode == 0, r.stdout
+        assert f"overlap={1 if name == 'overlap' else 0}" in r.stdout          # (stderr is merged into stdout by run())
+        last = {k: float(v) for k, v in re.findall(r"^(edge_num|ppr_latency) ([-+.e\d]+)$", r.stdout, flags=re.M)}
+        assert last["edge_num"] == c * nb and f"coming stream_batch_count={nb + 1}" in r.stdout
+        outs[name] = read_dump(dump)[src]
+    g = orc.Graph(V, e1, e2, directed, W, c)
+    s = orc.State(V, src, 1e-9)
+    s.sync_execute(g)
+    for _ in range(nb):
+        assert not g.stream_updates()
+        g.inc_construct(1)
+        s.sync_inc_execute(g)
+    for name, (p, r_) in outs.items():
+        assert np.max(np.abs(p - s.p)) < 1e-14 and np.max(np.abs(r_ - s.r)) < 1e-14, name
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nsrc", [3, 10, 18])
 @pytest.mark.parametrize("extra", [[], ["--no-groups"], ["--validate"]])
 def test_cli_multiple_sources_one_gpu(pagerank, small_bin, tmp_path, extra, nsrc):

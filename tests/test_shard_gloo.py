@@ -62,8 +62,9 @@ WORKER = textwrap.dedent("""
         time.sleep(0.05 * (rank + 1))          # rank 1 is the slow one
     dt, w = shard.timed_region(run, lambda: None, dist)
     units = shard.aggregate_units(wl.per_batch * steps * len(mine), dist)
+    seen, per_rank, backend = shard.rank_census(shard.timed_region.last_local, dist)   # the proof that N ranks ran (bench.py: ranks_seen)
     blocks = shard.line_blocks(rank, w)   # what bench.py's line carries at this rank / world size
-    json.dump(dict(rank=rank, world=w, sources=mine, pool=pool, dt=dt, units=units, psum=float(sum(s.p.sum() for s in states)), checksum=checksum, blocks=blocks),
+    json.dump(dict(rank=rank, world=w, sources=mine, pool=pool, dt=dt, units=units, seen=seen, per_rank=per_rank, backend=backend, psum=float(sum(s.p.sum() for s in states)), checksum=checksum, blocks=blocks),
               open(os.path.join({out!r}, "rank%d.json" % rank), "w"))
     dist.barrier()
     dist.destroy_process_group()
@@ -89,6 +90,10 @@ def test_two_rank_gloo_run(tmp_path):
     assert a["sources"] == a["pool"][0::2] and b["sources"] == a["pool"][1::2]   # ... and takes its round-robin share: 5 + 5
     assert a["dt"] == b["dt"] and a["dt"] >= 0.1            # MAX over ranks: the slow rank's time
     assert a["units"] == b["units"] == 10 * 6 * 3           # SUM over ranks of sources * c * steps
+    # the rank census: both ranks answered, every rank's own bracket time in rank order, the MAX of them is the reported time
+    assert a["seen"] == b["seen"] == 2 and a["backend"] == "gloo" and a["per_rank"] == b["per_rank"] and len(a["per_rank"]) == 2
+    assert abs(max(a["per_rank"]) - a["dt"]) < 1e-9 and a["per_rank"][1] > a["per_rank"][0]   # (rank 1 slept longer)
+    assert shard.rank_census(1.5) == (1, [1.5], None)
     assert a["psum"] != b["psum"]
     assert a["checksum"] == b["checksum"]                   # one stream file, written once
     # the N = 2 line is rank 0's and is as complete as the N = 1 line: parity, roofline and the CPU baseline (only the
