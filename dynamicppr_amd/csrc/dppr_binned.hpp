@@ -83,16 +83,17 @@ __global__ __launch_bounds__(BLOCK) void k_bin_vertex_block(const int *__restric
 //   word 2 = A-block | B-major position (31 bits) | head inside its A-block
 //            sorted by the A-block field, stable -> A-major
 constexpr int BIN_RL = 13, BIN_HL = 15; // rows of a B-block <= 64 x BIN_MAX_HB_TILES = 7 680, heads of an A-block <= 64 x BIN_MAX_HA_TILES = 17 408
-constexpr int BIN_W2_POS = BIN_HL, BIN_W2_A = BIN_HL + 31;
 
 // The keys come in (row, head) order: consecutive entries share their row or its neighbours (vblk_b[v] is a cached, coalesced
 // read), the heads are random -- their A-block is found by bisection of the block cuts (a few thousand entries, staged in LDS when
 // they fit `cuts_in_lds` ints) instead of a random 4-byte gather per edge out of a V-sized table (361 M of them on the friendster
 // stand-in: 4.0 ms of a 40-ms slide).
+// amajor = 0: word 1 (B-block | A-block | row | head); amajor = 1: the same edge's A-MAJOR word (A-block | B-block | row | head) -- the form the
+// persistent A-major array of the incremental tables is kept in (below): plain 64-bit order = (A, B, row, head).
 __global__ __launch_bounds__(BLOCK) void k_bin_keys(const uint64_t *__restrict__ out_keys, int Ed, int bits,
                                                     const int *__restrict__ acut, int n_a, int cuts_in_lds,
                                                     const int *__restrict__ vblk_b, const int *__restrict__ bcut, int abits,
-                                                    uint64_t *__restrict__ w1) {
+                                                    uint64_t *__restrict__ w1, int bbits = 0, int amajor = 0) {
     extern __shared__ int s_acut[];
     const int *cut = acut;
     if (cuts_in_lds) {
@@ -110,8 +111,8 @@ __global__ __launch_bounds__(BLOCK) void k_bin_keys(const uint64_t *__restrict__
             if (cut[mid] <= u) lo = mid; else hi = mid;
         }
         const int b = vblk_b[v];
-        w1[o] = ((((uint64_t)(uint32_t)b << abits) | (uint64_t)(uint32_t)lo) << (BIN_RL + BIN_HL)) |
-                ((uint64_t)(uint32_t)(v - bcut[b]) << BIN_HL) | (uint64_t)(uint32_t)(u - cut[lo]);
+        const uint64_t blocks = amajor ? (((uint64_t)(uint32_t)lo << bbits) | (uint64_t)(uint32_t)b) : (((uint64_t)(uint32_t)b << abits) | (uint64_t)(uint32_t)lo);
+        w1[o] = (blocks << (BIN_RL + BIN_HL)) | ((uint64_t)(uint32_t)(v - bcut[b]) << BIN_HL) | (uint64_t)(uint32_t)(u - cut[lo]);
     }
 }
 
@@ -212,23 +213,47 @@ __global__ __launch_bounds__(BIN_CS_NT) void k_bin_bmajor(const uint64_t *__rest
     }
 }
 
-// B-major order reached: row index of every position, and the words of the second (A-major) sort
-__global__ __launch_bounds__(BLOCK) void k_bin_fill_b(const uint64_t *__restrict__ w1s, int Ed, int abits, uint16_t *__restrict__ dl,
-                                                      uint64_t *__restrict__ w2) {
-    const uint64_t amask = (1ull << abits) - 1ull;
+// ---- Tables PATCHED per slide instead of re-sorted per epoch (round 5). Two radix sorts of the whole window were
+// 6 of a twitter-size slide's 14 ms of device work and 13 of a friendster-size one's 27 (k_bin_bmajor included) -- and since the graph
+// build runs beside the solve (dppr_slide_concurrent) every millisecond of it is a millisecond of wall time. The engine keeps both
+// orders PERSISTENT as sorted 64-bit words (B-major: word 1; A-major: A | B | row | head) under block cuts that stay FROZEN between
+// re-cuts (new ids extend the last blocks / append blocks; a re-cut every few dozen slides restores the balance). A slide then
+//   * forms the words of its 2c retired and 2c inserted edges (k_bin_keys, both forms), sorts those, and merges them into the two
+//     arrays with the key merge of the CSR build (k_del_positions + k_merge_tiles, dppr_builder.hpp): 16 bytes per edge and array;
+//   * finds every tile's first entry in both orders (k_bin_tile_starts: where the block pair changes) -- a tile is a run in both, in
+//     the same inner (row, head) order, so an edge's B-major position is  first_B(tile) + (its A-major index - first_A(tile));
+//   * writes dl from the B-major words and hl, apos from the A-major ones (k_bin_rows / k_bin_heads_pos).
+// The full build (first epoch, re-cut, renumbering, a merge that missed a key) produces the same two arrays by the sorts and runs the
+// same tail, so every binned test exercises the tail; tests/test_binned_tables_gpu.py holds the patched tables to the sorted ones.
+__global__ __launch_bounds__(BLOCK) void k_bin_to_amajor(const uint64_t *__restrict__ wb, int Ed, int abits, int bbits, uint64_t *__restrict__ wa) {
+    const uint64_t lo_mask = (1ull << (BIN_RL + BIN_HL)) - 1ull, amask = (1ull << abits) - 1ull;
     for (int q = blockIdx.x * BLOCK + threadIdx.x; q < Ed; q += gridDim.x * BLOCK) {
-        const uint64_t w = w1s[q];
-        dl[q] = (uint16_t)((w >> BIN_HL) & ((1u << BIN_RL) - 1u));
-        w2[q] = (((w >> (BIN_RL + BIN_HL)) & amask) << BIN_W2_A) | ((uint64_t)(uint32_t)q << BIN_W2_POS) | (w & ((1ull << BIN_HL) - 1ull));
+        const uint64_t w = wb[q], hi = w >> (BIN_RL + BIN_HL);
+        const uint64_t a = hi & amask, b = hi >> abits;
+        wa[q] = (((a << bbits) | b) << (BIN_RL + BIN_HL)) | (w & lo_mask);
     }
 }
-
-// A-major order reached: head index inside its block and B-major position of every entry
-__global__ __launch_bounds__(BLOCK) void k_bin_fill_a(const uint64_t *__restrict__ w2s, int Ed, uint16_t *__restrict__ hl, int *__restrict__ apos) {
+// first[first_block * n_second + second_block] = index of the first word of that block pair (only pairs that occur are written -- and read)
+__global__ __launch_bounds__(BLOCK) void k_bin_tile_starts(const uint64_t *__restrict__ w, int Ed, int second_bits, int n_second,
+                                                           int *__restrict__ first) {
+    const uint64_t smask = (1ull << second_bits) - 1ull;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < Ed; i += gridDim.x * BLOCK) {
+        const uint64_t hi = w[i] >> (BIN_RL + BIN_HL);
+        if (i == 0 || hi != (w[i - 1] >> (BIN_RL + BIN_HL))) first[(size_t)(hi >> second_bits) * (size_t)n_second + (size_t)(hi & smask)] = i;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_bin_rows(const uint64_t *__restrict__ wb, int Ed, uint16_t *__restrict__ dl) {
+    for (int q = blockIdx.x * BLOCK + threadIdx.x; q < Ed; q += gridDim.x * BLOCK) dl[q] = (uint16_t)((wb[q] >> BIN_HL) & ((1u << BIN_RL) - 1u));
+}
+__global__ __launch_bounds__(BLOCK) void k_bin_heads_pos(const uint64_t *__restrict__ wa, int Ed, int bbits, int n_a, int n_b,
+                                                         const int *__restrict__ first_a, const int *__restrict__ first_b,
+                                                         uint16_t *__restrict__ hl, int *__restrict__ apos) {
+    const uint64_t bmask = (1ull << bbits) - 1ull;
     for (int j = blockIdx.x * BLOCK + threadIdx.x; j < Ed; j += gridDim.x * BLOCK) {
-        const uint64_t w = w2s[j];
-        apos[j] = (int)((w >> BIN_W2_POS) & 0x7fffffffull);
+        const uint64_t w = wa[j], hi = w >> (BIN_RL + BIN_HL);
+        const size_t a = (size_t)(hi >> bbits), b = (size_t)(hi & bmask);
         hl[j] = (uint16_t)(w & ((1ull << BIN_HL) - 1ull));
+        apos[j] = first_b[b * (size_t)n_a + a] + (j - first_a[a * (size_t)n_b + b]);
     }
 }
 

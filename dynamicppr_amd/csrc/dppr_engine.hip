@@ -100,6 +100,9 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
     if (const char *v = getenv("DPPR_COST_MODEL")) e->cost_model = atoi(v) != 0;
     if (const char *v = getenv("DPPR_GROUPING_RADIX")) e->force_radix_grouping = atoi(v) != 0;
     if (const char *v = getenv("DPPR_TEST_MERGE_MISS")) e->test_force_merge_miss = atoi(v) != 0;
+    if (const char *v = getenv("DPPR_BIN_INCREMENTAL")) e->bin_incremental = atoi(v) != 0;
+    if (const char *v = getenv("DPPR_BIN_RECUT_EVERY")) e->bin_recut_every = std::max(1, atoi(v));
+    if (const char *v = getenv("DPPR_BIN_FROZEN_REBUILD")) e->bin_frozen_rebuild = atoi(v) != 0;
     if (const char *v = getenv("DPPR_GROUP_AT_SLIDE")) e->group_at_slide = atoi(v) != 0;
     if (const char *v = getenv("DPPR_GROUP_FULL_ROWS")) e->group_full_rows = atoi(v) != 0;
     e->device = device;
@@ -206,6 +209,7 @@ void dppr_destroy(dppr_engine *e) {
         (void)hipFree(ep.res_pk); (void)hipFree(ep.su_rng);
     }
     (void)hipFree(e->bin_vblk_b); (void)hipFree(e->bin_small); (void)hipFree(e->bin_vals); (void)hipFree(e->bin_tmp);
+    (void)hipFree(e->bin_wb); (void)hipFree(e->bin_wa); (void)hipFree(e->bin_first);
     (void)hipFree(e->w1); (void)hipFree(e->w2); (void)hipFree(e->outdeg);
     (void)hipFree(e->bar);
     (void)hipFree(e->res_arena);
@@ -522,6 +526,7 @@ static int slide_impl(dppr_engine *e, const int32_t *n1, const int32_t *n2, int3
     };
     bool renumbered = false;
     if (int rc = compact_ids(e, &renumbered)) return rc;
+    if (renumbered) e->bin_words_valid = false; // (the binned tables' words and cuts are in the old numbering)
     mark("renumbering check");
     if (!translate(e, n1, c, e->h_tmp1) || !translate(e, n2, c, e->h_tmp2))
         return fail(e, DPPR_ERR_INVALID, "slide: vertex id out of range");
@@ -573,10 +578,17 @@ static int slide_impl(dppr_engine *e, const int32_t *n1, const int32_t *n2, int3
     }
     if (rc) return rc;
     mark("sorted keys (merge / full sort)");
-    rc = build_epoch(e, ep);
+    BinBatch bb; // the slide's retired / inserted edges in the out-orientation: what the binned tables are patched with
+    if (inc) {
+        bb.del = e->directed ? e->bk[2] : e->bk[0];
+        bb.ins = e->directed ? e->bk[3] : e->bk[1];
+        bb.nd = bb.ni = c * per;
+    }
+    rc = build_epoch(e, ep, inc ? &bb : nullptr);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(e->bs));
     if (inc && (e->merge_miss_host != 0 || e->test_force_merge_miss)) {
+        e->bin_force_full = true;
         // a retired key was not among the kept sorted keys (an inconsistent window: never seen): the merged arrays
         // cannot be trusted -- the ring itself is right, so sort it afresh and build the epoch again
         e->merge_fallbacks++;
@@ -710,6 +722,7 @@ int dppr_debug_dump(dppr_engine *e, char *buf, int32_t cap) {
         e->directed, e->n_int, e->newest, (int)e->broken);
     add("last error: %s\n", e->err.empty() ? "(none)" : e->err.c_str());
     add("slides that discarded their key merge and re-sorted the window (a retired key was missing): %lld\n", e->merge_fallbacks);
+    add("binned-sweep tables: %lld epochs patched, %lld built by the sorts (%d slides since the cuts were made)\n", e->bin_patched, e->bin_rebuilt, e->bin_slides_since_cut);
     add("id lookahead (dppr_hint_next_batch): %lld id arrays taken from it so far (%lld entries resolved at the call), renumberings %llu\n", e->pre_hits, e->pre_misses, e->renumber_epoch);
     add("resident launches: mode %d ok %d retry %d time limit %llu ticks (100 MHz) rollcall_extra %d; schedule %d merge %d\n", e->persist_mode,
         (int)e->persist_ok, e->persist_retry, e->persist_ticks, e->persist_rollcall_extra, e->schedule, (int)e->merge_phases);
@@ -1466,6 +1479,25 @@ int dppr_bench_stream_copy(int device, int64_t bytes, int reps, float *out_ms) {
     (void)hipFree(src);
     (void)hipFree(dst);
     return err == hipSuccess ? DPPR_OK : DPPR_ERR_HIP;
+}
+
+int dppr_debug_bin_tables(dppr_engine *e, int32_t epoch, int32_t *n_a, int32_t *n_b, int32_t *n_edges, int32_t *acut, int32_t *bcut, uint16_t *hl,
+                          int32_t *apos, uint16_t *dl, int64_t *patched, int64_t *rebuilt) {
+    if (!e) return DPPR_ERR_INVALID;
+    GET_EPOCH(e, epoch);
+    if (patched) *patched = e->bin_patched;
+    if (rebuilt) *rebuilt = e->bin_rebuilt;
+    if (!ep.bin_valid) return fail(e, DPPR_ERR_INVALID, "debug_bin_tables: this epoch has no binned tables");
+    HIP_TRY(hipSetDevice(e->device));
+    if (n_a) *n_a = ep.n_a;
+    if (n_b) *n_b = ep.n_b;
+    if (n_edges) *n_edges = ep.Ed;
+    if (acut) HIP_TRY(hipMemcpy(acut, ep.acut, sizeof(int) * ((size_t)ep.n_a + 1), hipMemcpyDeviceToHost));
+    if (bcut) HIP_TRY(hipMemcpy(bcut, ep.bcut, sizeof(int) * ((size_t)ep.n_b + 1), hipMemcpyDeviceToHost));
+    if (hl) HIP_TRY(hipMemcpy(hl, ep.hl, sizeof(uint16_t) * (size_t)ep.Ed, hipMemcpyDeviceToHost));
+    if (apos) HIP_TRY(hipMemcpy(apos, ep.apos, sizeof(int) * (size_t)ep.Ed, hipMemcpyDeviceToHost));
+    if (dl) HIP_TRY(hipMemcpy(dl, ep.dl, sizeof(uint16_t) * (size_t)ep.Ed, hipMemcpyDeviceToHost));
+    return DPPR_OK;
 }
 
 unsigned long long dppr_heartbeat(const dppr_engine *e) { return e ? e->heartbeat.load(std::memory_order_relaxed) : 0ull; }

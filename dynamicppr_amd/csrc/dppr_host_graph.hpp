@@ -8,7 +8,11 @@
 namespace {
 
 int cut_sweep_groups(dppr_engine *e, Epoch &ep);
-int build_bins(dppr_engine *e, Epoch &ep);
+struct BinBatch { // out-orientation keys (row << bits | head) of a slide's retired and inserted edges, unsorted: what the binned tables are patched with
+    uint64_t *del = nullptr, *ins = nullptr;
+    int nd = 0, ni = 0;
+};
+int build_bins(dppr_engine *e, Epoch &ep, const BinBatch *batch = nullptr);
 bool resident_arena(dppr_engine *e, const Epoch &ep);
 int res_record_ranges(dppr_engine *e, Epoch &ep);
 
@@ -368,17 +372,16 @@ int sort_window_full(dppr_engine *e) {
 
 // One orientation of the incremental update: sorted' = (sorted minus deleted instances) merged with inserted.
 int merge_batch_keys(dppr_engine *e, uint64_t *&sorted, uint64_t *del_unsorted, uint64_t *del_sorted, int nd,
-                     uint64_t *ins_unsorted, uint64_t *ins_sorted, int ni) {
+                     uint64_t *ins_unsorted, uint64_t *ins_sorted, int ni, unsigned key_bits = 0, int miss_word = MERGE_MISS_WORD) {
     const int Ed = e->Ed;
+    if (key_bits == 0) key_bits = (unsigned)(2 * e->bits); // (the CSR keys; the binned tables' words say how many bits they use)
     size_t tmp = e->sort_tmp_bytes;
-    HIP_TRY(rocprim::radix_sort_keys(e->sort_tmp, tmp, del_unsorted, del_sorted, (size_t)nd, 0u, (unsigned)(2 * e->bits),
-                                     e->bs));
+    HIP_TRY(rocprim::radix_sort_keys(e->sort_tmp, tmp, del_unsorted, del_sorted, (size_t)nd, 0u, key_bits, e->bs));
     tmp = e->sort_tmp_bytes;
-    HIP_TRY(rocprim::radix_sort_keys(e->sort_tmp, tmp, ins_unsorted, ins_sorted, (size_t)ni, 0u, (unsigned)(2 * e->bits),
-                                     e->bs));
+    HIP_TRY(rocprim::radix_sort_keys(e->sort_tmp, tmp, ins_unsorted, ins_sorted, (size_t)ni, 0u, key_bits, e->bs));
     // retired positions, then one pass: every kept and every inserted key straight to its place (dppr_builder.hpp k_merge_tiles)
     hipLaunchKernelGGL(k_del_positions, dim3(grid_for(nd)), dim3(BLOCK), 0, e->bs, sorted, Ed, del_sorted, nd, e->delpos,
-                       e->hub_hist + MERGE_MISS_WORD);
+                       e->hub_hist + miss_word);
     const int n_tiles = (Ed + CMP_TILE - 1) / CMP_TILE;
     hipLaunchKernelGGL(k_merge_tiles, dim3(n_tiles), dim3(BLOCK), 0, e->bs, sorted, Ed, e->delpos, nd, ins_sorted, ni, e->keys_b,
                        (size_t)Ed - (size_t)nd + (size_t)ni);
@@ -522,7 +525,7 @@ constexpr int BIN_MAX_HA_TILES = 272, BIN_MAX_HB_TILES = 120;
 static_assert(BIN_MAX_HA_TILES * WAVE * (int)sizeof(double) + 4096 <= 160 * 1024, "k_bin_scatter: the largest A-block's slice of x + static LDS fits a gfx950 CU");
 static_assert(BIN_MAX_HB_TILES * WAVE * 20 + 4096 <= 160 * 1024, "k_bin_reduce: the largest B-block's rows + static LDS fit a gfx950 CU");
 static_assert(BIN_MAX_HB_TILES * WAVE <= (1 << BIN_RL) && BIN_MAX_HA_TILES * WAVE <= (1 << BIN_HL), "a row / head index inside its block fits its field of the sort words");
-static_assert(BIN_RL + BIN_HL + 32 <= 64 && BIN_W2_A + 16 <= 64, "sort words: two block numbers of <= 32 bits together, an A-block number of <= 16 bits (BIN_MAX_BLOCKS)");
+static_assert(BIN_RL + BIN_HL + 32 <= 64, "table words: two block numbers of <= 32 bits together above the in-block row and head indices");
 
 // An allocation of the (optional) binned-sweep tables that fails is not an error of the call that wanted them: the
 // partial allocations are released, the sticky HIP error is cleared and the epoch sweeps with k_pull_iter.
@@ -549,15 +552,18 @@ int bin_prepare(dppr_engine *e, bool *have) { // engine-level scratch, once (ide
     ok = ok && bin_alloc((void **)&e->bin_vblk_b, sizeof(int) * (size_t)e->V);
     ok = ok && bin_alloc((void **)&e->bin_small, sizeof(int) * BIN_SMALL_INTS);
     ok = ok && bin_alloc((void **)&e->bin_vals, sizeof(double) * (Edn + 64));
+    ok = ok && bin_alloc((void **)&e->bin_wb, sizeof(uint64_t) * Edn) && bin_alloc((void **)&e->bin_wa, sizeof(uint64_t) * Edn); // (rotate with keys_a / keys_b: same size)
     if (ok && !e->bin_tmp) {
         HIP_TRY(rocprim::radix_sort_keys(nullptr, e->bin_tmp_bytes, e->keys_a, e->keys_b, Edn, 0u, 64u, e->bs));
         ok = bin_alloc(&e->bin_tmp, std::max<size_t>(e->bin_tmp_bytes, 16));
     }
     if (!ok) { // out of memory: nothing half-built stays behind, the sweeps of this engine gather (k_pull_iter)
         (void)hipFree(e->bin_vblk_b); (void)hipFree(e->bin_small); (void)hipFree(e->bin_vals); (void)hipFree(e->bin_tmp);
+        (void)hipFree(e->bin_wb); (void)hipFree(e->bin_wa);
         e->bin_vblk_b = e->bin_small = nullptr;
         e->bin_vals = nullptr;
         e->bin_tmp = nullptr;
+        e->bin_wb = e->bin_wa = nullptr;
         return DPPR_OK;
     }
     // (the attribute belongs to the kernel, not to this engine: the largest shapes dppr_set_binned_sweep admits, so that engines
@@ -603,9 +609,28 @@ int bin_cut(dppr_engine *e, const int *row_ptr, int NV, int cap, long long targe
     return DPPR_OK;
 }
 
-int build_bins(dppr_engine *e, Epoch &ep) {
+// New ids since the cuts were frozen: the last block grows up to its vertex cap, further blocks are appended. Block numbers and
+// in-block indices of every existing vertex stay what they are -- the persistent words stay valid.
+static void bin_extend_cut(std::vector<int32_t> &cut, int cap, int NV) {
+    const int old_end = cut.back(), last_start = cut[cut.size() - 2];
+    if (NV <= old_end) return;
+    cut.pop_back();
+    int end = old_end - last_start < cap ? std::min(last_start + cap, NV) : old_end;
+    cut.push_back(end);
+    while (end < NV) {
+        end = std::min(end + cap, NV);
+        cut.push_back(end);
+    }
+}
+
+int build_bins(dppr_engine *e, Epoch &ep, const BinBatch *batch) {
     ep.bin_valid = false;
-    if (!bin_wanted(e) || e->Ed <= 0 || ep.grp_n_int <= 0) return DPPR_OK;
+    const bool force_full = e->bin_force_full;
+    e->bin_force_full = false;
+    if (!bin_wanted(e) || e->Ed <= 0 || ep.grp_n_int <= 0) {
+        e->bin_words_valid = false; // (not maintained through this slide)
+        return DPPR_OK;
+    }
     bool have = false;
     if (int rc = bin_prepare(e, &have)) return rc;
     if (!have) return DPPR_OK;
@@ -618,19 +643,58 @@ int build_bins(dppr_engine *e, Epoch &ep) {
             (void)hipFree(ep.hl); (void)hipFree(ep.dl); (void)hipFree(ep.apos);
             ep.hl = ep.dl = nullptr;
             ep.apos = nullptr;
+            e->bin_words_valid = false;
             return DPPR_OK; // (bin_valid stays false: this epoch's sweeps gather)
         }
     }
-    std::vector<int32_t> cut_a, cut_b;
-    if (int rc = bin_cut(e, ep.row_ptr, NV, e->bin_ha_tiles * WAVE, e->bin_target_a, cut_a)) return rc;
-    if (int rc = bin_cut(e, ep.out_row_ptr, NV, e->bin_hb_tiles * WAVE,
-                         e->bin_target > 0 ? e->bin_target : std::min<long long>(std::max<long long>(Ed / 256, 16384), 196608), cut_b)) return rc;
+    // ---- the block cuts: frozen ones (extended by the ids that arrived since) while the tables are being patched, fresh ones otherwise
+    const int cap_a = e->bin_ha_tiles * WAVE, cap_b = e->bin_hb_tiles * WAVE;
+    bool patch = e->bin_incremental && e->bin_words_valid && batch && !force_full && e->bin_slides_since_cut < e->bin_recut_every &&
+                 !e->bin_cut_a.empty() && NV >= e->bin_cut_ids;
+    bool keep_cuts = patch || (e->bin_frozen_rebuild && e->bin_words_valid && !force_full && !e->bin_cut_a.empty() && NV >= e->bin_cut_ids &&
+                               e->bin_slides_since_cut < e->bin_recut_every); // (tests: the sorts under the frozen cuts -- what the patched tables must equal)
+    if (keep_cuts) {
+        bin_extend_cut(e->bin_cut_a, cap_a, NV);
+        bin_extend_cut(e->bin_cut_b, cap_b, NV);
+        if ((int)e->bin_cut_a.size() - 1 > (1 << e->bin_abits) || (int)e->bin_cut_b.size() - 1 > (1 << e->bin_bbits) ||
+            (size_t)(e->bin_cut_a.size() - 1) * (size_t)(e->bin_cut_b.size() - 1) * 2 > e->bin_first_cap)
+            patch = keep_cuts = false; // the block numbers outgrew their fields / the tile tables: cut afresh
+    }
+    if (!keep_cuts) {
+        if (int rc = bin_cut(e, ep.row_ptr, NV, cap_a, e->bin_target_a, e->bin_cut_a)) return rc;
+        if (int rc = bin_cut(e, ep.out_row_ptr, NV, cap_b,
+                             e->bin_target > 0 ? e->bin_target : std::min<long long>(std::max<long long>(Ed / 256, 16384), 196608), e->bin_cut_b)) return rc;
+        // fields with room for the blocks that new ids will append before the next re-cut
+        const long long ra = (long long)e->bin_cut_a.size() - 1, rb = (long long)e->bin_cut_b.size() - 1;
+        e->bin_abits = e->bin_bbits = 1;
+        while ((1ll << e->bin_abits) < ra + ra / 8 + 16) e->bin_abits++;
+        while ((1ll << e->bin_bbits) < rb + rb / 8 + 16) e->bin_bbits++;
+        e->bin_slides_since_cut = 0;
+    }
+    e->bin_cut_ids = NV;
+    const std::vector<int32_t> &cut_a = e->bin_cut_a, &cut_b = e->bin_cut_b;
     ep.n_a = (int)cut_a.size() - 1;
     ep.n_b = (int)cut_b.size() - 1;
-    int abits = 1, bbits = 1;
-    while ((1 << abits) < ep.n_a) abits++;
-    while ((1 << bbits) < ep.n_b) bbits++;
-    if (abits + bbits > 32 || ep.n_a + 2 > BIN_MAX_BLOCKS || ep.n_b + 2 > BIN_MAX_BLOCKS) return DPPR_OK; // (a window of that many blocks: the sweep stays k_pull_iter)
+    const int abits = e->bin_abits, bbits = e->bin_bbits;
+    if (abits + bbits > 32 || ep.n_a + 2 > BIN_MAX_BLOCKS || ep.n_b + 2 > BIN_MAX_BLOCKS) { // (a window of that many blocks: the sweep stays k_pull_iter)
+        e->bin_words_valid = false;
+        return DPPR_OK;
+    }
+    if (!keep_cuts) { // the two tile tables (first entry of every block pair in either order), with the fields' headroom
+        const size_t need = (size_t)2 * ((size_t)ep.n_a + ep.n_a / 8 + 16) * ((size_t)ep.n_b + ep.n_b / 8 + 16);
+        if (need > e->bin_first_cap) {
+            HIP_TRY(hipStreamSynchronize(e->bs));
+            (void)hipFree(e->bin_first);
+            e->bin_first = nullptr;
+            e->bin_first_cap = 0;
+            if (hipMalloc((void **)&e->bin_first, sizeof(int) * need) != hipSuccess) {
+                (void)hipGetLastError();
+                e->bin_words_valid = false;
+                return DPPR_OK; // (no tables: this epoch's sweeps gather)
+            }
+            e->bin_first_cap = need;
+        }
+    }
     // per epoch: acut | astart | bcut (block tables), then the chunk table
     const size_t tab_ints = (size_t)2 * (ep.n_a + 1) + (ep.n_b + 1);
     if (tab_ints > ep.bin_tab_cap) {
@@ -648,36 +712,71 @@ int build_bins(dppr_engine *e, Epoch &ep) {
     hipLaunchKernelGGL(k_bin_vertex_block, dim3(grid_for(NV)), dim3(BLOCK), 0, e->bs, ep.acut, ep.n_a, NV, ep.row_ptr, (int *)nullptr, d_astart);
     int *d_bstart = e->bin_small; // (not kept: a B-block's edges are out_row_ptr[bcut[b]] .. out_row_ptr[bcut[b + 1]])
     hipLaunchKernelGGL(k_bin_vertex_block, dim3(grid_for(NV)), dim3(BLOCK), 0, e->bs, ep.bcut, ep.n_b, NV, ep.out_row_ptr, e->bin_vblk_b, d_bstart);
-    const uint64_t *out_keys = e->directed ? e->out_sorted : e->in_sorted;
     const bool cuts_in_lds = (size_t)(ep.n_a + 1) * sizeof(int) <= 48 * 1024;
-    hipLaunchKernelGGL(k_bin_keys, dim3(grid_for(Ed)), dim3(BLOCK), cuts_in_lds ? (size_t)(ep.n_a + 1) * sizeof(int) : 0, e->bs, out_keys, Ed,
-                       e->bits, ep.acut, ep.n_a, cuts_in_lds ? 1 : 0, e->bin_vblk_b, ep.bcut, abits, e->keys_b);
-    HIP_TRY(hipGetLastError());
+    const size_t cut_lds = cuts_in_lds ? (size_t)(ep.n_a + 1) * sizeof(int) : 0;
     // chunks of the A-major runs (a block of many edges is dealt to several workgroups of k_bin_scatter)
     std::vector<int32_t> astart((size_t)ep.n_a + 1);
     HIP_TRY(hipMemcpyAsync(astart.data(), d_astart, sizeof(int) * astart.size(), hipMemcpyDeviceToHost, e->bs));
-    size_t tmp = e->bin_tmp_bytes; // B-major: stable by (B-block, A-block); the words are in (row, head) order
-    const char *placement = getenv("DPPR_BIN_PLACEMENT"); // (tests / A-B runs: "counting" wherever it can run -- small windows never qualify by themselves --, "radix" never)
-    const bool cs_force = placement && !strcmp(placement, "counting"), cs_never = placement && !strcmp(placement, "radix");
-    // every B-block's segment grouped by A-block in one pass (k_bin_bmajor) where the radix sort would need FOUR passes over its
-    // 8-bit digits (friendster stand-in, 26 bits: 6.0 ms against 8.9; with three -- twitter, 23 bits -- the sort wins, 3.0 against 3.8:
-    // the single pass scatters 8-byte words over thousands of runs, a radix pass over 256)
-    if (ep.n_a <= BIN_CS_MAX_A && (abits + bbits > 24 || cs_force) && !cs_never) {
-        int n_pad = WAVE;
-        while (n_pad < ep.n_a) n_pad *= 2;
-        hipLaunchKernelGGL(k_bin_bmajor, dim3(ep.n_b), dim3(BIN_CS_NT), sizeof(int) * (size_t)n_pad, e->bs, e->keys_b, d_bstart, ep.bcut, ep.n_a,
-                           n_pad, abits, e->keys_a);
+    const unsigned word_bits = (unsigned)(BIN_RL + BIN_HL + abits + bbits);
+    if (patch) {
+        // ---- the slide's retired and inserted edges as words of both orders, merged into the two persistent arrays
+        HIP_TRY(hipMemsetAsync(e->hub_hist + MERGE_MISS_WORD + 1, 0, sizeof(int), e->bs));
+        for (int amajor = 0; amajor < 2; ++amajor) {
+            if (batch->nd > 0)
+                hipLaunchKernelGGL(k_bin_keys, dim3(grid_for(batch->nd)), dim3(BLOCK), cut_lds, e->bs, batch->del, batch->nd, e->bits, ep.acut, ep.n_a,
+                                   cuts_in_lds ? 1 : 0, e->bin_vblk_b, ep.bcut, abits, e->bks[0], bbits, amajor);
+            if (batch->ni > 0)
+                hipLaunchKernelGGL(k_bin_keys, dim3(grid_for(batch->ni)), dim3(BLOCK), cut_lds, e->bs, batch->ins, batch->ni, e->bits, ep.acut, ep.n_a,
+                                   cuts_in_lds ? 1 : 0, e->bin_vblk_b, ep.bcut, abits, e->bks[1], bbits, amajor);
+            HIP_TRY(hipGetLastError());
+            if (int rc = merge_batch_keys(e, amajor ? e->bin_wa : e->bin_wb, e->bks[0], e->bks[2], batch->nd, e->bks[1], e->bks[3], batch->ni, word_bits,
+                                          MERGE_MISS_WORD + 1)) return rc;
+        }
+        HIP_TRY(hipMemcpyAsync(&e->bin_miss_host, e->hub_hist + MERGE_MISS_WORD + 1, sizeof(int), hipMemcpyDeviceToHost, e->bs));
+        e->bin_patched++;
     } else {
-        HIP_TRY(rocprim::radix_sort_keys(e->bin_tmp, tmp, e->keys_b, e->keys_a, (size_t)Ed, (unsigned)(BIN_RL + BIN_HL),
-                                         (unsigned)(BIN_RL + BIN_HL + abits + bbits), e->bs));
+        // ---- both orders from the sorted out-orientation keys: word 1 of every edge, grouped B-major, then the A-major form sorted by A-block
+        const uint64_t *out_keys = e->directed ? e->out_sorted : e->in_sorted;
+        hipLaunchKernelGGL(k_bin_keys, dim3(grid_for(Ed)), dim3(BLOCK), cut_lds, e->bs, out_keys, Ed, e->bits, ep.acut, ep.n_a, cuts_in_lds ? 1 : 0,
+                           e->bin_vblk_b, ep.bcut, abits, e->keys_b, bbits, 0);
+        HIP_TRY(hipGetLastError());
+        size_t tmp = e->bin_tmp_bytes; // B-major: stable by (B-block, A-block); the words are in (row, head) order
+        const char *placement = getenv("DPPR_BIN_PLACEMENT"); // (tests / A-B runs: "counting" wherever it can run -- small windows never qualify by themselves --, "radix" never)
+        const bool cs_force = placement && !strcmp(placement, "counting"), cs_never = placement && !strcmp(placement, "radix");
+        // every B-block's segment grouped by A-block in one pass (k_bin_bmajor) where the radix sort would need FOUR passes over its
+        // 8-bit digits (friendster stand-in, 26 bits: 6.0 ms against 8.9; with three -- twitter, 23 bits -- the sort wins, 3.0 against 3.8:
+        // the single pass scatters 8-byte words over thousands of runs, a radix pass over 256)
+        if (ep.n_a <= BIN_CS_MAX_A && (abits + bbits > 24 || cs_force) && !cs_never) {
+            int n_pad = WAVE;
+            while (n_pad < ep.n_a) n_pad *= 2;
+            hipLaunchKernelGGL(k_bin_bmajor, dim3(ep.n_b), dim3(BIN_CS_NT), sizeof(int) * (size_t)n_pad, e->bs, e->keys_b, d_bstart, ep.bcut, ep.n_a,
+                               n_pad, abits, e->bin_wb);
+        } else {
+            HIP_TRY(rocprim::radix_sort_keys(e->bin_tmp, tmp, e->keys_b, e->bin_wb, (size_t)Ed, (unsigned)(BIN_RL + BIN_HL), word_bits, e->bs));
+        }
+        hipLaunchKernelGGL(k_bin_to_amajor, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->bs, e->bin_wb, Ed, abits, bbits, e->keys_b);
+        HIP_TRY(hipGetLastError());
+        tmp = e->bin_tmp_bytes;        // A-major: the B-major sequence, stable by A-block (the top field of the A-major form)
+        HIP_TRY(rocprim::radix_sort_keys(e->bin_tmp, tmp, e->keys_b, e->bin_wa, (size_t)Ed, (unsigned)(BIN_RL + BIN_HL + bbits), word_bits, e->bs));
+        e->bin_miss_host = 0;
+        e->bin_rebuilt++;
     }
-    hipLaunchKernelGGL(k_bin_fill_b, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->bs, e->keys_a, Ed, abits, ep.dl, e->keys_b);
+    // ---- the tail both ways: every tile's first entry in either order, then the three per-edge tables
+    int *first_b = e->bin_first, *first_a = e->bin_first + (size_t)ep.n_a * (size_t)ep.n_b;
+    hipLaunchKernelGGL(k_bin_tile_starts, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->bs, e->bin_wb, Ed, abits, ep.n_a, first_b);
+    hipLaunchKernelGGL(k_bin_tile_starts, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->bs, e->bin_wa, Ed, bbits, ep.n_b, first_a);
+    hipLaunchKernelGGL(k_bin_rows, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->bs, e->bin_wb, Ed, ep.dl);
+    hipLaunchKernelGGL(k_bin_heads_pos, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->bs, e->bin_wa, Ed, bbits, ep.n_a, ep.n_b, first_a, first_b, ep.hl, ep.apos);
     HIP_TRY(hipGetLastError());
-    tmp = e->bin_tmp_bytes;        // A-major: the B-major sequence, stable by A-block
-    HIP_TRY(rocprim::radix_sort_keys(e->bin_tmp, tmp, e->keys_b, e->keys_a, (size_t)Ed, (unsigned)BIN_W2_A, (unsigned)(BIN_W2_A + abits), e->bs));
-    hipLaunchKernelGGL(k_bin_fill_a, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->bs, e->keys_a, Ed, ep.hl, ep.apos);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(e->bs)); // astart has arrived; the cuts are locals
+    HIP_TRY(hipStreamSynchronize(e->bs)); // astart (and the patch's miss count) have arrived
+    if (patch && e->bin_miss_host != 0) {
+        // a retired edge's word was not in the persistent arrays (never on a consistent window): they cannot be trusted -- sort afresh
+        e->bin_words_valid = false;
+        e->bin_force_full = true;
+        return build_bins(e, ep, nullptr);
+    }
+    e->bin_words_valid = true;
+    e->bin_slides_since_cut++;
     std::vector<BinChunk> chunks;
     const int csize = (int)std::max<long long>(e->bin_chunk, 64);
     for (int a = 0; a < ep.n_a; ++a) {
@@ -703,7 +802,7 @@ int build_bins(dppr_engine *e, Epoch &ep) {
 }
 
 // Hub directory + in-CSR + out-CSR of `ep` from the persistent sorted keys and outdeg.
-int build_epoch(dppr_engine *e, Epoch &ep) {
+int build_epoch(dppr_engine *e, Epoch &ep, const BinBatch *batch = nullptr) {
     e->heartbeat.fetch_add(1, std::memory_order_relaxed);
     const int Ed = e->Ed;
     const int NV = e->n_int; // only vertices that ever had an edge (or are a source) exist internally
@@ -739,7 +838,7 @@ int build_epoch(dppr_engine *e, Epoch &ep) {
     e->heartbeat.fetch_add(1, std::memory_order_relaxed);
     if (int rc = cut_sweep_groups(e, ep)) return rc;
     e->heartbeat.fetch_add(1, std::memory_order_relaxed);
-    const int brc = build_bins(e, ep);
+    const int brc = build_bins(e, ep, batch);
     e->heartbeat.fetch_add(1, std::memory_order_relaxed);
     return brc;
 }

@@ -245,6 +245,21 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     int *bin_small = nullptr;       // quantile vertices | big rows | counter (bin_cut)
     long long bin_chunk = 32768;    // edges per workgroup of k_bin_scatter
     double *bin_vals = nullptr;     // the values in B-major order: what pass 1 hands to pass 2 (one loop runs at a time)
+    // the tables PATCHED per slide (dppr_binned.hpp, round 5): both orders persistent as sorted words under frozen block cuts
+    uint64_t *bin_wb = nullptr, *bin_wa = nullptr; // B-major / A-major words of the NEWEST epoch (rotate with keys_a / keys_b at a merge)
+    int *bin_first = nullptr;       // first entry of every block pair in either order: two tables of n_a x n_b ints
+    size_t bin_first_cap = 0;
+    std::vector<int32_t> bin_cut_a, bin_cut_b; // the cuts in use (first vertex of every block; frozen between re-cuts, extended by new ids)
+    int bin_abits = 0, bin_bbits = 0;   // width of the block-number fields of the words (with room for appended blocks)
+    int bin_cut_ids = 0;            // ids the cuts cover
+    bool bin_words_valid = false;   // bin_wb / bin_wa describe the newest epoch under bin_cut_a / bin_cut_b
+    int bin_slides_since_cut = 0;
+    bool bin_incremental = true;    // DPPR_BIN_INCREMENTAL=0: every epoch's tables by the two sorts (rounds 3-4)
+    int bin_recut_every = 32;       // slides between two fresh cuts (DPPR_BIN_RECUT_EVERY)
+    bool bin_frozen_rebuild = false; // (tests, DPPR_BIN_FROZEN_REBUILD=1: the sorts, but under the frozen cuts -- what the patched tables must equal bit for bit)
+    bool bin_force_full = false;    // the next build sorts afresh (a merge missed a key)
+    int bin_miss_host = 0;
+    long long bin_patched = 0, bin_rebuilt = 0; // epochs whose tables were patched / built by the sorts
     void *bin_tmp = nullptr;
     size_t bin_tmp_bytes = 0;
     bool bin_ready = false;         // scratch allocated, kernels' LDS sizes registered

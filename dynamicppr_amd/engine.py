@@ -59,7 +59,7 @@ EXPORTS = [
     "dppr_group_reset_stats", "dppr_set_group_seeding", "dppr_seed_lists", "dppr_set_sweep_bitmap", "dppr_set_group_resident", "dppr_set_resident_slots", "dppr_set_resident_update",
     "dppr_set_renumbering", "dppr_id_space", "dppr_set_group_push", "dppr_set_binned_sweep", "dppr_device_count", "dppr_set_phase_merge", "dppr_init_solve_at", "dppr_group_init_solve_at", "dppr_set_variant", "dppr_set_batch_grouping",
     "dppr_time_batch_grouping", "dppr_debug_dump", "dppr_hint_next_batch",
-    "dppr_bench_line_fills", "dppr_bench_stream_copy", "dppr_build_id", "dppr_heartbeat", "dppr_slide_concurrent", "dppr_renumbering_due",
+    "dppr_bench_line_fills", "dppr_bench_stream_copy", "dppr_build_id", "dppr_heartbeat", "dppr_slide_concurrent", "dppr_renumbering_due", "dppr_debug_bin_tables",
 ]
 
 
@@ -137,6 +137,8 @@ def lib():
     L.dppr_heartbeat.argtypes = [vp]
     L.dppr_slide_concurrent.argtypes = [vp, ip, ip, C.c_int32, ip]
     L.dppr_renumbering_due.argtypes = [vp]
+    u16p = C.POINTER(C.c_uint16)
+    L.dppr_debug_bin_tables.argtypes = [vp, C.c_int32, ip, ip, ip, ip, ip, u16p, ip, u16p, i64p, i64p]
     L.dppr_heartbeat.restype = C.c_ulonglong
     for name in EXPORTS:
         if name not in ("dppr_strerror", "dppr_last_error", "dppr_destroy", "dppr_build_id", "dppr_heartbeat"):
@@ -216,6 +218,24 @@ class Engine:
     def set_phase_merge(self, on, eps_divisor=0):
         """One loop for residuals of both signs, run to eps / eps_divisor (include/dppr.h); eager schedule only."""
         self._ck(self._L.dppr_set_phase_merge(self._h, int(on), int(eps_divisor)), "set_phase_merge")
+
+    def bin_tables(self, epoch=-1, arrays=True):
+        """Test hook: the binned-sweep tables of an epoch (dppr_debug_bin_tables) as a dict; None when the epoch has none."""
+        na, nb, ne, pa, rb = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
+        none16, none32 = C.POINTER(C.c_uint16)(), C.POINTER(C.c_int32)()
+        rc = self._L.dppr_debug_bin_tables(self._h, int(epoch), C.byref(na), C.byref(nb), C.byref(ne), none32, none32, none16, none32, none16, C.byref(pa), C.byref(rb))
+        out = {"patched": pa.value, "rebuilt": rb.value}
+        if rc:
+            return None if not arrays else dict(out, valid=False)
+        out.update(valid=True, n_a=na.value, n_b=nb.value, n_edges=ne.value)
+        if arrays:
+            acut, bcut = np.empty(na.value + 1, np.int32), np.empty(nb.value + 1, np.int32)
+            hl, dl, apos = np.empty(max(ne.value, 1), np.uint16), np.empty(max(ne.value, 1), np.uint16), np.empty(max(ne.value, 1), np.int32)
+            i32, u16 = C.POINTER(C.c_int32), C.POINTER(C.c_uint16)
+            self._ck(self._L.dppr_debug_bin_tables(self._h, int(epoch), None, None, None, acut.ctypes.data_as(i32), bcut.ctypes.data_as(i32), hl.ctypes.data_as(u16),
+                                                   apos.ctypes.data_as(i32), dl.ctypes.data_as(u16), None, None), "debug_bin_tables")
+            out.update(acut=acut, bcut=bcut, hl=hl[:ne.value], apos=apos[:ne.value], dl=dl[:ne.value])
+        return out
 
     def renumbering_due(self):
         return bool(self._L.dppr_renumbering_due(self._h))

@@ -189,8 +189,10 @@ int dppr_set_sweep_bitmap(dppr_engine *e, int on);
  *   min_ids      : mode 1 threshold (0 keeps 1 Mi vertices with an id: smaller windows run resident or cannot fill the chip with blocks)
  *   chunk_edges  : edges per workgroup of k_bin_scatter (0 keeps 32768)
  *   target_a_edges : edges an A-block is cut for (0 keeps 4 Mi: large, the longer the runs a tile's values are written in)
- * The layout costs 8 bytes per window edge and epoch plus 16 bytes per window edge of scratch, and is built in
- * dppr_slide / dppr_load_window (untimed, like the CSRs). Only valid right after dppr_create. */
+ * The layout costs 8 bytes per window edge and epoch plus 32 bytes per window edge of engine state (the values of pass 1, and both
+ * orders of the window's edges as sorted words), and is built in dppr_load_window and PATCHED by dppr_slide (untimed, like the CSRs):
+ * a slide merges the words of its retired and inserted edges into the two orders instead of sorting the window twice; the block
+ * cuts are renewed every 32 slides (DPPR_BIN_RECUT_EVERY; DPPR_BIN_INCREMENTAL=0: the sorts every epoch). Only valid right after dppr_create. */
 int dppr_set_binned_sweep(dppr_engine *e, int mode, int ha_tiles, int hb_tiles, int64_t target_edges, int64_t min_ids,
                           int64_t chunk_edges, int64_t target_a_edges);
 
@@ -399,6 +401,13 @@ int dppr_time_batch_grouping(dppr_engine *e, int32_t epoch, int32_t reps, float 
  * are read racily, which is what a post-mortem wants). No reference counterpart (its loop is host-driven,
  * gpu/PPRRevPushGPU.cuh:106-130, and cannot wait on a device-side barrier). */
 int dppr_debug_dump(dppr_engine *e, char *buf, int32_t cap);
+/* Test hook (ABI 4): the binned-sweep tables of an epoch (dppr_binned.hpp) -- block cuts (n_a + 1 / n_b + 1 first vertices, internal
+ * ids), and per edge the head index inside its A-block + B-major position (A-major order) and the row index inside its B-block
+ * (B-major order); how many epochs had their tables patched by the slide's merge and how many built by the sorts. Any pointer may
+ * be NULL. The patched tables must equal, bit for bit, what the sorts produce under the same cuts (tests/test_binned_tables_gpu.py). */
+int dppr_debug_bin_tables(dppr_engine *e, int32_t epoch, int32_t *n_a, int32_t *n_b, int32_t *n_edges, int32_t *acut, int32_t *bcut,
+                          uint16_t *hl, int32_t *apos, uint16_t *dl, int64_t *patched, int64_t *rebuilt);
+
 /* A counter that advances at every host read-back of a frontier loop and every stage of a graph build (ABI 4): a watchdog
  * samples it so that ONE long call (the first solve on a large window, a group's from-scratch solve) is told from a hang
  * (ADVICE r04). Callable from any thread. */

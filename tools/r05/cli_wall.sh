@@ -26,9 +26,10 @@ print(path, cfg.directed, src, wl.per_batch, min(10 * wl.per_batch, n - W))
 PY
 )
   rm -f $OUT/r05_instep_wall_$KEY.jsonl
-  for MODE in overlap lookahead serial; do
-    unset DPPR_NO_OVERLAP DPPR_NO_LOOKAHEAD
-    [ $MODE != overlap ] && export DPPR_NO_OVERLAP=1
+  for MODE in overlap overlap_tables_by_sorts lookahead lookahead_tables_by_sorts serial; do
+    unset DPPR_NO_OVERLAP DPPR_NO_LOOKAHEAD DPPR_BIN_INCREMENTAL
+    case $MODE in lookahead*|serial) export DPPR_NO_OVERLAP=1;; esac
+    case $MODE in *_tables_by_sorts) export DPPR_BIN_INCREMENTAL=0;; esac   # (rounds 3-4: the binned tables by two sorts per epoch instead of patched)
     [ $MODE = serial ] && export DPPR_NO_LOOKAHEAD=1
     DPPR_HOST_TIMES=1 DPPR_WATCHDOG_S=120 timeout 600 dynamicppr_amd/host/pagerank -d $FILE -a 0 -i $DIRECTED -y 1 -w 0.9 -n 1 -c $C -l $L -s $SRC \
       > $OUT/cli_wall_${KEY}_$MODE.out 2> $OUT/cli_wall_${KEY}_$MODE.err
@@ -50,5 +51,5 @@ print(json.dumps(row))
 PY
     tail -1 $OUT/r05_instep_wall_$KEY.jsonl
   done
-  unset DPPR_NO_OVERLAP DPPR_NO_LOOKAHEAD
+  unset DPPR_NO_OVERLAP DPPR_NO_LOOKAHEAD DPPR_BIN_INCREMENTAL
 done
