@@ -100,3 +100,35 @@ def test_a_patch_that_misses_a_word_sorts_afresh(monkeypatch):
     t = e.bin_tables(arrays=False)
     assert t["valid"] and t["rebuilt"] >= 10          # every slide fell back to the sorts (after its discarded patch)
     e.close()
+
+
+def test_full_size_window_forty_slides_on_patched_tables(monkeypatch):
+    """BASELINE.json configs[2] size, ONE source (its dense iterations are binned sweeps on this window): forty slides in step, the
+    tables patched at every one of them but the re-cuts (every 8 slides here); the size-independent properties -- |r| < eps, the loop
+    invariant against the window's edges -- hold after every eighth batch, and the tables really were patched."""
+    from dynamicppr_amd import datagen, stream as st
+    from tests.util import invariant_max_err_np
+    monkeypatch.setenv("DPPR_BIN_RECUT_EVERY", "8")
+    V, e1, e2, cfg = datagen.stand_in_stream("livejournal", "/tmp/dppr_data")
+    wl = st.workload_config(len(e1), 0.1, 0, 0.01, 100)
+    W, c, eps = wl.window, wl.per_batch, 1e-9
+    src = int(datagen.top_sources(V, e1, e2, W, cfg.directed, 10)[3])
+    e = eng.Engine(V, W, cfg.directed, c)
+    ss = st.SlidingStream(V, e1, e2, cfg.directed, wl)
+    e.load_window(*ss.serialize_edge_stream())
+    sl = e.add_source(src)
+    e.init_solve(sl, eps)
+    for k in range(1, 41):
+        assert not ss.stream_updates()
+        e.set_batch(*ss.batch_arrays())
+        e.slide(*ss.new_arrays())
+        e.update(sl, eps)
+        if k % 8 == 0:
+            w1, w2 = ss.serialize_edge_stream()
+            p, r = e.read(sl)
+            assert np.max(np.abs(r)) < eps, k
+            assert invariant_max_err_np(p, r, w1, w2, V, src) < 1e-13, k
+    t = e.bin_tables(arrays=False)
+    assert t["valid"] and t["patched"] >= 34 and 5 <= t["rebuilt"] <= 7      # the first build + a re-cut every 8 slides
+    assert e.stats(sl)["binned_sweeps"] > 100
+    e.close()
