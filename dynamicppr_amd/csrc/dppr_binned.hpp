@@ -8,21 +8,24 @@
 // a per-epoch layout of the window's edges:
 //
 //   * the heads u are cut into A-BLOCKS (consecutive vertices, at most 64 ha_tiles of them), the rows v into B-BLOCKS
-//     (at most 64 hb_tiles rows, about `target` out-edges, a hub row alone). The edges of A-block a, ordered by
-//     (B-block of v, v, u), are its A-major run [in_row_ptr[first head of a], in_row_ptr[first head of a + 1]); the edges
-//     of B-block b, ordered by (A-block of u, v, u), are its B-major run [out_row_ptr[first row of b], ...). Both runs
-//     hold the same edges tile by tile (a tile = the edges from A-block a into B-block b) in the same inner order.
-//   * k_bin_scatter (workgroups take chunks of an A-block's run): the block's slice of x is staged in LDS; the run is streamed
-//     (2-byte head index + 4-byte B-major position per edge) and x[u] is written to vals[position]: inside a tile the
-//     positions are consecutive, so a wave's 64 stores are runs of whole lines, not 64 sectors.
-//   * k_bin_reduce (one workgroup per B-block): row accumulators (starting at residual[v]), 1 / (outdeg + 1) and
-//     outdeg + 1 of the block's rows sit in LDS; the B-major run is streamed (8-byte value + 2-byte row index per
-//     edge), add = (1.0-ALPHA) * x[u] / (outdeg(v) + 1) exactly as gpu/ExpandRev.cuh:72 (push_term), runs of one row
-//     inside a wave are summed in registers first (segmented DPP scan) and cost ONE LDS atomic; then repair
+//     (at most 64 hb_tiles rows, about `target` out-edges, a hub row alone). A TILE = the edges from A-block a into B-block b;
+//     inside a tile the edges are ordered by (head, row), so the edges of one head into one B-block -- a RUN -- are neighbours.
+//     On a skewed window many edges share their run (twitter stand-in: 0.83 runs per edge under these cuts, tools/r06/dedup_count.py),
+//     and x[u] is handed from pass 1 to pass 2 once per RUN, not once per edge (round 6; rounds 3-5: once per edge, 24 B / edge).
+//   * k_bin_scatter (workgroups take chunks of an A-block's runs, A-major order (A, B, head)): the block's slice of x is staged in
+//     LDS; per run a 2-byte entry (head index inside the block + a "first run of its tile" bit) is streamed and x[u] is written to
+//     vals[run's B-major index]: inside a tile both orders list the runs by ascending head, so the destination is
+//     (A-major run index) + delta(tile) -- one 4-byte delta per TILE, found through the tile bits (ballot + per-64-runs ordinal).
+//   * k_bin_reduce (one workgroup per B-block): row accumulators (starting at residual[v]), 1 / (outdeg + 1) and outdeg + 1 of the
+//     block's rows sit in LDS; the B-major edge list is streamed (2 bytes per edge: row index inside the block + a "first edge of
+//     its run" bit), a wave's 64 edges need the <= 64 CONSECUTIVE values vals[vb .. ] (vb: one int per 64 edges, loaded independently
+//     of the edge entries; the lane's own value comes through a cross-lane read at the ordinal of its run),
+//     add = (1.0-ALPHA) * x[u] / (outdeg(v) + 1) exactly as gpu/ExpandRev.cuh:72 (push_term) into the row's LDS accumulator
+//     (a hub row alone in its block: the wave's terms are summed in registers first, segmented DPP scan, ONE LDS atomic); then repair
 //     (gpu/ExpandRev.cuh:708-743), threshold and the next snapshot per row, as k_pull_iter does them.
 //
-// 24 streamed bytes per edge in lines instead of a 64-byte sector per edge; no global atomics. Results equal
-// k_pull_iter's up to the order of each row's sum.
+// Streamed bytes per edge: 2 + rho (2 + 8 + 8) + 4 tiles / edge, rho = runs per edge (twitter stand-in 0.83: 17 B; rounds 3-5: 24);
+// no global atomics. Results equal k_pull_iter's up to the order of each row's sum.
 #pragma once
 
 #include "dppr_common.hpp"
@@ -75,64 +78,62 @@ __global__ __launch_bounds__(BLOCK) void k_bin_vertex_block(const int *__restric
     for (int k = blockIdx.x * BLOCK + threadIdx.x; k <= n_blocks; k += gridDim.x * BLOCK) start[k] = row_ptr[cut[k]];
 }
 
-// The two orders of the tables come out of two KEY-ONLY radix sorts of 64-bit words that carry everything the tables need (a
-// pair sort moves a 32-bit key and a 64-bit value: 12 bytes per entry and pass instead of 8, and the fill kernels looked the
-// blocks' first vertices up again):
-//   word 1 = B-block | A-block | row inside its B-block (BIN_RL bits) | head inside its A-block (BIN_HL bits)
-//            sorted by the two block fields, stable: the (row, head) order of the input survives inside a (B, A) cell -> B-major
-//   word 2 = A-block | B-major position (31 bits) | head inside its A-block
-//            sorted by the A-block field, stable -> A-major
+// The two orders of the tables are kept as sorted 64-bit words that carry everything the tables need:
+//   B-major word = B-block | A-block | head inside its A-block (BIN_HL bits) | row inside its B-block (BIN_RL bits)
+//   A-major word = A-block | B-block | head | row
+// plain 64-bit order = (blocks, head, row): a run (one head into one B-block) is a stretch of words equal above the row field,
+// a tile a stretch equal above the head field.
 constexpr int BIN_RL = 13, BIN_HL = 15; // rows of a B-block <= 64 x BIN_MAX_HB_TILES = 7 680, heads of an A-block <= 64 x BIN_MAX_HA_TILES = 17 408
+constexpr int BIN_LO = BIN_RL + BIN_HL; // bits below the block fields
+constexpr uint16_t BIN_FLAG = 0x8000u;  // top bit of a 2-byte table entry: first edge of its run (dl) / first run of its tile (hl)
 
-// The keys come in (row, head) order: consecutive entries share their row or its neighbours (vblk_b[v] is a cached, coalesced
-// read), the heads are random -- their A-block is found by bisection of the block cuts (a few thousand entries, staged in LDS when
-// they fit `cuts_in_lds` ints) instead of a random 4-byte gather per edge out of a V-sized table (361 M of them on the friendster
-// stand-in: 4.0 ms of a 40-ms slide).
-// amajor = 0: word 1 (B-block | A-block | row | head); amajor = 1: the same edge's A-MAJOR word (A-block | B-block | row | head) -- the form the
-// persistent A-major array of the incremental tables is kept in (below): plain 64-bit order = (A, B, row, head).
-__global__ __launch_bounds__(BLOCK) void k_bin_keys(const uint64_t *__restrict__ out_keys, int Ed, int bits,
-                                                    const int *__restrict__ acut, int n_a, int cuts_in_lds,
-                                                    const int *__restrict__ vblk_b, const int *__restrict__ bcut, int abits,
-                                                    uint64_t *__restrict__ w1, int bbits = 0, int amajor = 0) {
-    extern __shared__ int s_acut[];
-    const int *cut = acut;
+// The keys come in (head, row) order (the in-orientation keys of the CSR build): consecutive entries share their head or its
+// neighbours (vblk_a[u] is a cached, coalesced read), the rows are random -- their B-block is found by bisection of the block cuts
+// (a few thousand entries, staged in LDS when they fit `cuts_in_lds` ints) instead of a random 4-byte gather per edge out of a
+// V-sized table. amajor = 1: A-major word, 0: B-major word.
+__global__ __launch_bounds__(BLOCK) void k_bin_keys(const uint64_t *__restrict__ in_keys, int Ed, int bits,
+                                                    const int *__restrict__ bcut, int n_b, int cuts_in_lds,
+                                                    const int *__restrict__ vblk_a, const int *__restrict__ acut, int abits, int bbits,
+                                                    uint64_t *__restrict__ w, int amajor) {
+    extern __shared__ int s_bcut[];
+    const int *cut = bcut;
     if (cuts_in_lds) {
-        for (int k = threadIdx.x; k <= n_a; k += BLOCK) s_acut[k] = acut[k];
+        for (int k = threadIdx.x; k <= n_b; k += BLOCK) s_bcut[k] = bcut[k];
         __syncthreads();
-        cut = s_acut;
+        cut = s_bcut;
     }
     const uint64_t mask = (1ull << bits) - 1;
     for (int o = blockIdx.x * BLOCK + threadIdx.x; o < Ed; o += gridDim.x * BLOCK) {
-        const uint64_t k = out_keys[o];
-        const int v = (int)(k >> bits), u = (int)(k & mask);
-        int lo = 0, hi = n_a; // last block whose first vertex is <= u (k_bin_vertex_block's rule)
+        const uint64_t k = in_keys[o];
+        const int u = (int)(k >> bits), v = (int)(k & mask); // head, row
+        int lo = 0, hi = n_b; // last block whose first vertex is <= v (k_bin_vertex_block's rule)
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if (cut[mid] <= u) lo = mid; else hi = mid;
+            if (cut[mid] <= v) lo = mid; else hi = mid;
         }
-        const int b = vblk_b[v];
-        const uint64_t blocks = amajor ? (((uint64_t)(uint32_t)lo << bbits) | (uint64_t)(uint32_t)b) : (((uint64_t)(uint32_t)b << abits) | (uint64_t)(uint32_t)lo);
-        w1[o] = (blocks << (BIN_RL + BIN_HL)) | ((uint64_t)(uint32_t)(v - bcut[b]) << BIN_HL) | (uint64_t)(uint32_t)(u - cut[lo]);
+        const int a = vblk_a[u];
+        const uint64_t blocks = amajor ? (((uint64_t)(uint32_t)a << bbits) | (uint64_t)(uint32_t)lo) : (((uint64_t)(uint32_t)lo << abits) | (uint64_t)(uint32_t)a);
+        w[o] = (blocks << BIN_LO) | ((uint64_t)(uint32_t)(u - acut[a]) << BIN_RL) | (uint64_t)(uint32_t)(v - cut[lo]);
     }
 }
 
-// B-major order without a radix sort. The words arrive in (row, head) order, i.e. B-block-major already: what the first sort does is
-// group every B-block's segment by A-block, stably -- four radix passes over the whole window for a key of which the upper half is
-// sorted. Here one workgroup owns a B-block: a histogram of its segment over the A-blocks (LDS, all waves), an exclusive scan, and
-// then ONE wave walks the segment in order and places every word at (start of its A-block inside the segment + number of earlier
-// words of that A-block): the rank inside a 64-word step from ballots (one per bit of the A-block number: the lanes that agree in
-// every bit hold the same block; no memory access), the running starts in LDS (gathered once per step, advanced by the last lane of each A-block). Deterministic and equal to
-// the stable sort. A block that is ONE row (a hub alone in its block) is sorted already -- heads ascend -- and is copied by all waves.
-// Needs n_a <= BIN_CS_MAX_A counters; beyond, the radix sort stays.
-constexpr int BIN_CS_NT = 256, BIN_CS_MAX_A = 8192, BIN_CS_AHEAD = 8;
-__global__ __launch_bounds__(BIN_CS_NT) void k_bin_bmajor(const uint64_t *__restrict__ w1, const int *__restrict__ bstart,
-                                                          const int *__restrict__ bcut, int n_a, int n_pad, int abits,
-                                                          uint64_t *__restrict__ out) {
-    extern __shared__ int s_cnt[]; // n_pad (a power of two >= max(n_a, 64))
+// A-major order without a radix sort. The A-major words arrive in (head, row) order, i.e. A-block-major already: what the first sort
+// does is group every A-block's segment by B-block, stably -- several radix passes over the whole window for a key of which the upper
+// half is sorted. Here one workgroup owns an A-block: a histogram of its segment over the B-blocks (LDS, all waves), an exclusive scan,
+// and then ONE wave walks the segment in order and places every word at (start of its B-block inside the segment + number of earlier
+// words of that B-block): the rank inside a 64-word step from ballots (one per bit of the B-block number: the lanes that agree in
+// every bit hold the same block; no memory access), the running starts in LDS (gathered once per step, advanced by the last lane of
+// each B-block). Deterministic and equal to the stable sort. A block that is ONE head (a hub alone in its block) is sorted already --
+// rows ascend, so do their blocks -- and is copied by all waves. Needs n_cnt <= BIN_CS_MAX counters; beyond, the radix sort stays.
+constexpr int BIN_CS_NT = 256, BIN_CS_MAX = 8192, BIN_CS_AHEAD = 8;
+__global__ __launch_bounds__(BIN_CS_NT) void k_bin_group(const uint64_t *__restrict__ w1, const int *__restrict__ segstart,
+                                                         const int *__restrict__ segcut, int n_cnt, int n_pad, int cbits,
+                                                         uint64_t *__restrict__ out) {
+    extern __shared__ int s_cnt[]; // n_pad (a power of two >= max(n_cnt, 64))
     const int b = blockIdx.x, tid = threadIdx.x, lane = lane_id();
-    const int s0 = bstart[b], s1 = bstart[b + 1];
+    const int s0 = segstart[b], s1 = segstart[b + 1];
     if (s1 <= s0) return;
-    if (bcut[b + 1] - bcut[b] == 1) { // one row: in order already
+    if (segcut[b + 1] - segcut[b] == 1) { // one vertex: in order already
         int i = s0 + tid;
         for (; i + 7 * BIN_CS_NT < s1; i += 8 * BIN_CS_NT) { // (a hub's row can hold a million words: eight loads in flight per thread)
             uint64_t w[8];
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(BIN_CS_NT) void k_bin_bmajor(const uint64_t *__rest
         for (; i < s1; i += BIN_CS_NT) out[i] = w1[i];
         return;
     }
-    const uint32_t amask = (1u << abits) - 1u;
+    const uint32_t cmask = (1u << cbits) - 1u;
     for (int k = tid; k < n_pad; k += BIN_CS_NT) s_cnt[k] = 0;
     __syncthreads();
     {
@@ -154,13 +155,13 @@ __global__ __launch_bounds__(BIN_CS_NT) void k_bin_bmajor(const uint64_t *__rest
 #pragma unroll
             for (int k = 0; k < 4; ++k) w[k] = w1[i + k * BIN_CS_NT];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) atomicAdd(&s_cnt[(uint32_t)(w[k] >> (BIN_RL + BIN_HL)) & amask], 1);
+            for (int k = 0; k < 4; ++k) atomicAdd(&s_cnt[(uint32_t)(w[k] >> BIN_LO) & cmask], 1);
         }
-        for (; i < s1; i += BIN_CS_NT) atomicAdd(&s_cnt[(uint32_t)(w1[i] >> (BIN_RL + BIN_HL)) & amask], 1);
+        for (; i < s1; i += BIN_CS_NT) atomicAdd(&s_cnt[(uint32_t)(w1[i] >> BIN_LO) & cmask], 1);
     }
     __syncthreads();
     if (tid >= WAVE) return; // the walk is one wave's (nothing below needs a workgroup barrier)
-    { // exclusive scan over the A-blocks: a lane sums its n_pad / 64 consecutive counters, the wave scans the lane sums
+    { // exclusive scan over the counted blocks: a lane sums its n_pad / 64 consecutive counters, the wave scans the lane sums
         const int per = n_pad / WAVE;
         int sum = 0;
         for (int k = 0; k < per; ++k) sum += s_cnt[lane * per + k];
@@ -192,10 +193,10 @@ __global__ __launch_bounds__(BIN_CS_NT) void k_bin_bmajor(const uint64_t *__rest
         for (int h = 0; h < BIN_CS_AHEAD; ++h) {
             const int i = base + h * WAVE + lane;
             const bool valid = i < s1;
-            const int a = (int)((uint32_t)(w[h] >> (BIN_RL + BIN_HL)) & amask);
-            uint64_t m = __ballot(valid); // -> the valid lanes of this step that hold the same A-block as this lane: one ballot per key bit
+            const int a = (int)((uint32_t)(w[h] >> BIN_LO) & cmask);
+            uint64_t m = __ballot(valid); // -> the valid lanes of this step that hold the same block as this lane: one ballot per key bit
             if (!m) break;
-            for (int bit = 0; bit < abits; ++bit) {
+            for (int bit = 0; bit < cbits; ++bit) {
                 const bool set = (a >> bit) & 1;
                 const uint64_t bm = __ballot(valid && set);
                 m &= set ? bm : ~bm;
@@ -213,48 +214,119 @@ __global__ __launch_bounds__(BIN_CS_NT) void k_bin_bmajor(const uint64_t *__rest
     }
 }
 
-// ---- Tables PATCHED per slide instead of re-sorted per epoch (round 5). Two radix sorts of the whole window were
-// 6 of a twitter-size slide's 14 ms of device work and 13 of a friendster-size one's 27 (k_bin_bmajor included) -- and since the graph
-// build runs beside the solve (dppr_slide_concurrent) every millisecond of it is a millisecond of wall time. The engine keeps both
-// orders PERSISTENT as sorted 64-bit words (B-major: word 1; A-major: A | B | row | head) under block cuts that stay FROZEN between
-// re-cuts (new ids extend the last blocks / append blocks; a re-cut every few dozen slides restores the balance). A slide then
+// ---- Tables PATCHED per slide instead of re-sorted per epoch (round 5). The engine keeps both orders PERSISTENT
+// as sorted 64-bit words under block cuts that stay FROZEN between re-cuts (new ids extend the last blocks / append blocks; a re-cut
+// every few dozen slides restores the balance). A slide
 //   * forms the words of its 2c retired and 2c inserted edges (k_bin_keys, both forms), sorts those, and merges them into the two
 //     arrays with the key merge of the CSR build (k_del_positions + k_merge_tiles, dppr_builder.hpp): 16 bytes per edge and array;
-//   * finds every tile's first entry in both orders (k_bin_tile_starts: where the block pair changes) -- a tile is a run in both, in
-//     the same inner (row, head) order, so an edge's B-major position is  first_B(tile) + (its A-major index - first_A(tile));
-//   * writes dl from the B-major words and hl, apos from the A-major ones (k_bin_rows / k_bin_heads_pos).
-// The full build (first epoch, re-cut, renumbering, a merge that missed a key) produces the same two arrays by the sorts and runs the
-// same tail, so every binned test exercises the tail; tests/test_binned_tables_gpu.py holds the patched tables to the sorted ones.
-__global__ __launch_bounds__(BLOCK) void k_bin_to_amajor(const uint64_t *__restrict__ wb, int Ed, int abits, int bbits, uint64_t *__restrict__ wa) {
-    const uint64_t lo_mask = (1ull << (BIN_RL + BIN_HL)) - 1ull, amask = (1ull << abits) - 1ull;
+//   * and runs the TAIL below on the two arrays. The full build (first epoch, re-cut, renumbering, a merge that missed a key) produces
+//     the same two arrays by sorts and runs the same tail, so every binned test exercises it; tests/test_binned_tables_gpu.py holds
+//     the patched tables to the sorted ones bit for bit.
+// The tail (round 6: runs and tiles). Per aligned block of 64 words: how many runs / tiles START in it (k_bin_count), an exclusive
+// scan of those counts, and then
+//   * from the B-major words (k_bin_btables): dl[q] = row | first-of-run bit; vb[k] = index of the run that holds word 64 k (the
+//     values a wave's 64 edges need are vals[vb[k] ..], consecutive); vfirst[b, a] = run index of tile (a, b)'s first run;
+//   * from the A-major words (k_bin_atables): the RUN list hl[j] = head | first-of-tile bit (j = A-major run index), per tile (in
+//     A-major order) tdelta[t] = vfirst[b, a] - (A-major index of its first run), and arun[a] = first run of A-block a;
+//   * from the run list (k_bin_count16 + scan + k_bin_tb): tb[k] = ordinal of the tile that holds run 64 k.
+// swap the two block fields of a word: (H << lbits | L) -> (L << hbits | H)
+__global__ __launch_bounds__(BLOCK) void k_bin_swap_blocks(const uint64_t *__restrict__ win, int Ed, int lbits, int hbits, uint64_t *__restrict__ wout) {
+    const uint64_t lo_mask = (1ull << BIN_LO) - 1ull, lmask = (1ull << lbits) - 1ull;
     for (int q = blockIdx.x * BLOCK + threadIdx.x; q < Ed; q += gridDim.x * BLOCK) {
-        const uint64_t w = wb[q], hi = w >> (BIN_RL + BIN_HL);
-        const uint64_t a = hi & amask, b = hi >> abits;
-        wa[q] = (((a << bbits) | b) << (BIN_RL + BIN_HL)) | (w & lo_mask);
+        const uint64_t w = win[q], blocks = w >> BIN_LO;
+        const uint64_t l = blocks & lmask, h = blocks >> lbits;
+        wout[q] = (((l << hbits) | h) << BIN_LO) | (w & lo_mask);
     }
 }
-// first[first_block * n_second + second_block] = index of the first word of that block pair (only pairs that occur are written -- and read)
-__global__ __launch_bounds__(BLOCK) void k_bin_tile_starts(const uint64_t *__restrict__ w, int Ed, int second_bits, int n_second,
-                                                           int *__restrict__ first) {
-    const uint64_t smask = (1ull << second_bits) - 1ull;
-    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < Ed; i += gridDim.x * BLOCK) {
-        const uint64_t hi = w[i] >> (BIN_RL + BIN_HL);
-        if (i == 0 || hi != (w[i - 1] >> (BIN_RL + BIN_HL))) first[(size_t)(hi >> second_bits) * (size_t)n_second + (size_t)(hi & smask)] = i;
+// cnt[k] = (runs that start in words [64 k, 64 k + 64)) << 32 | tiles that start there; cnt[n_blk] = 0 (so that the scan's last entry is the total)
+__global__ __launch_bounds__(BLOCK) void k_bin_count(const uint64_t *__restrict__ w, int Ed, unsigned long long *__restrict__ cnt) {
+    const int n_blk = (Ed + WAVE - 1) / WAVE, lane = lane_id();
+    for (int k = blockIdx.x * WAVES_PER_BLOCK + wave_id(); k <= n_blk; k += gridDim.x * WAVES_PER_BLOCK) {
+        const int i = k * WAVE + lane;
+        bool rf = false, tf = false;
+        if (i < Ed) {
+            const uint64_t me = w[i], prev = i > 0 ? w[i - 1] : ~0ull;
+            rf = (me >> BIN_RL) != (prev >> BIN_RL);
+            tf = (me >> BIN_LO) != (prev >> BIN_LO);
+        }
+        const unsigned long long r = (unsigned long long)__popcll(__ballot(rf)), t = (unsigned long long)__popcll(__ballot(tf));
+        if (lane == 0) cnt[k] = (r << 32) | t;
     }
 }
-__global__ __launch_bounds__(BLOCK) void k_bin_rows(const uint64_t *__restrict__ wb, int Ed, uint16_t *__restrict__ dl) {
-    for (int q = blockIdx.x * BLOCK + threadIdx.x; q < Ed; q += gridDim.x * BLOCK) dl[q] = (uint16_t)((wb[q] >> BIN_HL) & ((1u << BIN_RL) - 1u));
+// X = exclusive scan of k_bin_count's counts over the B-major words (n_blk + 1 entries, the last one the totals)
+__global__ __launch_bounds__(BLOCK) void k_bin_btables(const uint64_t *__restrict__ wb, int Ed, const unsigned long long *__restrict__ X, int n_a, int abits,
+                                                       uint16_t *__restrict__ dl, int *__restrict__ vb, int *__restrict__ vfirst) {
+    const int n_blk = (Ed + WAVE - 1) / WAVE, lane = lane_id();
+    const uint64_t amask = (1ull << abits) - 1ull;
+    for (int k = blockIdx.x * WAVES_PER_BLOCK + wave_id(); k < n_blk; k += gridDim.x * WAVES_PER_BLOCK) {
+        const int q = k * WAVE + lane;
+        bool rf = false, tf = false;
+        uint64_t me = 0;
+        if (q < Ed) {
+            me = wb[q];
+            const uint64_t prev = q > 0 ? wb[q - 1] : ~0ull;
+            rf = (me >> BIN_RL) != (prev >> BIN_RL);
+            tf = (me >> BIN_LO) != (prev >> BIN_LO);
+        }
+        const uint64_t rm = __ballot(rf);
+        const int before = (int)(X[k] >> 32);
+        if (q < Ed) dl[q] = (uint16_t)((me & ((1u << BIN_RL) - 1u)) | (rf ? BIN_FLAG : 0));
+        if (tf) { // (a tile's first word starts a run: its index = the runs before it)
+            const uint64_t blocks = me >> BIN_LO;
+            vfirst[(size_t)(blocks >> abits) * (size_t)n_a + (size_t)(blocks & amask)] = before + mbcnt(rm);
+        }
+        if (lane == 0) {
+            vb[k] = before - 1 + (int)(rm & 1ull);
+            if (k == n_blk - 1) vb[n_blk] = (int)(X[n_blk] >> 32) - 1; // (the last run: what bounds the last block's value loads)
+        }
+    }
 }
-__global__ __launch_bounds__(BLOCK) void k_bin_heads_pos(const uint64_t *__restrict__ wa, int Ed, int bbits, int n_a, int n_b,
-                                                         const int *__restrict__ first_a, const int *__restrict__ first_b,
-                                                         uint16_t *__restrict__ hl, int *__restrict__ apos) {
+// X = the same scan over the A-major words
+__global__ __launch_bounds__(BLOCK) void k_bin_atables(const uint64_t *__restrict__ wa, int Ed, const unsigned long long *__restrict__ X, int n_a, int bbits,
+                                                       const int *__restrict__ vfirst, uint16_t *__restrict__ hl, int *__restrict__ tdelta,
+                                                       int *__restrict__ arun) {
+    const int n_blk = (Ed + WAVE - 1) / WAVE, lane = lane_id();
     const uint64_t bmask = (1ull << bbits) - 1ull;
-    for (int j = blockIdx.x * BLOCK + threadIdx.x; j < Ed; j += gridDim.x * BLOCK) {
-        const uint64_t w = wa[j], hi = w >> (BIN_RL + BIN_HL);
-        const size_t a = (size_t)(hi >> bbits), b = (size_t)(hi & bmask);
-        hl[j] = (uint16_t)(w & ((1ull << BIN_HL) - 1ull));
-        apos[j] = first_b[b * (size_t)n_a + a] + (j - first_a[a * (size_t)n_b + b]);
+    for (int k = blockIdx.x * WAVES_PER_BLOCK + wave_id(); k < n_blk; k += gridDim.x * WAVES_PER_BLOCK) {
+        const int i = k * WAVE + lane;
+        bool rf = false, tf = false, af = false;
+        uint64_t me = 0;
+        if (i < Ed) {
+            me = wa[i];
+            const uint64_t prev = i > 0 ? wa[i - 1] : ~0ull;
+            rf = (me >> BIN_RL) != (prev >> BIN_RL);
+            tf = (me >> BIN_LO) != (prev >> BIN_LO);
+            af = (me >> (BIN_LO + bbits)) != (prev >> (BIN_LO + bbits));
+        }
+        const uint64_t rm = __ballot(rf), tm = __ballot(tf);
+        const unsigned long long x = X[k];
+        if (rf) {
+            const int j = (int)(x >> 32) + mbcnt(rm);
+            hl[j] = (uint16_t)(((me >> BIN_RL) & ((1u << BIN_HL) - 1u)) | (tf ? BIN_FLAG : 0));
+            if (tf) {
+                const uint64_t blocks = me >> BIN_LO;
+                const size_t a = (size_t)(blocks >> bbits), b = (size_t)(blocks & bmask);
+                tdelta[(int)(x & 0xffffffffull) + mbcnt(tm)] = vfirst[b * (size_t)n_a + a] - j;
+                if (af) arun[a] = j;
+            }
+        }
     }
+}
+// the same count over the run list's tile bits (one int per 64 runs; cnt[n_rb] = 0)
+__global__ __launch_bounds__(BLOCK) void k_bin_count16(const uint16_t *__restrict__ hl, int R, int *__restrict__ cnt) {
+    const int n_rb = (R + WAVE - 1) / WAVE, lane = lane_id();
+    for (int k = blockIdx.x * WAVES_PER_BLOCK + wave_id(); k <= n_rb; k += gridDim.x * WAVES_PER_BLOCK) {
+        const int j = k * WAVE + lane;
+        const bool tf = j < R && (hl[j] & BIN_FLAG);
+        const int t = __popcll(__ballot(tf));
+        if (lane == 0) cnt[k] = t;
+    }
+}
+// tb[k] = ordinal of the tile that holds run 64 k (X2 = exclusive scan of k_bin_count16's counts); tb[n_rb] = the last tile
+__global__ __launch_bounds__(BLOCK) void k_bin_tb(const uint16_t *__restrict__ hl, int R, const int *__restrict__ X2, int *__restrict__ tb) {
+    const int n_rb = (R + WAVE - 1) / WAVE;
+    for (int k = blockIdx.x * BLOCK + threadIdx.x; k <= n_rb; k += gridDim.x * BLOCK)
+        tb[k] = k < n_rb ? X2[k] - 1 + ((hl[(size_t)k * WAVE] & BIN_FLAG) ? 1 : 0) : X2[n_rb] - 1;
 }
 
 // Diagnostic build only (-DDPPR_STAMPS, tools/r03/stamps_bin.sh): wall-clock (100 MHz) stamps per workgroup of the last
@@ -269,15 +341,19 @@ __device__ unsigned long long g_bin_stamps[2][16384 * 6];
 #define BSTAMP(K, i, val) ((void)0)
 #endif
 
-// Pass 1: vals[B-major position] = x[head] for a CHUNK of an A-block's edges (chunk = {block, first entry, end}: a block of
-// many edges is dealt to several workgroups, each stages the block's slice of x). LDS: that slice.
+// the lanes 1 .. lane of a wave (a table entry's ordinal inside its aligned block of 64 counts the bits set there)
+__device__ __forceinline__ uint64_t lanes_1_to_me() { return (~0ull >> (WAVE - 1 - lane_id())) & ~1ull; }
+
+// Pass 1: vals[run's B-major index] = x[head] for a CHUNK of an A-block's runs (chunk = {block, first run, end}: a block of
+// many runs is dealt to several workgroups, each stages the block's slice of x). LDS: that slice. A wave takes ALIGNED blocks of 64
+// runs (the tables tb / the tile bits count per aligned block) and masks the entries outside its chunk.
 struct BinChunk {
     int blk, j0, j1;
 };
 __global__ __launch_bounds__(BIN_NT) void k_bin_scatter(int NV, const int *__restrict__ cnt_in, const int *__restrict__ acut,
                                                         const BinChunk *__restrict__ chunks, const uint16_t *__restrict__ hl,
-                                                        const int *__restrict__ apos, const double *__restrict__ x,
-                                                        double *__restrict__ vals) {
+                                                        const int *__restrict__ tb, const int *__restrict__ tdelta, int R,
+                                                        const double *__restrict__ x, double *__restrict__ vals) {
     extern __shared__ double s_x[];
     if (*cnt_in == 0) return; // empty frontier: nothing is read or written (k_bin_reduce returns as well)
     const BinChunk ch = chunks[blockIdx.x];
@@ -288,17 +364,32 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_scatter(int NV, const int *__res
     for (int i = threadIdx.x; i < h1 - h0; i += BIN_NT) s_x[i] = x[h0 + i];
     __syncthreads();
     BSTAMP(0, 1, wall_clock64());
-    for (int j = j0 + (int)threadIdx.x; j < j1; j += BIN_NT * BIN_U) {
-        int h[BIN_U], q[BIN_U];
+    const int lane = lane_id();
+    const uint64_t below = lanes_1_to_me();
+    const int kb1 = (j1 + WAVE - 1) / WAVE;
+    for (int kb = j0 / WAVE + wave_id(); kb < kb1; kb += (BIN_NT / WAVE) * BIN_U) {
+        int hv[BIN_U], td[BIN_U];
 #pragma unroll
         for (int k = 0; k < BIN_U; ++k) {
-            const int jj = j + k * BIN_NT;
-            h[k] = jj < j1 ? (int)hl[jj] : -1;
-            q[k] = jj < j1 ? apos[jj] : 0;
+            const int kk = __builtin_amdgcn_readfirstlane(kb + k * (BIN_NT / WAVE));
+            hv[k] = -1;
+            td[k] = 0;
+            if (kk < kb1) {
+                const int jj = kk * WAVE + lane;
+                if (jj < R) hv[k] = (int)hl[jj];
+                const int t0 = tb[kk], t1 = tb[kk + 1];
+                if (lane <= t1 - t0) td[k] = tdelta[t0 + lane];
+            }
         }
 #pragma unroll
-        for (int k = 0; k < BIN_U; ++k)
-            if (h[k] >= 0) vals[q[k]] = s_x[h[k]];
+        for (int k = 0; k < BIN_U; ++k) {
+            const int kk = kb + k * (BIN_NT / WAVE);
+            if (kk >= kb1) break; // wave-uniform
+            const uint64_t tm = __ballot(hv[k] >= 0 && (hv[k] & BIN_FLAG));
+            const int delta = __shfl(td[k], __popcll(tm & below), WAVE);
+            const int jj = kk * WAVE + lane;
+            if (jj >= j0 && jj < j1) vals[jj + delta] = s_x[hv[k] & (BIN_FLAG - 1)];
+        }
     }
 #ifdef DPPR_STAMPS
     __syncthreads();
@@ -347,7 +438,7 @@ __device__ __forceinline__ double wave_segmented_sum(double x, bool head) {
 // the tables were built (they have no edge in this epoch, but may hold state).
 __global__ __launch_bounds__(BIN_NT) void k_bin_reduce(int NV, int NV_bin, int n_b, const int *__restrict__ cnt_in, const int *__restrict__ bcut,
                                                        int rows_cap, const int *__restrict__ out_row_ptr,
-                                                       const uint16_t *__restrict__ dl, const double *__restrict__ vals,
+                                                       const uint16_t *__restrict__ dl, const int *__restrict__ vb, int Ed, const double *__restrict__ vals,
                                                        const double *__restrict__ x, double *__restrict__ x_new,
                                                        double *__restrict__ r, double *__restrict__ p,
                                                        int *__restrict__ cnt_out, int *__restrict__ cnt_zero, int phase, double eps,
@@ -387,27 +478,43 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_reduce(int NV, int NV_bin, int n
     __syncthreads();
     BSTAMP(1, 1, wall_clock64());
     unsigned long long edges = 0;
-    for (int q0 = e0; q0 < e1; q0 += BIN_NT * BIN_U) { // workgroup-uniform trip count (the DPP steps below want whole waves);
-        const int q = q0 + (int)threadIdx.x;           // a wave's lanes hold 64 consecutive entries per k
-        double xv[BIN_U];
-        int row[BIN_U];
+    const uint64_t runs_below = lanes_1_to_me();
+    const int kb1 = (e1 + WAVE - 1) / WAVE;
+    // ALIGNED blocks of 64 edges (vb and the run bits count per aligned block); a wave's lanes hold 64 consecutive entries per k.
+    // The two loads of a block are independent: the edge entries, and the <= 64 consecutive values its runs need.
+    for (int kb = e0 / WAVE + w; kb < kb1; kb += (BIN_NT / WAVE) * BIN_U) {
+        double xw[BIN_U];
+        int dv[BIN_U];
 #pragma unroll
         for (int k = 0; k < BIN_U; ++k) {
-            const int qq = q + k * BIN_NT;
-            xv[k] = qq < e1 ? vals[qq] : 0.0;
-            row[k] = qq < e1 ? (int)dl[qq] : -1;
+            const int kk = __builtin_amdgcn_readfirstlane(kb + k * (BIN_NT / WAVE));
+            xw[k] = 0.0;
+            dv[k] = -1;
+            if (kk < kb1) {
+                const int qq = kk * WAVE + lane;
+                if (qq < Ed) dv[k] = (int)dl[qq];
+                const int i0 = vb[kk], i1 = vb[kk + 1];
+                if (lane <= i1 - i0) xw[k] = vals[i0 + lane];
+            }
         }
 #pragma unroll
         for (int k = 0; k < BIN_U; ++k) {
-            const bool nz = xv[k] != 0.0;
+            const int kk = kb + k * (BIN_NT / WAVE);
+            if (kk >= kb1) break; // wave-uniform
+            const uint64_t rm = __ballot(dv[k] >= 0 && (dv[k] & BIN_FLAG));
+            const int src = __popcll(rm & runs_below); // the lane that loaded this edge's run value
+            const double xv = __hiloint2double(__shfl(__double2hiint(xw[k]), src, WAVE), __shfl(__double2loint(xw[k]), src, WAVE));
+            const int qq = kk * WAVE + lane;
+            const int rowk = dv[k] & ((1 << BIN_RL) - 1);
+            const bool nz = qq >= e0 && qq < e1 && xv != 0.0;
             const uint64_t any = __ballot(nz);
             if (any == 0) continue; // wave-uniform
             edges += (unsigned long long)__popcll(any);
-            const int i = nz ? row[k] : -1 - lane; // a lane without a term is a run of its own
-            const double t = nz ? push_term(xv[k], (double)s_den[row[k]], s_rcp[row[k]]) : 0.0;
-            // Lanes of one row are neighbours (a tile's entries are in (row, head) order). Many short runs: one LDS atomic
-            // per lane (a run of k lanes is a k-way conflict, cheap for small k). Few long runs (a hub's row): the runs are
-            // summed in registers first and cost ONE atomic each -- thousands of atomics on one LDS word would serialise.
+            const int i = nz ? rowk : -1 - lane; // a lane without a term is a run of its own
+            const double t = nz ? push_term(xv, (double)s_den[rowk], s_rcp[rowk]) : 0.0;
+            // A tile's entries are in (head, row) order: neighbouring lanes hold different rows as a rule (one LDS atomic per lane)
+            // -- except in the block of a hub row, where all of them hold the same one: the runs are summed in registers first and
+            // cost ONE atomic each (thousands of atomics on one LDS word would serialise).
             const int below = __builtin_amdgcn_update_dpp(-0x7fffffff, i, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
             const bool head = lane == 0 || below != i;
             if (__popcll(__ballot(head)) >= 16) { // wave-uniform

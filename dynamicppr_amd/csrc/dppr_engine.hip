@@ -87,24 +87,31 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
             return bail(_e == hipErrorOutOfMemory ? DPPR_ERR_NOMEM : DPPR_ERR_HIP);     \
         }                                                                               \
     } while (0)
-    if (const char *v = getenv("DPPR_SWEEP_BITS")) e->sweep_bits = atoi(v) != 0; // diagnostic A/B switches
-    if (const char *v = getenv("DPPR_HOT_BLOCKS")) e->hot_blocks = atoi(v) != 0;
-    if (const char *v = getenv("DPPR_GSWEEP_HOT")) e->gsweep_hot_rows = std::max(0, atoi(v));
-    if (const char *v = getenv("DPPR_GSWEEP_GRID")) e->gsweep_grid_cap = std::max(1, std::min(atoi(v), STAT_SLOTS));
-    if (const char *v = getenv("DPPR_RENUMBER")) e->renumber_on = atoi(v) != 0;
-    if (const char *v = getenv("DPPR_RENUMBER_PCT")) e->renumber_growth_pct = std::max(1, atoi(v));
-    if (const char *v = getenv("DPPR_RENUMBER_MIN")) e->renumber_min_parked = std::max(1, atoi(v));
-    if (const char *v = getenv("DPPR_GROUP_PUSH")) e->gpush_enter_pairs = std::max(-1, atoi(v));
-    if (const char *v = getenv("DPPR_GROUP_PUSH_FACTOR")) e->gpush_auto_factor = std::max(1, atoi(v));
-    if (const char *v = getenv("DPPR_GGROUPS_MIN")) e->ggroups_min = std::max(1, atoi(v));
-    if (const char *v = getenv("DPPR_COST_MODEL")) e->cost_model = atoi(v) != 0;
-    if (const char *v = getenv("DPPR_GROUPING_RADIX")) e->force_radix_grouping = atoi(v) != 0;
-    if (const char *v = getenv("DPPR_TEST_MERGE_MISS")) e->test_force_merge_miss = atoi(v) != 0;
-    if (const char *v = getenv("DPPR_BIN_INCREMENTAL")) e->bin_incremental = atoi(v) != 0;
-    if (const char *v = getenv("DPPR_BIN_RECUT_EVERY")) e->bin_recut_every = std::max(1, atoi(v));
-    if (const char *v = getenv("DPPR_BIN_FROZEN_REBUILD")) e->bin_frozen_rebuild = atoi(v) != 0;
-    if (const char *v = getenv("DPPR_GROUP_AT_SLIDE")) e->group_at_slide = atoi(v) != 0;
-    if (const char *v = getenv("DPPR_GROUP_FULL_ROWS")) e->group_full_rows = atoi(v) != 0;
+    // Diagnostic switches (A/B runs, tests): every one of them is listed in INTEGRATION.md ("Environment variables"), none is needed
+    // in production, and one that is set says so on stderr -- a stray variable must not change the product's behaviour silently
+    auto diag_env = [](const char *name) -> const char * {
+        const char *v = getenv(name);
+        if (v && !getenv("DPPR_QUIET_SWITCHES")) fprintf(stderr, "dppr_create: diagnostic switch %s=%s in effect (INTEGRATION.md, Environment variables)\n", name, v);
+        return v;
+    };
+    if (const char *v = diag_env("DPPR_SWEEP_BITS")) e->sweep_bits = atoi(v) != 0; // diagnostic A/B switches
+    if (const char *v = diag_env("DPPR_HOT_BLOCKS")) e->hot_blocks = atoi(v) != 0;
+    if (const char *v = diag_env("DPPR_GSWEEP_HOT")) e->gsweep_hot_rows = std::max(0, atoi(v));
+    if (const char *v = diag_env("DPPR_GSWEEP_GRID")) e->gsweep_grid_cap = std::max(1, std::min(atoi(v), STAT_SLOTS));
+    if (const char *v = diag_env("DPPR_RENUMBER")) e->renumber_on = atoi(v) != 0;
+    if (const char *v = diag_env("DPPR_RENUMBER_PCT")) e->renumber_growth_pct = std::max(1, atoi(v));
+    if (const char *v = diag_env("DPPR_RENUMBER_MIN")) e->renumber_min_parked = std::max(1, atoi(v));
+    if (const char *v = diag_env("DPPR_GROUP_PUSH")) e->gpush_enter_pairs = std::max(-1, atoi(v));
+    if (const char *v = diag_env("DPPR_GROUP_PUSH_FACTOR")) e->gpush_auto_factor = std::max(1, atoi(v));
+    if (const char *v = diag_env("DPPR_GGROUPS_MIN")) e->ggroups_min = std::max(1, atoi(v));
+    if (const char *v = diag_env("DPPR_COST_MODEL")) e->cost_model = atoi(v) != 0;
+    if (const char *v = diag_env("DPPR_GROUPING_RADIX")) e->force_radix_grouping = atoi(v) != 0;
+    if (const char *v = diag_env("DPPR_TEST_MERGE_MISS")) e->test_force_merge_miss = atoi(v) != 0;
+    if (const char *v = diag_env("DPPR_BIN_INCREMENTAL")) e->bin_incremental = atoi(v) != 0;
+    if (const char *v = diag_env("DPPR_BIN_RECUT_EVERY")) e->bin_recut_every = std::max(1, atoi(v));
+    if (const char *v = diag_env("DPPR_BIN_FROZEN_REBUILD")) e->bin_frozen_rebuild = atoi(v) != 0;
+    if (const char *v = diag_env("DPPR_GROUP_AT_SLIDE")) e->group_at_slide = atoi(v) != 0;
+    if (const char *v = diag_env("DPPR_GROUP_FULL_ROWS")) e->group_full_rows = atoi(v) != 0;
     e->device = device;
     e->V = V;
     e->W = W;
@@ -205,10 +212,10 @@ void dppr_destroy(dppr_engine *e) {
     for (auto &ep : e->epochs) {
         (void)hipFree(ep.row_ptr); (void)hipFree(ep.adj); (void)hipFree(ep.out_row_ptr); (void)hipFree(ep.out_col); (void)hipFree(ep.b1); (void)hipFree(ep.b2);
         (void)hipFree(ep.deg_after); (void)hipFree(ep.ins); (void)hipFree(ep.sk); (void)hipFree(ep.sv); (void)hipFree(ep.hub_v); (void)hipFree(ep.hub_degp1); (void)hipFree(ep.grp_tile); (void)hipFree(ep.ggrp_tile); (void)hipFree(ep.gtab);
-        (void)hipFree(ep.acut); (void)hipFree(ep.chunks); (void)hipFree(ep.hl); (void)hipFree(ep.dl); (void)hipFree(ep.apos);
+        (void)hipFree(ep.acut); (void)hipFree(ep.chunks); (void)hipFree(ep.hl); (void)hipFree(ep.dl); (void)hipFree(ep.vb); (void)hipFree(ep.tb); (void)hipFree(ep.tdelta);
         (void)hipFree(ep.res_pk); (void)hipFree(ep.su_rng);
     }
-    (void)hipFree(e->bin_vblk_b); (void)hipFree(e->bin_small); (void)hipFree(e->bin_vals); (void)hipFree(e->bin_tmp);
+    (void)hipFree(e->bin_vblk_a); (void)hipFree(e->bin_small); (void)hipFree(e->bin_scan); (void)hipFree(e->bin_vals); (void)hipFree(e->bin_tmp);
     (void)hipFree(e->bin_wb); (void)hipFree(e->bin_wa); (void)hipFree(e->bin_first);
     (void)hipFree(e->w1); (void)hipFree(e->w2); (void)hipFree(e->outdeg);
     (void)hipFree(e->bar);
@@ -475,6 +482,7 @@ int dppr_hint_next_batch(dppr_engine *e, const int32_t *b1, const int32_t *b2, i
 int dppr_set_batch(dppr_engine *e, const int32_t *b1, const int32_t *b2, const uint8_t *ins, int32_t L) {
     if (!e || e->broken || L < 0 || L > 4 * e->c || (L > 0 && (!b1 || !b2 || !ins)))
         return fail(e, DPPR_ERR_INVALID, "set_batch: length exceeds 4*max_batch");
+    std::lock_guard<std::mutex> map_lk(e->map_mu); // (ids are assigned and rows moved below: not beside a dppr_read of the solver thread)
     if (!ids_in_range(e, b1, L) || !ids_in_range(e, b2, L) || !translate(e, b1, L, e->st_b1) || !translate(e, b2, L, e->st_b2))
         return fail(e, DPPR_ERR_INVALID, "set_batch: vertex id out of range");
     e->st_b1.resize((size_t)L);
@@ -525,12 +533,15 @@ static int slide_impl(dppr_engine *e, const int32_t *n1, const int32_t *n2, int3
         t_mark = now;
     };
     bool renumbered = false;
-    if (int rc = compact_ids(e, &renumbered)) return rc;
-    if (renumbered) e->bin_words_valid = false; // (the binned tables' words and cuts are in the old numbering)
-    mark("renumbering check");
-    if (!translate(e, n1, c, e->h_tmp1) || !translate(e, n2, c, e->h_tmp2))
-        return fail(e, DPPR_ERR_INVALID, "slide: vertex id out of range");
-    if (int rc = flush_moves(e)) return rc;
+    {
+        std::lock_guard<std::mutex> map_lk(e->map_mu); // the id-assigning head of the slide: maps and row moves change together
+        if (int rc = compact_ids(e, &renumbered)) return rc;
+        if (renumbered) e->bin_words_valid = false; // (the binned tables' words and cuts are in the old numbering)
+        mark("renumbering check");
+        if (!translate(e, n1, c, e->h_tmp1) || !translate(e, n2, c, e->h_tmp2))
+            return fail(e, DPPR_ERR_INVALID, "slide: vertex id out of range");
+        if (int rc = flush_moves(e)) return rc;
+    }
     mark("translate new edges");
     n1 = e->h_tmp1.data();
     n2 = e->h_tmp2.data();
@@ -578,10 +589,10 @@ static int slide_impl(dppr_engine *e, const int32_t *n1, const int32_t *n2, int3
     }
     if (rc) return rc;
     mark("sorted keys (merge / full sort)");
-    BinBatch bb; // the slide's retired / inserted edges in the out-orientation: what the binned tables are patched with
+    BinBatch bb; // the slide's retired / inserted edges in the in-orientation ((head, row) keys): what the binned tables are patched with
     if (inc) {
-        bb.del = e->directed ? e->bk[2] : e->bk[0];
-        bb.ins = e->directed ? e->bk[3] : e->bk[1];
+        bb.del = e->bk[0];
+        bb.ins = e->bk[1];
         bb.nd = bb.ni = c * per;
     }
     rc = build_epoch(e, ep, inc ? &bb : nullptr);
@@ -980,6 +991,7 @@ int dppr_update(dppr_engine *e, int32_t slot, int32_t epoch, double eps, float *
 int dppr_read(dppr_engine *e, int32_t slot, double *p, double *r) {
     GET_SLOT(e, slot);
     HIP_TRY(hipSetDevice(e->device));
+    std::lock_guard<std::mutex> map_lk(e->map_mu); // (beside a concurrent slide: the map copy and the gathers see one state of the id space)
     int rc = sync_map(e);
     if (rc) return rc;
     const double *src[2] = {s.p, s.r};
@@ -1319,6 +1331,7 @@ int dppr_group_read(dppr_engine *e, int32_t group, int32_t index, double *p, dou
     GET_GROUP(e, group);
     if (index < 0 || index >= g.n) return fail(e, DPPR_ERR_INVALID, "group_read: bad source index");
     HIP_TRY(hipSetDevice(e->device));
+    std::lock_guard<std::mutex> map_lk(e->map_mu); // (as dppr_read)
     int rc = sync_map(e);
     if (rc) return rc;
     const double *src[2] = {g.p, g.r};
@@ -1481,8 +1494,9 @@ int dppr_bench_stream_copy(int device, int64_t bytes, int reps, float *out_ms) {
     return err == hipSuccess ? DPPR_OK : DPPR_ERR_HIP;
 }
 
-int dppr_debug_bin_tables(dppr_engine *e, int32_t epoch, int32_t *n_a, int32_t *n_b, int32_t *n_edges, int32_t *acut, int32_t *bcut, uint16_t *hl,
-                          int32_t *apos, uint16_t *dl, int64_t *patched, int64_t *rebuilt) {
+int dppr_debug_bin_tables(dppr_engine *e, int32_t epoch, int32_t *n_a, int32_t *n_b, int32_t *n_edges, int32_t *n_runs, int32_t *n_tiles,
+                          int32_t *acut, int32_t *bcut, uint16_t *hl, int32_t *tdelta, int32_t *tb, uint16_t *dl, int32_t *vb,
+                          int64_t *patched, int64_t *rebuilt) {
     if (!e) return DPPR_ERR_INVALID;
     GET_EPOCH(e, epoch);
     if (patched) *patched = e->bin_patched;
@@ -1492,11 +1506,16 @@ int dppr_debug_bin_tables(dppr_engine *e, int32_t epoch, int32_t *n_a, int32_t *
     if (n_a) *n_a = ep.n_a;
     if (n_b) *n_b = ep.n_b;
     if (n_edges) *n_edges = ep.Ed;
+    if (n_runs) *n_runs = ep.n_runs;
+    if (n_tiles) *n_tiles = ep.n_tiles;
+    const size_t n_blk = ((size_t)ep.Ed + WAVE - 1) / WAVE, n_rb = ((size_t)ep.n_runs + WAVE - 1) / WAVE;
     if (acut) HIP_TRY(hipMemcpy(acut, ep.acut, sizeof(int) * ((size_t)ep.n_a + 1), hipMemcpyDeviceToHost));
     if (bcut) HIP_TRY(hipMemcpy(bcut, ep.bcut, sizeof(int) * ((size_t)ep.n_b + 1), hipMemcpyDeviceToHost));
-    if (hl) HIP_TRY(hipMemcpy(hl, ep.hl, sizeof(uint16_t) * (size_t)ep.Ed, hipMemcpyDeviceToHost));
-    if (apos) HIP_TRY(hipMemcpy(apos, ep.apos, sizeof(int) * (size_t)ep.Ed, hipMemcpyDeviceToHost));
+    if (hl) HIP_TRY(hipMemcpy(hl, ep.hl, sizeof(uint16_t) * (size_t)ep.n_runs, hipMemcpyDeviceToHost));
+    if (tdelta) HIP_TRY(hipMemcpy(tdelta, ep.tdelta, sizeof(int) * (size_t)ep.n_tiles, hipMemcpyDeviceToHost));
+    if (tb) HIP_TRY(hipMemcpy(tb, ep.tb, sizeof(int) * (n_rb + 1), hipMemcpyDeviceToHost));
     if (dl) HIP_TRY(hipMemcpy(dl, ep.dl, sizeof(uint16_t) * (size_t)ep.Ed, hipMemcpyDeviceToHost));
+    if (vb) HIP_TRY(hipMemcpy(vb, ep.vb, sizeof(int) * (n_blk + 1), hipMemcpyDeviceToHost));
     return DPPR_OK;
 }
 

@@ -94,7 +94,9 @@ int flush_moves(dppr_engine *e) {
 
 // Parked rows were inert under the eps they were parked with; a solve with a smaller one pushes them first.
 int settle_parked(dppr_engine *e, double *p, double *r, int w, double eps, double *park_eps, dppr_stats_t *st) {
-    if (e->n_parked == 0 || !(eps < *park_eps)) return DPPR_OK;
+    if (!(eps < *park_eps)) return DPPR_OK; // (the steady state of a stream: the parked zone is not even looked at)
+    std::lock_guard<std::mutex> map_lk(e->map_mu); // the parked zone's extent changes under a concurrent slide's revivals
+    if (e->n_parked == 0) return DPPR_OK;
     const size_t base = (size_t)(e->V - e->n_parked) * (size_t)w;
     const int64_t n = (int64_t)e->n_parked * w;
     int *cnt = e->hub_hist + 41; // scratch word
@@ -549,8 +551,9 @@ int bin_prepare(dppr_engine *e, bool *have) { // engine-level scratch, once (ide
     }
     const size_t Edn = (size_t)std::max(e->Ed, 1);
     bool ok = true;
-    ok = ok && bin_alloc((void **)&e->bin_vblk_b, sizeof(int) * (size_t)e->V);
+    ok = ok && bin_alloc((void **)&e->bin_vblk_a, sizeof(int) * (size_t)e->V);
     ok = ok && bin_alloc((void **)&e->bin_small, sizeof(int) * BIN_SMALL_INTS);
+    ok = ok && bin_alloc((void **)&e->bin_scan, sizeof(unsigned long long) * ((size_t)4 * (Edn / WAVE + 3)));
     ok = ok && bin_alloc((void **)&e->bin_vals, sizeof(double) * (Edn + 64));
     ok = ok && bin_alloc((void **)&e->bin_wb, sizeof(uint64_t) * Edn) && bin_alloc((void **)&e->bin_wa, sizeof(uint64_t) * Edn); // (rotate with keys_a / keys_b: same size)
     if (ok && !e->bin_tmp) {
@@ -558,9 +561,10 @@ int bin_prepare(dppr_engine *e, bool *have) { // engine-level scratch, once (ide
         ok = bin_alloc(&e->bin_tmp, std::max<size_t>(e->bin_tmp_bytes, 16));
     }
     if (!ok) { // out of memory: nothing half-built stays behind, the sweeps of this engine gather (k_pull_iter)
-        (void)hipFree(e->bin_vblk_b); (void)hipFree(e->bin_small); (void)hipFree(e->bin_vals); (void)hipFree(e->bin_tmp);
-        (void)hipFree(e->bin_wb); (void)hipFree(e->bin_wa);
-        e->bin_vblk_b = e->bin_small = nullptr;
+        (void)hipFree(e->bin_vblk_a); (void)hipFree(e->bin_small); (void)hipFree(e->bin_vals); (void)hipFree(e->bin_tmp);
+        (void)hipFree(e->bin_wb); (void)hipFree(e->bin_wa); (void)hipFree(e->bin_scan);
+        e->bin_vblk_a = e->bin_small = nullptr;
+        e->bin_scan = nullptr;
         e->bin_vals = nullptr;
         e->bin_tmp = nullptr;
         e->bin_wb = e->bin_wa = nullptr;
@@ -635,30 +639,35 @@ int build_bins(dppr_engine *e, Epoch &ep, const BinBatch *batch) {
     if (int rc = bin_prepare(e, &have)) return rc;
     if (!have) return DPPR_OK;
     const int Ed = e->Ed, NV = ep.grp_n_int;
-    if (!ep.hl || !ep.dl || !ep.apos) { // all three or none (a partial set from a failed attempt is released first)
-        const size_t Edn = (size_t)Ed;
-        const bool ok = bin_alloc((void **)&ep.hl, sizeof(uint16_t) * Edn) && bin_alloc((void **)&ep.dl, sizeof(uint16_t) * Edn) &&
-                        bin_alloc((void **)&ep.apos, sizeof(int) * Edn);
+    const int n_blk = (Ed + WAVE - 1) / WAVE; // aligned blocks of 64 words: the per-block tables have n_blk + 1 entries
+    if (!ep.hl || !ep.dl || !ep.vb || !ep.tb) { // all four or none (a partial set from a failed attempt is released first)
+        const size_t Edn = (size_t)Ed, nb1 = (size_t)n_blk + 2;
+        const bool ok = bin_alloc((void **)&ep.hl, sizeof(uint16_t) * (Edn + WAVE)) && bin_alloc((void **)&ep.dl, sizeof(uint16_t) * (Edn + WAVE)) &&
+                        bin_alloc((void **)&ep.vb, sizeof(int) * nb1) && bin_alloc((void **)&ep.tb, sizeof(int) * nb1);
         if (!ok) {
-            (void)hipFree(ep.hl); (void)hipFree(ep.dl); (void)hipFree(ep.apos);
+            (void)hipFree(ep.hl); (void)hipFree(ep.dl); (void)hipFree(ep.vb); (void)hipFree(ep.tb);
             ep.hl = ep.dl = nullptr;
-            ep.apos = nullptr;
+            ep.vb = ep.tb = nullptr;
             e->bin_words_valid = false;
             return DPPR_OK; // (bin_valid stays false: this epoch's sweeps gather)
         }
     }
+    // While the patch below is in progress the persistent words describe NEITHER epoch (one order merged, the other not yet): any
+    // early return leaves them marked invalid, and the next slide sorts afresh
+    const bool words_were_valid = e->bin_words_valid;
+    e->bin_words_valid = false;
     // ---- the block cuts: frozen ones (extended by the ids that arrived since) while the tables are being patched, fresh ones otherwise
     const int cap_a = e->bin_ha_tiles * WAVE, cap_b = e->bin_hb_tiles * WAVE;
-    bool patch = e->bin_incremental && e->bin_words_valid && batch && !force_full && e->bin_slides_since_cut < e->bin_recut_every &&
+    bool patch = e->bin_incremental && words_were_valid && batch && !force_full && e->bin_slides_since_cut < e->bin_recut_every &&
                  !e->bin_cut_a.empty() && NV >= e->bin_cut_ids;
-    bool keep_cuts = patch || (e->bin_frozen_rebuild && e->bin_words_valid && !force_full && !e->bin_cut_a.empty() && NV >= e->bin_cut_ids &&
+    bool keep_cuts = patch || (e->bin_frozen_rebuild && words_were_valid && !force_full && !e->bin_cut_a.empty() && NV >= e->bin_cut_ids &&
                                e->bin_slides_since_cut < e->bin_recut_every); // (tests: the sorts under the frozen cuts -- what the patched tables must equal)
     if (keep_cuts) {
         bin_extend_cut(e->bin_cut_a, cap_a, NV);
         bin_extend_cut(e->bin_cut_b, cap_b, NV);
         if ((int)e->bin_cut_a.size() - 1 > (1 << e->bin_abits) || (int)e->bin_cut_b.size() - 1 > (1 << e->bin_bbits) ||
-            (size_t)(e->bin_cut_a.size() - 1) * (size_t)(e->bin_cut_b.size() - 1) * 2 > e->bin_first_cap)
-            patch = keep_cuts = false; // the block numbers outgrew their fields / the tile tables: cut afresh
+            (size_t)(e->bin_cut_a.size() - 1) * (size_t)(e->bin_cut_b.size() - 1) > e->bin_first_cap)
+            patch = keep_cuts = false; // the block numbers outgrew their fields / the tile table: cut afresh
     }
     if (!keep_cuts) {
         if (int rc = bin_cut(e, ep.row_ptr, NV, cap_a, e->bin_target_a, e->bin_cut_a)) return rc;
@@ -676,12 +685,9 @@ int build_bins(dppr_engine *e, Epoch &ep, const BinBatch *batch) {
     ep.n_a = (int)cut_a.size() - 1;
     ep.n_b = (int)cut_b.size() - 1;
     const int abits = e->bin_abits, bbits = e->bin_bbits;
-    if (abits + bbits > 32 || ep.n_a + 2 > BIN_MAX_BLOCKS || ep.n_b + 2 > BIN_MAX_BLOCKS) { // (a window of that many blocks: the sweep stays k_pull_iter)
-        e->bin_words_valid = false;
-        return DPPR_OK;
-    }
-    if (!keep_cuts) { // the two tile tables (first entry of every block pair in either order), with the fields' headroom
-        const size_t need = (size_t)2 * ((size_t)ep.n_a + ep.n_a / 8 + 16) * ((size_t)ep.n_b + ep.n_b / 8 + 16);
+    if (abits + bbits > 32 || ep.n_a + 2 > BIN_MAX_BLOCKS || ep.n_b + 2 > BIN_MAX_BLOCKS) return DPPR_OK; // (a window of that many blocks: the sweep stays k_pull_iter)
+    if (!keep_cuts) { // the tile table (run index of every block pair's first run, B-major), with the fields' headroom
+        const size_t need = ((size_t)ep.n_a + ep.n_a / 8 + 16) * ((size_t)ep.n_b + ep.n_b / 8 + 16);
         if (need > e->bin_first_cap) {
             HIP_TRY(hipStreamSynchronize(e->bs));
             (void)hipFree(e->bin_first);
@@ -689,13 +695,12 @@ int build_bins(dppr_engine *e, Epoch &ep, const BinBatch *batch) {
             e->bin_first_cap = 0;
             if (hipMalloc((void **)&e->bin_first, sizeof(int) * need) != hipSuccess) {
                 (void)hipGetLastError();
-                e->bin_words_valid = false;
                 return DPPR_OK; // (no tables: this epoch's sweeps gather)
             }
             e->bin_first_cap = need;
         }
     }
-    // per epoch: acut | astart | bcut (block tables), then the chunk table
+    // per epoch: acut | arun | bcut (block tables), then the chunk table
     const size_t tab_ints = (size_t)2 * (ep.n_a + 1) + (ep.n_b + 1);
     if (tab_ints > ep.bin_tab_cap) {
         HIP_TRY(hipStreamSynchronize(e->bs));
@@ -705,86 +710,126 @@ int build_bins(dppr_engine *e, Epoch &ep, const BinBatch *batch) {
         HIP_TRY(hipMalloc((void **)&ep.acut, sizeof(int) * (tab_ints + tab_ints / 4 + 1024)));
         ep.bin_tab_cap = tab_ints + tab_ints / 4 + 1024;
     }
-    int *d_astart = ep.acut + (ep.n_a + 1);
-    ep.bcut = d_astart + (ep.n_a + 1);
+    int *d_arun = ep.acut + (ep.n_a + 1);
+    ep.bcut = d_arun + (ep.n_a + 1);
     HIP_TRY(hipMemcpyAsync(ep.acut, cut_a.data(), sizeof(int) * cut_a.size(), hipMemcpyHostToDevice, e->bs));
     HIP_TRY(hipMemcpyAsync(ep.bcut, cut_b.data(), sizeof(int) * cut_b.size(), hipMemcpyHostToDevice, e->bs));
-    hipLaunchKernelGGL(k_bin_vertex_block, dim3(grid_for(NV)), dim3(BLOCK), 0, e->bs, ep.acut, ep.n_a, NV, ep.row_ptr, (int *)nullptr, d_astart);
-    int *d_bstart = e->bin_small; // (not kept: a B-block's edges are out_row_ptr[bcut[b]] .. out_row_ptr[bcut[b + 1]])
-    hipLaunchKernelGGL(k_bin_vertex_block, dim3(grid_for(NV)), dim3(BLOCK), 0, e->bs, ep.bcut, ep.n_b, NV, ep.out_row_ptr, e->bin_vblk_b, d_bstart);
-    const bool cuts_in_lds = (size_t)(ep.n_a + 1) * sizeof(int) <= 48 * 1024;
-    const size_t cut_lds = cuts_in_lds ? (size_t)(ep.n_a + 1) * sizeof(int) : 0;
-    // chunks of the A-major runs (a block of many edges is dealt to several workgroups of k_bin_scatter)
-    std::vector<int32_t> astart((size_t)ep.n_a + 1);
-    HIP_TRY(hipMemcpyAsync(astart.data(), d_astart, sizeof(int) * astart.size(), hipMemcpyDeviceToHost, e->bs));
-    const unsigned word_bits = (unsigned)(BIN_RL + BIN_HL + abits + bbits);
+    int *d_astart = e->bin_small; // first in-CSR entry of every A-block (the full build's segments; not kept)
+    hipLaunchKernelGGL(k_bin_vertex_block, dim3(grid_for(NV)), dim3(BLOCK), 0, e->bs, ep.acut, ep.n_a, NV, ep.row_ptr, e->bin_vblk_a, d_astart);
+    const bool cuts_in_lds = (size_t)(ep.n_b + 1) * sizeof(int) <= 48 * 1024;
+    const size_t cut_lds = cuts_in_lds ? (size_t)(ep.n_b + 1) * sizeof(int) : 0;
+    const unsigned word_bits = (unsigned)(BIN_LO + abits + bbits);
     if (patch) {
         // ---- the slide's retired and inserted edges as words of both orders, merged into the two persistent arrays
         HIP_TRY(hipMemsetAsync(e->hub_hist + MERGE_MISS_WORD + 1, 0, sizeof(int), e->bs));
         for (int amajor = 0; amajor < 2; ++amajor) {
             if (batch->nd > 0)
-                hipLaunchKernelGGL(k_bin_keys, dim3(grid_for(batch->nd)), dim3(BLOCK), cut_lds, e->bs, batch->del, batch->nd, e->bits, ep.acut, ep.n_a,
-                                   cuts_in_lds ? 1 : 0, e->bin_vblk_b, ep.bcut, abits, e->bks[0], bbits, amajor);
+                hipLaunchKernelGGL(k_bin_keys, dim3(grid_for(batch->nd)), dim3(BLOCK), cut_lds, e->bs, batch->del, batch->nd, e->bits, ep.bcut, ep.n_b,
+                                   cuts_in_lds ? 1 : 0, e->bin_vblk_a, ep.acut, abits, bbits, e->bks[0], amajor);
             if (batch->ni > 0)
-                hipLaunchKernelGGL(k_bin_keys, dim3(grid_for(batch->ni)), dim3(BLOCK), cut_lds, e->bs, batch->ins, batch->ni, e->bits, ep.acut, ep.n_a,
-                                   cuts_in_lds ? 1 : 0, e->bin_vblk_b, ep.bcut, abits, e->bks[1], bbits, amajor);
+                hipLaunchKernelGGL(k_bin_keys, dim3(grid_for(batch->ni)), dim3(BLOCK), cut_lds, e->bs, batch->ins, batch->ni, e->bits, ep.bcut, ep.n_b,
+                                   cuts_in_lds ? 1 : 0, e->bin_vblk_a, ep.acut, abits, bbits, e->bks[1], amajor);
             HIP_TRY(hipGetLastError());
             if (int rc = merge_batch_keys(e, amajor ? e->bin_wa : e->bin_wb, e->bks[0], e->bks[2], batch->nd, e->bks[1], e->bks[3], batch->ni, word_bits,
                                           MERGE_MISS_WORD + 1)) return rc;
         }
         HIP_TRY(hipMemcpyAsync(&e->bin_miss_host, e->hub_hist + MERGE_MISS_WORD + 1, sizeof(int), hipMemcpyDeviceToHost, e->bs));
-        e->bin_patched++;
     } else {
-        // ---- both orders from the sorted out-orientation keys: word 1 of every edge, grouped B-major, then the A-major form sorted by A-block
-        const uint64_t *out_keys = e->directed ? e->out_sorted : e->in_sorted;
-        hipLaunchKernelGGL(k_bin_keys, dim3(grid_for(Ed)), dim3(BLOCK), cut_lds, e->bs, out_keys, Ed, e->bits, ep.acut, ep.n_a, cuts_in_lds ? 1 : 0,
-                           e->bin_vblk_b, ep.bcut, abits, e->keys_b, bbits, 0);
+        // ---- both orders from the sorted in-orientation keys ((head, row) order = A-block-major): the A-major word of every edge,
+        // every A-block's segment grouped by B-block, then the B-major form sorted by B-block
+        hipLaunchKernelGGL(k_bin_keys, dim3(grid_for(Ed)), dim3(BLOCK), cut_lds, e->bs, e->in_sorted, Ed, e->bits, ep.bcut, ep.n_b, cuts_in_lds ? 1 : 0,
+                           e->bin_vblk_a, ep.acut, abits, bbits, e->keys_b, 1);
         HIP_TRY(hipGetLastError());
-        size_t tmp = e->bin_tmp_bytes; // B-major: stable by (B-block, A-block); the words are in (row, head) order
+        size_t tmp = e->bin_tmp_bytes; // A-major: stable by (A-block, B-block); the words are in (head, row) order
         const char *placement = getenv("DPPR_BIN_PLACEMENT"); // (tests / A-B runs: "counting" wherever it can run -- small windows never qualify by themselves --, "radix" never)
         const bool cs_force = placement && !strcmp(placement, "counting"), cs_never = placement && !strcmp(placement, "radix");
-        // every B-block's segment grouped by A-block in one pass (k_bin_bmajor) where the radix sort would need FOUR passes over its
+        // every A-block's segment grouped by B-block in one pass (k_bin_group) where the radix sort would need FOUR passes over its
         // 8-bit digits (friendster stand-in, 26 bits: 6.0 ms against 8.9; with three -- twitter, 23 bits -- the sort wins, 3.0 against 3.8:
         // the single pass scatters 8-byte words over thousands of runs, a radix pass over 256)
-        if (ep.n_a <= BIN_CS_MAX_A && (abits + bbits > 24 || cs_force) && !cs_never) {
+        if (ep.n_b <= BIN_CS_MAX && (abits + bbits > 24 || cs_force) && !cs_never) {
             int n_pad = WAVE;
-            while (n_pad < ep.n_a) n_pad *= 2;
-            hipLaunchKernelGGL(k_bin_bmajor, dim3(ep.n_b), dim3(BIN_CS_NT), sizeof(int) * (size_t)n_pad, e->bs, e->keys_b, d_bstart, ep.bcut, ep.n_a,
-                               n_pad, abits, e->bin_wb);
+            while (n_pad < ep.n_b) n_pad *= 2;
+            hipLaunchKernelGGL(k_bin_group, dim3(ep.n_a), dim3(BIN_CS_NT), sizeof(int) * (size_t)n_pad, e->bs, e->keys_b, d_astart, ep.acut, ep.n_b,
+                               n_pad, bbits, e->bin_wa);
         } else {
-            HIP_TRY(rocprim::radix_sort_keys(e->bin_tmp, tmp, e->keys_b, e->bin_wb, (size_t)Ed, (unsigned)(BIN_RL + BIN_HL), word_bits, e->bs));
+            HIP_TRY(rocprim::radix_sort_keys(e->bin_tmp, tmp, e->keys_b, e->bin_wa, (size_t)Ed, (unsigned)BIN_LO, word_bits, e->bs));
         }
-        hipLaunchKernelGGL(k_bin_to_amajor, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->bs, e->bin_wb, Ed, abits, bbits, e->keys_b);
+        hipLaunchKernelGGL(k_bin_swap_blocks, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->bs, e->bin_wa, Ed, bbits, abits, e->keys_b);
         HIP_TRY(hipGetLastError());
-        tmp = e->bin_tmp_bytes;        // A-major: the B-major sequence, stable by A-block (the top field of the A-major form)
-        HIP_TRY(rocprim::radix_sort_keys(e->bin_tmp, tmp, e->keys_b, e->bin_wa, (size_t)Ed, (unsigned)(BIN_RL + BIN_HL + bbits), word_bits, e->bs));
+        tmp = e->bin_tmp_bytes;        // B-major: the A-major sequence, stable by B-block (the top field of the B-major form)
+        HIP_TRY(rocprim::radix_sort_keys(e->bin_tmp, tmp, e->keys_b, e->bin_wb, (size_t)Ed, (unsigned)(BIN_LO + abits), word_bits, e->bs));
         e->bin_miss_host = 0;
-        e->bin_rebuilt++;
     }
-    // ---- the tail both ways: every tile's first entry in either order, then the three per-edge tables
-    int *first_b = e->bin_first, *first_a = e->bin_first + (size_t)ep.n_a * (size_t)ep.n_b;
-    hipLaunchKernelGGL(k_bin_tile_starts, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->bs, e->bin_wb, Ed, abits, ep.n_a, first_b);
-    hipLaunchKernelGGL(k_bin_tile_starts, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->bs, e->bin_wa, Ed, bbits, ep.n_b, first_a);
-    hipLaunchKernelGGL(k_bin_rows, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->bs, e->bin_wb, Ed, ep.dl);
-    hipLaunchKernelGGL(k_bin_heads_pos, dim3(grid_for(Ed)), dim3(BLOCK), 0, e->bs, e->bin_wa, Ed, bbits, ep.n_a, ep.n_b, first_a, first_b, ep.hl, ep.apos);
+    // ---- the tail both ways (dppr_binned.hpp): runs and tiles counted per aligned block of 64 words, scanned, then the tables
+    unsigned long long *cnt_b = e->bin_scan, *x_b = cnt_b + (n_blk + 1), *cnt_a = x_b + (n_blk + 1), *x_a = cnt_a + (n_blk + 1);
+    const int wgrid = std::min(grid_for((long long)(n_blk + 1) * WAVE), 4096);
+    hipLaunchKernelGGL(k_bin_count, dim3(wgrid), dim3(BLOCK), 0, e->bs, e->bin_wb, Ed, cnt_b);
+    hipLaunchKernelGGL(k_bin_count, dim3(wgrid), dim3(BLOCK), 0, e->bs, e->bin_wa, Ed, cnt_a);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(e->bs)); // astart (and the patch's miss count) have arrived
+    {
+        size_t tmp = e->bin_tmp_bytes;
+        HIP_TRY(rocprim::exclusive_scan(e->bin_tmp, tmp, cnt_b, x_b, 0ull, (size_t)n_blk + 1, rocprim::plus<unsigned long long>(), e->bs));
+        tmp = e->bin_tmp_bytes;
+        HIP_TRY(rocprim::exclusive_scan(e->bin_tmp, tmp, cnt_a, x_a, 0ull, (size_t)n_blk + 1, rocprim::plus<unsigned long long>(), e->bs));
+    }
+    unsigned long long totals[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(&totals[0], x_a + n_blk, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->bs));
+    HIP_TRY(hipMemcpyAsync(&totals[1], x_b + n_blk, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->bs));
+    HIP_TRY(hipStreamSynchronize(e->bs)); // the totals (and the patch's miss count) have arrived
     if (patch && e->bin_miss_host != 0) {
         // a retired edge's word was not in the persistent arrays (never on a consistent window): they cannot be trusted -- sort afresh
-        e->bin_words_valid = false;
         e->bin_force_full = true;
         return build_bins(e, ep, nullptr);
     }
+    const int R = (int)(totals[0] >> 32), T = (int)(totals[0] & 0xffffffffull);
+    if (R != (int)(totals[1] >> 32) || T != (int)(totals[1] & 0xffffffffull) || R <= 0 || T <= 0)
+        return fail(e, DPPR_ERR_HIP, "binned tables: the two orders of the window's edges disagree about their runs / tiles");
+    if ((size_t)T + WAVE > ep.tdelta_cap) {
+        (void)hipFree(ep.tdelta);
+        ep.tdelta = nullptr;
+        ep.tdelta_cap = 0;
+        const size_t want = (size_t)T + (size_t)T / 4 + 1024;
+        if (hipMalloc((void **)&ep.tdelta, sizeof(int) * want) != hipSuccess) {
+            (void)hipGetLastError();
+            return DPPR_OK; // (this epoch's sweeps gather; the words were not kept either: the next slide sorts)
+        }
+        ep.tdelta_cap = want;
+    }
+    ep.n_runs = R;
+    ep.n_tiles = T;
+    const int n_rb = (R + WAVE - 1) / WAVE;
+    HIP_TRY(hipMemsetAsync(d_arun, 0xff, sizeof(int) * (size_t)(ep.n_a + 1), e->bs)); // -1: a block without an edge
+    hipLaunchKernelGGL(k_bin_btables, dim3(wgrid), dim3(BLOCK), 0, e->bs, e->bin_wb, Ed, x_b, ep.n_a, abits, ep.dl, ep.vb, e->bin_first);
+    hipLaunchKernelGGL(k_bin_atables, dim3(wgrid), dim3(BLOCK), 0, e->bs, e->bin_wa, Ed, x_a, ep.n_a, bbits, e->bin_first, ep.hl, ep.tdelta, d_arun);
+    int *cnt_r = reinterpret_cast<int *>(cnt_b), *x_r = cnt_r + (n_rb + 1); // (the B-major counts are done with)
+    hipLaunchKernelGGL(k_bin_count16, dim3(std::min(grid_for((long long)(n_rb + 1) * WAVE), 4096)), dim3(BLOCK), 0, e->bs, ep.hl, R, cnt_r);
+    HIP_TRY(hipGetLastError());
+    {
+        size_t tmp = e->bin_tmp_bytes;
+        HIP_TRY(rocprim::exclusive_scan(e->bin_tmp, tmp, cnt_r, x_r, 0, (size_t)n_rb + 1, rocprim::plus<int>(), e->bs));
+    }
+    hipLaunchKernelGGL(k_bin_tb, dim3(grid_for(n_rb + 1)), dim3(BLOCK), 0, e->bs, ep.hl, R, x_r, ep.tb);
+    HIP_TRY(hipGetLastError());
+    // chunks of the A-major run list (a block of many runs is dealt to several workgroups of k_bin_scatter; chunk starts inside a
+    // block are multiples of 64 runs: a wave works on aligned blocks of the tables)
+    std::vector<int32_t> arun((size_t)ep.n_a + 1);
+    HIP_TRY(hipMemcpyAsync(arun.data(), d_arun, sizeof(int) * arun.size(), hipMemcpyDeviceToHost, e->bs));
+    HIP_TRY(hipStreamSynchronize(e->bs));
+    arun[(size_t)ep.n_a] = R;
+    for (int a = ep.n_a - 1; a >= 0; --a)
+        if (arun[(size_t)a] < 0) arun[(size_t)a] = arun[(size_t)a + 1]; // (no edge: an empty range)
+    HIP_TRY(hipMemcpyAsync(d_arun, arun.data(), sizeof(int) * arun.size(), hipMemcpyHostToDevice, e->bs));
+    if (patch) e->bin_patched++; else e->bin_rebuilt++;
     e->bin_words_valid = true;
     e->bin_slides_since_cut++;
     std::vector<BinChunk> chunks;
-    const int csize = (int)std::max<long long>(e->bin_chunk, 64);
+    const int csize = (int)std::max<long long>((e->bin_chunk + WAVE - 1) / WAVE * WAVE, WAVE);
     for (int a = 0; a < ep.n_a; ++a) {
-        const int j0 = astart[(size_t)a], j1 = astart[(size_t)a + 1];
-        const int pieces = (j1 - j0 + csize - 1) / csize; // (a block without an edge: no workgroup)
-        for (int k = 0; k < pieces; ++k) {
-            const long long lo = j0 + (long long)(j1 - j0) * k / pieces, hi = j0 + (long long)(j1 - j0) * (k + 1) / pieces;
-            chunks.push_back(BinChunk{a, (int)lo, (int)hi});
+        const int j0 = arun[(size_t)a], j1 = arun[(size_t)a + 1];
+        for (int lo = j0; lo < j1;) {
+            const int hi = std::min(j1, (lo / WAVE) * WAVE + csize); // (ends on a multiple of 64 unless the block does)
+            chunks.push_back(BinChunk{a, lo, hi});
+            lo = hi;
         }
     }
     ep.n_chunks = (int)chunks.size();
@@ -796,6 +841,7 @@ int build_bins(dppr_engine *e, Epoch &ep, const BinBatch *batch) {
         ep.chunk_cap = chunks.size() + chunks.size() / 4 + 256;
     }
     if (!chunks.empty()) HIP_TRY(hipMemcpy(ep.chunks, chunks.data(), sizeof(BinChunk) * chunks.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipStreamSynchronize(e->bs));
     ep.bin_n_int = NV;
     ep.bin_valid = true;
     return DPPR_OK;

@@ -232,11 +232,11 @@ int run_frontier_loop(dppr_engine *e, Slot &s, const Epoch &ep, int phase, doubl
                 // the sweep as two streaming passes over the epoch's binned edge layout (dppr_binned.hpp)
                 if (ep.n_chunks > 0)
                     hipLaunchKernelGGL(k_bin_scatter, dim3(ep.n_chunks), dim3(BIN_NT), (size_t)e->bin_ha_tiles * WAVE * sizeof(double), e->stream,
-                                       ep.bin_n_int, s.cnt + cur, ep.acut, ep.chunks, ep.hl, ep.apos, s.x, e->bin_vals);
+                                       ep.bin_n_int, s.cnt + cur, ep.acut, ep.chunks, ep.hl, ep.tb, ep.tdelta, ep.n_runs, s.x, e->bin_vals);
                 const int rows_cap = e->bin_hb_tiles * WAVE;
                 hipLaunchKernelGGL(k_bin_reduce, dim3(ep.n_b + (ep.grp_n_int - ep.bin_n_int + rows_cap - 1) / rows_cap), dim3(BIN_NT),
                                    (size_t)rows_cap * 20, e->stream, ep.grp_n_int, ep.bin_n_int, ep.n_b, s.cnt + cur, ep.bcut, rows_cap,
-                                   ep.out_row_ptr, ep.dl, e->bin_vals, s.x,
+                                   ep.out_row_ptr, ep.dl, ep.vb, ep.Ed, e->bin_vals, s.x,
                                    s.x2, s.r, s.p, s.cnt + nxt, s.cnt + zer, phase, eps, s.dstats + 1, log_slot, e->directed ? ep.row_ptr : (const int *)nullptr,
                                    costly ? dsum + nxt : (unsigned long long *)nullptr);
                 std::swap(s.x, s.x2);

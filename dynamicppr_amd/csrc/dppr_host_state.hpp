@@ -56,8 +56,11 @@ struct Epoch {
     BinChunk *chunks = nullptr;           // work items of k_bin_scatter
     size_t chunk_cap = 0;
     int n_chunks = 0;
-    uint16_t *hl = nullptr, *dl = nullptr;
-    int *apos = nullptr;
+    uint16_t *hl = nullptr, *dl = nullptr; // hl: per RUN (A-major), head index + first-of-tile bit; dl: per edge (B-major), row index + first-of-run bit
+    int *vb = nullptr, *tb = nullptr;      // per aligned block of 64 edges: run that holds its first edge; per 64 runs: tile that holds the first run
+    int *tdelta = nullptr;                 // per tile (A-major order): B-major run index - A-major run index of its runs
+    size_t tdelta_cap = 0;
+    int n_runs = 0, n_tiles = 0;
     bool bin_valid = false;
     int bin_n_int = 0; // internal ids the tables cover (<= grp_n_int: later ids have no edge in this epoch)
     // slot table of the resident sweep (dppr_resident.hpp: k_res_slots), rebuilt with every group cut
@@ -160,6 +163,10 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
                                   // `stream`, so calls made one after the other need no cross-stream event; dppr_slide_concurrent runs beside a solver call.
     bool build_concurrent = false; // (builder thread only) the slide in progress may run beside dppr_update / dppr_group_update on an OLDER epoch
     std::mutex err_mu;             // `err` is written by whichever of the two threads fails
+    std::mutex map_mu;             // the id maps and the pending row moves: held by the builder from the first id it assigns to the end of the row
+                                   // moves (dppr_set_batch; the id-assigning head of a slide), and by a reader on the solver thread (dppr_read,
+                                   // dppr_group_read, settle_parked) from its copy of the map to the end of its gathers -- a read beside a
+                                   // concurrent slide sees either the maps and rows of before a revival or those of after it
     unsigned map_gen_on_device = 0; // IdSpace::map_gen the device copy of ext2int was taken at
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t evpool[2 * 64] = {};
@@ -241,13 +248,14 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     long long bin_target_a = 4ll << 20; // ... an A-block (its edges are dealt to workgroups of k_bin_scatter in chunks: large, so that tiles are long runs)
     long long bin_min_ids = 1ll << 19; // (smaller windows run resident or gather: R-MAT window of 2 M edges, ~0.65 M ids, single source: binned 2.66 ms per batch
                                        // against 3.26 gathering; window of 1 M edges, ~0.38 M ids: 2.45 against 1.47 -- tools/r04/midsize_probe.sh)
-    int *bin_vblk_b = nullptr;      // vertex -> B-block (V ints; the A-block of a head is found by bisection, k_bin_keys)
+    int *bin_vblk_a = nullptr;      // vertex -> A-block (V ints; the B-block of a row is found by bisection, k_bin_keys)
+    unsigned long long *bin_scan = nullptr; // counts and scans of the tables' tail (4 x (Ed / 64 + 3) words)
     int *bin_small = nullptr;       // quantile vertices | big rows | counter (bin_cut)
     long long bin_chunk = 32768;    // edges per workgroup of k_bin_scatter
     double *bin_vals = nullptr;     // the values in B-major order: what pass 1 hands to pass 2 (one loop runs at a time)
     // the tables PATCHED per slide (dppr_binned.hpp, round 5): both orders persistent as sorted words under frozen block cuts
     uint64_t *bin_wb = nullptr, *bin_wa = nullptr; // B-major / A-major words of the NEWEST epoch (rotate with keys_a / keys_b at a merge)
-    int *bin_first = nullptr;       // first entry of every block pair in either order: two tables of n_a x n_b ints
+    int *bin_first = nullptr;       // B-major run index of every block pair's first run: n_b x n_a ints (scratch of the tables' tail)
     size_t bin_first_cap = 0;
     std::vector<int32_t> bin_cut_a, bin_cut_b; // the cuts in use (first vertex of every block; frozen between re-cuts, extended by new ids)
     int bin_abits = 0, bin_bbits = 0;   // width of the block-number fields of the words (with room for appended blocks)

@@ -138,7 +138,7 @@ def lib():
     L.dppr_slide_concurrent.argtypes = [vp, ip, ip, C.c_int32, ip]
     L.dppr_renumbering_due.argtypes = [vp]
     u16p = C.POINTER(C.c_uint16)
-    L.dppr_debug_bin_tables.argtypes = [vp, C.c_int32, ip, ip, ip, ip, ip, u16p, ip, u16p, i64p, i64p]
+    L.dppr_debug_bin_tables.argtypes = [vp, C.c_int32, ip, ip, ip, ip, ip, ip, ip, u16p, ip, ip, u16p, ip, i64p, i64p]
     L.dppr_heartbeat.restype = C.c_ulonglong
     for name in EXPORTS:
         if name not in ("dppr_strerror", "dppr_last_error", "dppr_destroy", "dppr_build_id", "dppr_heartbeat"):
@@ -221,20 +221,23 @@ class Engine:
 
     def bin_tables(self, epoch=-1, arrays=True):
         """Test hook: the binned-sweep tables of an epoch (dppr_debug_bin_tables) as a dict; None when the epoch has none."""
-        na, nb, ne, pa, rb = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
-        none16, none32 = C.POINTER(C.c_uint16)(), C.POINTER(C.c_int32)()
-        rc = self._L.dppr_debug_bin_tables(self._h, int(epoch), C.byref(na), C.byref(nb), C.byref(ne), none32, none32, none16, none32, none16, C.byref(pa), C.byref(rb))
+        na, nb, ne, nr, nt, pa, rb = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
+        rc = self._L.dppr_debug_bin_tables(self._h, int(epoch), C.byref(na), C.byref(nb), C.byref(ne), C.byref(nr), C.byref(nt),
+                                           None, None, None, None, None, None, None, C.byref(pa), C.byref(rb))
         out = {"patched": pa.value, "rebuilt": rb.value}
         if rc:
             return None if not arrays else dict(out, valid=False)
-        out.update(valid=True, n_a=na.value, n_b=nb.value, n_edges=ne.value)
+        out.update(valid=True, n_a=na.value, n_b=nb.value, n_edges=ne.value, n_runs=nr.value, n_tiles=nt.value)
         if arrays:
+            n_blk, n_rb = (ne.value + 63) // 64, (nr.value + 63) // 64
             acut, bcut = np.empty(na.value + 1, np.int32), np.empty(nb.value + 1, np.int32)
-            hl, dl, apos = np.empty(max(ne.value, 1), np.uint16), np.empty(max(ne.value, 1), np.uint16), np.empty(max(ne.value, 1), np.int32)
+            hl, dl = np.empty(max(nr.value, 1), np.uint16), np.empty(max(ne.value, 1), np.uint16)
+            tdelta, tb, vb = np.empty(max(nt.value, 1), np.int32), np.empty(n_rb + 1, np.int32), np.empty(n_blk + 1, np.int32)
             i32, u16 = C.POINTER(C.c_int32), C.POINTER(C.c_uint16)
-            self._ck(self._L.dppr_debug_bin_tables(self._h, int(epoch), None, None, None, acut.ctypes.data_as(i32), bcut.ctypes.data_as(i32), hl.ctypes.data_as(u16),
-                                                   apos.ctypes.data_as(i32), dl.ctypes.data_as(u16), None, None), "debug_bin_tables")
-            out.update(acut=acut, bcut=bcut, hl=hl[:ne.value], apos=apos[:ne.value], dl=dl[:ne.value])
+            self._ck(self._L.dppr_debug_bin_tables(self._h, int(epoch), None, None, None, None, None, acut.ctypes.data_as(i32), bcut.ctypes.data_as(i32),
+                                                   hl.ctypes.data_as(u16), tdelta.ctypes.data_as(i32), tb.ctypes.data_as(i32), dl.ctypes.data_as(u16),
+                                                   vb.ctypes.data_as(i32), None, None), "debug_bin_tables")
+            out.update(acut=acut, bcut=bcut, hl=hl[:nr.value], tdelta=tdelta[:nt.value], tb=tb, dl=dl[:ne.value], vb=vb)
         return out
 
     def renumbering_due(self):

@@ -32,8 +32,14 @@ def config_source_pool(key: str, V: int, e1, e2, W: int, directed: int) -> list[
     return [int(x) for x in ids[:n]]
 
 
-def timed_region(run_steps: Callable[[], None], device_sync: Callable[[], None], dist=None):
-    """Barrier + device sync on both sides of ``run_steps``; returns (max-over-ranks seconds, world)."""
+def timed_region(run_steps: Callable[[], None], device_sync: Callable[[], None], dist=None, summed=None):
+    """Barrier + device sync on both sides of ``run_steps``; returns (max-over-ranks seconds, world).
+
+    ``summed`` is None: the seconds are the wall time of the whole bracket (the K steps back to back -- the pre-staged form).
+    ``summed`` is a one-element list: ``run_steps`` alternates an UNTIMED graph update with a timed step per batch, the way the
+    reference's loop does (gpu/PPRGPU.cuh:109-169), and adds every step's own synchronize-to-synchronize bracket to
+    ``summed[0]``; the seconds are then that SUM (MAX over ranks), the barrier pair still encloses the whole run and
+    ``timed_region.last_wall`` holds its wall time (graph updates included; MAX over ranks)."""
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
 
     def fence():
@@ -41,24 +47,32 @@ def timed_region(run_steps: Callable[[], None], device_sync: Callable[[], None],
         if world > 1:
             dist.barrier()
 
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        import torch
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     fence()
     t0 = time.perf_counter()
     run_steps()
     device_sync()
-    timed_region.last_local = time.perf_counter() - t0   # this rank's OWN steps, its device drained, before it waits for the others
-    if world > 1:                                        # (rank_census reports every rank's beside the MAX of the whole bracket)
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    own = time.perf_counter() - t0
+    # this rank's OWN steps, its device drained, before it waits for the others (rank_census reports every rank's beside the MAX)
+    timed_region.last_local = own if summed is None else float(summed[0])
     if world > 1:
-        import torch
-        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    timed_region.last_wall = max_over_ranks(wall)
+    dt = timed_region.last_wall if summed is None else max_over_ranks(float(summed[0]))
     return dt, world
 
 
 timed_region.last_local = 0.0
+timed_region.last_wall = 0.0
 
 
 def rank_census(value_local: float, dist=None):
@@ -85,6 +99,17 @@ def aggregate_units(units_local: int, dist=None) -> int:
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([units_local], dtype=torch.int64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
+def aggregate_min(flag_local: int, dist=None) -> int:
+    """A decision every rank must take the same way (e.g. "is there room for the extra block?"): MIN over ranks."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return int(flag_local)
+    import torch
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([int(flag_local)], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return int(t.item())
 
 

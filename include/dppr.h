@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DPPR_ABI_VERSION 4
+#define DPPR_ABI_VERSION 5
 
 typedef struct dppr_engine dppr_engine; /* opaque */
 
@@ -88,8 +88,8 @@ int dppr_device_count(void);
 /* IncrementalBatchUpdate replays a batch's records tail by tail, each tail's records in batch order (lock-free; the
  * reference serialises them with a spin lock per tail, gpu/StreamUpdate.cuh:50-72), after CopyOutDegree (gpu/StreamUpdate.cuh:7-17).
  * at_slide = 0 (DEFAULT since ABI 4): both run inside dppr_update / dppr_group_update / dppr_incremental_batch_update -- the
- * reference's bracket (gpu/PPRGPU.cuh:138-164 times all of IncrementalBatchUpdate). Up to 16 Ki records the grouping is one
- * ranking launch (k_su_group_rank), beyond that a device radix sort; a whole-batch resident launch takes the records raw and
+ * reference's bracket (gpu/PPRGPU.cuh:138-164 times all of IncrementalBatchUpdate). Up to 4 Ki records (SU_RANK_MAX) the grouping is one
+ * ranking launch (k_su_group_rank), beyond that a stable LDS radix placement on the tail id; a whole-batch resident launch takes the records raw and
  * groups them itself (dppr_resident.hpp). at_slide = 1 (rounds 3-4): the grouping and the degree gather, functions of the batch
  * alone, are done when the batch is uploaded (dppr_slide; for epochs that already exist: on entry to the next call, BEFORE its
  * event bracket opens) and the timed region holds only the replay. Same results bit for bit. */
@@ -401,12 +401,16 @@ int dppr_time_batch_grouping(dppr_engine *e, int32_t epoch, int32_t reps, float 
  * are read racily, which is what a post-mortem wants). No reference counterpart (its loop is host-driven,
  * gpu/PPRRevPushGPU.cuh:106-130, and cannot wait on a device-side barrier). */
 int dppr_debug_dump(dppr_engine *e, char *buf, int32_t cap);
-/* Test hook (ABI 4): the binned-sweep tables of an epoch (dppr_binned.hpp) -- block cuts (n_a + 1 / n_b + 1 first vertices, internal
- * ids), and per edge the head index inside its A-block + B-major position (A-major order) and the row index inside its B-block
- * (B-major order); how many epochs had their tables patched by the slide's merge and how many built by the sorts. Any pointer may
- * be NULL. The patched tables must equal, bit for bit, what the sorts produce under the same cuts (tests/test_binned_tables_gpu.py). */
-int dppr_debug_bin_tables(dppr_engine *e, int32_t epoch, int32_t *n_a, int32_t *n_b, int32_t *n_edges, int32_t *acut, int32_t *bcut,
-                          uint16_t *hl, int32_t *apos, uint16_t *dl, int64_t *patched, int64_t *rebuilt);
+/* Test hook (ABI 5): the binned-sweep tables of an epoch (dppr_binned.hpp) -- block cuts (n_a + 1 / n_b + 1 first vertices, internal
+ * ids); the RUN list in A-major order (n_runs entries: head index inside its A-block, top bit = first run of its tile), per tile
+ * (n_tiles, A-major order) the difference between its runs' B-major and A-major indices, per 64 runs the tile that holds the first of
+ * them (n_runs / 64 + 1 entries, rounded up); the EDGE list in B-major order (n_edges entries: row index inside its B-block, top bit =
+ * first edge of its run) and per 64 edges the run that holds the first of them (n_edges / 64 + 1 entries, rounded up); how many epochs
+ * had their tables patched by the slide's merge and how many built by the sorts. Any pointer may be NULL. The patched tables must
+ * equal, bit for bit, what the sorts produce under the same cuts (tests/test_binned_tables_gpu.py). */
+int dppr_debug_bin_tables(dppr_engine *e, int32_t epoch, int32_t *n_a, int32_t *n_b, int32_t *n_edges, int32_t *n_runs, int32_t *n_tiles,
+                          int32_t *acut, int32_t *bcut, uint16_t *hl, int32_t *tdelta, int32_t *tb, uint16_t *dl, int32_t *vb,
+                          int64_t *patched, int64_t *rebuilt);
 
 /* A counter that advances at every host read-back of a frontier loop and every stage of a graph build (ABI 4): a watchdog
  * samples it so that ONE long call (the first solve on a large window, a group's from-scratch solve) is told from a hang

@@ -32,7 +32,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} declared in include/dppr.h but not exported"
     assert sorted(eng.EXPORTS) == declared_symbols()
-    assert lib.dppr_abi_version() == 4   # 4: grouping inside the timed region by default, dppr_bench_line_fills / _stream_copy, dppr_build_id (round 5)
+    assert lib.dppr_abi_version() == 5   # 5: binned tables as runs + tiles (dppr_debug_bin_tables), map lock for reads beside a concurrent slide (round 6)
     # the library knows which sources it was built from, and says the same as the tree (profiles are stamped with it)
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -1,7 +1,8 @@
 """The binned-sweep tables PATCHED per slide (round 5, VERDICT r04 item 4: "patch the binned tables incrementally instead of two radix
 sorts per epoch"): a slide merges the words of its retired and inserted edges into the two persistent orders of the window's edges
 (k_del_positions + k_merge_tiles, as the CSR's key merge) under block cuts that stay frozen between re-cuts. Bar: after every slide
-the patched tables -- block cuts, head index + B-major position per A-major entry, row index per B-major entry -- equal BIT FOR BIT
+the patched tables -- block cuts, the run list (head index + tile bit) with the per-tile index differences, the edge list (row index + run
+bit) with the per-64 run / tile ordinals -- equal BIT FOR BIT
 what the two sorts produce under the same cuts (DPPR_BIN_FROZEN_REBUILD), on streams whose vertices come and go (new ids extend /
 append blocks), through re-cuts and renumberings; and the sweeps that read them give the synchronous oracle's p / r."""
 import numpy as np
@@ -14,6 +15,22 @@ from tests.test_renumbering_gpu import churn_stream
 pytestmark = pytest.mark.gpu
 SYNC_TOL = 1e-14
 TINY = (2, 1, 1, 64, 0, 64, 64)      # always binned; one-tile blocks of ~64 edges: dozens of A- and B-blocks on these windows
+
+
+def check_tables(t):
+    """What the two passes rely on (dppr_binned.hpp): every run is written by exactly one A-major entry (the destinations
+    j + tdelta[tile of j] are a permutation of the runs), the run bits of the edge list count the runs, and the per-64 tables
+    are the ordinals of the aligned blocks' first entries."""
+    R, T, Ed = t["n_runs"], t["n_tiles"], t["n_edges"]
+    tile_bit, run_bit = (t["hl"] & 0x8000) != 0, (t["dl"] & 0x8000) != 0
+    assert tile_bit[0] and run_bit[0] and int(tile_bit.sum()) == T and int(run_bit.sum()) == R
+    tile_of_run = np.cumsum(tile_bit) - 1
+    dest = np.arange(R) + t["tdelta"][tile_of_run]
+    assert np.array_equal(np.sort(dest), np.arange(R))
+    run_of_edge = np.cumsum(run_bit) - 1
+    assert np.array_equal(t["vb"][:-1], run_of_edge[::64]) and t["vb"][-1] == R - 1
+    assert np.array_equal(t["tb"][:-1], tile_of_run[::64]) and t["tb"][-1] == T - 1
+    assert int((t["hl"] & 0x7fff).max()) < 64 * 272 and int((t["dl"] & 0x7fff).max()) < 64 * 120
 
 
 def make_pair(monkeypatch, V, W, directed, c, recut, renumber):
@@ -55,9 +72,10 @@ def test_patched_tables_equal_the_sorted_ones(monkeypatch, directed, renumber):
         ta, tb = pat.bin_tables(), ref.bin_tables()
         assert ta["valid"] and tb["valid"], k
         assert (ta["n_a"], ta["n_b"], ta["n_edges"]) == (tb["n_a"], tb["n_b"], tb["n_edges"]), k
-        for key in ("acut", "bcut", "hl", "apos", "dl"):
+        assert (ta["n_runs"], ta["n_tiles"]) == (tb["n_runs"], tb["n_tiles"]) and 0 < ta["n_tiles"] <= ta["n_runs"] <= ta["n_edges"], k
+        for key in ("acut", "bcut", "hl", "tdelta", "tb", "dl", "vb"):
             assert np.array_equal(ta[key], tb[key]), (k, key)
-        assert np.array_equal(np.sort(ta["apos"]), np.arange(ta["n_edges"]))     # the B-major positions are a permutation of the edges
+        check_tables(ta)
         grew += int(k > 1 and ta["n_b"] != prev_nb)
         prev_nb = ta["n_b"]
         s.sync_inc_execute(g)

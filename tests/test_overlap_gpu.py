@@ -105,3 +105,56 @@ def test_slide_concurrent_needs_two_epochs():
         e.slide(e1[20:22], e2[20:22], concurrent=True)
     e.slide(e1[20:22], e2[20:22])          # the exclusive form still takes the staged batch
     e.close()
+
+
+@pytest.mark.parametrize("mode", ["single", "group"])
+def test_reads_beside_a_concurrent_slide_see_one_state_of_the_id_space(mode):
+    """dppr_read / dppr_group_read on the solver thread while the builder thread runs dppr_set_batch +
+    dppr_slide_concurrent. A graph update changes no solver state, so -- in the caller's ids -- p and r read DURING it must be what
+    they were before it, also for a parked vertex that the batch revives (its id changes first, its rows move later: the engine
+    holds its map lock from the first id it assigns to the end of the row moves, and a read holds it from its copy of the map to
+    the end of its gathers)."""
+    V, n_stream, batches = 4096, 9000, 40
+    e1, e2 = churn_stream(V, n_stream, 400, 5)
+    W, c, eps, directed = 600, 60, 1e-9, 1
+    stage = staged_batches(V, e1, e2, directed, W, c, batches)
+    g = orc.Graph(V, e1, e2, directed, W, c)
+    sources = [0, 1, 2] if mode == "group" else [0]
+    e = eng.Engine(V, W, directed, c, n_epochs=2, schedule=eng.SCHEDULE_SYNC)
+    e.set_renumbering(1, growth_pct=8, min_parked=8)
+    e.load_window(*g.window_edges())
+    handle = e.add_source_group(sources) if mode == "group" else e.add_source(sources[0])
+    (e.group_init_solve if mode == "group" else e.init_solve)(handle, eps)
+    read = (lambda: e.group_read(handle, len(sources) - 1)) if mode == "group" else (lambda: e.read(handle))
+
+    def build(k, concurrent, box):
+        e.set_batch(*stage[k - 1]["b"])
+        box.append(e.slide(*stage[k - 1]["n"], concurrent=concurrent))
+
+    box = []
+    build(1, False, box)
+    epoch = box[0]
+    reads_beside = revived_beside = 0
+    for k in range(1, batches):
+        (e.group_update if mode == "group" else e.update)(handle, eps, epoch=epoch)
+        p0, r0 = read()
+        box = []
+        if e.renumbering_due():
+            build(k + 1, False, box)               # an exclusive slide: the id space is renumbered (vertices get parked)
+        else:
+            before = e.id_space()["revivals"]
+            th = threading.Thread(target=build, args=(k + 1, True, box))
+            th.start()
+            while True:                            # reads for as long as the builder runs, and one after it
+                alive = th.is_alive()
+                p, r = read()
+                assert np.array_equal(p, p0) and np.array_equal(r, r0), k
+                reads_beside += 1
+                if not alive:
+                    break
+            th.join()
+            revived_beside += e.id_space()["revivals"] - before
+        epoch = box[0]
+    ids = e.id_space()
+    assert reads_beside >= batches and revived_beside >= 1 and ids["renumberings"] >= 1, (reads_beside, revived_beside, ids)
+    e.close()

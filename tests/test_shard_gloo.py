@@ -64,7 +64,18 @@ WORKER = textwrap.dedent("""
     units = shard.aggregate_units(wl.per_batch * steps * len(mine), dist)
     seen, per_rank, backend = shard.rank_census(shard.timed_region.last_local, dist)   # the proof that N ranks ran (bench.py: ranks_seen)
     blocks = shard.line_blocks(rank, w)   # what bench.py's line carries at this rank / world size
-    json.dump(dict(rank=rank, world=w, sources=mine, pool=pool, dt=dt, units=units, seen=seen, per_rank=per_rank, backend=backend, psum=float(sum(s.p.sum() for s in states)), checksum=checksum, blocks=blocks),
+    # the rolling-ring form of the timed region (bench.py default): per batch an UNTIMED graph update, then the timed step in
+    # its own bracket; the seconds are the SUM of the brackets, MAX over ranks; the barrier pair encloses the whole run
+    acc = [0.0]
+    def run_ring():
+        for _ in range(2):
+            time.sleep(0.04)                       # the untimed part
+            t = time.perf_counter()
+            time.sleep(0.03 * (rank + 1))          # the timed step (rank 1 is the slow one)
+            acc[0] += time.perf_counter() - t
+    dt_ring, _ = shard.timed_region(run_ring, lambda: None, dist, summed=acc)
+    ring = dict(dt=dt_ring, wall=shard.timed_region.last_wall, own=shard.timed_region.last_local, ok=shard.aggregate_min(1 if rank == 0 else 0, dist))
+    json.dump(dict(rank=rank, ring=ring, world=w, sources=mine, pool=pool, dt=dt, units=units, seen=seen, per_rank=per_rank, backend=backend, psum=float(sum(s.p.sum() for s in states)), checksum=checksum, blocks=blocks),
               open(os.path.join({out!r}, "rank%d.json" % rank), "w"))
     dist.barrier()
     dist.destroy_process_group()
@@ -95,6 +106,11 @@ def test_two_rank_gloo_run(tmp_path):
     # (a rank's own time ends when ITS steps are done, the bracket at the closing barrier: rank 1 sleeps 0.05 s longer and sets the MAX)
     assert a["per_rank"][1] > a["per_rank"][0] + 0.03 and 0 <= a["dt"] - max(a["per_rank"]) < 0.05
     assert shard.rank_census(1.5) == (1, [1.5], None)
+    # rolling ring: the reported seconds are the slow rank's SUM of brackets (2 x 0.06 s), not the wall (which holds 2 x 0.04 s of untimed work more)
+    ra, rb = a["ring"], b["ring"]
+    assert ra["dt"] == rb["dt"] and 0.12 <= ra["dt"] < 0.16 and abs(rb["own"] - rb["dt"]) < 1e-9 and 0.06 <= ra["own"] < 0.09
+    assert ra["wall"] == rb["wall"] and ra["wall"] >= ra["dt"] + 0.08
+    assert ra["ok"] == rb["ok"] == 0 and shard.aggregate_min(1) == 1        # a decision every rank takes the same way: MIN
     assert a["psum"] != b["psum"]
     assert a["checksum"] == b["checksum"]                   # one stream file, written once
     # the N = 2 line is rank 0's and is as complete as the N = 1 line: parity, roofline and the CPU baseline (only the
