@@ -37,6 +37,9 @@ constexpr int BIN_NT = 1024;   // threads of both passes
 #define DPPR_BIN_U 4           // (8, and a software-pipelined loop, were measured: 3-5 % slower on the twitter stand-in)
 #endif
 constexpr int BIN_U = DPPR_BIN_U; // entries in flight per lane
+#ifndef DPPR_BIN_WHATIF
+#define DPPR_BIN_WHATIF 0 // (timing experiments that compute WRONG results: bit 0 = no LDS atomics in pass 2, bit 1 = no divisor reads, bit 2 = no cross-lane value read)
+#endif
 
 // ---- block cuts (graph build, untimed). A cut is a list of first VERTICES, cut[0] = 0 < ... < cut[n_blocks] = NV; it holds
 // every multiple of the vertex cap, the first vertex behind every `target` edges of the CSR, and both sides of every row
@@ -350,7 +353,7 @@ __device__ __forceinline__ uint64_t lanes_1_to_me() { return (~0ull >> (WAVE - 1
 struct BinChunk {
     int blk, j0, j1;
 };
-__global__ __launch_bounds__(BIN_NT) void k_bin_scatter(int NV, const int *__restrict__ cnt_in, const int *__restrict__ acut,
+__global__ __launch_bounds__(BIN_NT, 8) void k_bin_scatter(int NV, const int *__restrict__ cnt_in, const int *__restrict__ acut,
                                                         const BinChunk *__restrict__ chunks, const uint16_t *__restrict__ hl,
                                                         const int *__restrict__ tb, const int *__restrict__ tdelta, int R,
                                                         const double *__restrict__ x, double *__restrict__ vals) {
@@ -367,18 +370,34 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_scatter(int NV, const int *__res
     const int lane = lane_id();
     const uint64_t below = lanes_1_to_me();
     const int kb1 = (j1 + WAVE - 1) / WAVE;
+    // The tile ordinals of a step's blocks are requested one step AHEAD: the per-tile differences are addressed with them, and two
+    // dependent round trips per step is what a streaming loop of this shape cannot hide (k_bin_reduce: 514 -> 674 us before this)
+    int t0n[BIN_U], t1n[BIN_U];
+#pragma unroll
+    for (int k = 0; k < BIN_U; ++k) {
+        const int kk = __builtin_amdgcn_readfirstlane(j0 / WAVE + wave_id() + k * (BIN_NT / WAVE)); // (wave-uniform: scalar loads, scalar registers)
+        t0n[k] = kk < kb1 ? tb[kk] : 0;
+        t1n[k] = kk < kb1 ? tb[kk + 1] : 0;
+    }
     for (int kb = j0 / WAVE + wave_id(); kb < kb1; kb += (BIN_NT / WAVE) * BIN_U) {
         int hv[BIN_U], td[BIN_U];
 #pragma unroll
         for (int k = 0; k < BIN_U; ++k) {
-            const int kk = __builtin_amdgcn_readfirstlane(kb + k * (BIN_NT / WAVE));
+            const int kk = kb + k * (BIN_NT / WAVE);
             hv[k] = -1;
             td[k] = 0;
             if (kk < kb1) {
                 const int jj = kk * WAVE + lane;
                 if (jj < R) hv[k] = (int)hl[jj];
-                const int t0 = tb[kk], t1 = tb[kk + 1];
-                if (lane <= t1 - t0) td[k] = tdelta[t0 + lane];
+                if (lane <= t1n[k] - t0n[k]) td[k] = tdelta[t0n[k] + lane];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < BIN_U; ++k) { // the next step's ordinals
+            const int kk = __builtin_amdgcn_readfirstlane(kb + (BIN_NT / WAVE) * BIN_U + k * (BIN_NT / WAVE));
+            if (kk < kb1) {
+                t0n[k] = tb[kk];
+                t1n[k] = tb[kk + 1];
             }
         }
 #pragma unroll
@@ -436,7 +455,7 @@ __device__ __forceinline__ double wave_segmented_sum(double x, bool head) {
 // Pass 2: the rows of B-block blockIdx.x. LDS (dynamic): per row accumulator (8) + reciprocal (8) + outdeg + 1 (4).
 // Workgroups beyond the n_b blocks take the rows [NV_bin, NV) in pieces of rows_cap: vertices that received their id after
 // the tables were built (they have no edge in this epoch, but may hold state).
-__global__ __launch_bounds__(BIN_NT) void k_bin_reduce(int NV, int NV_bin, int n_b, const int *__restrict__ cnt_in, const int *__restrict__ bcut,
+__global__ __launch_bounds__(BIN_NT, 8) void k_bin_reduce(int NV, int NV_bin, int n_b, const int *__restrict__ cnt_in, const int *__restrict__ bcut,
                                                        int rows_cap, const int *__restrict__ out_row_ptr,
                                                        const uint16_t *__restrict__ dl, const int *__restrict__ vb, int Ed, const double *__restrict__ vals,
                                                        const double *__restrict__ x, double *__restrict__ x_new,
@@ -482,19 +501,33 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_reduce(int NV, int NV_bin, int n
     const int kb1 = (e1 + WAVE - 1) / WAVE;
     // ALIGNED blocks of 64 edges (vb and the run bits count per aligned block); a wave's lanes hold 64 consecutive entries per k.
     // The two loads of a block are independent: the edge entries, and the <= 64 consecutive values its runs need.
+    int i0n[BIN_U], i1n[BIN_U]; // (requested one step ahead, as k_bin_scatter's tile ordinals)
+#pragma unroll
+    for (int k = 0; k < BIN_U; ++k) {
+        const int kk = __builtin_amdgcn_readfirstlane(e0 / WAVE + w + k * (BIN_NT / WAVE)); // (wave-uniform: scalar loads, scalar registers)
+        i0n[k] = kk < kb1 ? vb[kk] : 0;
+        i1n[k] = kk < kb1 ? vb[kk + 1] : 0;
+    }
     for (int kb = e0 / WAVE + w; kb < kb1; kb += (BIN_NT / WAVE) * BIN_U) {
         double xw[BIN_U];
         int dv[BIN_U];
 #pragma unroll
         for (int k = 0; k < BIN_U; ++k) {
-            const int kk = __builtin_amdgcn_readfirstlane(kb + k * (BIN_NT / WAVE));
+            const int kk = kb + k * (BIN_NT / WAVE);
             xw[k] = 0.0;
             dv[k] = -1;
             if (kk < kb1) {
                 const int qq = kk * WAVE + lane;
                 if (qq < Ed) dv[k] = (int)dl[qq];
-                const int i0 = vb[kk], i1 = vb[kk + 1];
-                if (lane <= i1 - i0) xw[k] = vals[i0 + lane];
+                if (lane <= i1n[k] - i0n[k]) xw[k] = vals[i0n[k] + lane];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < BIN_U; ++k) { // the next step's run ordinals
+            const int kk = __builtin_amdgcn_readfirstlane(kb + (BIN_NT / WAVE) * BIN_U + k * (BIN_NT / WAVE));
+            if (kk < kb1) {
+                i0n[k] = vb[kk];
+                i1n[k] = vb[kk + 1];
             }
         }
 #pragma unroll
@@ -503,7 +536,11 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_reduce(int NV, int NV_bin, int n
             if (kk >= kb1) break; // wave-uniform
             const uint64_t rm = __ballot(dv[k] >= 0 && (dv[k] & BIN_FLAG));
             const int src = __popcll(rm & runs_below); // the lane that loaded this edge's run value
+#if DPPR_BIN_WHATIF & 4
+            const double xv = xw[k] + (double)src * 1e-300;
+#else
             const double xv = __hiloint2double(__shfl(__double2hiint(xw[k]), src, WAVE), __shfl(__double2loint(xw[k]), src, WAVE));
+#endif
             const int qq = kk * WAVE + lane;
             const int rowk = dv[k] & ((1 << BIN_RL) - 1);
             const bool nz = qq >= e0 && qq < e1 && xv != 0.0;
@@ -511,12 +548,20 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_reduce(int NV, int NV_bin, int n
             if (any == 0) continue; // wave-uniform
             edges += (unsigned long long)__popcll(any);
             const int i = nz ? rowk : -1 - lane; // a lane without a term is a run of its own
+#if DPPR_BIN_WHATIF & 2
+            const double t = nz ? push_term(xv, 1024.0, 1.0 / 1024.0) : 0.0;
+#else
             const double t = nz ? push_term(xv, (double)s_den[rowk], s_rcp[rowk]) : 0.0;
+#endif
             // A tile's entries are in (head, row) order: neighbouring lanes hold different rows as a rule (one LDS atomic per lane)
             // -- except in the block of a hub row, where all of them hold the same one: the runs are summed in registers first and
             // cost ONE atomic each (thousands of atomics on one LDS word would serialise).
             const int below = __builtin_amdgcn_update_dpp(-0x7fffffff, i, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
             const bool head = lane == 0 || below != i;
+#if DPPR_BIN_WHATIF & 1
+            if (t == 1.2345e-300) s_acc[0] = t;
+            else
+#endif
             if (__popcll(__ballot(head)) >= 16) { // wave-uniform
                 if (nz) lds_add(&s_acc[i], t);
             } else {

@@ -165,6 +165,8 @@ int dppr_create(dppr_engine **out, int device, int32_t V, int32_t W, int directe
         HIP_TRY_C(hipMalloc((void **)&e->su_k[k], sizeof(uint32_t) * Ln));
         HIP_TRY_C(hipMalloc((void **)&e->su_v[k], sizeof(uint32_t) * Ln));
     }
+    HIP_TRY_C(hipMalloc((void **)&e->su_grp, sizeof(int) * (4 * SU_GRP_MAX_BUCKETS + 8)));
+    HIP_TRY_C(hipMemsetAsync(e->su_grp, 0, sizeof(int) * (4 * SU_GRP_MAX_BUCKETS + 8), e->stream)); // (the ranking launch leaves histogram and cursors cleared for the next batch)
     HIP_TRY_C(hipMalloc((void **)&e->su_term, sizeof(double) * Ln * GS_MAX)); // one term array per source lane of a group
     HIP_TRY_C(hipMalloc((void **)&e->su_ins, Ln));
     HIP_TRY_C(rocprim::radix_sort_pairs(nullptr, e->su_tmp_bytes, e->su_k[0], e->su_k[1], e->su_v[0], e->su_v[1], Ln,
@@ -226,7 +228,7 @@ void dppr_destroy(dppr_engine *e) {
     (void)hipFree(e->in_sorted); (void)hipFree(e->out_sorted); (void)hipFree(e->delpos);
     for (int k = 0; k < 4; ++k) { (void)hipFree(e->bk[k]); (void)hipFree(e->bks[k]); }
     for (int k = 0; k < 2; ++k) { (void)hipFree(e->su_k[k]); (void)hipFree(e->su_v[k]); }
-    (void)hipFree(e->su_term); (void)hipFree(e->su_ins); (void)hipFree(e->su_tmp);
+    (void)hipFree(e->su_term); (void)hipFree(e->su_ins); (void)hipFree(e->su_tmp); (void)hipFree(e->su_grp);
     if (e->pinned) (void)hipHostFree(e->pinned);
     if (e->dump_pin) (void)hipHostFree(e->dump_pin);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -697,20 +699,8 @@ int dppr_time_batch_grouping(dppr_engine *e, int32_t epoch, int32_t reps, float 
     if (L <= 0) return DPPR_OK;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
     int *deg_scratch = reinterpret_cast<int *>(e->su_term);
-    for (int k = 0; k < reps; ++k) {
-        // CopyOutDegree (gpu/StreamUpdate.cuh:7-17) + the stable grouping by tail, into scratch, as group_records_by_tail runs them
-        // inside the timed region (one ranking launch up to SU_RANK_MAX records; degree gather + keys + radix sort beyond)
-        if (L <= SU_RANK_MAX && !e->force_radix_grouping) {
-            hipLaunchKernelGGL(k_su_group_rank, dim3((L + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, ep.b1, L, ep.out_row_ptr, e->su_k[1],
-                               e->su_v[1], deg_scratch, (unsigned long long *)nullptr, 0, (int *)nullptr, 0);
-            continue;
-        }
-        hipLaunchKernelGGL(k_copy_out_degree, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, ep.out_row_ptr, deg_scratch);
-        hipLaunchKernelGGL(k_su_keys, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->su_k[0], e->su_v[0],
-                           (unsigned long long *)nullptr, 0, (int *)nullptr, 0);
-        size_t tmp = e->su_tmp_bytes;
-        HIP_TRY(rocprim::radix_sort_pairs(e->su_tmp, tmp, e->su_k[0], e->su_k[1], e->su_v[0], e->su_v[1], (size_t)L, 0u, (unsigned)e->bits, e->stream));
-    }
+    for (int k = 0; k < reps; ++k) // what group_records_by_tail enqueues inside the timed region, the degrees into scratch
+        if (int rc = enqueue_grouping(e, ep, deg_scratch, nullptr, 0, nullptr, 0)) return rc;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
     HIP_TRY(hipEventSynchronize(e->ev1));

@@ -558,6 +558,11 @@ int bin_prepare(dppr_engine *e, bool *have) { // engine-level scratch, once (ide
     ok = ok && bin_alloc((void **)&e->bin_wb, sizeof(uint64_t) * Edn) && bin_alloc((void **)&e->bin_wa, sizeof(uint64_t) * Edn); // (rotate with keys_a / keys_b: same size)
     if (ok && !e->bin_tmp) {
         HIP_TRY(rocprim::radix_sort_keys(nullptr, e->bin_tmp_bytes, e->keys_a, e->keys_b, Edn, 0u, 64u, e->bs));
+        size_t scan_bytes = 0, scan_bytes32 = 0; // (the scans of the tables' tail share the scratch: sized for whichever needs most)
+        HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr, 0ull, Edn / WAVE + 3,
+                                        rocprim::plus<unsigned long long>(), e->bs));
+        HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes32, (int *)nullptr, (int *)nullptr, 0, Edn / WAVE + 3, rocprim::plus<int>(), e->bs));
+        e->bin_tmp_bytes = std::max(e->bin_tmp_bytes, std::max(scan_bytes, scan_bytes32));
         ok = bin_alloc(&e->bin_tmp, std::max<size_t>(e->bin_tmp_bytes, 16));
     }
     if (!ok) { // out of memory: nothing half-built stays behind, the sweeps of this engine gather (k_pull_iter)
@@ -672,7 +677,7 @@ int build_bins(dppr_engine *e, Epoch &ep, const BinBatch *batch) {
     if (!keep_cuts) {
         if (int rc = bin_cut(e, ep.row_ptr, NV, cap_a, e->bin_target_a, e->bin_cut_a)) return rc;
         if (int rc = bin_cut(e, ep.out_row_ptr, NV, cap_b,
-                             e->bin_target > 0 ? e->bin_target : std::min<long long>(std::max<long long>(Ed / 256, 16384), 196608), e->bin_cut_b)) return rc;
+                             e->bin_target > 0 ? e->bin_target : std::min<long long>(std::max<long long>(Ed / 256, 16384), 393216), e->bin_cut_b)) return rc;
         // fields with room for the blocks that new ids will append before the next re-cut
         const long long ra = (long long)e->bin_cut_a.size() - 1, rb = (long long)e->bin_cut_b.size() - 1;
         e->bin_abits = e->bin_bbits = 1;

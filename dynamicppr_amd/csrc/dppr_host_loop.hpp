@@ -542,29 +542,47 @@ int epoch_group_records(dppr_engine *e, Epoch &ep) {
     return res_record_ranges(e, ep);
 }
 
-int group_records_by_tail(dppr_engine *e, const Epoch &ep, unsigned long long *zero, int nz, int *zero_ints, int nzi) {
+// CopyOutDegree (gpu/StreamUpdate.cuh:7-17; a tail's post-batch out-degree = the length of its row in the epoch's out-CSR, written to
+// `deg`) and the stable grouping of the L records by tail into su_k[1] / su_v[1], as the timed region runs them: ranked in one launch up
+// to SU_RANK_MAX records, bucketed + ranked (three launches, dppr_update.hpp) up to SU_GRP_MAX_RECORDS, the device radix sort beyond.
+int enqueue_grouping(dppr_engine *e, const Epoch &ep, int *deg, unsigned long long *zero, int nz, int *zero_ints, int nzi) {
     const int L = ep.L;
+    if (L <= SU_RANK_MAX && !e->force_radix_grouping) {
+        hipLaunchKernelGGL(k_su_group_rank, dim3((L + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, ep.b1, L, ep.out_row_ptr, e->su_k[1],
+                           e->su_v[1], deg, zero, nz, zero_ints, nzi);
+        HIP_TRY(hipGetLastError());
+        return DPPR_OK;
+    }
+    if (L <= SU_GRP_MAX_RECORDS && !e->force_radix_grouping && e->su_grp) {
+        // hand-written: bucket histogram (+ CopyOutDegree + the counters), unordered scatter into the buckets, ranking inside them:
+        // no library sort between the bracket's events
+        int nb = 64;
+        while (nb < SU_GRP_MAX_BUCKETS && nb * 512 < L) nb *= 2;
+        int *hist = e->su_grp, *cursor = hist + SU_GRP_MAX_BUCKETS, *ctl = cursor + SU_GRP_MAX_BUCKETS;
+        const int wgs = (L + SU_GRP_PER_WG - 1) / SU_GRP_PER_WG;
+        hipLaunchKernelGGL(k_su_grp_hist, dim3(wgs), dim3(BLOCK), 0, e->stream, ep.b1, L, nb, ep.out_row_ptr, deg, hist, zero, nz, zero_ints, nzi);
+        hipLaunchKernelGGL(k_su_grp_scatter, dim3(wgs), dim3(BLOCK), 0, e->stream, ep.b1, L, nb, hist, cursor, ctl, e->su_k[0], e->su_v[0]);
+        hipLaunchKernelGGL(k_su_grp_rank, dim3((L + BLOCK - 1) / BLOCK + nb), dim3(BLOCK), 0, e->stream, e->su_k[0], e->su_v[0], ctl, nb, e->su_k[1],
+                           e->su_v[1], hist, cursor);
+        HIP_TRY(hipGetLastError());
+        return DPPR_OK;
+    }
+    // (batches beyond 4 Mi records, or DPPR_GROUPING_RADIX=1: the device radix sort of rounds 1-5)
+    hipLaunchKernelGGL(k_copy_out_degree, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, ep.out_row_ptr, deg);
+    hipLaunchKernelGGL(k_su_keys, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->su_k[0], e->su_v[0], zero, nz, zero_ints, nzi);
+    size_t tmp = e->su_tmp_bytes;
+    HIP_TRY(rocprim::radix_sort_pairs(e->su_tmp, tmp, e->su_k[0], e->su_k[1], e->su_v[0], e->su_v[1], (size_t)L, 0u, (unsigned)e->bits, e->stream));
+    return DPPR_OK;
+}
+
+int group_records_by_tail(dppr_engine *e, const Epoch &ep, unsigned long long *zero, int nz, int *zero_ints, int nzi) {
     if (ep.grouped) { // only the counters (and the GridBar of a resident launch enqueued ahead) are cleared here
         if (nz > 0 || nzi > 0)
             hipLaunchKernelGGL(k_su_keys, dim3(1), dim3(BLOCK), 0, e->stream, ep.b1, 0, e->su_k[0], e->su_v[0], zero, nz, zero_ints, nzi);
         HIP_TRY(hipGetLastError());
         return DPPR_OK;
     }
-    // inside the timed region (default): CopyOutDegree (gpu/StreamUpdate.cuh:7-17; a tail's post-batch out-degree = the length of
-    // its row in this epoch's out-CSR) and the grouping by tail -- ranked in one launch up to SU_RANK_MAX records, radix-sorted beyond
-    if (L <= SU_RANK_MAX && !e->force_radix_grouping) {
-        hipLaunchKernelGGL(k_su_group_rank, dim3((L + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, e->stream, ep.b1, L, ep.out_row_ptr, e->su_k[1],
-                           e->su_v[1], ep.deg_after, zero, nz, zero_ints, nzi);
-        HIP_TRY(hipGetLastError());
-        return DPPR_OK;
-    }
-    hipLaunchKernelGGL(k_copy_out_degree, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, ep.out_row_ptr, ep.deg_after);
-    hipLaunchKernelGGL(k_su_keys, dim3(grid_for(L)), dim3(BLOCK), 0, e->stream, ep.b1, L, e->su_k[0], e->su_v[0], zero, nz,
-                       zero_ints, nzi);
-    size_t tmp = e->su_tmp_bytes;
-    HIP_TRY(rocprim::radix_sort_pairs(e->su_tmp, tmp, e->su_k[0], e->su_k[1], e->su_v[0], e->su_v[1], (size_t)L, 0u,
-                                      (unsigned)e->bits, e->stream));
-    return DPPR_OK;
+    return enqueue_grouping(e, ep, ep.deg_after, zero, nz, zero_ints, nzi); // inside the timed region (default)
 }
 
 // dppr_set_batch_grouping(1) after epochs were built: their records are grouped now, BEFORE the caller's event bracket opens

@@ -203,6 +203,7 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     uint64_t *keys_a = nullptr, *keys_b = nullptr;
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
+    int *su_grp = nullptr; // hand-written grouping of a large batch (dppr_update.hpp k_su_grp_*): histogram | cursors | bucket starts + slice starts
     // incremental maintenance (f1): batch keys, positions of the retired keys
     uint64_t *bk[4] = {nullptr, nullptr, nullptr, nullptr}; // del-in, ins-in, del-out, ins-out (unsorted)
     uint64_t *bks[4] = {nullptr, nullptr, nullptr, nullptr}; // the same, sorted
@@ -243,7 +244,7 @@ struct dppr_engine : dppr::IdSpace { // (the id maps, the parked zone and the pe
     // binned sweep of single-source loops on windows far beyond the L2s (dppr_binned.hpp, dppr_set_binned_sweep)
     int bin_mode = 1;               // 0: never, 1: when a source slot exists and the window has >= bin_min_ids vertices, 2: always
     int bin_ha_tiles = 128, bin_hb_tiles = 48; // an A-block holds at most 64 x ha_tiles heads (8 B of LDS each), a B-block 64 x hb_tiles rows (20 B each)
-    long long bin_target = 0;       // edges a B-block is cut for (one workgroup of k_bin_reduce); 0: from the window, clamp(Ed / 256, 16 K, 192 K)
+    long long bin_target = 0;       // edges a B-block is cut for (one workgroup of k_bin_reduce); 0: from the window, clamp(Ed / 256, 16 K, 384 K)
                                     // (measured: LiveJournal stand-in best at 16-32 K, twitter / friendster at 192 K)
     long long bin_target_a = 4ll << 20; // ... an A-block (its edges are dealt to workgroups of k_bin_scatter in chunks: large, so that tiles are long runs)
     long long bin_min_ids = 1ll << 19; // (smaller windows run resident or gather: R-MAT window of 2 M edges, ~0.65 M ids, single source: binned 2.66 ms per batch

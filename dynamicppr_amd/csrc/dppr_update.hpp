@@ -104,6 +104,141 @@ __global__ __launch_bounds__(BLOCK) void k_su_group_rank(const int *__restrict__
     }
 }
 
+// ---- The grouping of LARGER batches inside the timed region, without a library sort (round 6; rounds 1-5:
+// rocprim::radix_sort_pairs -- a block sort and eight merge launches for the headline's 138 K records). Three launches:
+//   k_su_grp_hist    : histogram of the tails' LOW bits (nb <= 4 096 buckets; LDS per workgroup, one global add
+//                      per workgroup and occupied bucket) + CopyOutDegree + the loop's counters cleared;
+//   k_su_grp_scatter : every workgroup scans the nb counts itself (no scan launch), claims room for its 2 048 records per bucket
+//                      with one atomic each and writes (tail, index) pairs into the buckets -- in NO particular order inside one;
+//   k_su_grp_rank    : one workgroup per 256 records of a bucket: record i goes to  bucket start + #{j in the bucket :
+//                      (tail_j, j) < (tail_i, i)} -- k_su_group_rank's rule inside a bucket, the pairs passing through LDS in tiles.
+// The result is a stable GROUPING by tail: every tail's records side by side in batch order, tails ascending inside a bucket (that is all
+// IncrementalBatchUpdate and the seeding need: leaders are found by comparing neighbours). The LOW bits pick the bucket on purpose: ids are
+// numbered by falling in-degree (dppr_idspace.hpp), and the id range of the first high-bit bucket owned a third of a twitter-size batch's
+// records -- 39 ms of ranking. Work per thread of the last launch = the size of its bucket (a few hundred records; a hub tail's thousands
+// at most; a batch whose records all share ONE tail degenerates to L comparisons per thread -- bounded, never seen).
+constexpr int SU_GRP_MAX_BUCKETS = 4096, SU_GRP_PER_WG = 2048, SU_GRP_TILE = 2048, SU_GRP_MAX_RECORDS = 1 << 22;
+__global__ __launch_bounds__(BLOCK) void k_su_grp_hist(const int *__restrict__ e1, int L, int nb, const int *__restrict__ out_row_ptr,
+                                                      int *__restrict__ deg_after, int *__restrict__ hist, unsigned long long *__restrict__ zero, int nz,
+                                                      int *__restrict__ zero_ints, int nzi) {
+    __shared__ int s_h[SU_GRP_MAX_BUCKETS];
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < nz; i += BLOCK) zero[i] = 0ull;
+        for (int i = threadIdx.x; i < nzi; i += BLOCK) zero_ints[i] = 0;
+    }
+    for (int k = threadIdx.x; k < nb; k += BLOCK) s_h[k] = 0;
+    __syncthreads();
+    const int i0 = blockIdx.x * SU_GRP_PER_WG, i1 = min(i0 + SU_GRP_PER_WG, L);
+    for (int i = i0 + threadIdx.x; i < i1; i += BLOCK) {
+        const int t = e1[i];
+        deg_after[i] = out_row_ptr[t + 1] - out_row_ptr[t]; // CopyOutDegree (gpu/StreamUpdate.cuh:7-17)
+        atomicAdd(&s_h[t & (nb - 1)], 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nb; k += BLOCK)
+        if (s_h[k]) atomicAdd(&hist[k], s_h[k]);
+}
+// ctl: [0, nb] bucket starts, [nb + 1, 2 nb + 1] first slice (256 records) of every bucket, written by workgroup 0 for the ranking launch
+__global__ __launch_bounds__(BLOCK) void k_su_grp_scatter(const int *__restrict__ e1, int L, int nb, const int *__restrict__ hist,
+                                                         int *__restrict__ cursor, int *__restrict__ ctl, uint32_t *__restrict__ tk,
+                                                         uint32_t *__restrict__ tv) {
+    __shared__ int s_start[SU_GRP_MAX_BUCKETS], s_cnt[SU_GRP_MAX_BUCKETS];
+    __shared__ int s_wsum[WAVES_PER_BLOCK], s_wsl[WAVES_PER_BLOCK];
+    const int lane = lane_id(), w = wave_id();
+    // exclusive scan of the nb counts (and of their slice counts): each thread owns nb / BLOCK consecutive buckets
+    const int per = (nb + BLOCK - 1) / BLOCK;
+    int mine = 0, mine_sl = 0;
+    for (int k = 0; k < per; ++k) {
+        const int b = threadIdx.x * per + k;
+        const int c = b < nb ? hist[b] : 0;
+        mine += c;
+        mine_sl += (c + BLOCK - 1) / BLOCK;
+    }
+    const int inc = wave_inclusive_scan(mine), inc_sl = wave_inclusive_scan(mine_sl);
+    if (lane == WAVE - 1) {
+        s_wsum[w] = inc;
+        s_wsl[w] = inc_sl;
+    }
+    __syncthreads();
+    int run = inc - mine, run_sl = inc_sl - mine_sl;
+    for (int k = 0; k < w; ++k) {
+        run += s_wsum[k];
+        run_sl += s_wsl[k];
+    }
+    for (int k = 0; k < per; ++k) {
+        const int b = threadIdx.x * per + k;
+        if (b < nb) {
+            const int c = hist[b];
+            s_start[b] = run;
+            s_cnt[b] = 0;
+            if (blockIdx.x == 0) {
+                ctl[b] = run;
+                ctl[nb + 1 + b] = run_sl;
+            }
+            run += c;
+            run_sl += (c + BLOCK - 1) / BLOCK;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == BLOCK - 1) {
+        ctl[nb] = run; // (= L)
+        ctl[2 * nb + 1] = run_sl;
+    }
+    __syncthreads();
+    // this workgroup's records: count per bucket, one global claim per occupied bucket, then the placements
+    const int i0 = blockIdx.x * SU_GRP_PER_WG, i1 = min(i0 + SU_GRP_PER_WG, L);
+    for (int i = i0 + threadIdx.x; i < i1; i += BLOCK) atomicAdd(&s_cnt[e1[i] & (nb - 1)], 1);
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += BLOCK) {
+        const int c = s_cnt[b];
+        if (c) s_start[b] += atomicAdd(&cursor[b], c);
+        s_cnt[b] = 0;
+    }
+    __syncthreads();
+    for (int i = i0 + threadIdx.x; i < i1; i += BLOCK) {
+        const int t = e1[i], b = t & (nb - 1);
+        const int pos = s_start[b] + atomicAdd(&s_cnt[b], 1);
+        tk[pos] = (uint32_t)t;
+        tv[pos] = (uint32_t)i;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_su_grp_rank(const uint32_t *__restrict__ tk, const uint32_t *__restrict__ tv, const int *__restrict__ ctl, int nb,
+                                                      uint32_t *__restrict__ skeys, uint32_t *__restrict__ svals, int *__restrict__ hist,
+                                                      int *__restrict__ cursor) {
+    __shared__ unsigned long long s_key[SU_GRP_TILE];
+    const int *bstart = ctl, *sstart = ctl + nb + 1;
+    const int wg = blockIdx.x;
+    if (wg >= sstart[nb]) return; // (the grid is the upper bound L / 256 + nb)
+    int lo = 0, hi = nb; // the bucket of this slice: the LAST bucket whose first slice is <= wg (empty buckets share their successor's)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (sstart[mid] <= wg) lo = mid; else hi = mid;
+    }
+    const int b = lo, base = bstart[b], n = bstart[b + 1] - base;
+    const int i = (wg - sstart[b]) * BLOCK + (int)threadIdx.x;
+    const unsigned long long me = i < n ? ((unsigned long long)tk[base + i] << 32) | tv[base + i] : ~0ull;
+    int rank = 0;
+    for (int j0 = 0; j0 < n; j0 += SU_GRP_TILE) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < SU_GRP_TILE; k += BLOCK)
+            s_key[k] = j0 + k < n ? ((unsigned long long)tk[base + j0 + k] << 32) | tv[base + j0 + k] : ~0ull; // (padding ranks behind every record)
+        __syncthreads();
+        const int m = min(SU_GRP_TILE, n - j0);
+        int k = 0;
+        for (; k + 3 < m; k += 4)
+            rank += (s_key[k] < me ? 1 : 0) + (s_key[k + 1] < me ? 1 : 0) + (s_key[k + 2] < me ? 1 : 0) + (s_key[k + 3] < me ? 1 : 0);
+        for (; k < m; ++k) rank += s_key[k] < me ? 1 : 0;
+    }
+    if (i < n) {
+        skeys[base + rank] = (uint32_t)(me >> 32);
+        svals[base + rank] = (uint32_t)me;
+    }
+    // the counters of the NEXT batch's first two launches (this launch reads neither): cleared by the slices of bucket 0 .. nb / 256
+    if (wg * BLOCK + (int)threadIdx.x < nb) {
+        hist[wg * BLOCK + threadIdx.x] = 0;
+        cursor[wg * BLOCK + threadIdx.x] = 0;
+    }
+}
+
 // CopyOutDegree for the larger batches (the radix-sort path): post-batch out-degree of every record's tail from the epoch's out-CSR
 __global__ __launch_bounds__(BLOCK) void k_copy_out_degree(const int *__restrict__ e1, int L, const int *__restrict__ out_row_ptr,
                                                           int *__restrict__ deg_after) {

@@ -457,6 +457,10 @@ protected:
         std::cout << "edge_num " << cur_edge_num << std::endl;
         std::cout << "ppr_latency " << (solves > 0 ? t / solves : 0) << std::endl;
         std::cout << "ppr_throughput " << cur_edge_num / t * 1000.0 << std::endl;
+        // which loop produced the two figures above: with the graph of batch k + 1 built BESIDE the solve of batch k the
+        // builder shares the device with the timed region, and ppr_latency comes out a few per cent above the serial loop's
+        // (DPPR_NO_OVERLAP=1: the reference's loop shape, what tools/sweep.py and bench.py measure)
+        std::cout << "graph_update " << (overlap_ ? "overlapped" : "serial") << std::endl;
     }
     bool quiet_;
 };

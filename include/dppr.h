@@ -184,13 +184,14 @@ int dppr_set_sweep_bitmap(dppr_engine *e, int on);
  *                  an id, 2 always (tests: tiny windows)
  *   ha_tiles     : an A-block holds at most 64 x ha_tiles heads (8 bytes of LDS per head; 0 keeps the default, 128)
  *   hb_tiles     : a B-block holds at most 64 x hb_tiles rows (20 bytes of LDS per row; 0 keeps 48)
- *   target_edges : edges a B-block is cut for (0 keeps the automatic choice, clamp(window edges / 256, 16 Ki, 192 Ki)); a row of a
- *                  quarter of that is a block of its own
+ *   target_edges : edges a B-block is cut for (0 keeps the automatic choice, clamp(window edges / 256, 16 Ki, 384 Ki): twitter stand-in,
+ *                  single source, 192 Ki / 384 Ki / 768 Ki: 74.6 / 70.2 / 77.7 ms per batch); a row of a quarter of that is a block of its own
  *   min_ids      : mode 1 threshold (0 keeps 1 Mi vertices with an id: smaller windows run resident or cannot fill the chip with blocks)
  *   chunk_edges  : edges per workgroup of k_bin_scatter (0 keeps 32768)
  *   target_a_edges : edges an A-block is cut for (0 keeps 4 Mi: large, the longer the runs a tile's values are written in)
- * The layout costs 8 bytes per window edge and epoch plus 32 bytes per window edge of engine state (the values of pass 1, and both
- * orders of the window's edges as sorted words), and is built in dppr_load_window and PATCHED by dppr_slide (untimed, like the CSRs):
+ * The layout costs at most 4 bytes per window edge and epoch (2 per edge + 2 per run + 4 per tile) plus 32 bytes per window edge of engine
+ * state (the values of pass 1, and both orders of the window's edges as sorted words), and is built in dppr_load_window and PATCHED by
+ * dppr_slide (untimed, like the CSRs):
  * a slide merges the words of its retired and inserted edges into the two orders instead of sorting the window twice; the block
  * cuts are renewed every 32 slides (DPPR_BIN_RECUT_EVERY; DPPR_BIN_INCREMENTAL=0: the sorts every epoch). Only valid right after dppr_create. */
 int dppr_set_binned_sweep(dppr_engine *e, int mode, int ha_tiles, int hb_tiles, int64_t target_edges, int64_t min_ids,

@@ -44,7 +44,8 @@ def cut(trace_csv, stats_csv, outdir):
     # device sort). The k_su_keys of a slide-time grouping belongs to the SLIDE and is not a mark.
     # With the update applied inside the resident launch (PLAN_UPDATE) a batch is k_su_keys (counter clear) -> k_pull_resident.
     # Round 5 (grouping and CopyOutDegree inside the timed region by default): a batch starts at k_su_group_rank (one launch: degrees,
-    # grouping, counter clear) or, beyond 16 K records, at k_copy_out_degree -> k_su_keys -> device sort.
+    # grouping, counter clear) or, beyond 4 Ki records, at k_su_grp_hist -> k_su_grp_scatter -> k_su_grp_rank (round 6; rounds 1-5 and
+    # DPPR_GROUPING_RADIX=1: k_copy_out_degree -> k_su_keys -> device sort).
     marks = []
     for i, (n, _, _) in enumerate(ev):
         if n == "k_su_keys" and i + 1 < len(ev) and ev[i + 1][0].startswith("k_pull_resident"):
@@ -58,6 +59,9 @@ def cut(trace_csv, stats_csv, outdir):
         if j >= 0 and ev[j][0] == "k_su_group_rank":
             marks.append(j)
             continue
+        if j >= 2 and ev[j][0] == "k_su_grp_rank" and ev[j - 1][0] == "k_su_grp_scatter" and ev[j - 2][0] == "k_su_grp_hist":
+            marks.append(j - 2)   # round 6: the hand-written grouping of a batch beyond 4 Ki records (its first launch also does CopyOutDegree)
+            continue
         if j >= 0 and ev[j][0] == "k_su_keys":
             marks.append(j - 1 if j >= 1 and ev[j - 1][0] == "k_copy_out_degree" else j)
             continue
@@ -65,7 +69,7 @@ def cut(trace_csv, stats_csv, outdir):
     batches = [(marks[i], marks[i + 1]) for i in range(len(marks) - 1)]
     spans = []
     slide_kernels = ("k_make", "k_deg", "k_mark", "k_del_pos", "k_merge_tiles", "k_build", "k_assign", "k_tile", "k_gather_deg", "k_gtables", "k_bin_keys", "k_bin_fill", "k_bin_vertex",
-                     "k_bin_quant", "k_bin_big", "k_in_degree", "k_number", "k_live", "k_remap", "k_permute", "k_rows", "k_res_")
+                     "k_bin_quant", "k_bin_big", "k_bin_count", "k_bin_btables", "k_bin_atables", "k_bin_tb", "k_bin_swap", "k_bin_group", "k_in_degree", "k_number", "k_live", "k_remap", "k_permute", "k_rows", "k_res_")
     for lo, hi in batches:                                                       # a batch ends where the next slide's kernels begin
         seg = []
         for x in ev[lo:hi]:
@@ -168,18 +172,26 @@ def check(directory):
             print(f"FAIL {tag}: roofline.frac {roof['frac']:.3f} in {os.path.basename(b_path)}, {frac_csv:.3f} from {os.path.basename(st_path)} "
                   f"({roof['algorithmic_bytes_per_launch'] / 1e6:.1f} MB per launch / {avg_ns / 1e3:.1f} us)")
             bad += 1
+        # Round 6 on: the algorithmic bytes are priced for the form that ran (a pull form performs no residual RMW
+        # per edge), so that they do not exceed what the counters saw: frac <= 1.1 x frac_traffic wherever a counter profile exists
+        if int(rnd[1:]) >= 6 and roof.get("frac_traffic") is not None and roof["frac"] > 1.1 * roof["frac_traffic"]:
+            print(f"FAIL {tag}: roofline.frac {roof['frac']:.3f} exceeds 1.1 x frac_traffic {roof['frac_traffic']:.3f}: the byte model claims more than the counters saw")
+            bad += 1
         del per
     # Round 5 on: the artefacts say which build of the library produced them (profiles/rNN_manifest.json, tools/r05/manifest.py).
     # A kernel change without a re-capture must not go unnoticed: the tree's build id (tools/build_id.py) has to be the manifest's,
     # every bench line and counter summary has to carry it, and every stamped kind of artefact has to be listed.
     stamped = 0
-    for m_path in sorted(glob.glob(os.path.join(directory, "r*_manifest.json"))):
+    manifests = sorted(glob.glob(os.path.join(directory, "r*_manifest.json")))
+    for m_path in manifests:
         rnd = os.path.basename(m_path).split("_")[0]
         man = json.load(open(m_path))
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         import build_id as _bid
         real_profiles = os.path.abspath(directory) == os.path.join(_bid.ROOT, "profiles")
-        if real_profiles and man.get("build_id") != _bid.tree_build_id():
+        # (the NEWEST round's manifest is the one the tree has to match; an older round's artefacts stay what they were captured on --
+        # they are still held to their own manifest below)
+        if real_profiles and m_path == manifests[-1] and man.get("build_id") != _bid.tree_build_id():
             print(f"FAIL {os.path.basename(m_path)}: captured on build {man.get('build_id')}, the tree is build {_bid.tree_build_id()} -- "
                   f"kernel / engine sources changed after the capture: re-capture (tools/{rnd}/capture.sh) or revert")
             bad += 1
