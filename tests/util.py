@@ -11,7 +11,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def golden_names():
     names = (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return sorted(n for n in names if not n.startswith(("tools_", "fullsize_")))   # tools_*: offline data tools; fullsize_*: tests/test_fullsize_golden_gpu.py
+    return sorted(n for n in names if not n.startswith(("tools_", "fullsize_", "bench_")))   # tools_*: offline data tools; fullsize_*: tests/test_fullsize_golden_gpu.py; bench_*: bench.py + tests/test_bench_golden.py
 
 
 def load_golden(name):
