@@ -187,7 +187,7 @@ int dppr_set_sweep_bitmap(dppr_engine *e, int on);
  *   target_edges : edges a B-block is cut for (0 keeps the automatic choice, clamp(window edges / 256, 16 Ki, 384 Ki): twitter stand-in,
  *                  single source, 192 Ki / 384 Ki / 768 Ki: 74.6 / 70.2 / 77.7 ms per batch); a row of a quarter of that is a block of its own
  *   min_ids      : mode 1 threshold (0 keeps 1 Mi vertices with an id: smaller windows run resident or cannot fill the chip with blocks)
- *   chunk_edges  : edges per workgroup of k_bin_scatter (0 keeps 32768)
+ *   chunk_edges  : runs (one head into one B-block: the unit x[u] travels in since ABI 5) per workgroup of k_bin_scatter (0 keeps 32768)
  *   target_a_edges : edges an A-block is cut for (0 keeps 4 Mi: large, the longer the runs a tile's values are written in)
  * The layout costs at most 4 bytes per window edge and epoch (2 per edge + 2 per run + 4 per tile) plus 32 bytes per window edge of engine
  * state (the values of pass 1, and both orders of the window's edges as sorted words), and is built in dppr_load_window and PATCHED by
@@ -228,7 +228,11 @@ int dppr_slide(dppr_engine *e, const int32_t *new_e1, const int32_t *new_e2, int
  * entry of epoch k + 1 - n_epochs, which nothing may still be solving on). The builder works on its own HIP stream and scratch;
  * what it shares with the solver are the state rows of vertices that are NEW or REVIVED in batch k + 1, which no older epoch
  * touches. Such a slide never renumbers the id space and never grows the resident-launch arena: when dppr_renumbering_due(e)
- * says so, make the next graph update an exclusive dppr_slide (after the solver call has returned). Same results. */
+ * says so, make the next graph update an exclusive dppr_slide (after the solver call has returned). Same results.
+ * dppr_read / dppr_group_read beside the builder (ABI 5): the engine holds its id-map lock from the first id a batch assigns or revives
+ * to the end of the row moves that go with it, and a read holds it from its copy of the map to the end of its gathers -- a read sees
+ * the id space of before a revival or of after it, never a mixture (it may wait for the builder's id-assigning head, never for the
+ * graph build itself). */
 int dppr_slide_concurrent(dppr_engine *e, const int32_t *new_e1, const int32_t *new_e2, int32_t c, int32_t *out_epoch);
 int dppr_renumbering_due(const dppr_engine *e);
 
