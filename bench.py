@@ -46,7 +46,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH
 HBM_ACHIEVABLE_GBPS = 6300.0  # ... and what a streaming copy reaches there ("~6.3 TB/s achievable")
 NORTH_STAR_TOL = 1e-9   # BASELINE.json: "within the repo's 1e-9 tolerance"
 RING = 3                # graph epochs resident in HBM on the rolling ring (the one being solved, the one built last, one spare)
-BIG_WINDOW = 4_000_000  # stream edges in the window from which two sources per GPU are solved one after the other (binned sweeps)
+BIG_WINDOW = 4_000_000  # stream edges in the window from which a few sources per GPU are solved one after the other (binned sweeps)
+SERIES_MAX = 3          # ... up to this many sources per GPU (beyond: one source group)
 
 # per config: (sources per GPU, how they are picked). The 8-GPU configurations of BASELINE.json (twitter: 8 top-10 sources,
 # friendster: the 10 sources of a top1000 file) are FIXED source sets dealt round-robin over the ranks (0 = "the config's own
@@ -203,6 +204,8 @@ def strong_block(a, ctx):
         ok_here = int(psutil.virtual_memory().available >= (6 << 30) * ctx.world)   # (one node: every rank sees the same pool)
     except Exception:  # noqa: BLE001
         pass
+    if ctx.world > shard.CONFIG_SOURCE_SETS["twitter"][0]:
+        return {"skipped": f"more ranks ({ctx.world}) than the configuration has sources"} if ctx.rank == 0 else None
     ok_all = shard.aggregate_min(ok_here, ctx.dist)
     if not ok_all:
         return {"skipped": "not enough host memory for every rank's copy of the stream prefix (about 6 GB per rank)"} if ctx.rank == 0 else None
@@ -300,10 +303,12 @@ def run_workload(a, ctx):
     tune = {kv.split("=")[0]: (tuple(int(x) for x in kv.split("=")[1].split(",")) if "," in kv else int(kv.split("=")[1])) for kv in a.tune}
     if "merge_phases" in tune:
         a.no_merged = True   # (the whole run is on the merged loop: tuning / A-B runs)
-    # Two sources on a window whose single-source path runs binned sweeps are cheaper one after the other than as a group (a group's
-    # sweep costs about the same for 2 as for 8 sources: twitter stand-in 279 ms against 2 x 91, friendster 494 against 2 x 185;
-    # from 3 sources on the group wins) -- what a rank of the 8-GPU deals of configs[3] / [4] holds
-    pair_as_singles = S == 2 and W >= BIG_WINDOW and not a.force_group
+    # Two or three sources on a window whose single-source path runs binned sweeps are cheaper one after the other than as a group (a
+    # group's sweep costs about the same for 2 as for 8 sources). Measured per batch on one MI355X (tools/r06/rank_loads.sh): twitter stand-in
+    # 1 / 2 in series / 4 as a group / 8 as a group: 69.8 / 133.3 / 212.6 / 245 ms; friendster 1 / 2 in series / 3 as a group / 5 / 10 as a
+    # group: 99.9 / 206.5 / 421.7 / 496.5 / 531 ms -- three friendster sources in series would take 3 x 100, so up to THREE go in series
+    # (twitter: 3 x 70 = a group of 3-4; from 4 on the group wins) -- what a rank of the 8-GPU deals of configs[3] / [4] holds
+    pair_as_singles = 2 <= S <= SERIES_MAX and W >= BIG_WINDOW and not a.force_group
     as_group = S > 1 and not pair_as_singles
 
     # ---------------- the epochs resident in HBM: a rolling ring (default) or every epoch of the run (--prestage) ----------------
@@ -320,8 +325,9 @@ def run_workload(a, ctx):
     if a.hbm_limit_gb is not None:
         free0 = min(free0, int(a.hbm_limit_gb * 1e9))
     share = max(1, -(-world // ctx.ndev))   # ranks sharing this device (a smoke run of the N > 1 path on a small node)
-    if plan["plan_bytes"] * share > 0.94 * free0:
-        sys.exit(f"bench.py: HBM plan does not fit: {plan['plan_bytes'] / 1e9:.1f} GB per rank ({n_resident} resident epochs x "
+    fits = plan["plan_bytes"] * share <= 0.94 * free0
+    if not shard.aggregate_min(int(fits), D):   # (every rank takes the same decision: a refusal on one device must not leave the others at a barrier)
+        sys.exit(("" if not fits else f"[rank {rank}] another rank's plan does not fit; this rank's would: ") + f"bench.py: HBM plan does not fit: {plan['plan_bytes'] / 1e9:.1f} GB per rank ({n_resident} resident epochs x "
                  f"{plan['epoch_bytes'] / 1e9:.2f} GB + engine {plan['engine_bytes'] / 1e9:.1f} GB + source state "
                  f"{plan['source_state_bytes'] / 1e9:.1f} GB) x {share} rank(s) on this device against {free0 / 1e9:.1f} GB free of "
                  f"{total_hbm / 1e9:.1f} GB" + ("; drop --prestage (rolling ring of 3 epochs)" if a.prestage else ""))
@@ -566,7 +572,7 @@ def run_workload(a, ctx):
                                    + (f"the configuration's {total_sources} sources" if scaling == "strong" else f"{S} source(s) per GPU")
                                    + f" from degree ranks {'[10,1000) (a top1000 file)' if pick == 'top1000' else '[0,10) (the top10 file)'}"
                                    + (f", dealt round-robin over {world} GPU(s)" if scaling == "strong" else "")
-                                   + (", a GPU's two sources solved one after the other (single-source path)" if pair_as_singles else
+                                   + (f", a GPU's {S} sources solved one after the other (single-source path)" if pair_as_singles else
                                       ", a GPU's sources streamed together as one source group over one graph replica" if S > 1 else ""),
                        "V": V, "stream_edges": int(stream_len), "window": W, "batch_c": c, "records_L": L,
                        "sources": sources, "schedule": a.schedule,
@@ -782,7 +788,7 @@ class SingleSolver:
 
 
 class PairSolver:
-    """Two sources on the single-source path, one after the other, over the same pre-staged epochs."""
+    """Two or three sources on the single-source path, one after the other, over the same resident epochs."""
 
     def __init__(self, e, sources):
         self.e, self.parts = e, [SingleSolver(e, s) for s in sources]
@@ -801,8 +807,8 @@ class PairSolver:
             p.begin_timed()
 
     def stats(self):
-        a, b = (p.stats() for p in self.parts)
-        return {k: a[k] + b[k] for k in a}
+        every = [p.stats() for p in self.parts]
+        return {k: sum(st[k] for st in every) for k in every[0]}
 
     def profile(self, eps, stage, k0, n):
         return self.parts[0].profile(eps, stage, k0, n)   # (the kernel is the same for both: the first source follows the further batches)

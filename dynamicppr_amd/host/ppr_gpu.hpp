@@ -95,9 +95,9 @@ public:
         // several sources on one device are solved together, up to 16 per group (multi-source batched
         // sweeps); --split keeps the reference's one-source-at-a-time driver flow
         use_groups = source_vertex_ids.size() > 1 && !gSplitInterface && !gNoGroups;
-        // two sources on a large window: one after the other on the single-source path (binned sweeps) beats a group, whose sweep
-        // costs about the same for 2 as for 8 sources (twitter stand-in 279 ms against 2 x 91, friendster 494 against 2 x 185)
-        if (use_groups && source_vertex_ids.size() == 2 && graph->sliding_window_size >= 4000000) use_groups = false;
+        // two or three sources on a large window: one after the other on the single-source path (binned sweeps) beats a group, whose
+        // sweep costs about the same for 2 as for 8 sources (friendster stand-in, 3 sources: 422 ms per batch as a group, 3 x 100 in series)
+        if (use_groups && source_vertex_ids.size() <= 3 && graph->sliding_window_size >= 4000000) use_groups = false;
         if (gProfile) DPPR_CHECK(engine, dppr_set_profiling(engine, 1));
         if (!quiet_) std::cout << "start..." << std::endl;
         if (use_groups) {
