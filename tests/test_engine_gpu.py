@@ -163,12 +163,17 @@ def test_incremental_batch_update_hub_tail_many_records():
     assert np.array_equal(r, sc.s.r)
 
 
+@pytest.mark.parametrize("grouping", ["hand-written", "device-radix-sort"])
 @pytest.mark.parametrize("shape", ["group-beyond-lds-window", "more-records-than-one-grid-pass", "hub-tail-in-a-large-batch"])
-def test_incremental_batch_update_large_batches(shape):
+def test_incremental_batch_update_large_batches(shape, grouping, monkeypatch):
     """k_su_apply_fused stages 1024 sorted records per workgroup in LDS: a tail group longer than the window finishes
     from global memory. From 65 536 records on, the terms of all records are computed in parallel first and the group leaders
     walk contiguous arrays (k_su_terms + k_su_apply: a hub's tail owns thousands of records there), over several grid
-    passes -- all still bit-identical to the CPU order."""
+    passes -- all still bit-identical to the CPU order. The records of these batches (12 000 / 540 000 / 120 000) are grouped inside the
+    call by the hand-written bucket + rank kernels (round 6: k_su_grp_hist / _scatter / _rank; a hub tail of 36 000 records sits in ONE
+    bucket) or -- the fallback for batches beyond 4 Mi records, DPPR_GROUPING_RADIX=1 -- by the device radix sort: same residuals."""
+    if grouping == "device-radix-sort":
+        monkeypatch.setenv("DPPR_GROUPING_RADIX", "1")
     rng = np.random.default_rng(7)
     if shape == "group-beyond-lds-window":
         V, W, c, n = 64, 4000, 3000, 12000          # 70 % of the records share tail 5: a ~4000-record group
