@@ -150,3 +150,52 @@ def test_full_size_window_forty_slides_on_patched_tables(monkeypatch):
     assert t["valid"] and t["patched"] >= 34 and 5 <= t["rebuilt"] <= 7      # the first build + a re-cut every 8 slides
     assert e.stats(sl)["binned_sweeps"] > 100
     e.close()
+
+
+@pytest.mark.parametrize("shape", ["zipf-heads", "one-head-star", "one-row-star"])
+@pytest.mark.parametrize("directed", [1, 0])
+def test_long_runs_and_stars_through_the_binned_sweep(shape, directed):
+    """Round 6: a RUN (the edges of one head into one B-block) is the unit x[u] travels in. Windows whose runs are LONG -- heads drawn
+    from a Zipf law, one head that every edge points to, one row that every edge starts from -- exercise runs that cross the aligned
+    64-entry blocks of the tables, tiles of a single run and tiles of hundreds: the tables satisfy what the passes rely on and the sweeps
+    give the synchronous oracle's p / r after every batch."""
+    rng = np.random.default_rng(5)
+    V, n, W, c, eps = 2048, 12000, 4000, 100, 1e-9
+    if shape == "zipf-heads":
+        e2 = (rng.zipf(1.3, n) % V).astype(np.int32)
+        e1 = rng.integers(0, V, n).astype(np.int32)
+    elif shape == "one-head-star":
+        e2 = np.where(rng.random(n) < 0.9, 7, rng.integers(0, V, n)).astype(np.int32)
+        e1 = rng.integers(0, V, n).astype(np.int32)
+    else:
+        e1 = np.where(rng.random(n) < 0.9, 7, rng.integers(0, V, n)).astype(np.int32)
+        e2 = rng.integers(0, V, n).astype(np.int32)
+    e2 = np.where(e2 == e1, (e2 + 1) % V, e2).astype(np.int32)
+    e = eng.Engine(V, W, directed, c, schedule=eng.SCHEDULE_SYNC, pull_min_frontier=1, persistent=0, binned=TINY)
+    g = orc.Graph(V, e1, e2, directed, W, c)
+    s = orc.State(V, 7, eps)
+    e.load_window(*g.window_edges())
+    sl = e.add_source(7)
+    e.init_solve(sl, eps)
+    s.sync_execute(g)
+    p, r = e.read(sl)
+    assert np.max(np.abs(p - s.p)) < SYNC_TOL and np.max(np.abs(r - s.r)) < SYNC_TOL
+    longest = 0
+    for k in range(12):
+        assert not g.stream_updates()
+        g.inc_construct(1)
+        e.set_batch(*g.batch())
+        e.slide(*g.new_stream())
+        t = e.bin_tables()
+        assert t["valid"], k
+        check_tables(t)
+        starts = np.flatnonzero((t["dl"] & 0x8000) != 0)
+        longest = max(longest, int(np.max(np.diff(np.append(starts, t["n_edges"])))))
+        s.sync_inc_execute(g)
+        e.update(sl, eps)
+        p, r = e.read(sl)
+        assert np.max(np.abs(p - s.p)) < SYNC_TOL and np.max(np.abs(r - s.r)) < SYNC_TOL, k
+    assert e.stats(sl)["binned_sweeps"] > 0
+    if shape != "one-row-star":
+        assert longest >= 8, longest        # (a hub head's edges into one B-block: runs far beyond one entry)
+    e.close()
