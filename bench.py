@@ -345,7 +345,11 @@ def run_workload(a, ctx):
         gpu/PPRGPU.cuh:114-135), solver.update(eps, k) = the timed part."""
 
         def __init__(self, setup=None):
+            gp = {k: tune.pop(k) for k in ("gpush_enter_pairs", "gpush_max_edges") if k in tune}   # (tuning runs: dppr_set_group_push)
             self.e = eng.Engine(V, W, directed, c, n_epochs=n_resident, device=local_rank, schedule=schedule, **tune)
+            tune.update(gp)
+            if gp:
+                self.e.set_group_push(gp.get("gpush_enter_pairs", -1), 0, gp.get("gpush_max_edges", 0))
             if setup:
                 setup(self.e)
             self.ss = st.SlidingStream(V, e1, e2, directed, wl)

@@ -79,7 +79,10 @@ int group_push_tail(dppr_engine *e, Group &g, const Epoch &ep, int phase, double
     *entered = true;
     const int credit_first = *owed ? 1 : 0; // (iteration 0 of this mode settles it; every later one credits as it snapshots)
     // what an iteration may cost here: a sweep's floor is ~0.02 us per sweep group, a returning f64 atomic ~1 / 20 000 us
-    const long long max_edges = e->gpush_max_edges > 0 ? e->gpush_max_edges : std::max<long long>(4096, 200ll * std::max(ep.n_ggroups, 1));
+    // (round 6: 20 in-edges per sweep group, was 200 -- on the headline's 3 075 groups a push iteration of up to 615 K in-edges x 10 sources cost up
+    // to 540 us where a near-empty sweep costs 50-85: bound 615 K / 150 K / 60 K / 40 K / 20 K -> 12.37 / 12.24 / 12.18 / 12.19 / 12.23 ms per batch,
+    // two runs each on one box; twitter / friendster groups and resident-size windows: unchanged)
+    const long long max_edges = e->gpush_max_edges > 0 ? e->gpush_max_edges : std::max<long long>(4096, 20ll * std::max(ep.n_ggroups, 1));
     const int grid = 256;
     static const bool trace = getenv("DPPR_GROUP_TRACE") != nullptr;
     int it_done = 0;

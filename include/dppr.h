@@ -183,7 +183,7 @@ int dppr_set_sweep_bitmap(dppr_engine *e, int on);
  *   mode         : 0 never, 1 (default) when a source slot exists and the window has at least min_ids vertices with
  *                  an id, 2 always (tests: tiny windows)
  *   ha_tiles     : an A-block holds at most 64 x ha_tiles heads (8 bytes of LDS per head; 0 keeps the default, 128)
- *   hb_tiles     : a B-block holds at most 64 x hb_tiles rows (20 bytes of LDS per row; 0 keeps 48)
+ *   hb_tiles     : a B-block holds at most 64 x hb_tiles rows (20 bytes of LDS per row; 0 keeps 60 = 77 KB, two workgroups per CU)
  *   target_edges : edges a B-block is cut for (0 keeps the automatic choice, clamp(window edges / 256, 16 Ki, 384 Ki): twitter stand-in,
  *                  single source, 192 Ki / 384 Ki / 768 Ki: 74.6 / 70.2 / 77.7 ms per batch); a row of a quarter of that is a block of its own
  *   min_ids      : mode 1 threshold (0 keeps 1 Mi vertices with an id: smaller windows run resident or cannot fill the chip with blocks)
@@ -341,7 +341,7 @@ int dppr_set_resident_update(dppr_engine *e, int on);
  * synchronous schedule, same results up to the order of the sums. enter_pairs: -1 (default) = automatic: below
  * max(64, 2 pairs per sweep group) -- the factor 2 can be changed for tuning runs with the environment variable
  * DPPR_GROUP_PUSH_FACTOR, read in dppr_create --, 0 = never, N = below N pairs; an iteration with more in-edges than the floor is worth sends
- * the loop back to sweeps (max_edges: that bound on an iteration's in-edges; 0 = automatic, 200 per sweep group), to
+ * the loop back to sweeps (max_edges: that bound on an iteration's in-edges; 0 = automatic, 20 per sweep group), to
  * try again on a much smaller frontier. list_cap: vertices a frontier list holds (0: keep; default 2^20). Windows
  * whose groups run as multi-sweep launches do not use it. */
 int dppr_set_group_push(dppr_engine *e, int enter_pairs, int list_cap, int64_t max_edges);
